@@ -1,0 +1,75 @@
+"""Loaders for the committed fixtures under tests/golden/ (see make_golden_c1.py)."""
+import os
+
+import numpy as np
+
+import mlease_amd  # noqa: F401
+from mlease_amd.dataset import PartitionBlock, PartitionedData
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_c1() -> PartitionedData:
+    z = np.load(os.path.join(GOLDEN, "c1_partitions.npz"))
+    nb = int(z["num_blocks"])
+    blocks = []
+    for k in range(nb):
+        p = "p%d_" % k
+        rp = z[p + "row_ptr"].astype(np.int64)
+        l2g = z[p + "l2g"].astype(np.int32)
+        blocks.append(PartitionBlock(k, len(rp) - 1, len(l2g), rp, z[p + "col_idx"].astype(np.int32),
+                                     z[p + "val"].astype(np.float32), z[p + "y"].astype(np.int8),
+                                     z[p + "weight"].astype(np.float32), z[p + "offset"].astype(np.float32), l2g))
+    return PartitionedData(blocks, [str(s) for s in z["feature_names"]], nb)
+
+
+def load_c1_golden():
+    return np.load(os.path.join(GOLDEN, "c1_golden.npz"))
+
+
+def synth_sparse(seed, nrows, nfeat, nnz_per_row, num_blocks, binary=False, weights=False, offsets=False):
+    """Small seeded sparse problem with partition-local feature spaces (some features absent per partition)."""
+    rng = np.random.default_rng(seed)
+    beta = rng.normal(0, 0.5, nfeat)
+    blocks_rows = [[] for _ in range(num_blocks)]
+    for i in range(nrows):
+        m = max(1, int(rng.poisson(nnz_per_row)))
+        cols = rng.choice(nfeat, size=min(m, nfeat), replace=False)
+        vals = np.ones(len(cols), np.float32) if binary else rng.normal(0, 1, len(cols)).astype(np.float32)
+        s = float(np.dot(beta[cols], vals)) - 0.5
+        y = 1 if rng.random() < 1 / (1 + np.exp(-s)) else 0
+        w = np.float32(rng.uniform(0.5, 2.0)) if weights else np.float32(1)
+        o = np.float32(rng.normal(0, 0.3)) if offsets else np.float32(0)
+        blocks_rows[i % num_blocks].append((cols, vals, y, w, o))
+    gseen = {}
+    blocks = []
+    for k, rows in enumerate(blocks_rows):
+        lidx = {}
+        rp, ci, vv, ys, ws, os_ = [0], [], [], [], [], []
+        for cols, vals, y, w, o in rows:
+            ent = []
+            for c, v in zip(cols, vals):
+                if c not in lidx:
+                    lidx[c] = len(lidx)
+                    gseen.setdefault(int(c), len(gseen))
+                ent.append((lidx[c], v))
+            ent.sort(key=lambda e: e[0])
+            ci += [e[0] for e in ent]
+            vv += [e[1] for e in ent]
+            rp.append(len(ci))
+            ys.append(1 if y == 1 else -1)
+            ws.append(w)
+            os_.append(o)
+        inv = sorted(lidx.items(), key=lambda kv: kv[1])
+        blocks.append((k, rp, ci, vv, ys, ws, os_, [c for c, _ in inv]))
+    ng = len(gseen) + 1
+    out = []
+    for k, rp, ci, vv, ys, ws, os_, lcols in blocks:
+        l2g = np.asarray([gseen[int(c)] for c in lcols] + [ng - 1], np.int32)
+        out.append(PartitionBlock(k, len(ys), len(l2g), np.asarray(rp, np.int64), np.asarray(ci, np.int32),
+                                  None if binary else np.asarray(vv, np.float32), np.asarray(ys, np.int8),
+                                  np.asarray(ws, np.float32), np.asarray(os_, np.float32), l2g))
+    names = [None] * (ng - 1)
+    for c, g in gseen.items():
+        names[g] = "f%d" % c
+    return PartitionedData(out, names, num_blocks)

@@ -1,0 +1,194 @@
+"""ctypes wrapper around oracle/liboracle.so (the C restatement of the reference path).
+
+Test infrastructure: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+only -- never by the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ORACLE_DIR = os.path.join(_ROOT, "oracle")
+_LIB_PATH = os.path.join(_ORACLE_DIR, "liboracle.so")
+
+
+class TronStats(C.Structure):
+    _fields_ = [("newton_iters", C.c_int), ("accepted", C.c_int), ("cg_iters", C.c_int),
+                ("x_passes", C.c_int), ("fun_evals", C.c_int), ("grad_evals", C.c_int),
+                ("hv_evals", C.c_int), ("f", C.c_double), ("gnorm", C.c_double), ("gnorm1", C.c_double)]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_ORACLE_DIR, "admm_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _ORACLE_DIR, "-s", "liboracle.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        vp, i32, f64, f32 = C.c_void_p, C.c_int, C.c_double, C.c_float
+        L.orc_dataset_create.restype = vp
+        L.orc_dataset_create.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp]
+        L.orc_dataset_destroy.argtypes = [vp]
+        L.orc_eval.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+        L.orc_train.argtypes = [vp, vp, vp, vp, f64, i32, vp]
+        L.orc_admm_create.restype = vp
+        L.orc_admm_create.argtypes = [i32, i32, i32, i32, vp, vp, i32]
+        L.orc_admm_destroy.argtypes = [vp]
+        L.orc_admm_set_partition.argtypes = [vp, i32, vp, vp]
+        L.orc_admm_solve_local.argtypes = [vp, f64, f32, i32]
+        L.orc_admm_xbar.restype = C.POINTER(C.c_double)
+        L.orc_admm_xbar.argtypes = [vp]
+        L.orc_admm_ubar.restype = C.POINTER(C.c_double)
+        L.orc_admm_ubar.argtypes = [vp]
+        L.orc_admm_finish.argtypes = [vp, vp, vp]
+        L.orc_admm_iterate.argtypes = [vp, f64, f32, i32, vp, vp]
+        L.orc_admm_get_z.argtypes = [vp, vp, vp]
+        L.orc_admm_set_state.argtypes = [vp, vp, vp]
+        L.orc_admm_get_partition_model.argtypes = [vp, i32, i32, vp, vp, vp]
+        L.orc_admm_get_stats.argtypes = [vp, vp]
+        L.orc_float_to_string_to_double.restype = f64
+        L.orc_float_to_string_to_double.argtypes = [f32]
+        L.orc_admm_run.restype = i32
+        L.orc_admm_run.argtypes = [vp, i32, f64, i32, i32, vp, vp]
+        _lib = L
+    return _lib
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class OracleDataset:
+    """One partition in the reference's row-sparse layout (built from the C-ABI CSR block)."""
+
+    def __init__(self, l, n_local, row_ptr, col_idx, val, y, weight, offset):
+        self.l, self.n = int(l), int(n_local)
+        self._keep = [np.ascontiguousarray(row_ptr, np.int64), np.ascontiguousarray(col_idx, np.int32),
+                      None if val is None else np.ascontiguousarray(val, np.float32),
+                      np.ascontiguousarray(y, np.int8), np.ascontiguousarray(weight, np.float32),
+                      np.ascontiguousarray(offset, np.float32)]
+        k = self._keep
+        self.h = lib().orc_dataset_create(self.l, self.n, _p(k[0]), _p(k[1]), _p(k[2]), _p(k[3]), _p(k[4]), _p(k[5]))
+
+    @classmethod
+    def from_block(cls, b) -> "OracleDataset":
+        return cls(b.l, b.n_local, b.row_ptr, b.col_idx, b.val, b.y, b.weight, b.offset)
+
+    def eval(self, w, prior_mean, prior_var, s=None):
+        w = np.ascontiguousarray(w, np.float64)
+        pm = np.ascontiguousarray(prior_mean, np.float64)
+        pv = np.ascontiguousarray(prior_var, np.float64)
+        f = C.c_double()
+        g = np.empty(self.n)
+        Hs = np.empty(self.n) if s is not None else None
+        s_ = None if s is None else np.ascontiguousarray(s, np.float64)
+        lib().orc_eval(self.h, _p(w), _p(pm), _p(pv), _p(s_), C.byref(f), _p(g), _p(Hs))
+        return f.value, g, Hs
+
+    def train(self, init, prior_mean, prior_var, epsilon, max_iter=10000):
+        w = np.array(init, dtype=np.float64, copy=True)
+        pm = np.ascontiguousarray(prior_mean, np.float64)
+        pv = np.ascontiguousarray(prior_var, np.float64)
+        st = TronStats()
+        lib().orc_train(self.h, _p(w), _p(pm), _p(pv), float(epsilon), int(max_iter), C.byref(st))
+        return w, st
+
+    def __del__(self):
+        try:
+            lib().orc_dataset_destroy(self.h)
+        except Exception:
+            pass
+
+
+class OracleAdmm:
+    """The reference ADMM loop over in-memory partition blocks (CPU oracle)."""
+
+    def __init__(self, blocks: Sequence, n_global: int, lambdas: Sequence[float], rhos: Sequence[float],
+                 num_blocks: Optional[int] = None, penalize_intercept: bool = False):
+        order = np.argsort(np.asarray(lambdas, dtype=np.float32), kind="stable")
+        self.lambdas = np.ascontiguousarray(np.asarray(lambdas, dtype=np.float32)[order])
+        self.rhos = np.ascontiguousarray(np.asarray(rhos, dtype=np.float32)[order])
+        self.nlocal = len(blocks)
+        self.N = int(num_blocks if num_blocks is not None else len(blocks))
+        self.ng, self.nl = int(n_global), len(lambdas)
+        self.h = lib().orc_admm_create(self.N, self.nlocal, self.ng, self.nl, _p(self.lambdas), _p(self.rhos),
+                                       int(penalize_intercept))
+        self.ds: List[OracleDataset] = []
+        for k, b in enumerate(blocks):
+            d = OracleDataset.from_block(b)
+            self.ds.append(d)
+            l2g = np.ascontiguousarray(b.local_to_global, np.int32)
+            lib().orc_admm_set_partition(self.h, k, d.h, _p(l2g))
+
+    def solve_local(self, epsilon, rho_adapt_rate=1.0, nthreads=1):
+        lib().orc_admm_solve_local(self.h, float(epsilon), float(rho_adapt_rate), int(nthreads))
+
+    def partial_means(self):
+        n = self.nl * self.ng
+        xb = np.ctypeslib.as_array(lib().orc_admm_xbar(self.h), shape=(n,))
+        ub = np.ctypeslib.as_array(lib().orc_admm_ubar(self.h), shape=(n,))
+        return xb, ub        # views into the oracle's buffers (writable: all-reduce in place)
+
+    def finish(self):
+        mx, mn = C.c_double(), C.c_double()
+        lib().orc_admm_finish(self.h, C.byref(mx), C.byref(mn))
+        return mx.value, mn.value
+
+    def iterate(self, epsilon, rho_adapt_rate=1.0, nthreads=1):
+        mx, mn = C.c_double(), C.c_double()
+        lib().orc_admm_iterate(self.h, float(epsilon), float(rho_adapt_rate), int(nthreads), C.byref(mx), C.byref(mn))
+        return mx.value, mn.value
+
+    def run(self, niter, epsilon_stop=1e-4, aggressive=False, nthreads=1):
+        diffs = np.zeros(2 * niter)
+        eps = np.zeros(niter)
+        done = lib().orc_admm_run(self.h, int(niter), float(epsilon_stop), int(aggressive), int(nthreads),
+                                  _p(diffs), _p(eps))
+        return done, diffs.reshape(-1, 2)[:done], eps[:done]
+
+    def z(self):
+        Z = np.empty((self.nl, self.ng))
+        z32 = np.empty((self.nl, self.ng), np.float32)
+        lib().orc_admm_get_z(self.h, _p(Z), _p(z32))
+        return Z, z32
+
+    def set_state(self, Z=None, u=None):
+        Z_ = None if Z is None else np.ascontiguousarray(Z, np.float64)
+        u_ = None if u is None else np.ascontiguousarray(u, np.float32)
+        lib().orc_admm_set_state(self.h, _p(Z_), _p(u_))
+
+    def partition_model(self, k, li):
+        b = np.empty(self.ng, np.float32)
+        upx = np.empty(self.ng, np.float32)
+        un = np.empty(self.ng, np.float32)
+        lib().orc_admm_get_partition_model(self.h, int(k), int(li), _p(b), _p(upx), _p(un))
+        return b, upx, un
+
+    def stats(self):
+        arr = (TronStats * (self.nlocal * self.nl))()
+        lib().orc_admm_get_stats(self.h, arr)
+        return list(arr)
+
+    def __del__(self):
+        try:
+            lib().orc_admm_destroy(self.h)
+        except Exception:
+            pass
+
+
+def float_to_string_to_double(e) -> float:
+    return lib().orc_float_to_string_to_double(float(np.float32(e)))
