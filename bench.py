@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native ADMM L2-logistic hot path.
+
+Metric (BASELINE.json): partition Newton-solves/sec on synthetic dense 1M x 1K, 64 partitions, single
+lambda (configs[1]); one "step" = one ADMM iteration = one batched TRON solve of every (partition, lambda)
+problem + the consensus z/u update. Inputs are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU, weak scaling (64 partitions of 15 625 x 1000 per GPU, num.blocks = 64 N,
+partition k -> rank k mod N), consensus means all-reduced over RCCL (torch.distributed backend "nccl").
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+SEED = 20260925
+
+
+def gen_partition(torch, dev, pid, rows, nfeat, beta, bias):
+    """Synthetic C2 partition, generated on the GPU: x ~ N(0,1) fp32, y ~ Bernoulli(sigmoid(x.beta* + b))."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(SEED + 7919 * pid)
+    X = torch.randn((rows, nfeat), generator=g, device=dev, dtype=torch.float32)
+    logit = X.double() @ beta + bias
+    yy = torch.bernoulli(torch.sigmoid(logit), generator=g)
+    y = torch.where(yy > 0.5, 1, -1).to(torch.int8)
+    return X, y
+
+
+def cpu_baseline(sample, nfeat, iters, threads):
+    """The oracle (C restatement of the reference path) on the host cores: its own ADMM job over the sampled
+    partitions (num.blocks = len(sample)), `iters` iterations from z = 0, one thread per partition solve."""
+    import oracle_lib as ol
+    from mlease_amd.dataset import PartitionBlock
+    blocks = []
+    for k, (Xh, yh) in enumerate(sample):
+        l = Xh.shape[0]
+        blocks.append(PartitionBlock(k, l, nfeat + 1, np.arange(0, (l + 1) * nfeat, nfeat, dtype=np.int64),
+                                     np.tile(np.arange(nfeat, dtype=np.int32), l), Xh.reshape(-1), yh,
+                                     np.ones(l, np.float32), np.zeros(l, np.float32), np.arange(nfeat + 1, dtype=np.int32)))
+    oc = ol.OracleAdmm(blocks, nfeat + 1, [1.0], [1.0])
+    t0 = time.perf_counter()
+    passes = 0
+    for _ in range(iters):
+        oc.iterate(0.01, 1.0, nthreads=threads)
+        passes += sum(s.x_passes for s in oc.stats())
+    dt = time.perf_counter() - t0
+    return len(blocks) * iters / dt, passes / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows-per-partition", type=int, default=15625)
+    ap.add_argument("--features", type=int, default=1000)
+    ap.add_argument("--partitions-per-gpu", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="partitions in the CPU-baseline sample")
+    ap.add_argument("--cpu-iters", type=int, default=1)
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events")
+    args = ap.parse_args()
+
+    import torch
+    import mlease_amd  # noqa: F401
+    from mlease_amd import admm
+    from mlease_amd.hip_engine import HipAdmmEngine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    P, rows, nf = args.partitions_per_gpu, args.rows_per_partition, args.features
+    N = P * world
+    stream = torch.cuda.current_stream().cuda_stream
+    eng = HipAdmmEngine(nf + 1, [1.0], [1.0], N, device=local_rank, stream=stream, profiling=not args.no_profile)
+    gb = torch.Generator(device="cpu")
+    gb.manual_seed(SEED)
+    beta = (0.1 * torch.randn(nf, generator=gb, dtype=torch.float64)).to(dev)
+    sample = []
+    for i in range(P):
+        pid = i * world + rank                                     # partition k -> rank k mod G
+        X, y = gen_partition(torch, dev, pid, rows, nf, beta, -1.0)
+        torch.cuda.synchronize()
+        eng.add_partition_dense_device(pid, X.data_ptr(), rows, nf, nf, y.data_ptr())
+        if rank == 0 and world == 1 and not args.no_cpu_baseline and i < args.cpu_sample:
+            sample.append((X.cpu().numpy(), y.cpu().numpy()))
+        del X, y
+    eng.finalize()
+    torch.cuda.synchronize()
+
+    def all_reduce(t):
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # eps schedule of the driver loop (jobs/RegressionAdmmTrain.java:279,338-346)
+    e = np.float32(0.01)
+    mindiff = 99999999.0
+    it = 0
+    acc = dict(solves=0, newton=0, cg=0, passes_ref=0, passes_dev=0, ticks=0, alg_bytes=0.0, xpass_ms=0.0,
+               total_ms=0.0, launches=0)
+
+    def step(timed):
+        nonlocal e, mindiff, it
+        it += 1
+        if it > 1 and mindiff < 0.001:
+            e = np.float32(e / np.float32(10))
+        st = eng.solve_local(admm.float_string_roundtrip(e), 1.0)
+        all_reduce(eng.consensus_tensor())
+        fin = eng.consensus_finish()
+        mindiff = fin.mindiff
+        if timed:
+            acc["solves"] += st.solves; acc["newton"] += st.newton_iters; acc["cg"] += st.cg_iters
+            acc["passes_ref"] += st.x_passes_ref; acc["passes_dev"] += st.x_passes_dev; acc["ticks"] += st.ticks
+            acc["alg_bytes"] += st.alg_bytes_dev; acc["xpass_ms"] += st.xpass_ms; acc["total_ms"] += st.total_ms
+            acc["launches"] += st.xpass_launches
+        return fin
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fin = step(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        cnt = torch.tensor([acc["solves"], acc["passes_ref"], acc["passes_dev"], acc["cg"], acc["newton"]], device=dev, dtype=torch.float64)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        tot_solves, tot_pref, tot_pdev, tot_cg, tot_newton = [float(x) for x in cnt.tolist()]
+    else:
+        tot_solves, tot_pref, tot_pdev, tot_cg, tot_newton = acc["solves"], acc["passes_ref"], acc["passes_dev"], acc["cg"], acc["newton"]
+
+    out = None
+    if rank == 0:
+        value = tot_solves / dt
+        roof = None
+        if acc["xpass_ms"] > 0:
+            achieved = acc["alg_bytes"] / (acc["xpass_ms"] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "k_xpass_dense<4,4>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "alg_bytes_per_launch": acc["alg_bytes"] / max(1, acc["launches"]),
+                    "avg_launch_ms": acc["xpass_ms"] / max(1, acc["launches"]), "launches": acc["launches"],
+                    "xpass_share_of_step": round(acc["xpass_ms"] / (dt * 1e3), 4)}
+        out = {"metric": "partition Newton-solves/sec (ADMM L2-LR, dense 1Mx1K, 64 partitions/GPU)",
+               "value": round(value, 3), "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[1]: synthetic dense %d rows x %d features, %d partitions%s, lambda=1, rho=1, "
+                                      "fp32-stored X, fp64 arithmetic" % (rows * N, nf, N, " (64 per GPU)" if world > 1 else ""),
+                          "rows": rows * N, "features": nf, "partitions": N, "lambda": [1.0], "rho": [1.0],
+                          "admm_iterations_timed": [args.warmup + 1, args.warmup + args.steps],
+                          "exchange": "rccl all_reduce of [xbar|ubar] (%d doubles)" % (2 * (nf + 1)) if world > 1 else "none (1 GPU)"},
+               "work": {"solves": tot_solves, "tron_iters_per_s": round(tot_newton / dt, 2), "cg_steps_per_s": round(tot_cg / dt, 2),
+                        "x_passes_ref_per_s": round(tot_pref / dt, 2), "x_passes_dev_per_s": round(tot_pdev / dt, 2),
+                        "passes_ref_per_solve": round(tot_pref / max(1.0, tot_solves), 2),
+                        "passes_dev_per_solve": round(tot_pdev / max(1.0, tot_solves), 2), "ticks": acc["ticks"],
+                        "last_maxdiff": fin.maxdiff},
+               "roofline": roof}
+        if sample:
+            threads = os.cpu_count() or 1
+            threads = min(threads, len(sample))
+            v, pps, cdt = cpu_baseline(sample, nf, args.cpu_iters, threads)
+            out["cpu_baseline"] = {"value": round(v, 4), "unit": "solves/s", "cores": threads, "kind": "port",
+                                   "sample": "oracle/admm_oracle.c (-O2, fp64, one thread per partition solve) on %d of the %d "
+                                             "partitions as its own num.blocks=%d ADMM job, iterations 1..%d from z=0, %.1f s wall"
+                                             % (len(sample), N, len(sample), args.cpu_iters, cdt),
+                                   "x_passes_ref_per_s": round(pps, 2), "host_cores_available": os.cpu_count()}
+            out["gpu_over_cpu"] = {"solves_per_s": round(value / v, 2), "x_passes_ref_per_s": round(tot_pref / dt / pps, 2)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

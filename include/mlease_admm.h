@@ -1,0 +1,181 @@
+/*
+ * mlease_admm.h -- C-ABI of the MI355X-native ADMM L2-logistic trainer (libmlease_hip.so).
+ *
+ * Drop-in boundary for ONE path of linkedin/ml-ease (seam S3):
+ * everything between "launch the AdmmMapper/AdmmReducer MapReduce job" and "z, u and
+ * maxdiff of this iteration are known" inside RegressionAdmmTrain.run, i.e.
+ *
+ *   AvroUtils.runAvroJob(conf)            jobs/RegressionAdmmTrain.java:357
+ *     AdmmReducer.reduce                  jobs/RegressionAdmmTrain.java:641-718
+ *       LibLinear.train                   liblinearfunc/LibLinear.java:221-398
+ *         Tron.tron / trcg                de/bwaldvogel/liblinear/Tron.java:30-179
+ *           LogisticRegressionL2.fun/grad/Hv  liblinearfunc/LogisticRegressionL2.java:156-248
+ *   LinearModelUtils.meanModel x2         jobs/RegressionAdmmTrain.java:362-364
+ *   z-update (L2)                         jobs/RegressionAdmmTrain.java:365-405
+ *   computeU                              jobs/RegressionAdmmTrain.java:736-765
+ *   maxdiff / mindiff                     jobs/RegressionAdmmTrain.java:455-472
+ *
+ * The reference has no FFI of its own (100 % Java); these entry points are what a JNI class
+ * bound into a patched RegressionAdmmTrain.run would call (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - C linkage, plain pointers and sizes, no exceptions cross the boundary.
+ *   - Every function returns MLX_OK (0) or a negative MLX_ERR_* code; mlx_last_error(h) gives
+ *     the message. The Java shim maps any non-zero code to IOException("Model fitting error!")
+ *     like jobs/RegressionAdmmTrain.java:713-716.
+ *   - The caller owns all host buffers and may free them when the call returns; the library
+ *     owns device memory behind the opaque handle.
+ *   - One handle drives ONE GPU; one host thread per handle; calls are blocking; a handle is not
+ *     thread-safe; distinct handles are independent (multi-GPU = one handle per GPU, partitions
+ *     k -> rank k mod G, consensus means summed across handles, see mlx_admm_solve_local).
+ *   - Index spaces: GLOBAL coefficient index j in [0, n_global); the intercept "(INTERCEPT)"
+ *     (liblinearfunc/LibLinearDataset.java:92) is ALWAYS global index n_global-1. LOCAL index in
+ *     [0, n_local) per partition, the partition's first-seen feature order
+ *     (liblinearfunc/LibLinearDataset.java:467-478); the intercept is local index n_local-1 and is NOT
+ *     stored in the row data: the library appends it with value bias = 1.0 exactly as
+ *     LibLinearDataset.finish does (liblinearfunc/LibLinearDataset.java:592-615).
+ *   - lambda order: lambda[] must be sorted ascending; problem (partition k, lambda index li) is
+ *     the reduce task with key k*n_lambda+li (jobs/RegressionAdmmTrain.java:636-638,647-650).
+ */
+#ifndef MLEASE_ADMM_H
+#define MLEASE_ADMM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mlx_context *mlx_handle;
+
+enum {
+    MLX_OK = 0,
+    MLX_ERR_INVALID = -1,        /* bad argument / call order */
+    MLX_ERR_HIP = -2,            /* a HIP runtime call failed */
+    MLX_ERR_NO_DEVICE = -3,      /* no usable gfx950 device */
+    MLX_ERR_MODEL_FITTING = -4,  /* a solve did not terminate (tick cap) or produced NaN */
+    MLX_ERR_MISSING_MODELS = -5, /* "Some models failed!" (utils/LinearModelUtils.java:80-83) */
+    MLX_ERR_COMM = -6            /* RCCL failure */
+};
+
+/* Counters of one mlx_admm_iterate / mlx_admm_solve_local call (this handle's partitions only). */
+typedef struct mlx_stats {
+    double maxdiff;          /* max_lambda ||z - z_prev||_inf  (jobs/RegressionAdmmTrain.java:455-472) */
+    double mindiff;          /* min_lambda ...                                                         */
+    int64_t solves;          /* (partition, lambda) problems solved = LibLinear.train calls            */
+    int64_t newton_iters;    /* trcg calls (accepted + rejected TRON iterations)                       */
+    int64_t accepted;        /* accepted TRON steps                                                    */
+    int64_t cg_iters;        /* CG steps = Hv evaluations                                              */
+    int64_t x_passes_ref;    /* passes over X the REFERENCE would make: 3 + sum(2cg+1+acc) per solve   */
+    int64_t x_passes_dev;    /* passes over X this library made: 1 + sum(cg+1) per solve               */
+    int64_t ticks;           /* lock-step device ticks (one X pass of every unfinished problem)        */
+    double alg_bytes_dev;    /* algorithmic HBM bytes of the X-pass kernels launched       */
+    double xpass_ms;         /* device time inside the X-pass kernels (HIP events), 0 if profiling off */
+    double total_ms;         /* device time of the whole call (HIP events)                             */
+    int64_t xpass_launches;  /* number of X-pass kernel launches                                       */
+} mlx_stats;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+int mlx_create(int device_id, mlx_handle *out);
+int mlx_destroy(mlx_handle h);
+const char *mlx_last_error(mlx_handle h);          /* valid until the next call on h; h may be NULL */
+/* Run all work of this handle on an existing hipStream_t (e.g. torch's current stream); NULL = own stream. */
+int mlx_set_stream(mlx_handle h, void *hip_stream);
+/* 1 = time the X-pass kernels with HIP events (stats.xpass_ms); costs one event pair per launch. */
+int mlx_set_profiling(mlx_handle h, int enable);
+
+/* ---- problem definition -------------------------------------------------------------------
+ * num_blocks  = num.blocks of the job: the FIXED divisor of the consensus mean
+ *               (consumers/MeanLinearModelConsumer.java:61), also when this handle holds only a shard.
+ * lambda/rho  = float32 as parsed by the driver (jobs/RegressionAdmmTrain.java:164-183), ascending lambda.
+ * lambda_map  = NULL, or per-global-feature lambda (NaN = use the global lambda), the dense form of
+ *               the lambda.map file (jobs/RegressionAdmmTrain.java:383-386); entry n_global-1 ignored.
+ * Replaces: JobConf keys num.blocks/lambda/rho/penalize.intercept (jobs/RegressionAdmmTrain.java:138-185,302). */
+int mlx_set_problem(mlx_handle h, int32_t n_global, int32_t n_lambda, const float *lambda,
+                    const float *rho, int32_t num_blocks, int32_t penalize_intercept,
+                    const float *lambda_map);
+
+/* regularizer: 2 = L2 consensus shrinkage (default; jobs/RegressionAdmmTrain.java:378-405),
+ * 1 = L1 iterative thresholding (:406-451). Call between mlx_set_problem and mlx_finalize. */
+int mlx_set_regularizer(mlx_handle h, int32_t regularizer);
+
+/* One partition = the rows one AdmmReducer receives (jobs/RegressionAdmmTrain.java:686-690), uploaded
+ * ONCE and shared by all lambdas and all iterations. Replaces LibLinearDataset.addInstanceAvro+finish
+ * (liblinearfunc/LibLinearDataset.java:413-484,586-658; binary: LibLinearBinaryDataset.java:426-515).
+ *   row_ptr[l+1], col_idx[nnz]: CSR, 0-based local ids in [0, n_local-1), sorted per row, intercept excluded
+ *   val[nnz]   float32 feature values, or NULL for binary.feature (all 1)
+ *   y[l]       +1 / -1  (response 0 and -1 both map to -1, LibLinearDataset.java:419-423)
+ *   weight[l], offset[l] float32 (RegressionPrepareOutput.avsc:28-33); NULL = all 1 / all 0
+ *   local_to_global[n_local] with local_to_global[n_local-1] == n_global-1
+ * partition_id is the GLOBAL id in [0, num_blocks); a handle may hold any subset. */
+int mlx_add_partition_csr(mlx_handle h, int32_t partition_id, int32_t l, int32_t n_local, int64_t nnz,
+                          const int64_t *row_ptr, const int32_t *col_idx, const float *val,
+                          const int8_t *y, const float *weight, const float *offset,
+                          const int32_t *local_to_global);
+
+/* Dense tile form for partitions in which every row carries every feature (BASELINE config #2):
+ * X is row-major [l][ld] float32, the first n_feat columns used; n_local = n_feat+1.
+ * x_on_device != 0: X, y, weight, offset are DEVICE pointers (synthetic data generated on the GPU). */
+int mlx_add_partition_dense(mlx_handle h, int32_t partition_id, int32_t l, int32_t n_feat, int64_t ld,
+                            const float *X, const int8_t *y, const float *weight, const float *offset,
+                            const int32_t *local_to_global, int32_t x_on_device);
+
+/* Allocate solver state after the last mlx_add_partition_*; z = 0, u = 0 (iteration 1 of
+ * jobs/RegressionAdmmTrain.java:155,184,310-312). */
+int mlx_finalize(mlx_handle h);
+
+/* Resume / warm start: z[n_lambda][n_global] (double, the driver's z) and
+ * u[local partitions in add order][n_lambda][n_global] float32 (the u file); NULL leaves as is. */
+int mlx_set_state(mlx_handle h, const double *z, const float *u);
+
+/* ---- one ADMM iteration ---------------------------------------------------------------------
+ * mlx_admm_iterate == mlx_admm_solve_local + (RCCL all-reduce of the means if mlx_comm_init was
+ * called) + mlx_admm_consensus_finish; it is one trip of the loop body
+ * jobs/RegressionAdmmTrain.java:357-472.
+ *   liblinear_epsilon = Double.parseDouble(String.valueOf(float eps)) as the reducer sees it (:346,:702)
+ *   rho_adapt_rate    = conf RHO_ADAPT_RATE (:316,:326,:621,:653-658); 1.0f = none */
+int mlx_admm_iterate(mlx_handle h, double liblinear_epsilon, float rho_adapt_rate, mlx_stats *stats);
+
+/* Split form for callers that run the exchange step themselves (one process per GPU under
+ * torch.distributed): solve all local (partition, lambda) problems and leave this shard's partial
+ * means  xbar = sum_k (1/num_blocks) f32(beta_k),  ubar = sum_k (1/num_blocks) u_k  in one device
+ * buffer of 2*n_lambda*n_global doubles ([xbar | ubar]); the caller sums that buffer over all
+ * shards (ncclAllReduce / all_reduce(SUM)) and then calls mlx_admm_consensus_finish. */
+int mlx_admm_solve_local(mlx_handle h, double liblinear_epsilon, float rho_adapt_rate, mlx_stats *stats);
+int mlx_consensus_buffer(mlx_handle h, void **device_ptr, size_t *count_doubles);
+int mlx_admm_consensus_finish(mlx_handle h, mlx_stats *stats);
+
+/* ---- results ------------------------------------------------------------------------------- */
+/* Driver z in double and as the float32 the final-model file holds (models/LinearModel.java:703,716). */
+int mlx_get_z(mlx_handle h, double *z_double /* may be NULL */, float *z_float /* may be NULL */);
+/* iter-i/model parity dumps: the reducer outputs of the last iteration for one local partition
+ * (index in add order) and lambda: model, uplusx (jobs/RegressionAdmmTrain.java:706-711) and the u
+ * that computeU derives for the next iteration (:752-757). Any pointer may be NULL. */
+int mlx_get_partition_model(mlx_handle h, int32_t local_index, int32_t lambda_index, float *beta,
+                            float *uplusx, float *u_next);
+/* Per-problem counters of the last solve: out[q*4 + {0,1,2,3}] = newton_iters, accepted, cg_iters,
+ * x_passes_ref for q = local_index*n_lambda + lambda_index. */
+int mlx_get_solve_counters(mlx_handle h, int32_t *out);
+
+/* ---- unit-test seam S2 == LibLinear.train (liblinearfunc/LibLinear.java:200-228) ---------------
+ * Solve ONE problem on local partition `local_index` with explicit dense arrays in the partition's
+ * LOCAL index space: w[n_local] holds initParam on entry and the TRON result on exit;
+ * prior_var[n_local] (per-coordinate), epsilon as parsed from the option string. */
+int mlx_solve_one(mlx_handle h, int32_t local_index, double *w, const double *prior_mean,
+                  const double *prior_var, double epsilon, int32_t max_iter, int32_t *counters4,
+                  double *f_out, double *gnorm_out, double *gnorm1_out);
+
+/* ---- multi-GPU exchange inside the library (RCCL over xGMI) ---------------------------------
+ * Replaces the gather of iter-i/model + iter-i/u files to the driver (SURVEY 2a collective table). */
+#define MLX_UNIQUE_ID_BYTES 128
+int mlx_comm_get_unique_id(char out[MLX_UNIQUE_ID_BYTES]);
+int mlx_comm_init(mlx_handle h, const char unique_id[MLX_UNIQUE_ID_BYTES], int32_t nranks, int32_t rank);
+
+/* Library build info, e.g. "mlease_hip gfx950 <date>". */
+const char *mlx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLEASE_ADMM_H */

@@ -7,6 +7,6 @@ indexing (``dataset.py``) and the avro container formats (``avro_io.py``).
 The directory name carries a hyphen (repo contract); import it as ``mlease_amd`` through the
 loader shim ``mlease_amd.py`` at the repository root.
 """
-from . import avro_io, dataset  # noqa: F401
+from . import admm, avro_io, dataset, hip_engine  # noqa: F401
 
-__all__ = ["avro_io", "dataset"]
+__all__ = ["admm", "avro_io", "dataset", "hip_engine"]

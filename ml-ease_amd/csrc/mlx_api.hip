@@ -1,0 +1,832 @@
+// mlx_api.hip -- host side of the C-ABI in include/mlease_admm.h: device memory, partition upload
+// (CSR -> CSR+CSC segments, dense tile), the tick loop that drives the batched TRON solve, the
+// consensus step and the RCCL exchange. One handle = one GPU = one host thread.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/mlease_admm.h"
+#include "mlx_kernels.h"
+#include "mlx_types.h"
+
+namespace {
+
+constexpr int CSC_SEG = 512;          // max entries of one CSC work item (8 lanes)
+constexpr int DEFAULT_MAX_ITER = 10000;   // llf/LibLinear.java:97
+constexpr int64_t TICK_CAP = 2000000;
+
+struct PartHost {
+    int pid = 0, l = 0, n_local = 0, n_feat = 0;
+    bool dense = false, hasval = false, all_present = false;
+    int64_t nnz = 0, ld = 0;
+    int nblk = 0, rows_per_blk = 0, n_items = 0, rowgroup = 64, pos = 0, neg = 0;
+    PartDev dev{};
+    double *c0 = nullptr;
+};
+
+}  // namespace
+
+struct mlx_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool profiling = false;
+    std::string err;
+
+    int n_global = 0, n_lambda = 0, num_blocks = 0, penalize_intercept = 0, regularizer = 2;
+    bool problem_set = false, finalized = false;
+    std::vector<float> lambda, rho, lambda_map;
+    std::vector<PartHost> parts;
+    std::vector<void *> allocs;
+
+    int nprob = 0;
+    PartDev *d_parts = nullptr;
+    ProbDev *d_probs = nullptr;            // nprob + 1 (scratch problem for mlx_solve_one)
+    std::vector<ProbDev> h_probs;
+    int *d_qdense = nullptr, *d_qcsr = nullptr, *d_qscratch = nullptr;
+    int nq_dense = 0, nq_csr = 0;
+    int maxblk_dense = 0, maxblk_csr = 0, max_nfeat_dense = 0, max_items = 0, rowgroup = 64, max_nlocal = 0, max_l = 0;
+    int64_t max_parts_len = 0;
+    bool csr_hasval = false, any_absent = false;
+    int step_threads = 256;
+
+    double *d_Z = nullptr;
+    float *d_z32 = nullptr, *d_u = nullptr, *d_B = nullptr, *d_UPX = nullptr;
+    double *d_cons = nullptr;              // [xbar | ubar], 2 * n_lambda * n_global
+    bool cons_external = false;
+    double *d_weight_l = nullptr, *d_pinv_l = nullptr, *d_cmap = nullptr;
+    unsigned long long *d_diffbits = nullptr;
+    int *d_done = nullptr;
+    int *h_done = nullptr;                 // pinned [2]
+    unsigned long long *h_diff = nullptr;  // pinned [n_lambda]
+    hipEvent_t ev_batch[2] = {nullptr, nullptr};
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    // scratch vectors of the solve_one problem
+    double *sc_vec[8] = {nullptr}, *sc_pinv = nullptr;
+
+    ncclComm_t comm = nullptr;
+    int comm_nranks = 1;
+
+    mlx_stats last{};
+};
+
+namespace {
+
+thread_local std::string g_err_nohandle;
+
+int fail(mlx_handle h, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    else g_err_nohandle = buf;
+    return code;
+}
+
+#define HIPCHECK(h, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(h, MLX_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+int dev_alloc(mlx_handle h, T **p, size_t count)
+{
+    void *q = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return fail(h, MLX_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    h->allocs.push_back(q);
+    *p = static_cast<T *>(q);
+    return MLX_OK;
+}
+
+template <typename T>
+int dev_upload(mlx_handle h, T **p, const T *src, size_t count)
+{
+    int rc = dev_alloc(h, p, count);
+    if (rc) return rc;
+    if (count) HIPCHECK(h, hipMemcpy(*p, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return MLX_OK;
+}
+
+int check_common_rows(mlx_handle h, int32_t partition_id, int32_t l, const int32_t *l2g, int32_t n_local)
+{
+    if (!h->problem_set) return fail(h, MLX_ERR_INVALID, "mlx_set_problem must be called before adding partitions");
+    if (h->finalized) return fail(h, MLX_ERR_INVALID, "partitions cannot be added after mlx_finalize");
+    if (partition_id < 0 || partition_id >= h->num_blocks)
+        return fail(h, MLX_ERR_INVALID, "Map key is wrong! key has to be in the range of [0,numPartitions-1]. (partition %d)", partition_id);
+    if (l <= 0) return fail(h, MLX_ERR_MISSING_MODELS, "partition %d has no rows: its reducer would emit no model (Some models failed!)", partition_id);
+    if (n_local < 1 || n_local > h->n_global) return fail(h, MLX_ERR_INVALID, "n_local=%d out of range (n_global=%d)", n_local, h->n_global);
+    if (!l2g) return fail(h, MLX_ERR_INVALID, "local_to_global is NULL");
+    if (l2g[n_local - 1] != h->n_global - 1) return fail(h, MLX_ERR_INVALID, "local_to_global[n_local-1] must be the intercept (n_global-1)");
+    for (int j = 0; j < n_local; j++)
+        if (l2g[j] < 0 || l2g[j] >= h->n_global) return fail(h, MLX_ERR_INVALID, "local_to_global[%d]=%d out of range", j, l2g[j]);
+    for (auto &p : h->parts)
+        if (p.pid == partition_id) return fail(h, MLX_ERR_INVALID, "partition %d added twice", partition_id);
+    return MLX_OK;
+}
+
+int upload_row_meta(mlx_handle h, PartHost &ph, int32_t l, const int8_t *y, const float *weight, const float *offset,
+                    bool on_device)
+{
+    std::vector<int8_t> yh(l);
+    if (on_device) HIPCHECK(h, hipMemcpy(yh.data(), y, l, hipMemcpyDeviceToHost));
+    else memcpy(yh.data(), y, l);
+    int pos = 0;
+    for (int i = 0; i < l; i++) {
+        if (yh[i] != 1 && yh[i] != -1) return fail(h, MLX_ERR_INVALID, "y[%d]=%d: labels must be +1/-1", i, (int)yh[i]);
+        pos += (yh[i] == 1);
+    }
+    ph.pos = pos;
+    ph.neg = l - pos;
+    int8_t *dy; float *dw, *dof;
+    int rc;
+    if ((rc = dev_upload(h, &dy, yh.data(), l))) return rc;
+    std::vector<float> tmp(l);
+    if (weight) {
+        if (on_device) HIPCHECK(h, hipMemcpy(tmp.data(), weight, sizeof(float) * l, hipMemcpyDeviceToHost));
+        else memcpy(tmp.data(), weight, sizeof(float) * l);
+        for (int i = 0; i < l; i++)
+            if (tmp[i] < 0) return fail(h, MLX_ERR_INVALID, "weight = %g (weight cannot < 0)", tmp[i]);
+    } else std::fill(tmp.begin(), tmp.end(), 1.0f);
+    if ((rc = dev_upload(h, &dw, tmp.data(), l))) return rc;
+    if (offset) {
+        if (on_device) HIPCHECK(h, hipMemcpy(tmp.data(), offset, sizeof(float) * l, hipMemcpyDeviceToHost));
+        else memcpy(tmp.data(), offset, sizeof(float) * l);
+    } else std::fill(tmp.begin(), tmp.end(), 0.0f);
+    if ((rc = dev_upload(h, &dof, tmp.data(), l))) return rc;
+    ph.dev.y = dy; ph.dev.wt = dw; ph.dev.off = dof;
+    return MLX_OK;
+}
+
+hipEvent_t next_event(mlx_handle h)
+{
+    if (h->ev_used == h->ev_pool.size()) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        h->ev_pool.push_back(e);
+    }
+    return h->ev_pool[h->ev_used++];
+}
+
+// One X pass over every unfinished problem of the given lists (+ optional event bracket).
+int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int nqc)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->profiling) { e0 = next_event(h); e1 = next_event(h); hipEventRecord(e0, h->stream); }
+    if (nqd > 0 && mlxk_xpass_dense(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->maxblk_dense, h->max_nfeat_dense))
+        return fail(h, MLX_ERR_INVALID, "dense tile wider than 2048 features is not supported; use the CSR form");
+    if (nqc > 0) mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_items, h->rowgroup, h->csr_hasval);
+    if (h->profiling) hipEventRecord(e1, h->stream);
+    return MLX_OK;
+}
+
+// Drive ticks until `count` problems starting at `first` are DONE.
+int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, const int *qcsr, int nqc, int64_t *ticks_out)
+{
+    HIPCHECK(h, hipMemsetAsync(h->d_done, 0, sizeof(int), h->stream));
+    h->h_done[0] = h->h_done[1] = 0;
+    const int batch = 4;
+    int64_t ticks = 0;
+    int slot = 0;
+    bool have_prev = false;
+    int rc;
+    for (;;) {
+        for (int i = 0; i < batch; i++) {
+            if ((rc = launch_xpass(h, qdense, nqd, qcsr, nqc))) return rc;
+            mlxk_tron_step(h->stream, h->d_parts, h->d_probs, count, first, h->step_threads, h->d_done);
+            ticks++;
+        }
+        HIPCHECK(h, hipMemcpyAsync(&h->h_done[slot], h->d_done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(h, hipEventRecord(h->ev_batch[slot], h->stream));
+        if (have_prev) {
+            HIPCHECK(h, hipEventSynchronize(h->ev_batch[slot ^ 1]));
+            if (h->h_done[slot ^ 1] >= count) break;      // the batch just queued runs as no-ops
+        }
+        have_prev = true;
+        slot ^= 1;
+        if (ticks > TICK_CAP) return fail(h, MLX_ERR_MODEL_FITTING, "Model fitting error! solve did not terminate within %lld ticks", (long long)TICK_CAP);
+    }
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    HIPCHECK(h, hipGetLastError());
+    if (ticks_out) *ticks_out = ticks;
+    return MLX_OK;
+}
+
+double alg_bytes_per_tick(const PartHost &p)
+{
+    // DESIGN.md "Algorithmic bytes": dense fused pass 4*l*n_feat + 8*l + 8*n ; CSR tick = row pass + column pass,
+    // each nnz*(4+s_val) + 8*l + 8*n.
+    const double l = p.l, n = p.n_local;
+    if (p.dense) return 4.0 * l * p.n_feat + 8.0 * l + 8.0 * n;
+    const double sval = p.hasval ? 4.0 : 0.0;
+    return 2.0 * ((double)p.nnz * (4.0 + sval) + 8.0 * l + 8.0 * n);
+}
+
+int finish_part(mlx_handle h, PartHost &ph)
+{
+    ph.dev.l = ph.l; ph.dev.n_local = ph.n_local; ph.dev.n_feat = ph.n_feat; ph.dev.dense = ph.dense ? 1 : 0;
+    ph.dev.nblk = ph.nblk; ph.dev.rows_per_blk = ph.rows_per_blk; ph.dev.pos = ph.pos; ph.dev.neg = ph.neg;
+    ph.dev.ld = ph.ld; ph.dev.nnz = ph.nnz; ph.dev.n_items = ph.n_items; ph.dev.rowgroup = ph.rowgroup;
+    int rc = dev_alloc(h, &ph.c0, (size_t)ph.n_local);
+    if (rc) return rc;
+    ph.dev.c0 = ph.c0;
+    h->parts.push_back(ph);
+    return MLX_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char *mlx_version(void) { return "mlease_hip gfx950 r1 (" __DATE__ ")"; }
+
+const char *mlx_last_error(mlx_handle h) { return h ? h->err.c_str() : g_err_nohandle.c_str(); }
+
+int mlx_create(int device_id, mlx_handle *out)
+{
+    if (!out) return fail(nullptr, MLX_ERR_INVALID, "out is NULL");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, MLX_ERR_NO_DEVICE, "no HIP device visible: the MI355X path has no CPU fallback");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, MLX_ERR_NO_DEVICE, "device %d out of range (%d devices)", device_id, ndev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return fail(nullptr, MLX_ERR_HIP, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, MLX_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", device_id, prop.gcnArchName);
+    mlx_context *h = new mlx_context();
+    h->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess) { delete h; return fail(nullptr, MLX_ERR_HIP, "hipSetDevice failed"); }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(nullptr, MLX_ERR_HIP, "hipStreamCreate failed"); }
+    h->own_stream = true;
+    hipEventCreateWithFlags(&h->ev_batch[0], hipEventDisableTiming);
+    hipEventCreateWithFlags(&h->ev_batch[1], hipEventDisableTiming);
+    hipEventCreate(&h->ev_t0);
+    hipEventCreate(&h->ev_t1);
+    *out = h;
+    return MLX_OK;
+}
+
+int mlx_destroy(mlx_handle h)
+{
+    if (!h) return MLX_OK;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    if (h->comm) ncclCommDestroy(h->comm);
+    for (void *p : h->allocs) hipFree(p);
+    if (h->h_done) hipHostFree(h->h_done);
+    if (h->h_diff) hipHostFree(h->h_diff);
+    for (auto e : h->ev_pool) hipEventDestroy(e);
+    for (auto e : h->ev_batch) if (e) hipEventDestroy(e);
+    if (h->ev_t0) hipEventDestroy(h->ev_t0);
+    if (h->ev_t1) hipEventDestroy(h->ev_t1);
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return MLX_OK;
+}
+
+int mlx_set_stream(mlx_handle h, void *hip_stream)
+{
+    if (!h) return MLX_ERR_INVALID;
+    hipSetDevice(h->device);
+    if (h->own_stream && h->stream) { hipStreamSynchronize(h->stream); hipStreamDestroy(h->stream); }
+    if (hip_stream) { h->stream = static_cast<hipStream_t>(hip_stream); h->own_stream = false; }
+    else { HIPCHECK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    return MLX_OK;
+}
+
+int mlx_set_profiling(mlx_handle h, int enable)
+{
+    if (!h) return MLX_ERR_INVALID;
+    h->profiling = enable != 0;
+    return MLX_OK;
+}
+
+int mlx_set_problem(mlx_handle h, int32_t n_global, int32_t n_lambda, const float *lambda, const float *rho,
+                    int32_t num_blocks, int32_t penalize_intercept, const float *lambda_map)
+{
+    if (!h) return MLX_ERR_INVALID;
+    if (h->problem_set) return fail(h, MLX_ERR_INVALID, "mlx_set_problem called twice");
+    if (n_global < 1 || n_lambda < 1 || num_blocks < 1 || !lambda || !rho) return fail(h, MLX_ERR_INVALID, "bad problem sizes");
+    for (int i = 0; i < n_lambda; i++) {
+        if (i && !(lambda[i] > lambda[i - 1])) return fail(h, MLX_ERR_INVALID, "lambda[] must be strictly ascending (jobs/RegressionAdmmTrain.java:636-638)");
+        if (!(rho[i] > 0)) return fail(h, MLX_ERR_INVALID, "rho must be > 0");
+    }
+    h->n_global = n_global; h->n_lambda = n_lambda; h->num_blocks = num_blocks;
+    h->penalize_intercept = penalize_intercept ? 1 : 0;
+    h->lambda.assign(lambda, lambda + n_lambda);
+    h->rho.assign(rho, rho + n_lambda);
+    if (lambda_map) h->lambda_map.assign(lambda_map, lambda_map + n_global);
+    h->problem_set = true;
+    return MLX_OK;
+}
+
+int mlx_set_regularizer(mlx_handle h, int32_t regularizer)
+{
+    if (!h) return MLX_ERR_INVALID;
+    if (regularizer != 1 && regularizer != 2) return fail(h, MLX_ERR_INVALID, "Only L1 and L2 regularization supported!");
+    h->regularizer = regularizer;
+    return MLX_OK;
+}
+
+int mlx_add_partition_csr(mlx_handle h, int32_t partition_id, int32_t l, int32_t n_local, int64_t nnz,
+                          const int64_t *row_ptr, const int32_t *col_idx, const float *val, const int8_t *y,
+                          const float *weight, const float *offset, const int32_t *local_to_global)
+{
+    if (!h) return MLX_ERR_INVALID;
+    hipSetDevice(h->device);
+    int rc = check_common_rows(h, partition_id, l, local_to_global, n_local);
+    if (rc) return rc;
+    if (!row_ptr || (nnz > 0 && !col_idx) || !y) return fail(h, MLX_ERR_INVALID, "NULL row data");
+    if (row_ptr[0] != 0 || row_ptr[l] != nnz) return fail(h, MLX_ERR_INVALID, "row_ptr[0] must be 0 and row_ptr[l] == nnz");
+    if (nnz >= (int64_t)std::numeric_limits<int32_t>::max()) return fail(h, MLX_ERR_INVALID, "partition nnz must be < 2^31");
+    const int nf = n_local - 1;
+    std::vector<int32_t> rp(l + 1), colcnt(nf + 1, 0);
+    for (int i = 0; i <= l; i++) {
+        if (i && row_ptr[i] < row_ptr[i - 1]) return fail(h, MLX_ERR_INVALID, "row_ptr not monotone at %d", i);
+        rp[i] = (int32_t)row_ptr[i];
+    }
+    for (int64_t k = 0; k < nnz; k++) {
+        if (col_idx[k] < 0 || col_idx[k] >= nf) return fail(h, MLX_ERR_INVALID, "col_idx[%lld]=%d out of [0,%d)", (long long)k, col_idx[k], nf);
+        colcnt[col_idx[k] + 1]++;
+    }
+    PartHost ph;
+    ph.pid = partition_id; ph.l = l; ph.n_local = n_local; ph.n_feat = nf; ph.dense = false; ph.hasval = (val != nullptr);
+    ph.nnz = nnz; ph.all_present = (n_local == h->n_global);
+    // CSC (rows ascending inside a column = the order XTv accumulates in, llf/LogisticRegressionL2.java:140-145)
+    std::vector<int32_t> cp(colcnt);
+    for (int j = 0; j < nf; j++) cp[j + 1] += cp[j];
+    std::vector<int32_t> fill(cp.begin(), cp.end() - 1), cri((size_t)nnz);
+    std::vector<float> cval(val ? (size_t)nnz : 0);
+    for (int i = 0; i < l; i++)
+        for (int32_t k = rp[i]; k < rp[i + 1]; k++) {
+            const int32_t dst = fill[col_idx[k]]++;
+            cri[dst] = i;
+            if (val) cval[dst] = val[k];
+        }
+    // column segments of <= CSC_SEG entries
+    std::vector<int32_t> item_ptr, col_item(nf + 1);
+    item_ptr.reserve(nf + nnz / CSC_SEG + 2);
+    for (int j = 0; j < nf; j++) {
+        col_item[j] = (int32_t)item_ptr.size();
+        int32_t b = cp[j];
+        const int32_t e = cp[j + 1];
+        do {
+            item_ptr.push_back(b);
+            b = std::min(e, b + CSC_SEG);
+        } while (b < e);
+    }
+    col_item[nf] = (int32_t)item_ptr.size();
+    ph.n_items = (int)item_ptr.size();
+    item_ptr.push_back((int32_t)nnz);
+    // row pass geometry
+    const double avg = l ? (double)nnz / l : 0.0;
+    int G = 8;
+    while (G < 64 && avg > 4.0 * G) G *= 2;
+    ph.rowgroup = G;
+    const int gpb = 256 / G;
+    int rpb = std::max(gpb * 4, (l + 1023) / 1024);
+    rpb = (rpb + gpb - 1) / gpb * gpb;
+    ph.rows_per_blk = rpb;
+    ph.nblk = (l + rpb - 1) / rpb;
+
+    int32_t *d_rp, *d_ci, *d_cri, *d_item, *d_colitem, *d_l2g;
+    float *d_val = nullptr, *d_cval = nullptr;
+    if ((rc = dev_upload(h, &d_rp, rp.data(), rp.size()))) return rc;
+    if ((rc = dev_upload(h, &d_ci, col_idx, (size_t)nnz))) return rc;
+    if ((rc = dev_upload(h, &d_cri, cri.data(), cri.size()))) return rc;
+    if (val) {
+        if ((rc = dev_upload(h, &d_val, val, (size_t)nnz))) return rc;
+        if ((rc = dev_upload(h, &d_cval, cval.data(), cval.size()))) return rc;
+    }
+    if ((rc = dev_upload(h, &d_item, item_ptr.data(), item_ptr.size()))) return rc;
+    if ((rc = dev_upload(h, &d_colitem, col_item.data(), col_item.size()))) return rc;
+    if ((rc = dev_upload(h, &d_l2g, local_to_global, (size_t)n_local))) return rc;
+    ph.dev.rp = d_rp; ph.dev.ci = d_ci; ph.dev.val = d_val; ph.dev.cri = d_cri; ph.dev.cval = d_cval;
+    ph.dev.item_ptr = d_item; ph.dev.col_item = d_colitem; ph.dev.l2g = d_l2g; ph.dev.X = nullptr;
+    if ((rc = upload_row_meta(h, ph, l, y, weight, offset, false))) return rc;
+    return finish_part(h, ph);
+}
+
+int mlx_add_partition_dense(mlx_handle h, int32_t partition_id, int32_t l, int32_t n_feat, int64_t ld, const float *X,
+                            const int8_t *y, const float *weight, const float *offset, const int32_t *local_to_global,
+                            int32_t x_on_device)
+{
+    if (!h) return MLX_ERR_INVALID;
+    hipSetDevice(h->device);
+    const int n_local = n_feat + 1;
+    int rc = check_common_rows(h, partition_id, l, local_to_global, n_local);
+    if (rc) return rc;
+    if (!X || !y || n_feat < 1 || ld < n_feat) return fail(h, MLX_ERR_INVALID, "bad dense tile arguments");
+    if (n_feat > 2048) return fail(h, MLX_ERR_INVALID, "dense tile wider than 2048 features is not supported; use the CSR form");
+    PartHost ph;
+    ph.pid = partition_id; ph.l = l; ph.n_local = n_local; ph.n_feat = n_feat; ph.dense = true; ph.hasval = true;
+    ph.nnz = (int64_t)l * n_feat; ph.all_present = (n_local == h->n_global);
+    ph.ld = (n_feat + 3) / 4 * 4;
+    float *dX;
+    if ((rc = dev_alloc(h, &dX, (size_t)l * ph.ld))) return rc;
+    if (ph.ld != n_feat) HIPCHECK(h, hipMemset(dX, 0, sizeof(float) * (size_t)l * ph.ld));
+    HIPCHECK(h, hipMemcpy2D(dX, sizeof(float) * ph.ld, X, sizeof(float) * ld, sizeof(float) * n_feat, l,
+                            x_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    int32_t *d_l2g;
+    if ((rc = dev_upload(h, &d_l2g, local_to_global, (size_t)n_local))) return rc;
+    ph.dev.X = dX; ph.dev.l2g = d_l2g;
+    int rpb = 256;
+    if ((l + rpb - 1) / rpb > 1024) rpb = ((l + 1023) / 1024 + 31) / 32 * 32;
+    ph.rows_per_blk = rpb;
+    ph.nblk = (l + rpb - 1) / rpb;
+    if ((rc = upload_row_meta(h, ph, l, y, weight, offset, x_on_device != 0))) return rc;
+    return finish_part(h, ph);
+}
+
+int mlx_finalize(mlx_handle h)
+{
+    if (!h) return MLX_ERR_INVALID;
+    if (h->finalized) return fail(h, MLX_ERR_INVALID, "mlx_finalize called twice");
+    if (h->parts.empty()) return fail(h, MLX_ERR_MISSING_MODELS, "no partitions added");
+    hipSetDevice(h->device);
+    int rc;
+    const int np = (int)h->parts.size(), nl = h->n_lambda, ng = h->n_global;
+    h->nprob = np * nl;
+    std::vector<PartDev> pd(np);
+    for (int k = 0; k < np; k++) pd[k] = h->parts[k].dev;
+    if ((rc = dev_upload(h, &h->d_parts, pd.data(), pd.size()))) return rc;
+
+    // geometry maxima
+    std::vector<int> qd, qc;
+    for (int k = 0; k < np; k++) {
+        const PartHost &p = h->parts[k];
+        h->max_nlocal = std::max(h->max_nlocal, p.n_local);
+        h->max_l = std::max(h->max_l, p.l);
+        if (!p.all_present) h->any_absent = true;
+        const int64_t plen = p.dense ? (int64_t)p.nblk * p.n_local : (int64_t)p.n_items;
+        h->max_parts_len = std::max(h->max_parts_len, plen);
+        if (p.dense) { h->maxblk_dense = std::max(h->maxblk_dense, p.nblk); h->max_nfeat_dense = std::max(h->max_nfeat_dense, p.n_feat); }
+        else {
+            h->maxblk_csr = std::max(h->maxblk_csr, p.nblk); h->max_items = std::max(h->max_items, p.n_items);
+            h->csr_hasval = h->csr_hasval || p.hasval;
+        }
+        for (int li = 0; li < nl; li++) (p.dense ? qd : qc).push_back(k * nl + li);
+    }
+    // a single row-group width / value mode for all CSR partitions of the handle
+    bool first_csr = true;
+    for (auto &p : h->parts) if (!p.dense) {
+        if (first_csr) { h->rowgroup = p.rowgroup; first_csr = false; }
+        else h->rowgroup = std::max(h->rowgroup, p.rowgroup);
+        if (p.hasval != h->csr_hasval) return fail(h, MLX_ERR_INVALID, "binary.feature and valued CSR partitions cannot be mixed in one handle");
+    }
+    h->nq_dense = (int)qd.size(); h->nq_csr = (int)qc.size();
+    if ((rc = dev_upload(h, &h->d_qdense, qd.data(), qd.size()))) return rc;
+    if ((rc = dev_upload(h, &h->d_qcsr, qc.data(), qc.size()))) return rc;
+    h->step_threads = h->max_nlocal > 4096 ? 1024 : 256;
+
+    // problems (+1 scratch for mlx_solve_one)
+    h->h_probs.assign(h->nprob + 1, ProbDev{});
+    auto alloc_vecs = [&](ProbDev &pr, int n_local, int l, int64_t plen, int nblk, bool dense) -> int {
+        double **vs[8] = {&pr.w, &pr.w_new, &pr.g, &pr.s, &pr.r, &pr.d, &pr.Hd, &pr.m};
+        int r2;
+        for (auto v : vs) if ((r2 = dev_alloc(h, v, (size_t)n_local))) return r2;
+        if ((r2 = dev_alloc(h, &pr.wd[0], (size_t)l))) return r2;
+        if ((r2 = dev_alloc(h, &pr.wd[1], (size_t)l))) return r2;
+        if (!dense && (r2 = dev_alloc(h, &pr.coef, (size_t)l))) return r2;
+        if ((r2 = dev_alloc(h, &pr.parts, (size_t)plen))) return r2;
+        if ((r2 = dev_alloc(h, &pr.lossp, (size_t)nblk))) return r2;
+        if ((r2 = dev_alloc(h, &pr.csump, (size_t)nblk))) return r2;
+        return MLX_OK;
+    };
+    for (int k = 0; k < np; k++) {
+        const PartHost &p = h->parts[k];
+        for (int li = 0; li < nl; li++) {
+            ProbDev &pr = h->h_probs[k * nl + li];
+            pr.part = k; pr.lambda_idx = li; pr.phase = PH_DONE;
+            const int64_t plen = p.dense ? (int64_t)p.nblk * p.n_local : (int64_t)p.n_items;
+            if ((rc = alloc_vecs(pr, p.n_local, p.l, plen, p.nblk, p.dense))) return rc;
+        }
+    }
+    {
+        ProbDev &pr = h->h_probs[h->nprob];
+        pr.part = 0; pr.phase = PH_DONE;
+        int maxblk = std::max(h->maxblk_dense, h->maxblk_csr);
+        if ((rc = alloc_vecs(pr, h->max_nlocal, h->max_l, h->max_parts_len, maxblk, false))) return rc;
+        if ((rc = dev_alloc(h, &h->sc_pinv, (size_t)h->max_nlocal))) return rc;
+        const int sidx = h->nprob;
+        if ((rc = dev_upload(h, &h->d_qscratch, &sidx, 1))) return rc;
+    }
+
+    // c0 = X' t0: one EVAL pass at w = 0 on the first problem of every partition
+    std::vector<int> qfirst_d, qfirst_c, qfirst_all;
+    std::vector<double *> c0ptrs;
+    for (int k = 0; k < np; k++) {
+        ProbDev &pr = h->h_probs[k * nl];
+        pr.phase = PH_EVAL; pr.dsel = 0;
+        HIPCHECK(h, hipMemset(pr.w_new, 0, sizeof(double) * h->parts[k].n_local));
+        (h->parts[k].dense ? qfirst_d : qfirst_c).push_back(k * nl);
+    }
+    for (int q : qfirst_d) { qfirst_all.push_back(q); c0ptrs.push_back(h->parts[q / nl].c0); }
+    for (int q : qfirst_c) { qfirst_all.push_back(q); c0ptrs.push_back(h->parts[q / nl].c0); }
+    if ((rc = dev_upload(h, &h->d_probs, h->h_probs.data(), h->h_probs.size()))) return rc;
+    {
+        int *d_qfd, *d_qfc, *d_qfa;
+        double **d_c0;
+        if ((rc = dev_upload(h, &d_qfd, qfirst_d.data(), qfirst_d.size()))) return rc;
+        if ((rc = dev_upload(h, &d_qfc, qfirst_c.data(), qfirst_c.size()))) return rc;
+        if ((rc = dev_upload(h, &d_qfa, qfirst_all.data(), qfirst_all.size()))) return rc;
+        if ((rc = dev_upload(h, &d_c0, c0ptrs.data(), c0ptrs.size()))) return rc;
+        const bool prof = h->profiling;
+        h->profiling = false;
+        rc = launch_xpass(h, d_qfd, (int)qfirst_d.size(), d_qfc, (int)qfirst_c.size());
+        h->profiling = prof;
+        if (rc) return rc;
+        mlxk_collect_c0(h->stream, h->d_parts, h->d_probs, d_qfa, (int)qfirst_all.size(), d_c0);
+        HIPCHECK(h, hipStreamSynchronize(h->stream));
+        HIPCHECK(h, hipGetLastError());
+    }
+    for (int k = 0; k < np; k++) h->h_probs[k * nl].phase = PH_DONE;
+    HIPCHECK(h, hipMemcpy(h->d_probs, h->h_probs.data(), sizeof(ProbDev) * h->h_probs.size(), hipMemcpyHostToDevice));
+
+    // consensus state
+    const size_t zl = (size_t)nl * ng, pl = zl * np;
+    if ((rc = dev_alloc(h, &h->d_Z, zl))) return rc;
+    if ((rc = dev_alloc(h, &h->d_z32, zl))) return rc;
+    if ((rc = dev_alloc(h, &h->d_u, pl))) return rc;
+    if ((rc = dev_alloc(h, &h->d_B, pl))) return rc;
+    if ((rc = dev_alloc(h, &h->d_UPX, pl))) return rc;
+    if ((rc = dev_alloc(h, &h->d_cons, 2 * zl))) return rc;
+    if ((rc = dev_alloc(h, &h->d_diffbits, (size_t)nl))) return rc;
+    if ((rc = dev_alloc(h, &h->d_done, 1))) return rc;
+    if ((rc = dev_alloc(h, &h->d_pinv_l, (size_t)nl))) return rc;
+    HIPCHECK(h, hipMemset(h->d_Z, 0, sizeof(double) * zl));
+    HIPCHECK(h, hipMemset(h->d_z32, 0, sizeof(float) * zl));
+    HIPCHECK(h, hipMemset(h->d_u, 0, sizeof(float) * pl));
+    HIPCHECK(h, hipMemset(h->d_B, 0, sizeof(float) * pl));
+    HIPCHECK(h, hipMemset(h->d_UPX, 0, sizeof(float) * pl));
+    HIPCHECK(h, hipHostMalloc((void **)&h->h_done, 2 * sizeof(int)));
+    HIPCHECK(h, hipHostMalloc((void **)&h->h_diff, nl * sizeof(unsigned long long)));
+
+    // z-update weights: float arithmetic then widened (jobs/RegressionAdmmTrain.java:374-386 L2, :411-416 L1)
+    std::vector<double> wl(nl);
+    const int N = h->num_blocks;
+    for (int li = 0; li < nl; li++) {
+        const float l = h->lambda[li], r = h->rho[li];
+        if (h->regularizer == 2) { const float wf = N * r / (l + N * r); wl[li] = (double)wf; }
+        else { const float rn = r * N; wl[li] = (double)l / ((double)rn + 0.0); }
+    }
+    if ((rc = dev_upload(h, &h->d_weight_l, wl.data(), wl.size()))) return rc;
+    if (!h->lambda_map.empty() && h->regularizer == 2) {
+        std::vector<double> cm(zl);
+        for (int li = 0; li < nl; li++) {
+            const float r = h->rho[li];
+            const float nr = N * r;
+            for (int j = 0; j < ng; j++) {
+                const float lj = h->lambda_map[j];
+                cm[(size_t)li * ng + j] = std::isnan(lj) ? wl[li] : (double)nr / ((double)(float)(lj + nr) + 0.0);
+            }
+        }
+        if ((rc = dev_upload(h, &h->d_cmap, cm.data(), cm.size()))) return rc;
+    }
+    h->finalized = true;
+    return MLX_OK;
+}
+
+int mlx_set_state(mlx_handle h, const double *z, const float *u)
+{
+    if (!h || !h->finalized) return fail(h, MLX_ERR_INVALID, "mlx_finalize first");
+    hipSetDevice(h->device);
+    const size_t zl = (size_t)h->n_lambda * h->n_global;
+    if (z) {
+        HIPCHECK(h, hipMemcpy(h->d_Z, z, sizeof(double) * zl, hipMemcpyHostToDevice));
+        mlxk_round_z(h->stream, (int64_t)zl, h->d_Z, h->d_z32);
+        HIPCHECK(h, hipStreamSynchronize(h->stream));
+    }
+    if (u) HIPCHECK(h, hipMemcpy(h->d_u, u, sizeof(float) * zl * h->parts.size(), hipMemcpyHostToDevice));
+    return MLX_OK;
+}
+
+int mlx_admm_solve_local(mlx_handle h, double liblinear_epsilon, float rho_adapt_rate, mlx_stats *stats)
+{
+    if (!h || !h->finalized) return fail(h, MLX_ERR_INVALID, "mlx_finalize first");
+    hipSetDevice(h->device);
+    const int nl = h->n_lambda, ng = h->n_global, np = (int)h->parts.size();
+    // prior precision per lambda: 1/(1/rho') with rho' = rho * rate (jobs/...:652-658,705; llf/LogisticRegressionL2.java:107-109)
+    std::vector<double> pinv(nl);
+    for (int li = 0; li < nl; li++) {
+        double rho = (double)h->rho[li];
+        if (rho_adapt_rate != 1.0f) rho = rho * (double)rho_adapt_rate;
+        const double pv = 1.0 / rho;
+        pinv[li] = 1.0 / pv;
+    }
+    HIPCHECK(h, hipMemcpyAsync(h->d_pinv_l, pinv.data(), sizeof(double) * nl, hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));     // pinv is a stack vector
+    h->ev_used = 0;
+    HIPCHECK(h, hipEventRecord(h->ev_t0, h->stream));
+    mlxk_setup(h->stream, h->d_parts, h->d_probs, h->nprob, nl, ng, h->max_nlocal, h->d_z32, h->d_u, h->d_pinv_l,
+               liblinear_epsilon, DEFAULT_MAX_ITER);
+    int64_t ticks = 0;
+    int rc = run_ticks(h, 0, h->nprob, h->d_qdense, h->nq_dense, h->d_qcsr, h->nq_csr, &ticks);
+    if (rc) return rc;
+    mlxk_outputs(h->stream, h->d_parts, h->d_probs, h->nprob, nl, ng, h->max_nlocal, h->any_absent, h->d_z32, h->d_u,
+                 h->d_B, h->d_UPX);
+    mlxk_partial_means(h->stream, np, nl, ng, 1.0 / h->num_blocks, h->d_B, h->d_u, h->d_cons, h->d_cons + (size_t)nl * ng);
+    HIPCHECK(h, hipEventRecord(h->ev_t1, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(h->h_probs.data(), h->d_probs, sizeof(ProbDev) * h->nprob, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    HIPCHECK(h, hipGetLastError());
+
+    mlx_stats s{};
+    s.solves = h->nprob;
+    s.ticks = ticks;
+    for (int q = 0; q < h->nprob; q++) {
+        const ProbDev &pr = h->h_probs[q];
+        if (pr.status != ST_OK || pr.phase != PH_DONE)
+            return fail(h, MLX_ERR_MODEL_FITTING, "Model fitting error! partition %d lambda %d: status %d (NaN in objective/gradient)",
+                        h->parts[pr.part].pid, pr.lambda_idx, pr.status);
+        s.newton_iters += pr.newton; s.accepted += pr.accepted; s.cg_iters += pr.cg_total;
+        s.x_passes_ref += 3 + 2 * (int64_t)pr.cg_total + pr.newton + pr.accepted;
+        const PartHost &p = h->parts[pr.part];
+        s.x_passes_dev += (int64_t)pr.ticks * (p.dense ? 1 : 2);
+        s.alg_bytes_dev += (double)pr.ticks * alg_bytes_per_tick(p);
+    }
+    float ms = 0;
+    hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1);
+    s.total_ms = ms;
+    if (h->profiling) {
+        double acc = 0;
+        for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+            float m2 = 0;
+            if (hipEventElapsedTime(&m2, h->ev_pool[i], h->ev_pool[i + 1]) == hipSuccess) acc += m2;
+        }
+        s.xpass_ms = acc;
+        s.xpass_launches = (int64_t)(h->ev_used / 2);
+    } else {
+        s.xpass_launches = ticks;
+    }
+    h->last = s;
+    if (stats) *stats = s;
+    return MLX_OK;
+}
+
+int mlx_consensus_buffer(mlx_handle h, void **device_ptr, size_t *count_doubles)
+{
+    if (!h || !h->finalized) return fail(h, MLX_ERR_INVALID, "mlx_finalize first");
+    if (device_ptr) *device_ptr = h->d_cons;
+    if (count_doubles) *count_doubles = 2 * (size_t)h->n_lambda * h->n_global;
+    return MLX_OK;
+}
+
+int mlx_admm_consensus_finish(mlx_handle h, mlx_stats *stats)
+{
+    if (!h || !h->finalized) return fail(h, MLX_ERR_INVALID, "mlx_finalize first");
+    hipSetDevice(h->device);
+    const int nl = h->n_lambda, ng = h->n_global, np = (int)h->parts.size();
+    HIPCHECK(h, hipMemsetAsync(h->d_diffbits, 0, sizeof(unsigned long long) * nl, h->stream));
+    mlxk_z_update(h->stream, nl, ng, h->regularizer, h->penalize_intercept, h->d_weight_l, h->d_cmap, h->d_cons,
+                  h->d_cons + (size_t)nl * ng, h->d_Z, h->d_z32, h->d_diffbits);
+    mlxk_u_update(h->stream, np, nl, ng, h->d_UPX, h->d_Z, h->d_u);
+    HIPCHECK(h, hipMemcpyAsync(h->h_diff, h->d_diffbits, sizeof(unsigned long long) * nl, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    HIPCHECK(h, hipGetLastError());
+    double mindiff = 99999999, maxdiff = 0;
+    for (int li = 0; li < nl; li++) {
+        double d;
+        memcpy(&d, &h->h_diff[li], sizeof d);
+        if (mindiff > d) mindiff = d;
+        if (maxdiff < d) maxdiff = d;
+    }
+    h->last.maxdiff = maxdiff; h->last.mindiff = mindiff;
+    if (stats) *stats = h->last;
+    return MLX_OK;
+}
+
+int mlx_admm_iterate(mlx_handle h, double liblinear_epsilon, float rho_adapt_rate, mlx_stats *stats)
+{
+    int rc = mlx_admm_solve_local(h, liblinear_epsilon, rho_adapt_rate, nullptr);
+    if (rc) return rc;
+    if (h->comm && h->comm_nranks > 1) {
+        const size_t cnt = 2 * (size_t)h->n_lambda * h->n_global;
+        ncclResult_t r = ncclAllReduce(h->d_cons, h->d_cons, cnt, ncclDouble, ncclSum, h->comm, h->stream);
+        if (r != ncclSuccess) return fail(h, MLX_ERR_COMM, "ncclAllReduce failed: %s", ncclGetErrorString(r));
+    } else if ((int)h->parts.size() != h->num_blocks) {
+        return fail(h, MLX_ERR_MISSING_MODELS, "Some models failed! this handle holds %zu of %d partitions and no communicator is set",
+                    h->parts.size(), h->num_blocks);
+    }
+    return mlx_admm_consensus_finish(h, stats);
+}
+
+int mlx_get_z(mlx_handle h, double *z_double, float *z_float)
+{
+    if (!h || !h->finalized) return fail(h, MLX_ERR_INVALID, "mlx_finalize first");
+    hipSetDevice(h->device);
+    const size_t zl = (size_t)h->n_lambda * h->n_global;
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    if (z_double) HIPCHECK(h, hipMemcpy(z_double, h->d_Z, sizeof(double) * zl, hipMemcpyDeviceToHost));
+    if (z_float) HIPCHECK(h, hipMemcpy(z_float, h->d_z32, sizeof(float) * zl, hipMemcpyDeviceToHost));
+    return MLX_OK;
+}
+
+int mlx_get_partition_model(mlx_handle h, int32_t local_index, int32_t lambda_index, float *beta, float *uplusx, float *u_next)
+{
+    if (!h || !h->finalized) return fail(h, MLX_ERR_INVALID, "mlx_finalize first");
+    if (local_index < 0 || local_index >= (int)h->parts.size() || lambda_index < 0 || lambda_index >= h->n_lambda)
+        return fail(h, MLX_ERR_INVALID, "partition/lambda index out of range");
+    hipSetDevice(h->device);
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    const size_t ng = h->n_global, off = ((size_t)local_index * h->n_lambda + lambda_index) * ng;
+    if (beta) HIPCHECK(h, hipMemcpy(beta, h->d_B + off, sizeof(float) * ng, hipMemcpyDeviceToHost));
+    if (uplusx) HIPCHECK(h, hipMemcpy(uplusx, h->d_UPX + off, sizeof(float) * ng, hipMemcpyDeviceToHost));
+    if (u_next) HIPCHECK(h, hipMemcpy(u_next, h->d_u + off, sizeof(float) * ng, hipMemcpyDeviceToHost));
+    return MLX_OK;
+}
+
+int mlx_get_solve_counters(mlx_handle h, int32_t *out)
+{
+    if (!h || !h->finalized || !out) return fail(h, MLX_ERR_INVALID, "mlx_finalize first");
+    for (int q = 0; q < h->nprob; q++) {
+        const ProbDev &pr = h->h_probs[q];
+        out[q * 4 + 0] = pr.newton; out[q * 4 + 1] = pr.accepted; out[q * 4 + 2] = pr.cg_total;
+        out[q * 4 + 3] = 3 + 2 * pr.cg_total + pr.newton + pr.accepted;
+    }
+    return MLX_OK;
+}
+
+int mlx_solve_one(mlx_handle h, int32_t local_index, double *w, const double *prior_mean, const double *prior_var,
+                  double epsilon, int32_t max_iter, int32_t *counters4, double *f_out, double *gnorm_out, double *gnorm1_out)
+{
+    if (!h || !h->finalized) return fail(h, MLX_ERR_INVALID, "mlx_finalize first");
+    if (local_index < 0 || local_index >= (int)h->parts.size() || !w || !prior_var) return fail(h, MLX_ERR_INVALID, "bad arguments");
+    hipSetDevice(h->device);
+    const PartHost &p = h->parts[local_index];
+    const int n = p.n_local;
+    ProbDev pr = h->h_probs[h->nprob];
+    pr.part = local_index; pr.lambda_idx = 0;
+    std::vector<double> pinv(n), pm(n, 0.0);
+    for (int j = 0; j < n; j++) pinv[j] = 1.0 / prior_var[j];              // llf/LogisticRegressionL2.java:107-109
+    if (prior_mean) memcpy(pm.data(), prior_mean, sizeof(double) * n);
+    HIPCHECK(h, hipMemcpy(pr.w, w, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIPCHECK(h, hipMemcpy(pr.w_new, w, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIPCHECK(h, hipMemcpy(pr.m, pm.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    HIPCHECK(h, hipMemcpy(h->sc_pinv, pinv.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    pr.pinv_vec = h->sc_pinv; pr.pinv = 0;
+    pr.eps = epsilon * (double)std::min(p.pos, p.neg) / (double)p.l;       // llf/LibLinear.java:310-311
+    pr.max_iter = max_iter > 0 ? max_iter : DEFAULT_MAX_ITER;
+    pr.phase = PH_EVAL0; pr.iter = 1; pr.dsel = 0; pr.cg_iter = 0;
+    pr.newton = pr.accepted = pr.cg_total = pr.ticks = 0; pr.status = ST_OK;
+    pr.f = pr.delta = pr.gnorm = pr.gnorm1 = pr.rTr = pr.cgtol = pr.prered = pr.gs = 0;
+    HIPCHECK(h, hipMemcpy(h->d_probs + h->nprob, &pr, sizeof(ProbDev), hipMemcpyHostToDevice));
+    const bool prof = h->profiling;
+    h->profiling = false;
+    int rc = run_ticks(h, h->nprob, 1, h->d_qscratch, p.dense ? 1 : 0, h->d_qscratch, p.dense ? 0 : 1, nullptr);
+    h->profiling = prof;
+    if (rc) return rc;
+    HIPCHECK(h, hipMemcpy(&pr, h->d_probs + h->nprob, sizeof(ProbDev), hipMemcpyDeviceToHost));
+    if (pr.status != ST_OK) return fail(h, MLX_ERR_MODEL_FITTING, "Model fitting error! status %d", pr.status);
+    HIPCHECK(h, hipMemcpy(w, pr.w, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (counters4) {
+        counters4[0] = pr.newton; counters4[1] = pr.accepted; counters4[2] = pr.cg_total;
+        counters4[3] = 3 + 2 * pr.cg_total + pr.newton + pr.accepted;
+    }
+    if (f_out) *f_out = pr.f;
+    if (gnorm_out) *gnorm_out = pr.gnorm;
+    if (gnorm1_out) *gnorm1_out = pr.gnorm1;
+    return MLX_OK;
+}
+
+int mlx_comm_get_unique_id(char out[MLX_UNIQUE_ID_BYTES])
+{
+    static_assert(sizeof(ncclUniqueId) <= MLX_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, MLX_ERR_COMM, "ncclGetUniqueId failed: %s", ncclGetErrorString(r));
+    memset(out, 0, MLX_UNIQUE_ID_BYTES);
+    memcpy(out, &id, sizeof id);
+    return MLX_OK;
+}
+
+int mlx_comm_init(mlx_handle h, const char unique_id[MLX_UNIQUE_ID_BYTES], int32_t nranks, int32_t rank)
+{
+    if (!h) return MLX_ERR_INVALID;
+    hipSetDevice(h->device);
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof id);
+    ncclResult_t r = ncclCommInitRank(&h->comm, nranks, id, rank);
+    if (r != ncclSuccess) return fail(h, MLX_ERR_COMM, "ncclCommInitRank failed: %s", ncclGetErrorString(r));
+    h->comm_nranks = nranks;
+    return MLX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,29 @@
+// mlx_kernels.h -- launch wrappers of the gfx950 kernels in mlx_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct PartDev;
+struct ProbDev;
+
+// One X pass for the problems in qlist (device array of problem indices). Returns -1 if unsupported width.
+int mlxk_xpass_dense(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
+                     int max_nfeat);
+int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
+                   int max_items, int rowgroup, bool hasval);
+// TRON/CG control flow for problems [first, first+nprob)
+void mlxk_tron_step(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int first, int threads,
+                    int *done_counter);
+void mlxk_collect_c0(hipStream_t st, const PartDev *parts, const ProbDev *probs, const int *qlist, int nq,
+                     double *const *c0_ptrs);
+void mlxk_setup(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int n_lambda, int n_global,
+                int max_nlocal, const float *z32, const float *u, const double *pinv_l, double epsilon, int max_iter);
+void mlxk_outputs(hipStream_t st, const PartDev *parts, const ProbDev *probs, int nprob, int n_lambda, int n_global,
+                  int max_nlocal, bool any_absent, const float *z32, const float *u, float *B, float *UPX);
+void mlxk_partial_means(hipStream_t st, int nlocal, int n_lambda, int n_global, double invN, const float *B,
+                        const float *u, double *xbar, double *ubar);
+void mlxk_z_update(hipStream_t st, int n_lambda, int n_global, int regularizer, int penalize_intercept,
+                   const double *weight_l, const double *cmap, const double *xbar, const double *ubar, double *Z,
+                   float *z32, unsigned long long *diffbits);
+void mlxk_u_update(hipStream_t st, int nlocal, int n_lambda, int n_global, const float *UPX, const double *Z, float *u);
+void mlxk_round_z(hipStream_t st, int64_t n, const double *Z, float *z32);

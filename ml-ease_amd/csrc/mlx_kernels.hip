@@ -1,0 +1,848 @@
+// mlx_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the batched TRON solve and the
+// ADMM consensus. No library calls, no CUDA shims: HIP C++ for MI355X only.
+//
+// Execution model (DESIGN.md "Tick machine"): every (partition, lambda) problem advances in
+// lock-step TICKS. One tick = one pass over X for every unfinished problem (k_xpass_dense, or
+// k_rowpass_csr + k_colpass_csc) followed by k_tron_step, which owns all of Tron's control flow
+// (bw/Tron.java:30-179) for its problem and decides what the next pass computes:
+//     PH_CG    pass computes  X' diag(wt*D) X d          (the Hv of llf/LogisticRegressionL2.java:231-248)
+//     PH_EVAL  pass computes  loss(w_new), D(w_new), X' t(w_new)  (fun + grad fused, :156-225)
+// Fusions relative to the reference (all exact in real arithmetic, fp64 throughout):
+//   * Hv reads X once (row tile in registers: dot, scale, rank-1 accumulate) instead of Xv + XTv;
+//   * fun and grad share one pass; after a rejected step the trial D is discarded (wd double buffer);
+//   * grad(0)'s data term X' t0 is a per-partition constant (c0), computed once at upload.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mlx_kernels.h"
+#include "mlx_types.h"
+
+#define WAVE 64
+
+// ------------------------------------------------------------------------------------------------
+// wave / block reductions (deterministic trees; fp64)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_allreduce_sum(double x)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, WAVE);
+    return x;
+}
+__device__ __forceinline__ double wave_allreduce_max(double x)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x = fmax(x, __shfl_xor(x, m, WAVE));
+    return x;
+}
+template <int G>
+__device__ __forceinline__ double group_allreduce_sum(double x)
+{
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) x += __shfl_xor(x, m, WAVE);
+    return x;
+}
+
+// Sum of up to 3 values over the block, result broadcast to every thread. scratch: >= 3*16 doubles.
+template <int NVAL>
+__device__ __forceinline__ void block_allreduce_sum(double (&v)[NVAL], double *scratch)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int i = 0; i < NVAL; i++) v[i] = wave_allreduce_sum(v[i]);
+    __syncthreads();   // scratch reuse
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NVAL; i++) scratch[i * 16 + wave] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NVAL; i++) {
+        double a = 0;
+        for (int w = 0; w < nw; w++) a += scratch[i * 16 + w];
+        v[i] = a;
+    }
+}
+__device__ __forceinline__ double block_allreduce_max(double x, double *scratch)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    x = wave_allreduce_max(x);
+    __syncthreads();
+    if (lane == 0) scratch[wave] = x;
+    __syncthreads();
+    double a = scratch[0];
+    for (int w = 1; w < nw; w++) a = fmax(a, scratch[w]);
+    return a;
+}
+
+// bw/Tron.java:220-252 euclideanNorm: scale * sqrt(sum((v/scale)^2)) with scale = max|v|
+// (the Java keeps a running scale; same value up to the last bits).
+__device__ __forceinline__ double block_norm(const double *__restrict__ v, int n, double *scratch)
+{
+    double mx = 0;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) mx = fmax(mx, fabs(v[j]));
+    mx = block_allreduce_max(mx, scratch);
+    if (!(mx > 0)) return (mx == 0) ? 0.0 : mx;   // 0, or NaN propagates
+    double a[1] = {0};
+    for (int j = threadIdx.x; j < n; j += blockDim.x) { double t = fabs(v[j]) / mx; a[0] += t * t; }
+    block_allreduce_sum<1>(a, scratch);
+    return mx * sqrt(a[0]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// row-wise scalar maps
+// ------------------------------------------------------------------------------------------------
+// fun + grad at one row (llf/LogisticRegressionL2.java:172-178, :211-215): z = x.w + offset
+__device__ __forceinline__ void row_eval(double z, int y, double wt, double &loss, double &wd, double &coef)
+{
+    const double yz = (double)y * z;
+    if (yz >= 0) loss = wt * log1p(exp(-yz));
+    else loss = wt * (-yz + log1p(exp(yz)));
+    const double p = 1.0 / (1.0 + exp(-yz));
+    wd = wt * (p * (1.0 - p));          // weight[i] * D[i]  (:243 multiplies in this order)
+    coef = wt * (p - 1.0) * (double)y;  // :215
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense X pass: one read of the fp32 tile per pass, fp64 accumulate
+// ------------------------------------------------------------------------------------------------
+// Block = 256 threads = 4 waves; a wave owns whole rows: lane l holds float4 #(c*64+l) of the row
+// (c < NV), i.e. 16*NV bytes per lane per row, loaded as 1 KiB-per-instruction coalesced reads.
+// Per row: partial dot -> wave all-reduce -> row coefficient -> rank-1 accumulate into the lane's
+// 4*NV fp64 column accumulators. U rows are in flight per wave for ILP.
+template <int NV, int U>
+__global__ void __launch_bounds__(256)
+k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int q = qlist[blockIdx.y];
+    ProbDev &pr = probs[q];
+    const int phase = pr.phase;
+    if (phase == PH_DONE) return;
+    const PartDev &pa = parts[pr.part];
+    const int b = blockIdx.x;
+    if (b >= pa.nblk) return;
+    const int nf = pa.n_feat, n = nf + 1;
+    const int64_t ld = pa.ld;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool cg = (phase == PH_CG);
+    const double *__restrict__ v = cg ? pr.d : pr.w_new;
+    const double *__restrict__ wdcur = pr.wd[pr.dsel];
+    double *__restrict__ wdnew = pr.wd[pr.dsel ^ 1];
+    const float *__restrict__ X = pa.X;
+
+    double vr[NV][4];
+#pragma unroll
+    for (int c = 0; c < NV; c++) {
+        const int col0 = (c * 64 + lane) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) vr[c][e] = (col0 + e < nf) ? v[col0 + e] : 0.0;
+    }
+    const double vb = v[nf];
+    double acc[NV][4];
+#pragma unroll
+    for (int c = 0; c < NV; c++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[c][e] = 0.0;
+    double accb = 0.0, lossacc = 0.0;
+
+    const int r0 = b * pa.rows_per_blk;
+    const int r1 = min(pa.l, r0 + pa.rows_per_blk);
+    for (int rb = r0 + wave * U; rb < r1; rb += 4 * U) {
+        float4 x[U][NV];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int row = rb + u;
+            const float *__restrict__ xr = X + (int64_t)row * ld;
+#pragma unroll
+            for (int c = 0; c < NV; c++) {
+                const int col0 = (c * 64 + lane) * 4;
+                if (row < r1 && col0 < ld) x[u][c] = *reinterpret_cast<const float4 *>(xr + col0);
+                else x[u][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        double t[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            double a = 0.0;
+#pragma unroll
+            for (int c = 0; c < NV; c++) {
+                a += (double)x[u][c].x * vr[c][0];
+                a += (double)x[u][c].y * vr[c][1];
+                a += (double)x[u][c].z * vr[c][2];
+                a += (double)x[u][c].w * vr[c][3];
+            }
+            t[u] = a;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) t[u] = wave_allreduce_sum(t[u]) + vb;
+        // lane u (< U) owns row rb+u for the scalar map, then broadcasts its coefficient
+        double tm = t[0];
+#pragma unroll
+        for (int u = 1; u < U; u++) tm = (lane == u) ? t[u] : tm;
+        const int myrow = rb + lane;
+        double coef_m = 0.0;
+        if (lane < U && myrow < r1) {
+            if (cg) {
+                coef_m = wdcur[myrow] * tm;                          // wa[i] = weight*D * (X s)[i], :243
+            } else {
+                double loss, wdv;
+                row_eval(tm + (double)pa.off[myrow], (int)pa.y[myrow], (double)pa.wt[myrow], loss, wdv, coef_m);
+                wdnew[myrow] = wdv;
+                lossacc += loss;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const double cf = __shfl(coef_m, u, WAVE);
+            accb += cf;
+#pragma unroll
+            for (int c = 0; c < NV; c++) {
+                acc[c][0] += (double)x[u][c].x * cf;
+                acc[c][1] += (double)x[u][c].y * cf;
+                acc[c][2] += (double)x[u][c].z * cf;
+                acc[c][3] += (double)x[u][c].w * cf;
+            }
+        }
+    }
+
+    // cross-wave reduction in LDS, fixed wave order -> deterministic partials
+    const int NC = NV * 256;                 // padded columns per wave slice
+    double *red = smem;                      // [4][NC]
+    double *redb = smem + 4 * NC;            // [4] intercept, [4] loss
+#pragma unroll
+    for (int c = 0; c < NV; c++) {
+        const int col0 = (c * 64 + lane) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) red[wave * NC + col0 + e] = acc[c][e];
+    }
+    lossacc = wave_allreduce_sum(lossacc);
+    if (lane == 0) { redb[wave] = accb; redb[4 + wave] = lossacc; }
+    __syncthreads();
+    double *__restrict__ outp = pr.parts + (int64_t)b * n;
+    for (int j = threadIdx.x; j < nf; j += 256)
+        outp[j] = ((red[j] + red[NC + j]) + red[2 * NC + j]) + red[3 * NC + j];
+    if (threadIdx.x == 0) {
+        outp[nf] = ((redb[0] + redb[1]) + redb[2]) + redb[3];
+        pr.lossp[b] = ((redb[4] + redb[5]) + redb[6]) + redb[7];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sparse X pass, part 1: CSR rows -> row coefficients (gather of v, G lanes per row)
+// ------------------------------------------------------------------------------------------------
+template <int G, bool HASVAL>
+__global__ void __launch_bounds__(256)
+k_rowpass_csr(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist)
+{
+    __shared__ double scratch[48];
+    const int q = qlist[blockIdx.y];
+    ProbDev &pr = probs[q];
+    const int phase = pr.phase;
+    if (phase == PH_DONE) return;
+    const PartDev &pa = parts[pr.part];
+    const int b = blockIdx.x;
+    if (b >= pa.nblk) return;
+    const bool cg = (phase == PH_CG);
+    const double *__restrict__ v = cg ? pr.d : pr.w_new;
+    const double *__restrict__ wdcur = pr.wd[pr.dsel];
+    double *__restrict__ wdnew = pr.wd[pr.dsel ^ 1];
+    double *__restrict__ coef = pr.coef;
+    const int32_t *__restrict__ rp = pa.rp;
+    const int32_t *__restrict__ ci = pa.ci;
+    const float *__restrict__ val = pa.val;
+    const double vb = v[pa.n_feat];
+    constexpr int GPB = 256 / G;
+    const int gid = threadIdx.x / G, gl = threadIdx.x % G;
+    const int r0 = b * pa.rows_per_blk;
+    const int r1 = min(pa.l, r0 + pa.rows_per_blk);
+    double red[2] = {0.0, 0.0};          // loss, sum of coef
+    for (int base = r0; base < r1; base += GPB) {
+        const int row = base + gid;
+        const bool valid = row < r1;
+        double a = 0.0;
+        if (valid) {
+            const int k0 = rp[row], k1 = rp[row + 1];
+            for (int k = k0 + gl; k < k1; k += G) {
+                const double xv = HASVAL ? (double)val[k] : 1.0;
+                a += v[ci[k]] * xv;
+            }
+        }
+        a = group_allreduce_sum<G>(a);
+        if (valid && gl == 0) {
+            const double t = a + vb;
+            double cf;
+            if (cg) {
+                cf = wdcur[row] * t;
+            } else {
+                double loss, wdv;
+                row_eval(t + (double)pa.off[row], (int)pa.y[row], (double)pa.wt[row], loss, wdv, cf);
+                wdnew[row] = wdv;
+                red[0] += loss;
+            }
+            coef[row] = cf;
+            red[1] += cf;
+        }
+    }
+    block_allreduce_sum<2>(red, scratch);
+    if (threadIdx.x == 0) { pr.lossp[b] = red[0]; pr.csump[b] = red[1]; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sparse X pass, part 2: CSC column segments -> X' coef (gather of coef, 8 lanes per segment)
+// ------------------------------------------------------------------------------------------------
+template <bool HASVAL>
+__global__ void __launch_bounds__(256)
+k_colpass_csc(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist)
+{
+    const int q = qlist[blockIdx.y];
+    ProbDev &pr = probs[q];
+    if (pr.phase == PH_DONE) return;
+    const PartDev &pa = parts[pr.part];
+    const int item = blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int gl = threadIdx.x & 7;
+    const bool valid = item < pa.n_items;
+    double a = 0.0;
+    if (valid) {
+        const double *__restrict__ coef = pr.coef;
+        const int32_t *__restrict__ cri = pa.cri;
+        const float *__restrict__ cval = pa.cval;
+        const int k0 = pa.item_ptr[item], k1 = pa.item_ptr[item + 1];
+        for (int k = k0 + gl; k < k1; k += 8) {
+            const double xv = HASVAL ? (double)cval[k] : 1.0;
+            a += coef[cri[k]] * xv;
+        }
+    }
+    a = group_allreduce_sum<8>(a);
+    if (valid && gl == 0) pr.parts[item] = a;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-iteration problem setup: warm start z~, prior mean z~ - u_k on the partition's local index set
+// (jobs/RegressionAdmmTrain.java:692-698 ; llf/LibLinear.java:236-245 initSetup)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_setup(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int nprob, int n_lambda, int n_global,
+        const float *__restrict__ z32, const float *__restrict__ u, const double *__restrict__ pinv_l,
+        double epsilon, int max_iter)
+{
+    const int q = blockIdx.y;
+    if (q >= nprob) return;
+    ProbDev &pr = probs[q];
+    const PartDev &pa = parts[pr.part];
+    const int n = pa.n_local;
+    const float *__restrict__ zl = z32 + (int64_t)pr.lambda_idx * n_global;
+    const float *__restrict__ uk = u + ((int64_t)pr.part * n_lambda + pr.lambda_idx) * n_global;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+        const int gj = pa.l2g[j];
+        const double zt = (double)zl[gj], uj = (double)uk[gj];
+        pr.w[j] = zt;
+        pr.w_new[j] = zt;
+        pr.m[j] = -1.0 * uj + 1.0 * zt;       // priormean.linearCombine(-1, 1, initvalue)
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        pr.pinv = pinv_l[pr.lambda_idx];
+        pr.pinv_vec = nullptr;
+        const int mn = pa.pos < pa.neg ? pa.pos : pa.neg;
+        pr.eps = epsilon * (double)mn / (double)pa.l;     // llf/LibLinear.java:310-311
+        pr.max_iter = max_iter;
+        pr.phase = PH_EVAL0;
+        pr.iter = 1;
+        pr.cg_iter = 0;
+        pr.newton = pr.accepted = pr.cg_total = pr.ticks = 0;
+        pr.status = ST_OK;
+        pr.f = pr.delta = pr.gnorm = pr.gnorm1 = pr.rTr = pr.cgtol = pr.prered = pr.gs = 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TRON / CG control flow: one workgroup per problem, one call per tick (bw/Tron.java:30-179).
+// Elementwise updates mirror the Java statement by statement with contraction OFF (Java never
+// fuses a*b+c); only the reductions (dot, norm) use a tree instead of a sequential sum.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double pinv_at(const ProbDev &pr, int j)
+{
+    return pr.pinv_vec ? pr.pinv_vec[j] : pr.pinv;
+}
+
+// out = X' c assembled from the pass partials in a fixed order (dense: per-block slices; CSR: column
+// segments in row order + the intercept's per-block coefficient sums).
+__device__ __forceinline__ void assemble_out(const PartDev &pa, const ProbDev &pr, double *__restrict__ out)
+{
+    const int n = pa.n_local, nf = pa.n_feat;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (pa.dense) {
+        const int P = pa.nblk;
+        for (int j = tid; j < n; j += nt) {
+            double a = 0.0;
+            for (int p = 0; p < P; p++) a += pr.parts[(int64_t)p * n + j];
+            out[j] = a;
+        }
+    } else {
+        for (int j = tid; j < nf; j += nt) {
+            double a = 0.0;
+            const int i0 = pa.col_item[j], i1 = pa.col_item[j + 1];
+            for (int it = i0; it < i1; it++) a += pr.parts[it];
+            out[j] = a;
+        }
+        if (tid == 0) {
+            double a = 0.0;
+            for (int p = 0; p < pa.nblk; p++) a += pr.csump[p];
+            out[nf] = a;
+        }
+    }
+}
+
+// c0 = X' t0 (data part of grad(0)) from an EVAL pass at w = 0; run once per partition at finalize.
+__global__ void __launch_bounds__(256)
+k_collect_c0(const PartDev *__restrict__ parts, const ProbDev *__restrict__ probs, const int *__restrict__ qlist,
+             double *const *__restrict__ c0_ptrs)
+{
+    const ProbDev &pr = probs[qlist[blockIdx.x]];
+    assemble_out(parts[pr.part], pr, c0_ptrs[blockIdx.x]);
+}
+
+__global__ void __launch_bounds__(1024)
+k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int nprob, int *__restrict__ done_counter)
+{
+#pragma clang fp contract(off)
+    __shared__ double scratch[64];
+    const int q = blockIdx.x;
+    if (q >= nprob) return;
+    ProbDev &pr = probs[q];
+    const int phase = pr.phase;
+    if (phase == PH_DONE) return;
+    const PartDev &pa = parts[pr.part];
+    const int n = pa.n_local, nf = pa.n_feat;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    double *__restrict__ w = pr.w, *__restrict__ w_new = pr.w_new, *__restrict__ g = pr.g;
+    double *__restrict__ s = pr.s, *__restrict__ r = pr.r, *__restrict__ d = pr.d, *__restrict__ Hd = pr.Hd;
+    const double *__restrict__ m = pr.m;
+
+    assemble_out(pa, pr, Hd);
+    __syncthreads();
+
+    const double rTr0 = pr.rTr, delta0 = pr.delta, cgtol0 = pr.cgtol, eps0 = pr.eps, gnorm1_0 = pr.gnorm1;
+    double gnorm_cur = pr.gnorm;
+    bool start_trcg = false, finished = false;
+
+    if (phase == PH_CG) {
+        // ---- one CG step (bw/Tron.java:145-175)
+        double a1[1] = {0.0};
+        for (int j = tid; j < n; j += nt) {
+            const double hd = d[j] * pinv_at(pr, j) + Hd[j];      // Hs[i] = (s[i]*priorVar_inv[i] + Hs[i]) * 1
+            Hd[j] = hd;
+            a1[0] += d[j] * hd;
+        }
+        block_allreduce_sum<1>(a1, scratch);
+        double alpha = rTr0 / a1[0];
+        for (int j = tid; j < n; j += nt) s[j] += alpha * d[j];    // daxpy(alpha, d, s)
+        __syncthreads();
+        const double snorm = block_norm(s, n, scratch);
+        bool end_cg = false;
+        if (snorm > delta0) {
+            // cg reaches trust region boundary (:150-168)
+            alpha = -alpha;
+            double a3[3] = {0.0, 0.0, 0.0};
+            for (int j = tid; j < n; j += nt) {
+                const double sj = s[j] + alpha * d[j];
+                s[j] = sj;
+                a3[0] += sj * d[j];
+                a3[1] += sj * sj;
+                a3[2] += d[j] * d[j];
+            }
+            block_allreduce_sum<3>(a3, scratch);
+            const double std_ = a3[0], sts = a3[1], dtd = a3[2];
+            const double dsq = delta0 * delta0;
+            const double rad = sqrt(std_ * std_ + dtd * (dsq - sts));
+            if (std_ >= 0) alpha = (dsq - sts) / (std_ + rad);
+            else alpha = (rad - std_) / dtd;
+            const double nalpha = -alpha;
+            for (int j = tid; j < n; j += nt) {
+                s[j] += alpha * d[j];
+                r[j] += nalpha * Hd[j];
+            }
+            end_cg = true;
+        } else {
+            alpha = -alpha;
+            double a2[1] = {0.0};
+            for (int j = tid; j < n; j += nt) {
+                const double rj = r[j] + alpha * Hd[j];
+                r[j] = rj;
+                a2[0] += rj * rj;
+            }
+            block_allreduce_sum<1>(a2, scratch);
+            const double rnew = a2[0];
+            const double beta = rnew / rTr0;
+            for (int j = tid; j < n; j += nt) {
+                double dj = d[j];
+                if (beta != 1.0) dj = dj * beta;                   // scale(beta, d)
+                d[j] = dj + 1.0 * r[j];                            // daxpy(one, r, d)
+            }
+            __syncthreads();
+            const double rnorm = block_norm(r, n, scratch);
+            if (tid == 0) pr.rTr = rnew;
+            if (rnorm <= cgtol0) end_cg = true;                  // loop-top test of the next trip (:144)
+        }
+        __syncthreads();
+        if (tid == 0) { pr.cg_iter += 1; pr.ticks += 1; }
+        if (end_cg) {
+            // back in tron(): w_new = w + s, gs, prered (:69-73)
+            double a2[2] = {0.0, 0.0};
+            for (int j = tid; j < n; j += nt) {
+                w_new[j] = w[j] + 1.0 * s[j];
+                a2[0] += g[j] * s[j];
+                a2[1] += s[j] * r[j];
+            }
+            block_allreduce_sum<2>(a2, scratch);
+            if (tid == 0) {
+                pr.gs = a2[0];
+                pr.prered = -0.5 * (a2[0] - a2[1]);
+                pr.newton += 1;
+                pr.cg_total += pr.cg_iter;
+                pr.phase = PH_EVAL;
+            }
+        }
+        return;
+    }
+
+    // ---- PH_EVAL0 / PH_EVAL: objective and gradient at w_new
+    double a1[1] = {0.0};
+    for (int j = tid; j < n; j += nt) {
+        const double t = w_new[j] - m[j];
+        const double pj = pinv_at(pr, j);
+        a1[0] += t * t * pj;                                        // fun :187-188
+        Hd[j] = t * pj + Hd[j];                                     // grad :224 (multiplier 1)
+    }
+    block_allreduce_sum<1>(a1, scratch);
+    double loss = 0.0;
+    for (int p = 0; p < pa.nblk; p++) loss += pr.lossp[p];          // every thread, same order
+    double fnew = 2.0 * loss;
+    fnew = fnew + a1[0];
+    fnew = fnew / 2.0;
+    __syncthreads();
+
+    if (phase == PH_EVAL0) {
+        // Tron prologue (:47-62): gnorm1 = ||grad(0)||, f, g, delta at the warm start
+        for (int j = tid; j < n; j += nt) {
+            g[j] = Hd[j];
+            s[j] = (0.0 - m[j]) * pinv_at(pr, j) + pa.c0[j];        // grad(0) staged in s[]
+        }
+        __syncthreads();
+        const double gnorm1 = block_norm(s, n, scratch);
+        const double gnorm = block_norm(g, n, scratch);
+        if (tid == 0) {
+            pr.f = fnew; pr.gnorm1 = gnorm1; pr.gnorm = gnorm; pr.delta = gnorm;
+            pr.dsel ^= 1; pr.ticks += 1;
+        }
+        gnorm_cur = gnorm;
+        if (gnorm <= eps0 * gnorm1) finished = true;               // search = 0
+        else start_trcg = true;
+        if (!(fnew == fnew) || !(gnorm == gnorm)) { finished = true; start_trcg = false; if (tid == 0) pr.status = ST_NAN; }
+    } else {
+        const double eta0 = 1e-4, eta1 = 0.25, eta2 = 0.75;
+        const double sigma1 = 0.25, sigma2 = 0.5, sigma3 = 4;
+        double f = pr.f, delta = delta0, gnorm = gnorm_cur;
+        const double gs = pr.gs, prered = pr.prered;
+        const double actred = f - fnew;
+        const double snorm = block_norm(s, n, scratch);
+        if (pr.iter == 1) delta = fmin(delta, snorm);
+        double alpha;
+        if (fnew - f - gs <= 0) alpha = sigma3;
+        else alpha = fmax(sigma1, -0.5 * (gs / (fnew - f - gs)));
+        if (actred < eta0 * prered) delta = fmin(fmax(alpha, sigma1) * snorm, sigma2 * delta);
+        else if (actred < eta1 * prered) delta = fmax(sigma1 * delta, fmin(alpha * snorm, sigma2 * delta));
+        else if (actred < eta2 * prered) delta = fmax(sigma1 * delta, fmin(alpha * snorm, sigma3 * delta));
+        else delta = fmax(delta, fmin(alpha * snorm, sigma3 * delta));
+        int iter = pr.iter;
+        bool brk = false;
+        const bool accept = actred > eta0 * prered;
+        if (accept) {
+            iter++;
+            for (int j = tid; j < n; j += nt) { w[j] = w_new[j]; g[j] = Hd[j]; }
+            f = fnew;
+            __syncthreads();
+            gnorm = block_norm(g, n, scratch);
+            if (gnorm <= eps0 * gnorm1_0) brk = true;
+        }
+        if (!brk) {
+            if (f < -1.0e+32) brk = true;
+            else if (fabs(actred) <= 0 && prered <= 0) brk = true;
+            else if (fabs(actred) <= 1.0e-12 * fabs(f) && fabs(prered) <= 1.0e-12 * fabs(f)) brk = true;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            pr.f = f; pr.delta = delta; pr.gnorm = gnorm; pr.iter = iter; pr.ticks += 1;
+            if (accept) { pr.accepted += 1; pr.dsel ^= 1; }
+        }
+        if (!(fnew == fnew) || !(gnorm == gnorm)) { brk = true; if (tid == 0) pr.status = ST_NAN; }
+        gnorm_cur = gnorm;
+        if (brk || iter > pr.max_iter) finished = true;            // while (iter <= max_iter && search)
+        else start_trcg = true;
+    }
+
+    if (start_trcg) {
+        // trcg prologue (:133-141): s = 0, r = -g, d = r, cgtol = 0.1||g||, rTr = r.r
+        double a2[1] = {0.0};
+        for (int j = tid; j < n; j += nt) {
+            const double rj = -g[j];
+            s[j] = 0.0; r[j] = rj; d[j] = rj;
+            a2[0] += rj * rj;
+        }
+        block_allreduce_sum<1>(a2, scratch);
+        const double gn = gnorm_cur;      // ||r|| = ||-g|| = ||g||
+        if (tid == 0) {
+            pr.rTr = a2[0];
+            pr.cgtol = 0.1 * gn;
+            pr.cg_iter = 0;
+        }
+        if (gn <= 0.1 * gn) {
+            // CG loop exits at once (:144) with s = 0: evaluate the (null) step like the reference does
+            for (int j = tid; j < n; j += nt) w_new[j] = w[j] + 1.0 * 0.0;
+            if (tid == 0) { pr.gs = 0.0; pr.prered = -0.5 * (0.0 - 0.0); pr.newton += 1; pr.phase = PH_EVAL; }
+        } else if (tid == 0) {
+            pr.phase = PH_CG;
+        }
+    }
+    if (finished && tid == 0) {
+        pr.phase = PH_DONE;
+        atomicAdd(done_counter, 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// reducer outputs: beta_k and u_k + beta_k as float32 (jobs/RegressionAdmmTrain.java:706-711;
+// absent features keep priorMean = z~ - u_k, llf/LibLinear.java:373-383)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_outputs_absent(const ProbDev *__restrict__ probs, int nprob, int n_lambda, int n_global,
+                 const float *__restrict__ z32, const float *__restrict__ u, float *__restrict__ B,
+                 float *__restrict__ UPX)
+{
+#pragma clang fp contract(off)
+    const int q = blockIdx.y;
+    if (q >= nprob) return;
+    const ProbDev &pr = probs[q];
+    const int64_t base = ((int64_t)pr.part * n_lambda + pr.lambda_idx) * n_global;
+    const float *__restrict__ zl = z32 + (int64_t)pr.lambda_idx * n_global;
+    for (int gj = blockIdx.x * 256 + threadIdx.x; gj < n_global; gj += gridDim.x * 256) {
+        const double zt = (double)zl[gj], uj = (double)u[base + gj];
+        const double beta = -1.0 * uj + 1.0 * zt;
+        B[base + gj] = (float)beta;
+        UPX[base + gj] = (float)(1.0 * uj + 1.0 * beta);
+    }
+}
+__global__ void __launch_bounds__(256)
+k_outputs_present(const PartDev *__restrict__ parts, const ProbDev *__restrict__ probs, int nprob, int n_lambda,
+                  int n_global, const float *__restrict__ u, float *__restrict__ B, float *__restrict__ UPX)
+{
+#pragma clang fp contract(off)
+    const int q = blockIdx.y;
+    if (q >= nprob) return;
+    const ProbDev &pr = probs[q];
+    const PartDev &pa = parts[pr.part];
+    const int64_t base = ((int64_t)pr.part * n_lambda + pr.lambda_idx) * n_global;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < pa.n_local; j += gridDim.x * 256) {
+        const int gj = pa.l2g[j];
+        const double uj = (double)u[base + gj], wj = pr.w[j];
+        B[base + gj] = (float)wj;
+        UPX[base + gj] = (float)(1.0 * uj + 1.0 * wj);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// consensus
+// ------------------------------------------------------------------------------------------------
+// partial means of this shard, sequential over local partitions in add order:
+// acc = 1.0*acc + (1/N)*f32 (consumers/MeanLinearModelConsumer.java:61, models/LinearModel.java:181-201)
+__global__ void __launch_bounds__(256)
+k_partial_means(int nlocal, int n_lambda, int n_global, double invN, const float *__restrict__ B,
+                const float *__restrict__ u, double *__restrict__ xbar, double *__restrict__ ubar)
+{
+#pragma clang fp contract(off)
+    const int64_t tot = (int64_t)n_lambda * n_global;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+        double xb = 0.0, ub = 0.0;
+        for (int k = 0; k < nlocal; k++) {
+            const int64_t o = (int64_t)k * tot + i;
+            xb = 1.0 * xb + invN * (double)B[o];
+            ub = 1.0 * ub + invN * (double)u[o];
+        }
+        xbar[i] = xb;
+        ubar[i] = ub;
+    }
+}
+
+// z-update + per-lambda ||z - z_prev||_inf (jobs/RegressionAdmmTrain.java:365-405 L2, :406-451 L1, :455-472)
+__global__ void __launch_bounds__(256)
+k_z_update(int n_lambda, int n_global, int regularizer, int penalize_intercept, const double *__restrict__ weight_l,
+           const double *__restrict__ cmap /* [n_lambda][n_global] per-feature weight or nullptr */,
+           const double *__restrict__ xbar, const double *__restrict__ ubar, double *__restrict__ Z,
+           float *__restrict__ z32, unsigned long long *__restrict__ diffbits)
+{
+#pragma clang fp contract(off)
+    __shared__ double scratch[16];
+    const int li = blockIdx.y;
+    const double weight = weight_l[li];
+    double mx = 0.0;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n_global; j += gridDim.x * 256) {
+        const int64_t i = (int64_t)li * n_global + j;
+        const double xb = xbar[i], ub = ubar[i];
+        double zn;
+        const bool icpt = (j == n_global - 1);
+        if (icpt && !penalize_intercept) {
+            zn = xb + ub;
+        } else if (regularizer == 2) {
+            const double c = (cmap && !icpt) ? cmap[i] : weight;
+            zn = 0.0 + c * xb;
+            zn = 1.0 * zn + c * ub;
+        } else {
+            zn = 0.0 + 1.0 * xb;
+            zn = 1.0 * zn + 1.0 * ub;
+            if (!icpt) {                                   // iterative thresholding :424-436 (coefficients only)
+                if (zn > weight) zn = zn - weight;
+                else if (zn < -weight) zn = zn + weight;
+            }
+        }
+        const double dv = fabs(1.0 * Z[i] + -1.0 * zn);
+        mx = fmax(mx, dv);
+        Z[i] = zn;
+        z32[i] = (float)zn;
+    }
+    mx = block_allreduce_max(mx, scratch);
+    if (threadIdx.x == 0) atomicMax(&diffbits[li], (unsigned long long)__double_as_longlong(mx));
+}
+
+// u_k = f32( f32(u_k + beta_k) - Z ), Z in double (computeU, jobs/RegressionAdmmTrain.java:752-757)
+__global__ void __launch_bounds__(256)
+k_u_update(int nlocal, int n_lambda, int n_global, const float *__restrict__ UPX, const double *__restrict__ Z,
+           float *__restrict__ u)
+{
+#pragma clang fp contract(off)
+    const int64_t tot = (int64_t)n_lambda * n_global;
+    const int64_t all = tot * nlocal;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < all; i += (int64_t)gridDim.x * 256) {
+        const int64_t zi = i % tot;
+        u[i] = (float)(1.0 * (double)UPX[i] + -1.0 * Z[zi]);
+    }
+}
+
+__global__ void k_round_z(int64_t n, const double *__restrict__ Z, float *__restrict__ z32)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) z32[i] = (float)Z[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+#define LAUNCH_DENSE(NV, U)                                                                                   \
+    hipLaunchKernelGGL((k_xpass_dense<NV, U>), dim3(maxblk, nq), dim3(256), (4 * NV * 256 + 16) * sizeof(double), \
+                       st, parts, probs, qlist)
+
+int mlxk_xpass_dense(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
+                     int max_nfeat)
+{
+    if (nq <= 0) return 0;
+    if (max_nfeat <= 256) LAUNCH_DENSE(1, 8);
+    else if (max_nfeat <= 512) LAUNCH_DENSE(2, 4);
+    else if (max_nfeat <= 1024) LAUNCH_DENSE(4, 4);
+    else if (max_nfeat <= 2048) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xpass_dense<8, 2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (4 * 8 * 256 + 16) * (int)sizeof(double));
+            attr_set = true;
+        }
+        LAUNCH_DENSE(8, 2);
+    }
+    else return -1;
+    return 0;
+}
+
+template <int G>
+static void launch_rowpass(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq,
+                           int maxblk, bool hasval)
+{
+    if (hasval) hipLaunchKernelGGL((k_rowpass_csr<G, true>), dim3(maxblk, nq), dim3(256), 0, st, parts, probs, qlist);
+    else hipLaunchKernelGGL((k_rowpass_csr<G, false>), dim3(maxblk, nq), dim3(256), 0, st, parts, probs, qlist);
+}
+
+int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
+                   int max_items, int rowgroup, bool hasval)
+{
+    if (nq <= 0) return 0;
+    switch (rowgroup) {
+    case 8: launch_rowpass<8>(st, parts, probs, qlist, nq, maxblk, hasval); break;
+    case 16: launch_rowpass<16>(st, parts, probs, qlist, nq, maxblk, hasval); break;
+    case 32: launch_rowpass<32>(st, parts, probs, qlist, nq, maxblk, hasval); break;
+    default: launch_rowpass<64>(st, parts, probs, qlist, nq, maxblk, hasval); break;
+    }
+    const int gx = (max_items + 31) / 32;
+    if (gx > 0) {
+        if (hasval) hipLaunchKernelGGL((k_colpass_csc<true>), dim3(gx, nq), dim3(256), 0, st, parts, probs, qlist);
+        else hipLaunchKernelGGL((k_colpass_csc<false>), dim3(gx, nq), dim3(256), 0, st, parts, probs, qlist);
+    }
+    return 0;
+}
+
+void mlxk_tron_step(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int first, int threads,
+                    int *done_counter)
+{
+    hipLaunchKernelGGL(k_tron_step, dim3(nprob), dim3(threads), 0, st, parts, probs + first, nprob, done_counter);
+}
+
+void mlxk_collect_c0(hipStream_t st, const PartDev *parts, const ProbDev *probs, const int *qlist, int nq,
+                     double *const *c0_ptrs)
+{
+    if (nq > 0) hipLaunchKernelGGL(k_collect_c0, dim3(nq), dim3(256), 0, st, parts, probs, qlist, c0_ptrs);
+}
+
+void mlxk_setup(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int n_lambda, int n_global,
+                int max_nlocal, const float *z32, const float *u, const double *pinv_l, double epsilon, int max_iter)
+{
+    const int gx = max(1, min(64, (max_nlocal + 255) / 256));
+    hipLaunchKernelGGL(k_setup, dim3(gx, nprob), dim3(256), 0, st, parts, probs, nprob, n_lambda, n_global, z32, u,
+                       pinv_l, epsilon, max_iter);
+}
+
+void mlxk_outputs(hipStream_t st, const PartDev *parts, const ProbDev *probs, int nprob, int n_lambda, int n_global,
+                  int max_nlocal, bool any_absent, const float *z32, const float *u, float *B, float *UPX)
+{
+    if (any_absent) {
+        const int gx = max(1, min(64, (n_global + 255) / 256));
+        hipLaunchKernelGGL(k_outputs_absent, dim3(gx, nprob), dim3(256), 0, st, probs, nprob, n_lambda, n_global, z32,
+                           u, B, UPX);
+    }
+    const int gx = max(1, min(64, (max_nlocal + 255) / 256));
+    hipLaunchKernelGGL(k_outputs_present, dim3(gx, nprob), dim3(256), 0, st, parts, probs, nprob, n_lambda, n_global,
+                       u, B, UPX);
+}
+
+void mlxk_partial_means(hipStream_t st, int nlocal, int n_lambda, int n_global, double invN, const float *B,
+                        const float *u, double *xbar, double *ubar)
+{
+    const int64_t tot = (int64_t)n_lambda * n_global;
+    const int gx = (int)max((int64_t)1, min((int64_t)2048, (tot + 255) / 256));
+    hipLaunchKernelGGL(k_partial_means, dim3(gx), dim3(256), 0, st, nlocal, n_lambda, n_global, invN, B, u, xbar, ubar);
+}
+
+void mlxk_z_update(hipStream_t st, int n_lambda, int n_global, int regularizer, int penalize_intercept,
+                   const double *weight_l, const double *cmap, const double *xbar, const double *ubar, double *Z,
+                   float *z32, unsigned long long *diffbits)
+{
+    const int gx = max(1, min(256, (n_global + 255) / 256));
+    hipLaunchKernelGGL(k_z_update, dim3(gx, n_lambda), dim3(256), 0, st, n_lambda, n_global, regularizer,
+                       penalize_intercept, weight_l, cmap, xbar, ubar, Z, z32, diffbits);
+}
+
+void mlxk_u_update(hipStream_t st, int nlocal, int n_lambda, int n_global, const float *UPX, const double *Z, float *u)
+{
+    const int64_t all = (int64_t)nlocal * n_lambda * n_global;
+    const int gx = (int)max((int64_t)1, min((int64_t)4096, (all + 255) / 256));
+    hipLaunchKernelGGL(k_u_update, dim3(gx), dim3(256), 0, st, nlocal, n_lambda, n_global, UPX, Z, u);
+}
+
+void mlxk_round_z(hipStream_t st, int64_t n, const double *Z, float *z32)
+{
+    const int gx = (int)max((int64_t)1, min((int64_t)1024, (n + 255) / 256));
+    hipLaunchKernelGGL(k_round_z, dim3(gx), dim3(256), 0, st, n, Z, z32);
+}

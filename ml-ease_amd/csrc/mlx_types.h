@@ -1,0 +1,62 @@
+// mlx_types.h -- device-visible descriptors shared by the kernels and the C-ABI host code.
+//
+// HBM layout (DESIGN.md "Data layout"): per local partition one PartDev (row data, uploaded once,
+// shared by every lambda and every ADMM iteration); per (partition, lambda) problem one ProbDev
+// (TRON scalars + pointers to its n_local-sized fp64 work vectors).
+#pragma once
+#include <stdint.h>
+
+enum { PH_DONE = 0, PH_EVAL0 = 1, PH_CG = 2, PH_EVAL = 3 };
+enum { ST_OK = 0, ST_NAN = 1, ST_TICKCAP = 2 };
+
+struct PartDev {
+    int32_t l;             // rows
+    int32_t n_local;       // features incl. intercept (intercept = local index n_local-1, implicit column of 1.0)
+    int32_t n_feat;        // n_local - 1
+    int32_t dense;         // 1: X dense tile, 0: CSR+CSC
+    int32_t nblk;          // workgroups per X pass over this partition (row chunks)
+    int32_t rows_per_blk;
+    int32_t pos, neg;      // #y==+1, #y==-1 (llf/LibLinear.java:272-276)
+    int64_t ld;            // dense row stride in floats (multiple of 4, zero padded)
+    int64_t nnz;
+    const float *X;        // dense [l][ld]
+    const int32_t *rp;     // CSR row pointer [l+1] (intercept excluded)
+    const int32_t *ci;     // CSR local column ids [nnz]
+    const float *val;      // CSR values [nnz] or nullptr (binary.feature)
+    const int32_t *cri;    // CSC row ids [nnz] (column-major order)
+    const float *cval;     // CSC values [nnz] or nullptr
+    const int32_t *item_ptr;   // [n_items+1] CSC segments (<= SEG entries each), columns in order
+    const int32_t *col_item;   // [n_feat+1] first item of each column
+    int32_t n_items;
+    int32_t rowgroup;      // lanes per row in the CSR row pass (8..64)
+    const int8_t *y;       // +1/-1
+    const float *wt;       // instance weight
+    const float *off;      // offset
+    const int32_t *l2g;    // local -> global
+    const double *c0;      // X' t0 with t0_i = wt_i (sigma(y_i off_i) - 1) y_i : data part of grad(0), fixed per partition
+};
+
+struct ProbDev {
+    int32_t part;          // local partition index
+    int32_t lambda_idx;
+    int32_t phase;
+    int32_t dsel;          // which wd[] buffer belongs to the last accepted point
+    int32_t iter;          // Tron's iter (accepted steps + 1)
+    int32_t max_iter;
+    int32_t cg_iter;       // CG steps of the current trcg call
+    int32_t newton, accepted, cg_total, ticks;
+    int32_t status;
+    double f, delta, gnorm, gnorm1, eps, rTr, cgtol, prered, gs;
+    double pinv;           // scalar prior precision 1/(1/rho) (used when pinv_vec == nullptr)
+    const double *pinv_vec;    // per-coordinate 1/priorVar (mlx_solve_one) or nullptr
+    double *w, *w_new, *g, *s, *r, *d, *Hd, *m;   // n_local each
+    double *wd[2];         // [l] wt_i * D_i at the accepted / trial point
+    double *coef;          // [l] row coefficients of the current pass (CSR path only)
+    double *parts;         // dense: [nblk][n_local] partial X'c ; CSR: itemsum [n_items]
+    double *lossp;         // [nblk] partial loss sums
+    double *csump;         // [nblk] partial sums of coef (CSR intercept column)
+};
+
+struct ConsDev {           // consensus parameters per lambda
+    double weight;         // L2: (double)(float)(N*rho/(lambda+N*rho)) ; L1: lambda/(rho*N)
+};

@@ -219,7 +219,11 @@ def f32(x):
 
 def float_str_roundtrip(e: np.float32) -> float:
     """String.valueOf(float) -> Double.parseDouble (jobs/RegressionAdmmTrain.java:346,702; utils/Util.java:145-155)."""
-    return float(repr(np.float32(e)).replace("np.float32(", "").rstrip(")"))
+    f = np.float32(e)
+    s = np.format_float_scientific(f, unique=True, trim="0")
+    if len(s.split("e")[0].replace(".", "").replace("-", "").rstrip("0")) <= 1:
+        s = "%.1e" % float(f)          # Java prints >= 2 significant digits (1.4E-45, not 1E-45)
+    return float(s)
 
 
 class AdmmNumpy:

@@ -588,7 +588,7 @@ void orc_admm_get_stats(const orc_admm *a, orc_tron_stats *out)
 double orc_float_to_string_to_double(float e)
 {
     char buf[64];
-    for (int prec = 1; prec <= 9; prec++) {
+    for (int prec = 2; prec <= 9; prec++) {   /* Java prints at least two significant digits (1.4E-45, not 1E-45) */
         snprintf(buf, sizeof buf, "%.*g", prec, (double)e);
         if (strtof(buf, NULL) == e) break;
     }

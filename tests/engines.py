@@ -1,0 +1,43 @@
+"""Test-side adaptor: the CPU oracle behind the engine protocol of mlease_amd.admm.AdmmTrain.
+
+Lives in tests/ on purpose: the product package never routes through the oracle.
+"""
+import numpy as np
+import torch
+
+import oracle_lib as ol
+
+
+class _Fin:
+    def __init__(self, mx, mn):
+        self.maxdiff, self.mindiff = mx, mn
+
+
+class OracleEngine:
+    def __init__(self, blocks, n_global, lambdas, rhos, num_blocks, penalize_intercept=False, nthreads=2):
+        self.o = ol.OracleAdmm(blocks, n_global, lambdas, rhos, num_blocks=num_blocks,
+                               penalize_intercept=penalize_intercept)
+        self.nthreads = nthreads
+        n = self.o.nl * self.o.ng
+        self._buf = np.zeros(2 * n)
+
+    def solve_local(self, eps, rate=1.0):
+        self.o.solve_local(eps, rate, self.nthreads)
+        xb, ub = self.o.partial_means()
+        n = len(xb)
+        self._buf[:n] = xb
+        self._buf[n:] = ub
+        return None
+
+    def consensus_tensor(self):
+        return torch.from_numpy(self._buf)
+
+    def consensus_finish(self):
+        xb, ub = self.o.partial_means()
+        n = len(xb)
+        xb[:] = self._buf[:n]
+        ub[:] = self._buf[n:]
+        return _Fin(*self.o.finish())
+
+    def z(self):
+        return self.o.z()

@@ -1,0 +1,224 @@
+"""CPU tests of the host logic: C-ABI exports, driver loop (eps schedule / stop rule), config parsing,
+avro formats, Prepare semantics, dataset indexing rules, and the sharded exchange over gloo."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import mlease_amd  # noqa: F401
+from mlease_amd import admm, avro_io, dataset, hip_engine
+import oracle_lib as ol
+from engines import OracleEngine
+from fixtures import load_c1, load_c1_golden, synth_sparse
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ----------------------------------------------------------------------------- C-ABI
+def test_abi_library_exports_every_declared_symbol():
+    """libmlease_hip.so loads without a GPU and exports exactly what include/mlease_admm.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "mlease_admm.h")).read()
+    declared = set(re.findall(r"\b(mlx_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"mlx_context"}
+    assert declared == set(hip_engine.ABI_SYMBOLS), declared ^ set(hip_engine.ABI_SYMBOLS)
+    lib = hip_engine.load_library()
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert b"gfx950" in lib.mlx_version()
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no HIP device|no CPU fallback|mlx_create failed"):
+        hip_engine.HipAdmmEngine(10, [1.0], [1.0], 1)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "ml-ease_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".c")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle_lib" not in src and "admm_numpy" not in src and "liboracle" not in src, f
+
+
+# ----------------------------------------------------------------------------- driver loop
+def test_driver_loop_matches_oracle_run(c1=None):
+    c1 = load_c1()
+    gold = load_c1_golden()
+    cfg = admm.AdmmConfig(num_blocks=8, lambdas=[1.0], num_iters=20)
+    lam, rho = cfg.sorted_lambda_rho()
+    assert (lam, rho) == ([1.0], [1.0])
+    eng = OracleEngine(c1.blocks, c1.n_global, lam, rho, 8)
+    tr = admm.AdmmTrain(cfg, eng)
+    hist = tr.run()
+    assert len(hist) == 20
+    assert np.array_equal([h.liblinear_epsilon for h in hist], gold["eps"])
+    assert np.array_equal([[h.maxdiff, h.mindiff] for h in hist], gold["diffs"])
+    models = tr.final_models()
+    assert list(models) == ["1.0"]
+    assert np.array_equal(models["1.0"], gold["Z"][-1][0].astype(np.float32))
+
+
+def test_driver_stop_rule_and_eps_decay():
+    """Converges on a tiny easy problem: eps decays in float32 once mindiff<1e-3, stop needs eps<=1e-5 (:338-346,:493)."""
+    pd = synth_sparse(3, 400, 6, 3, 2)
+    cfg = admm.AdmmConfig(num_blocks=2, lambdas=[5.0], num_iters=200)
+    lam, rho = cfg.sorted_lambda_rho()
+    tr = admm.AdmmTrain(cfg, OracleEngine(pd.blocks, pd.n_global, lam, rho, 2))
+    hist = tr.run()
+    oc = ol.OracleAdmm(pd.blocks, pd.n_global, lam, rho)
+    done, diffs, eps = oc.run(200)
+    assert len(hist) == done < 200
+    assert np.array_equal([h.liblinear_epsilon for h in hist], eps)
+    assert hist[-1].maxdiff < 1e-4 and hist[-1].liblinear_epsilon <= 1.0001e-5
+    e = [h.liblinear_epsilon for h in hist]
+    assert e[0] == 0.01 and 9.999999e-4 in e
+
+
+def test_config_defaults_and_rho_table(tmp_path):
+    job = tmp_path / "sample.job"
+    job.write_text("# comment\ninput.paths=/a\noutput.base.path = /out\nnum.blocks=20\nlambda=1,10,100,1000\n"
+                   "num.iters=20\nregularizer=2\ntest.loglik.per.iter=true\nforce.output.overwrite=true\n")
+    cfg = admm.AdmmConfig.from_properties(admm.parse_job_file(str(job)))
+    assert cfg.num_blocks == 20 and cfg.num_iters == 20 and cfg.epsilon == 1e-4 and not cfg.penalize_intercept
+    lam, rho = cfg.sorted_lambda_rho()
+    assert lam == [1.0, 10.0, 100.0, 1000.0] and rho == [1.0, 1.0, 1.0, 10.0]      # :174-181
+    with pytest.raises(IOError):
+        admm.AdmmConfig.from_properties({"output.base.path": "/o", "num.blocks": "2", "lambda": "1", "regularizer": "3"})
+    with pytest.raises(IOError):
+        admm.AdmmConfig.from_properties({"output.base.path": "/o", "num.blocks": "2", "lambda": "1,2", "rho": "1",
+                                         "regularizer": "2"})
+    assert admm.AdmmConfig(num_blocks=2, lambdas=[1.0], num_iters=1).num_iters == 1
+    # default num.iters is 10 (:139)
+    assert admm.AdmmConfig.from_properties({"output.base.path": "/o", "num.blocks": "2", "lambda": "1",
+                                            "regularizer": "2"}).num_iters == 10
+
+
+def test_java_float_strings():
+    j = admm.java_float_to_string
+    assert [j(x) for x in (1.0, 10.0, 100.0, 0.1, 0.3, 1000.0, 1e7, 1e-3, 1e-4, 300.0)] == \
+        ["1.0", "10.0", "100.0", "0.1", "0.3", "1000.0", "1.0E7", "0.001", "1.0E-4", "300.0"]
+    assert j(np.float32(0.01) / np.float32(10)) == "9.999999E-4"
+    assert j(np.float32(1.4e-45)) == "1.4E-45"
+    e = np.float32(0.01)
+    for _ in range(70):
+        assert admm.float_string_roundtrip(e) == ol.float_to_string_to_double(e)
+        e = np.float32(e / np.float32(10))
+
+
+# ----------------------------------------------------------------------------- formats
+def test_avro_roundtrip_models_and_prepared_rows(tmp_path):
+    names = ["a", "b" + dataset.TERM_SEP + "t1", "c"]
+    models = {"1.0": np.array([0.5, -1.25, 0.0, 2.0], np.float32), "10.0": np.array([1, 2, 3, 4], np.float32)}
+    p = str(tmp_path / "final-model" / "part-r-00000.avro")
+    admm.write_linear_models(p, models, names)
+    recs = avro_io.read_records(p)
+    assert recs[0]["model"][0] == {"name": "(INTERCEPT)", "term": "", "value": 2.0}      # intercept first, :700-704
+    assert recs[0]["model"][2] == {"name": "b", "term": "t1", "value": -1.25}
+    back = admm.read_linear_models(p, names)
+    assert all(np.array_equal(back[k], models[k]) for k in models)
+    rows = [dataset.PreparedRow("3", 1, [("f", "", np.float32(0.25)), ("g", "x", np.float32(-1))], np.float32(0.5), np.float32(0.125))]
+    p2 = str(tmp_path / "tmp-data" / "part-00000.avro")
+    avro_io.write_container(p2, avro_io.PREPARE_OUTPUT_SCHEMA, [r.to_avro() for r in rows], codec="null")
+    r2 = dataset.PreparedRow.from_avro(avro_io.read_records(p2)[0])
+    assert r2 == rows[0]
+    # directory read picks up part files in name order
+    assert len(avro_io.read_records(str(tmp_path / "tmp-data"))) == 1
+
+
+def test_prepare_semantics():
+    recs = [{"response": 1, "weight": 4, "offset": 1, "features": [{"name": "a", "term": None, "value": 0.1}]},
+            {"click": True, "response": 0, "features": [{"name": "a", "term": "t", "value": 2}]},
+            {"label": 0, "response": 0, "features": []}]
+    rows = dataset.prepare_rows(recs, 4, num_click_replicates=2, key_fn=lambda i, r: 3)
+    # positive row: weight / replicates (:159-162), replicated into consecutive partitions with wrap (:172-186)
+    assert [r.key for r in rows[:2]] == ["3", "0"] and rows[0].weight == np.float32(2.0)
+    assert rows[0].features[0][2] == np.float32(0.1) and rows[0].offset == np.float32(1.0)
+    # response = last non-null of click/response/label (utils/Util.java:309-337): record 2 -> response 0 overrides click
+    assert rows[2].response == 0 and rows[2].features == [("a", "t", np.float32(2.0))]
+    assert rows[3].response == 0 and rows[3].features == []
+    with pytest.raises(IOError):
+        dataset.prepare_rows([{"features": []}], 2)
+    with pytest.raises(IOError):
+        dataset.prepare_rows([{"response": 1, "features": None}], 2)
+    # map.key given: no replication
+    rows = dataset.prepare_rows([dict(recs[0], pk=1)], 4, map_key="pk", num_click_replicates=3)
+    assert len(rows) == 1 and rows[0].key == "1"
+    # binary.feature ignores values
+    rows = dataset.prepare_rows(recs[:1], 4, binary_feature=True, key_fn=lambda i, r: 0)
+    assert rows[0].features[0][2] == np.float32(1.0)
+
+
+def test_partition_indexing_rules():
+    mk = dataset.PreparedRow
+    rows = [mk("0", 1, [("b", "", np.float32(2)), ("a", "x", np.float32(3))], np.float32(1), np.float32(0)),
+            mk("0", 0, [("a", "x", np.float32(5)), ("c", "", np.float32(7)), ("b", "", np.float32(1))], np.float32(2), np.float32(0.5)),
+            mk("1", -1, [("c", "", np.float32(1))], np.float32(1), np.float32(0))]
+    pd = dataset.build_partitions(rows, 2)
+    b0, b1 = pd.blocks
+    # first-seen ids: b->0, a^Ax->1, c->2 ; rows sorted by local id ; intercept implicit (last local index)
+    assert pd.feature_names == ["b", "a" + dataset.TERM_SEP + "x", "c"] and pd.n_global == 4
+    assert b0.n_local == 4 and list(b0.col_idx) == [0, 1, 0, 1, 2] and list(b0.val) == [2, 3, 1, 5, 7]
+    assert list(b0.y) == [1, -1] and list(b1.y) == [-1]
+    assert list(b1.local_to_global) == [2, 3] and list(b0.local_to_global) == [0, 1, 2, 3]
+    with pytest.raises(dataset.ModelFittingError):
+        dataset.build_partitions([mk("0", 2, [], np.float32(1), np.float32(0))], 1)
+    with pytest.raises(dataset.ModelFittingError):
+        dataset.build_partitions([mk("0", 1, [], np.float32(-1), np.float32(0))], 1)
+    with pytest.raises(dataset.ModelFittingError):
+        dataset.build_partitions([mk("0", 1, [("(INTERCEPT)", "", np.float32(1))], np.float32(1), np.float32(0))], 1)
+    with pytest.raises(dataset.ModelFittingError):
+        dataset.build_partitions([mk("0", 1, [("a", "", np.float32(2))], np.float32(1), np.float32(0))], 1, binary_feature=True)
+    with pytest.raises(RuntimeError):
+        dataset.build_partitions([mk("5", 1, [], np.float32(1), np.float32(0))], 2)
+
+
+# ----------------------------------------------------------------------------- sharded exchange over gloo
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests"); sys.path.insert(0, {root!r} + "/oracle")
+import numpy as np, torch, torch.distributed as dist
+import mlease_amd
+from mlease_amd import admm
+from engines import OracleEngine
+from fixtures import load_c1
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
+rank = dist.get_rank()
+c1 = load_c1()
+cfg = admm.AdmmConfig(num_blocks=8, lambdas=[1.0, 10.0], num_iters=4)
+lam, rho = cfg.sorted_lambda_rho()
+mine = [b for b in c1.blocks if b.partition_id % 2 == rank]          # partition k -> rank k mod G
+eng = OracleEngine(mine, c1.n_global, lam, rho, 8)
+tr = admm.AdmmTrain(cfg, eng, all_reduce=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+hist = tr.run()
+Z, z32 = eng.z()
+np.save({out!r} + "/z%d.npy" % rank, Z)
+np.save({out!r} + "/d%d.npy" % rank, np.array([[h.maxdiff, h.mindiff] for h in hist]))
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_gloo_sharded_consensus(tmp_path):
+    """world_size=2 on CPU: partitions sharded k mod 2, [xbar|ubar] all-reduced, identical z on both ranks and
+    equal (after the float32 write) to the single-process run."""
+    port = 29000 + (os.getpid() % 2000)
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT, port=port, out=str(tmp_path)))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    z0, z1 = np.load(tmp_path / "z0.npy"), np.load(tmp_path / "z1.npy")
+    assert np.array_equal(z0, z1)
+    c1 = load_c1()
+    oc = ol.OracleAdmm(c1.blocks, c1.n_global, [1.0, 10.0], [1.0, 1.0])
+    done, diffs, _ = oc.run(4)
+    assert np.array_equal(z0.astype(np.float32), oc.z()[1])
+    assert np.allclose(np.load(tmp_path / "d0.npy"), diffs, rtol=1e-12, atol=0)
