@@ -71,8 +71,8 @@ def main():
     ap.add_argument("--features", type=int, default=1000)
     ap.add_argument("--partitions-per-gpu", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=8, help="partitions in the CPU-baseline sample")
-    ap.add_argument("--cpu-iters", type=int, default=1)
+    ap.add_argument("--cpu-sample", type=int, default=32, help="partitions in the CPU-baseline sample")
+    ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events")
     args = ap.parse_args()
 
@@ -132,6 +132,9 @@ def main():
     it = 0
     acc = dict(solves=0, newton=0, cg=0, passes_ref=0, passes_dev=0, ticks=0, alg_bytes=0.0, xpass_ms=0.0,
                total_ms=0.0, launches=0)
+    # every X-pass launch of the process (finalize's c0 pass + warmup + timed): what a rocprofv3 run of this
+    # command sees, used to turn its FETCH_SIZE/WRITE_SIZE sums into HBM bytes per algorithmic byte
+    allrun = dict(alg_bytes=P * (4.0 * rows * nf + 8.0 * rows + 8.0 * (nf + 1)), launches=1)
 
     def step(timed):
         nonlocal e, mindiff, it
@@ -142,6 +145,8 @@ def main():
         all_reduce(eng.consensus_tensor())
         fin = eng.consensus_finish()
         mindiff = fin.mindiff
+        allrun["alg_bytes"] += st.alg_bytes_dev
+        allrun["launches"] += st.ticks
         if timed:
             acc["solves"] += st.solves; acc["newton"] += st.newton_iters; acc["cg"] += st.cg_iters
             acc["passes_ref"] += st.x_passes_ref; acc["passes_dev"] += st.x_passes_dev; acc["ticks"] += st.ticks
@@ -171,10 +176,18 @@ def main():
     if rank == 0:
         value = tot_solves / dt
         roof = None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            # HBM bytes per algorithmic byte of this kernel, from the committed rocprofv3 PMC passes of this very
+            # command (profiles/README.md): 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE over all its launches
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            traffic = tj["hbm_bytes_per_alg_byte"] * acc["alg_bytes"] / max(1, acc["launches"])
         if acc["xpass_ms"] > 0:
             achieved = acc["alg_bytes"] / (acc["xpass_ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "k_xpass_dense<4,4>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "alg_bytes_per_launch": acc["alg_bytes"] / max(1, acc["launches"]),
                     "avg_launch_ms": acc["xpass_ms"] / max(1, acc["launches"]), "launches": acc["launches"],
                     "xpass_share_of_step": round(acc["xpass_ms"] / (dt * 1e3), 4)}
@@ -192,7 +205,8 @@ def main():
                         "passes_ref_per_solve": round(tot_pref / max(1.0, tot_solves), 2),
                         "passes_dev_per_solve": round(tot_pdev / max(1.0, tot_solves), 2), "ticks": acc["ticks"],
                         "last_maxdiff": fin.maxdiff},
-               "roofline": roof}
+               "roofline": roof,
+               "all_launches": {"xpass_launches_incl_c0_and_warmup": allrun["launches"], "alg_bytes": allrun["alg_bytes"]}}
         if sample:
             threads = os.cpu_count() or 1
             threads = min(threads, len(sample))

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -27,7 +28,7 @@ struct PartHost {
     int pid = 0, l = 0, n_local = 0, n_feat = 0;
     bool dense = false, hasval = false, all_present = false;
     int64_t nnz = 0, ld = 0;
-    int nblk = 0, rows_per_blk = 0, n_items = 0, rowgroup = 64, pos = 0, neg = 0;
+    int nblk = 0, nblk_min = 1, rows_per_blk = 0, n_items = 0, rowgroup = 64, pos = 0, neg = 0;
     PartDev dev{};
     double *c0 = nullptr;
 };
@@ -57,6 +58,7 @@ struct mlx_context {
     int64_t max_parts_len = 0;
     bool csr_hasval = false, any_absent = false;
     int step_threads = 256;
+    int target_wgs = 1024;                 // dense pass: workgroups wanted per launch (chunk-granularity policy)
 
     double *d_Z = nullptr;
     float *d_z32 = nullptr, *d_u = nullptr, *d_B = nullptr, *d_UPX = nullptr;
@@ -185,11 +187,11 @@ hipEvent_t next_event(mlx_handle h)
 }
 
 // One X pass over every unfinished problem of the given lists (+ optional event bracket).
-int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int nqc)
+int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int nqc, int nrun)
 {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) { e0 = next_event(h); e1 = next_event(h); hipEventRecord(e0, h->stream); }
-    if (nqd > 0 && mlxk_xpass_dense(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->maxblk_dense, h->max_nfeat_dense))
+    if (nqd > 0 && mlxk_xpass_dense(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->maxblk_dense, h->max_nfeat_dense, nrun, h->d_done, h->target_wgs))
         return fail(h, MLX_ERR_INVALID, "dense tile wider than 2048 features is not supported; use the CSR form");
     if (nqc > 0) mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_items, h->rowgroup, h->csr_hasval);
     if (h->profiling) hipEventRecord(e1, h->stream);
@@ -208,7 +210,7 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
     int rc;
     for (;;) {
         for (int i = 0; i < batch; i++) {
-            if ((rc = launch_xpass(h, qdense, nqd, qcsr, nqc))) return rc;
+            if ((rc = launch_xpass(h, qdense, nqd, qcsr, nqc, count))) return rc;
             mlxk_tron_step(h->stream, h->d_parts, h->d_probs, count, first, h->step_threads, h->d_done);
             ticks++;
         }
@@ -216,6 +218,7 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
         HIPCHECK(h, hipEventRecord(h->ev_batch[slot], h->stream));
         if (have_prev) {
             HIPCHECK(h, hipEventSynchronize(h->ev_batch[slot ^ 1]));
+            if (getenv("MLX_TRACE")) fprintf(stderr, "[mlx] ticks=%lld done=%d/%d\n", (long long)(ticks - batch), h->h_done[slot ^ 1], count);
             if (h->h_done[slot ^ 1] >= count) break;      // the batch just queued runs as no-ops
         }
         have_prev = true;
@@ -241,7 +244,7 @@ double alg_bytes_per_tick(const PartHost &p)
 int finish_part(mlx_handle h, PartHost &ph)
 {
     ph.dev.l = ph.l; ph.dev.n_local = ph.n_local; ph.dev.n_feat = ph.n_feat; ph.dev.dense = ph.dense ? 1 : 0;
-    ph.dev.nblk = ph.nblk; ph.dev.rows_per_blk = ph.rows_per_blk; ph.dev.pos = ph.pos; ph.dev.neg = ph.neg;
+    ph.dev.nblk = ph.nblk; ph.dev.nblk_min = ph.nblk_min; ph.dev.rows_per_blk = ph.rows_per_blk; ph.dev.pos = ph.pos; ph.dev.neg = ph.neg;
     ph.dev.ld = ph.ld; ph.dev.nnz = ph.nnz; ph.dev.n_items = ph.n_items; ph.dev.rowgroup = ph.rowgroup;
     int rc = dev_alloc(h, &ph.c0, (size_t)ph.n_local);
     if (rc) return rc;
@@ -447,10 +450,20 @@ int mlx_add_partition_dense(mlx_handle h, int32_t partition_id, int32_t l, int32
     int32_t *d_l2g;
     if ((rc = dev_upload(h, &d_l2g, local_to_global, (size_t)n_local))) return rc;
     ph.dev.X = dX; ph.dev.l2g = d_l2g;
-    int rpb = 256;
-    if ((l + rpb - 1) / rpb > 1024) rpb = ((l + 1023) / 1024 + 31) / 32 * 32;
-    ph.rows_per_blk = rpb;
-    ph.nblk = (l + rpb - 1) / rpb;
+    // Row chunk per workgroup. Measured on 64 x (15625 x 1000) (profiles/r1_notes.md): 512 rows/chunk is the
+    // optimum (5.9 TB/s); finer chunks pay per-block prologue/epilogue, and a finer launch grid whose surplus
+    // blocks exit at once still costs ~12 ns per no-op block. The pass can pick between a fine and a coarse
+    // chunking from the live count of unfinished problems (dense_rows_per_blk); by default both are equal.
+    int fine = l >= 4096 ? 512 : std::max(16, ((l + 7) / 8 + 15) / 16 * 16);
+    if ((l + fine - 1) / fine > 1024) fine = ((l + 1023) / 1024 + 15) / 16 * 16;
+    int coarse = fine;
+    if (const char *e = getenv("MLX_DENSE_RPB")) fine = coarse = std::max(16, atoi(e) / 16 * 16);   // A/B knobs
+    if (const char *e = getenv("MLX_DENSE_RPB_FINE")) fine = std::max(16, atoi(e) / 16 * 16);
+    if (const char *e = getenv("MLX_DENSE_RPB_COARSE")) coarse = std::max(fine, atoi(e) / 16 * 16);
+    if (const char *e = getenv("MLX_TARGET_WGS")) h->target_wgs = std::max(1, atoi(e));
+    ph.rows_per_blk = fine;
+    ph.nblk = (l + fine - 1) / fine;
+    ph.nblk_min = (l + coarse - 1) / coarse;
     if ((rc = upload_row_meta(h, ph, l, y, weight, offset, x_on_device != 0))) return rc;
     return finish_part(h, ph);
 }
@@ -494,7 +507,7 @@ int mlx_finalize(mlx_handle h)
     h->nq_dense = (int)qd.size(); h->nq_csr = (int)qc.size();
     if ((rc = dev_upload(h, &h->d_qdense, qd.data(), qd.size()))) return rc;
     if ((rc = dev_upload(h, &h->d_qcsr, qc.data(), qc.size()))) return rc;
-    h->step_threads = h->max_nlocal > 4096 ? 1024 : 256;
+    h->step_threads = (h->max_nlocal > 4096 || (h->nq_dense > 0 && h->max_nlocal >= 512)) ? 1024 : 256;
 
     // problems (+1 scratch for mlx_solve_one)
     h->h_probs.assign(h->nprob + 1, ProbDev{});
@@ -529,6 +542,9 @@ int mlx_finalize(mlx_handle h)
         if ((rc = dev_upload(h, &h->d_qscratch, &sidx, 1))) return rc;
     }
 
+    if ((rc = dev_alloc(h, &h->d_done, 1))) return rc;
+    HIPCHECK(h, hipMemset(h->d_done, 0, sizeof(int)));
+
     // c0 = X' t0: one EVAL pass at w = 0 on the first problem of every partition
     std::vector<int> qfirst_d, qfirst_c, qfirst_all;
     std::vector<double *> c0ptrs;
@@ -550,7 +566,7 @@ int mlx_finalize(mlx_handle h)
         if ((rc = dev_upload(h, &d_c0, c0ptrs.data(), c0ptrs.size()))) return rc;
         const bool prof = h->profiling;
         h->profiling = false;
-        rc = launch_xpass(h, d_qfd, (int)qfirst_d.size(), d_qfc, (int)qfirst_c.size());
+        rc = launch_xpass(h, d_qfd, (int)qfirst_d.size(), d_qfc, (int)qfirst_c.size(), np);
         h->profiling = prof;
         if (rc) return rc;
         mlxk_collect_c0(h->stream, h->d_parts, h->d_probs, d_qfa, (int)qfirst_all.size(), d_c0);
@@ -569,7 +585,6 @@ int mlx_finalize(mlx_handle h)
     if ((rc = dev_alloc(h, &h->d_UPX, pl))) return rc;
     if ((rc = dev_alloc(h, &h->d_cons, 2 * zl))) return rc;
     if ((rc = dev_alloc(h, &h->d_diffbits, (size_t)nl))) return rc;
-    if ((rc = dev_alloc(h, &h->d_done, 1))) return rc;
     if ((rc = dev_alloc(h, &h->d_pinv_l, (size_t)nl))) return rc;
     HIPCHECK(h, hipMemset(h->d_Z, 0, sizeof(double) * zl));
     HIPCHECK(h, hipMemset(h->d_z32, 0, sizeof(float) * zl));

@@ -7,8 +7,9 @@ struct PartDev;
 struct ProbDev;
 
 // One X pass for the problems in qlist (device array of problem indices). Returns -1 if unsupported width.
+// nrun = problems driven by this tick loop, done_counter = device count of finished ones (granularity policy).
 int mlxk_xpass_dense(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
-                     int max_nfeat);
+                     int max_nfeat, int nrun, const int *done_counter, int target_wgs);
 int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
                    int max_items, int rowgroup, bool hasval);
 // TRON/CG control flow for problems [first, first+nprob)

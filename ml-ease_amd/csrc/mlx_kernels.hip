@@ -109,9 +109,21 @@ __device__ __forceinline__ void row_eval(double z, int y, double wt, double &los
 // (c < NV), i.e. 16*NV bytes per lane per row, loaded as 1 KiB-per-instruction coalesced reads.
 // Per row: partial dot -> wave all-reduce -> row coefficient -> rank-1 accumulate into the lane's
 // 4*NV fp64 column accumulators. U rows are in flight per wave for ILP.
+//
+// Row-chunk granularity adapts to how many problems are still running (dense_rows_per_blk): with all
+// problems active the chunks are coarse (least per-block prologue/epilogue, measured +5 %), in the tail
+// of a tick sequence the few remaining problems are cut into many chunks so they still fill 256 CUs.
+__device__ __forceinline__ int dense_rows_per_blk(const PartDev &pa, int active, int target_wgs)
+{
+    const int want = (target_wgs + active - 1) / active;
+    const int nb = min(max(want, pa.nblk_min), pa.nblk);
+    return ((pa.l + nb - 1) / nb + 15) & ~15;
+}
+
 template <int NV, int U>
 __global__ void __launch_bounds__(256)
-k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist)
+k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist,
+              int nrun, const int *__restrict__ done_counter, int target_wgs)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int q = qlist[blockIdx.y];
@@ -120,7 +132,10 @@ k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     if (phase == PH_DONE) return;
     const PartDev &pa = parts[pr.part];
     const int b = blockIdx.x;
-    if (b >= pa.nblk) return;
+    const int rpb = dense_rows_per_blk(pa, max(1, nrun - *done_counter), target_wgs);
+    const int nblk = (pa.l + rpb - 1) / rpb;
+    if (b >= nblk) return;
+    if (b == 0 && threadIdx.x == 0) pr.cur_nblk = nblk;
     const int nf = pa.n_feat, n = nf + 1;
     const int64_t ld = pa.ld;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -145,19 +160,22 @@ k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
         for (int e = 0; e < 4; e++) acc[c][e] = 0.0;
     double accb = 0.0, lossacc = 0.0;
 
-    const int r0 = b * pa.rows_per_blk;
-    const int r1 = min(pa.l, r0 + pa.rows_per_blk);
+    const int r0 = b * rpb;
+    const int r1 = min(pa.l, r0 + rpb);
     for (int rb = r0 + wave * U; rb < r1; rb += 4 * U) {
         float4 x[U][NV];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int row = rb + u;
+            // Unconditional loads (clamped addresses): a predicated load makes hipcc wait vmcnt(0) after
+            // every single load (16 serialized round trips per batch, measured 3.2 -> 5.8 TB/s). Rows past
+            // r1 re-read row r1-1 and get coefficient 0; lanes past the row width re-read its last
+            // float4 against vr == 0, and their accumulators are never stored.
+            const int row = min(rb + u, r1 - 1);
             const float *__restrict__ xr = X + (int64_t)row * ld;
 #pragma unroll
             for (int c = 0; c < NV; c++) {
-                const int col0 = (c * 64 + lane) * 4;
-                if (row < r1 && col0 < ld) x[u][c] = *reinterpret_cast<const float4 *>(xr + col0);
-                else x[u][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int col0 = min((c * 64 + lane) * 4, (int)ld - 4);
+                x[u][c] = *reinterpret_cast<const float4 *>(xr + col0);
             }
         }
         double t[U];
@@ -175,6 +193,13 @@ k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
         }
 #pragma unroll
         for (int u = 0; u < U; u++) t[u] = wave_allreduce_sum(t[u]) + vb;
+        // Keep the tile as fp32 in registers and convert again for the accumulate phase: without this
+        // barrier hipcc keeps the 16*U*NV converted doubles alive (256 VGPR + AGPR spill = 1 wave/SIMD).
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int c = 0; c < NV; c++)
+                asm volatile("" : "+v"(x[u][c].x), "+v"(x[u][c].y), "+v"(x[u][c].z), "+v"(x[u][c].w));
         // lane u (< U) owns row rb+u for the scalar map, then broadcasts its coefficient
         double tm = t[0];
 #pragma unroll
@@ -366,29 +391,53 @@ __device__ __forceinline__ double pinv_at(const ProbDev &pr, int j)
 
 // out = X' c assembled from the pass partials in a fixed order (dense: per-block slices; CSR: column
 // segments in row order + the intercept's per-block coefficient sums).
-__device__ __forceinline__ void assemble_out(const PartDev &pa, const ProbDev &pr, double *__restrict__ out)
+// Deterministic sum of a short global array over the block (strided per-thread partials, then the block tree).
+__device__ __forceinline__ double block_sum_array(const double *__restrict__ a, int cnt, double *scratch)
+{
+    double v[1] = {0.0};
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) v[0] += a[i];
+    block_allreduce_sum<1>(v, scratch);
+    return v[0];
+}
+
+__device__ __forceinline__ void assemble_out(const PartDev &pa, const ProbDev &pr, double *__restrict__ out,
+                                             double *scratch, double *stage /* LDS, blockDim.x doubles */)
 {
     const int n = pa.n_local, nf = pa.n_feat;
     const int tid = threadIdx.x, nt = blockDim.x;
     if (pa.dense) {
-        const int P = pa.nblk;
-        for (int j = tid; j < n; j += nt) {
+        // thread = (slice group g, column c): 256 columns x nt/256 groups; each group walks its slices with
+        // several loads in flight (a single thread walking all P slices is latency-bound: 85 us -> ~10 us).
+        const int P = pr.cur_nblk;
+        const int CW = nt < 256 ? nt : 256, NG = nt / CW;
+        const int c = tid % CW, g = tid / CW;
+        const double *__restrict__ parts = pr.parts;
+        for (int base = 0; base < n; base += CW) {
+            const int j = base + c;
             double a = 0.0;
-            for (int p = 0; p < P; p++) a += pr.parts[(int64_t)p * n + j];
-            out[j] = a;
+            if (j < n) {
+#pragma unroll 4
+                for (int p = g; p < P; p += NG) a += parts[(int64_t)p * n + j];
+            }
+            stage[g * CW + c] = a;
+            __syncthreads();
+            if (g == 0 && j < n) {
+                double t = stage[c];
+                for (int k = 1; k < NG; k++) t += stage[k * CW + c];
+                out[j] = t;
+            }
+            __syncthreads();
         }
     } else {
+        const double *__restrict__ parts = pr.parts;
         for (int j = tid; j < nf; j += nt) {
             double a = 0.0;
             const int i0 = pa.col_item[j], i1 = pa.col_item[j + 1];
-            for (int it = i0; it < i1; it++) a += pr.parts[it];
+            for (int it = i0; it < i1; it++) a += parts[it];
             out[j] = a;
         }
-        if (tid == 0) {
-            double a = 0.0;
-            for (int p = 0; p < pa.nblk; p++) a += pr.csump[p];
-            out[nf] = a;
-        }
+        const double cs = block_sum_array(pr.csump, pa.nblk, scratch);
+        if (tid == 0) out[nf] = cs;
     }
 }
 
@@ -397,8 +446,10 @@ __global__ void __launch_bounds__(256)
 k_collect_c0(const PartDev *__restrict__ parts, const ProbDev *__restrict__ probs, const int *__restrict__ qlist,
              double *const *__restrict__ c0_ptrs)
 {
+    __shared__ double scratch[64];
+    __shared__ double stage[256];
     const ProbDev &pr = probs[qlist[blockIdx.x]];
-    assemble_out(parts[pr.part], pr, c0_ptrs[blockIdx.x]);
+    assemble_out(parts[pr.part], pr, c0_ptrs[blockIdx.x], scratch, stage);
 }
 
 __global__ void __launch_bounds__(1024)
@@ -406,19 +457,20 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
 {
 #pragma clang fp contract(off)
     __shared__ double scratch[64];
+    __shared__ double stage[1024];
     const int q = blockIdx.x;
     if (q >= nprob) return;
     ProbDev &pr = probs[q];
     const int phase = pr.phase;
     if (phase == PH_DONE) return;
     const PartDev &pa = parts[pr.part];
-    const int n = pa.n_local, nf = pa.n_feat;
+    const int n = pa.n_local;
     const int tid = threadIdx.x, nt = blockDim.x;
     double *__restrict__ w = pr.w, *__restrict__ w_new = pr.w_new, *__restrict__ g = pr.g;
     double *__restrict__ s = pr.s, *__restrict__ r = pr.r, *__restrict__ d = pr.d, *__restrict__ Hd = pr.Hd;
     const double *__restrict__ m = pr.m;
 
-    assemble_out(pa, pr, Hd);
+    assemble_out(pa, pr, Hd, scratch, stage);
     __syncthreads();
 
     const double rTr0 = pr.rTr, delta0 = pr.delta, cgtol0 = pr.cgtol, eps0 = pr.eps, gnorm1_0 = pr.gnorm1;
@@ -514,8 +566,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
         Hd[j] = t * pj + Hd[j];                                     // grad :224 (multiplier 1)
     }
     block_allreduce_sum<1>(a1, scratch);
-    double loss = 0.0;
-    for (int p = 0; p < pa.nblk; p++) loss += pr.lossp[p];          // every thread, same order
+    const double loss = block_sum_array(pr.lossp, pa.dense ? pr.cur_nblk : pa.nblk, scratch);
     double fnew = 2.0 * loss;
     fnew = fnew + a1[0];
     fnew = fnew / 2.0;
@@ -736,10 +787,10 @@ __global__ void k_round_z(int64_t n, const double *__restrict__ Z, float *__rest
 // ------------------------------------------------------------------------------------------------
 #define LAUNCH_DENSE(NV, U)                                                                                   \
     hipLaunchKernelGGL((k_xpass_dense<NV, U>), dim3(maxblk, nq), dim3(256), (4 * NV * 256 + 16) * sizeof(double), \
-                       st, parts, probs, qlist)
+                       st, parts, probs, qlist, nrun, done_counter, target_wgs)
 
 int mlxk_xpass_dense(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
-                     int max_nfeat)
+                     int max_nfeat, int nrun, const int *done_counter, int target_wgs)
 {
     if (nq <= 0) return 0;
     if (max_nfeat <= 256) LAUNCH_DENSE(1, 8);

@@ -139,7 +139,7 @@ def test_dense_tile_path_equals_csr_path_and_oracle():
 @pytest.mark.parametrize("binary", [False, True])
 def test_sparse_absent_features_weights_offsets(binary):
     """Partition-local feature spaces (absent features keep z-u), instance weights, offsets, binary.feature."""
-    pd = synth_sparse(21 + binary, 3000, 400, 6, 5, binary=binary, weights=True, offsets=True)
+    pd = synth_sparse(21 + binary, 3000, 2500, 6, 5, binary=binary, weights=True, offsets=True)
     assert any(b.n_local < pd.n_global for b in pd.blocks)
     lam, rho = [0.5, 200.0], [1.0, 10.0]
     oc = ol.OracleAdmm(pd.blocks, pd.n_global, lam, rho)
