@@ -93,7 +93,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:          # under torch.distributed.run also at N=1 (RCCL path)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)

@@ -254,3 +254,29 @@ def test_full_size_partition_properties():
     wo, st = ol.OracleDataset.from_block(pdm.blocks[0]).train(np.zeros(n), pm, pv, 0.01)
     assert (cnt[0], cnt[2]) == (st.newton_iters, st.cg_iters)
     assert np.max(np.abs(w - wo)) <= 1e-9 * np.max(np.abs(wo))
+
+
+def test_library_rccl_communicator_single_rank(c1):
+    """mlx_comm_init + the all-reduce inside mlx_admm_iterate (RCCL), world size 1: same result as without."""
+    a = make_engine(c1, [1.0], [1.0])
+    b = make_engine(c1, [1.0], [1.0])
+    b.comm_init(HipAdmmEngine.comm_unique_id(), 1, 0)
+    for _ in range(2):
+        a.iterate(0.01)
+        b.iterate(0.01)
+    assert np.array_equal(a.z()[0], b.z()[0])
+
+
+def test_split_api_with_torch_alias_tensor(c1):
+    """solve_local -> (caller all-reduce on the aliased [xbar|ubar] tensor) -> consensus_finish == iterate."""
+    import torch
+    a = make_engine(c1, [1.0, 10.0], [1.0, 1.0])
+    b = make_engine(c1, [1.0, 10.0], [1.0, 1.0])
+    for _ in range(2):
+        a.iterate(0.01)
+        b.solve_local(0.01)
+        t = b.consensus_tensor()
+        assert t.is_cuda and t.dtype == torch.float64 and t.numel() == 2 * 2 * c1.n_global
+        t.mul_(1.0)                      # touches the library's buffer in place through torch
+        b.consensus_finish()
+    assert np.array_equal(a.z()[0], b.z()[0])
