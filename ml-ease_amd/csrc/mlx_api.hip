@@ -28,6 +28,7 @@ struct PartHost {
     int pid = 0, l = 0, n_local = 0, n_feat = 0;
     bool dense = false, hasval = false, all_present = false;
     int64_t nnz = 0, ld = 0;
+    int n_short = 0, n_long = 0;
     int nblk = 0, nblk_min = 1, rows_per_blk = 0, n_items = 0, rowgroup = 64, pos = 0, neg = 0;
     PartDev dev{};
     double *c0 = nullptr;
@@ -54,7 +55,7 @@ struct mlx_context {
     std::vector<ProbDev> h_probs;
     int *d_qdense = nullptr, *d_qcsr = nullptr, *d_qscratch = nullptr;
     int nq_dense = 0, nq_csr = 0;
-    int maxblk_dense = 0, maxblk_csr = 0, max_nfeat_dense = 0, max_items = 0, rowgroup = 64, max_nlocal = 0, max_l = 0;
+    int maxblk_dense = 0, maxblk_csr = 0, max_nfeat_dense = 0, max_items = 0, max_short = 0, max_long = 0, rowgroup = 64, max_nlocal = 0, max_l = 0;
     int64_t max_parts_len = 0;
     bool csr_hasval = false, any_absent = false;
     int step_threads = 256;
@@ -193,7 +194,7 @@ int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
     if (h->profiling) { e0 = next_event(h); e1 = next_event(h); hipEventRecord(e0, h->stream); }
     if (nqd > 0 && mlxk_xpass_dense(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->maxblk_dense, h->max_nfeat_dense, nrun, h->d_done, h->target_wgs))
         return fail(h, MLX_ERR_INVALID, "dense tile wider than 2048 features is not supported; use the CSR form");
-    if (nqc > 0) mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_items, h->rowgroup, h->csr_hasval);
+    if (nqc > 0) mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_short, h->max_long, h->rowgroup, h->csr_hasval);
     if (h->profiling) hipEventRecord(e1, h->stream);
     return MLX_OK;
 }
@@ -398,10 +399,13 @@ int mlx_add_partition_csr(mlx_handle h, int32_t partition_id, int32_t l, int32_t
     col_item[nf] = (int32_t)item_ptr.size();
     ph.n_items = (int)item_ptr.size();
     item_ptr.push_back((int32_t)nnz);
+    std::vector<int32_t> ishort, ilong;
+    for (int it = 0; it < ph.n_items; it++) (item_ptr[it + 1] - item_ptr[it] > 64 ? ilong : ishort).push_back(it);
+    ph.n_short = (int)ishort.size(); ph.n_long = (int)ilong.size();
     // row pass geometry
     const double avg = l ? (double)nnz / l : 0.0;
     int G = 8;
-    while (G < 64 && avg > 4.0 * G) G *= 2;
+    while (G < 64 && avg > 4.0 * G) G *= 2;        // one round = G lanes x 4 entries
     ph.rowgroup = G;
     const int gpb = 256 / G;
     int rpb = std::max(gpb * 4, (l + 1023) / 1024);
@@ -409,7 +413,7 @@ int mlx_add_partition_csr(mlx_handle h, int32_t partition_id, int32_t l, int32_t
     ph.rows_per_blk = rpb;
     ph.nblk = (l + rpb - 1) / rpb;
 
-    int32_t *d_rp, *d_ci, *d_cri, *d_item, *d_colitem, *d_l2g;
+    int32_t *d_rp, *d_ci, *d_cri, *d_item, *d_colitem, *d_l2g, *d_ishort, *d_ilong;
     float *d_val = nullptr, *d_cval = nullptr;
     if ((rc = dev_upload(h, &d_rp, rp.data(), rp.size()))) return rc;
     if ((rc = dev_upload(h, &d_ci, col_idx, (size_t)nnz))) return rc;
@@ -420,8 +424,11 @@ int mlx_add_partition_csr(mlx_handle h, int32_t partition_id, int32_t l, int32_t
     }
     if ((rc = dev_upload(h, &d_item, item_ptr.data(), item_ptr.size()))) return rc;
     if ((rc = dev_upload(h, &d_colitem, col_item.data(), col_item.size()))) return rc;
+    if ((rc = dev_upload(h, &d_ishort, ishort.data(), ishort.size()))) return rc;
+    if ((rc = dev_upload(h, &d_ilong, ilong.data(), ilong.size()))) return rc;
     if ((rc = dev_upload(h, &d_l2g, local_to_global, (size_t)n_local))) return rc;
     ph.dev.rp = d_rp; ph.dev.ci = d_ci; ph.dev.val = d_val; ph.dev.cri = d_cri; ph.dev.cval = d_cval;
+    ph.dev.items_short = d_ishort; ph.dev.items_long = d_ilong; ph.dev.n_short = ph.n_short; ph.dev.n_long = ph.n_long;
     ph.dev.item_ptr = d_item; ph.dev.col_item = d_colitem; ph.dev.l2g = d_l2g; ph.dev.X = nullptr;
     if ((rc = upload_row_meta(h, ph, l, y, weight, offset, false))) return rc;
     return finish_part(h, ph);
@@ -493,6 +500,7 @@ int mlx_finalize(mlx_handle h)
         if (p.dense) { h->maxblk_dense = std::max(h->maxblk_dense, p.nblk); h->max_nfeat_dense = std::max(h->max_nfeat_dense, p.n_feat); }
         else {
             h->maxblk_csr = std::max(h->maxblk_csr, p.nblk); h->max_items = std::max(h->max_items, p.n_items);
+            h->max_short = std::max(h->max_short, p.n_short); h->max_long = std::max(h->max_long, p.n_long);
             h->csr_hasval = h->csr_hasval || p.hasval;
         }
         for (int li = 0; li < nl; li++) (p.dense ? qd : qc).push_back(k * nl + li);

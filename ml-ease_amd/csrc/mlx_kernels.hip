@@ -253,8 +253,12 @@ k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
 }
 
 // ------------------------------------------------------------------------------------------------
-// sparse X pass, part 1: CSR rows -> row coefficients (gather of v, G lanes per row)
+// sparse X pass, part 1: CSR rows -> row coefficients (gather of v)
 // ------------------------------------------------------------------------------------------------
+// G lanes per row, RU entries per lane per round: a round is ONE index load + ONE dependent gather per
+// lane with G*RU entries of the row in flight (20-nnz rows: one round at G=8). All loads are unconditional
+// with clamped addresses (a predicated load would be waited for individually, see k_xpass_dense).
+#define RU 4
 template <int G, bool HASVAL>
 __global__ void __launch_bounds__(256)
 k_rowpass_csr(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist)
@@ -284,12 +288,32 @@ k_rowpass_csr(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     for (int base = r0; base < r1; base += GPB) {
         const int row = base + gid;
         const bool valid = row < r1;
+        const int rowc = min(row, r1 - 1);
+        const int k0 = rp[rowc];
+        const int k1 = valid ? rp[rowc + 1] : k0;
+        // row metadata early, so its latency overlaps the gathers
+        const double wdv0 = cg ? wdcur[rowc] : 0.0;
+        const float offv = cg ? 0.f : pa.off[rowc];
+        const float wtv = cg ? 0.f : pa.wt[rowc];
+        const int yv = cg ? 0 : (int)pa.y[rowc];
         double a = 0.0;
-        if (valid) {
-            const int k0 = rp[row], k1 = rp[row + 1];
-            for (int k = k0 + gl; k < k1; k += G) {
-                const double xv = HASVAL ? (double)val[k] : 1.0;
-                a += v[ci[k]] * xv;
+        for (int kb = k0; kb < k1; kb += G * RU) {
+            int idx[RU];
+            float xv[RU];
+#pragma unroll
+            for (int u = 0; u < RU; u++) {
+                const int kc = min(kb + gl + u * G, k1 - 1);
+                idx[u] = ci[kc];
+                if (HASVAL) xv[u] = val[kc];
+            }
+            double vv[RU];
+#pragma unroll
+            for (int u = 0; u < RU; u++) vv[u] = v[idx[u]];
+#pragma unroll
+            for (int u = 0; u < RU; u++) {
+                const bool in = (kb + gl + u * G) < k1;
+                const double term = HASVAL ? vv[u] * (double)xv[u] : vv[u];
+                a += in ? term : 0.0;
             }
         }
         a = group_allreduce_sum<G>(a);
@@ -297,10 +321,10 @@ k_rowpass_csr(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
             const double t = a + vb;
             double cf;
             if (cg) {
-                cf = wdcur[row] * t;
+                cf = wdv0 * t;
             } else {
                 double loss, wdv;
-                row_eval(t + (double)pa.off[row], (int)pa.y[row], (double)pa.wt[row], loss, wdv, cf);
+                row_eval(t + (double)offv, yv, (double)wtv, loss, wdv, cf);
                 wdnew[row] = wdv;
                 red[0] += loss;
             }
@@ -313,31 +337,53 @@ k_rowpass_csr(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
 }
 
 // ------------------------------------------------------------------------------------------------
-// sparse X pass, part 2: CSC column segments -> X' coef (gather of coef, 8 lanes per segment)
+// sparse X pass, part 2: CSC column segments ("items", <= 512 entries) -> X' coef (gather of coef)
 // ------------------------------------------------------------------------------------------------
-template <bool HASVAL>
+// One round per item: G lanes x CU entries in flight. Short items (<= 64 entries: the long tail of
+// rare features, mostly 1-3 entries) take an 8-lane group; long items (65..512) a whole wave.
+#define CU 8
+template <int G, bool HASVAL>
 __global__ void __launch_bounds__(256)
-k_colpass_csc(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist)
+k_colpass_items(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist)
 {
     const int q = qlist[blockIdx.y];
     ProbDev &pr = probs[q];
     if (pr.phase == PH_DONE) return;
     const PartDev &pa = parts[pr.part];
-    const int item = blockIdx.x * 32 + (threadIdx.x >> 3);
-    const int gl = threadIdx.x & 7;
-    const bool valid = item < pa.n_items;
+    constexpr bool LONG = (G == 64);
+    const int nlist = LONG ? pa.n_long : pa.n_short;
+    const int32_t *__restrict__ list = LONG ? pa.items_long : pa.items_short;
+    const int slot = blockIdx.x * (256 / G) + threadIdx.x / G;
+    const int gl = threadIdx.x % G;
+    if (blockIdx.x * (256 / G) >= nlist) return;
+    const bool valid = slot < nlist;
+    const int item = list[min(slot, nlist - 1)];
+    const double *__restrict__ coef = pr.coef;
+    const int32_t *__restrict__ cri = pa.cri;
+    const float *__restrict__ cval = pa.cval;
+    const int k0 = pa.item_ptr[item];
+    const int k1 = valid ? pa.item_ptr[item + 1] : k0;
     double a = 0.0;
-    if (valid) {
-        const double *__restrict__ coef = pr.coef;
-        const int32_t *__restrict__ cri = pa.cri;
-        const float *__restrict__ cval = pa.cval;
-        const int k0 = pa.item_ptr[item], k1 = pa.item_ptr[item + 1];
-        for (int k = k0 + gl; k < k1; k += 8) {
-            const double xv = HASVAL ? (double)cval[k] : 1.0;
-            a += coef[cri[k]] * xv;
+    for (int kb = k0; kb < k1; kb += G * CU) {
+        int idx[CU];
+        float xv[CU];
+#pragma unroll
+        for (int u = 0; u < CU; u++) {
+            const int kc = min(kb + gl + u * G, k1 - 1);
+            idx[u] = cri[kc];
+            if (HASVAL) xv[u] = cval[kc];
+        }
+        double cc[CU];
+#pragma unroll
+        for (int u = 0; u < CU; u++) cc[u] = coef[idx[u]];
+#pragma unroll
+        for (int u = 0; u < CU; u++) {
+            const bool in = (kb + gl + u * G) < k1;
+            const double term = HASVAL ? cc[u] * (double)xv[u] : cc[u];
+            a += in ? term : 0.0;
         }
     }
-    a = group_allreduce_sum<8>(a);
+    a = group_allreduce_sum<G>(a);
     if (valid && gl == 0) pr.parts[item] = a;
 }
 
@@ -818,7 +864,7 @@ static void launch_rowpass(hipStream_t st, const PartDev *parts, ProbDev *probs,
 }
 
 int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
-                   int max_items, int rowgroup, bool hasval)
+                   int max_short, int max_long, int rowgroup, bool hasval)
 {
     if (nq <= 0) return 0;
     switch (rowgroup) {
@@ -827,10 +873,14 @@ int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const i
     case 32: launch_rowpass<32>(st, parts, probs, qlist, nq, maxblk, hasval); break;
     default: launch_rowpass<64>(st, parts, probs, qlist, nq, maxblk, hasval); break;
     }
-    const int gx = (max_items + 31) / 32;
-    if (gx > 0) {
-        if (hasval) hipLaunchKernelGGL((k_colpass_csc<true>), dim3(gx, nq), dim3(256), 0, st, parts, probs, qlist);
-        else hipLaunchKernelGGL((k_colpass_csc<false>), dim3(gx, nq), dim3(256), 0, st, parts, probs, qlist);
+    const int gs = (max_short + 31) / 32, gl = (max_long + 3) / 4;
+    if (gl > 0) {
+        if (hasval) hipLaunchKernelGGL((k_colpass_items<64, true>), dim3(gl, nq), dim3(256), 0, st, parts, probs, qlist);
+        else hipLaunchKernelGGL((k_colpass_items<64, false>), dim3(gl, nq), dim3(256), 0, st, parts, probs, qlist);
+    }
+    if (gs > 0) {
+        if (hasval) hipLaunchKernelGGL((k_colpass_items<8, true>), dim3(gs, nq), dim3(256), 0, st, parts, probs, qlist);
+        else hipLaunchKernelGGL((k_colpass_items<8, false>), dim3(gs, nq), dim3(256), 0, st, parts, probs, qlist);
     }
     return 0;
 }

@@ -29,6 +29,9 @@ struct PartDev {
     const int32_t *item_ptr;   // [n_items+1] CSC segments (<= SEG entries each), columns in order
     const int32_t *col_item;   // [n_feat+1] first item of each column
     int32_t n_items;
+    const int32_t *items_short;  // item ids with <= 64 entries (8-lane groups)
+    const int32_t *items_long;   // item ids with 65..512 entries (one wave each)
+    int32_t n_short, n_long;
     int32_t rowgroup;      // lanes per row in the CSR row pass (8..64)
     const int8_t *y;       // +1/-1
     const float *wt;       // instance weight

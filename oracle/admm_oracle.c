@@ -386,6 +386,8 @@ typedef struct orc_admm {
     int nlambda;
     float *lambda, *rho; /* sorted ascending by lambda (jobs/RegressionAdmmTrain.java:636-638) */
     int penalize_intercept;
+    int regularizer;     /* 2 = L2 (default), 1 = L1 (jobs/RegressionAdmmTrain.java:143-147,378,406) */
+    float *lambda_map;   /* NULL or [n_global] per-feature lambda, NaN = none (lambda.map, :188-197,383-386) */
     orc_dataset **ds;    /* [nlocal] (borrowed) */
     int **l2g;           /* [nlocal][n_local] local->global */
     double *Z;           /* [nlambda][n_global] driver z, double (jobs/...:155,365-405) */
@@ -403,6 +405,8 @@ orc_admm *orc_admm_create(int nblocks, int nlocal, int n_global, int nlambda, co
     orc_admm *a = (orc_admm *)calloc(1, sizeof(*a));
     a->nblocks = nblocks; a->nlocal = nlocal; a->n_global = n_global; a->nlambda = nlambda;
     a->penalize_intercept = penalize_intercept;
+    a->regularizer = 2;
+    a->lambda_map = NULL;
     a->lambda = (float *)malloc(sizeof(float) * (size_t)nlambda);
     a->rho = (float *)malloc(sizeof(float) * (size_t)nlambda);
     memcpy(a->lambda, lambda, sizeof(float) * (size_t)nlambda);
@@ -424,8 +428,20 @@ void orc_admm_destroy(orc_admm *a)
 {
     if (!a) return;
     for (int k = 0; k < a->nlocal; k++) free(a->l2g[k]);
+    free(a->lambda_map);
     free(a->lambda); free(a->rho); free(a->ds); free(a->l2g); free(a->Z); free(a->xbar); free(a->ubar);
     free(a->u); free(a->B); free(a->UPX); free(a->stats); free(a);
+}
+
+void orc_admm_set_options(orc_admm *a, int regularizer, const float *lambda_map)
+{
+    a->regularizer = regularizer;
+    free(a->lambda_map);
+    a->lambda_map = NULL;
+    if (lambda_map) {
+        a->lambda_map = (float *)malloc(sizeof(float) * (size_t)a->n_global);
+        memcpy(a->lambda_map, lambda_map, sizeof(float) * (size_t)a->n_global);
+    }
 }
 
 void orc_admm_set_partition(orc_admm *a, int k, orc_dataset *d, const int32_t *local_to_global)
@@ -518,12 +534,26 @@ void orc_admm_finish(orc_admm *a, double *maxdiff_out, double *mindiff_out)
         double *Z = a->Z + (size_t)li * ng;
         const double *xb = a->xbar + (size_t)li * ng, *ub = a->ubar + (size_t)li * ng;
         float l = a->lambda[li], r = a->rho[li];
-        double weight = a->nblocks * r / (l + a->nblocks * r);   /* float arithmetic, then widened: :374-381 */
+        double weight;
+        if (a->regularizer == 2) weight = a->nblocks * r / (l + a->nblocks * r);   /* float arithmetic, then widened: :374-381 */
+        else weight = l / (r * a->nblocks + 0.0);                                   /* L1 threshold :411 */
         double diff = 0;
         for (size_t j = 0; j < ng; j++) {
             double zn;
-            if (j == ng - 1 && !a->penalize_intercept) zn = xb[j] + ub[j];      /* :392-403 */
-            else { zn = 0 + weight * xb[j]; zn = 1.0 * zn + weight * ub[j]; }   /* :387-391 */
+            int icpt = (j == ng - 1);
+            if (icpt && !a->penalize_intercept) zn = xb[j] + ub[j];                  /* :392-403 / :438-449 */
+            else if (a->regularizer == 2) {
+                double c = weight;
+                if (!icpt && a->lambda_map && !isnan(a->lambda_map[j]))              /* weightmap :383-386 */
+                    c = a->nblocks * r / (a->lambda_map[j] + a->nblocks * r + 0.0);
+                zn = 0 + c * xb[j]; zn = 1.0 * zn + c * ub[j];                       /* :387-391 */
+            } else {
+                zn = 0 + 1.0 * xb[j]; zn = 1.0 * zn + 1.0 * ub[j];                   /* :418-422 */
+                if (!icpt) {                                                          /* iterative thresholding :424-436 */
+                    if (zn > weight) zn = zn - weight;
+                    else if (zn < -weight) zn = zn + weight;
+                }
+            }
             double dv = fabs(1 * Z[j] + -1 * zn);                               /* :463-464 */
             if (diff < dv) diff = dv;
             Z[j] = zn;

@@ -73,3 +73,39 @@ def synth_sparse(seed, nrows, nfeat, nnz_per_row, num_blocks, binary=False, weig
     for c, g in gseen.items():
         names[g] = "f%d" % c
     return PartitionedData(out, names, num_blocks)
+
+
+def onehot_blocks(rows, partitions, seed=5, fields=20, levels=5000):
+    """BASELINE configs[2]-style data at any scale: `fields` categorical fields x `levels` one-hot binary features,
+    Zipf(1.1) levels, rare positives (intercept -3); partition-local compaction (sorted local ids)."""
+    rng = np.random.default_rng(seed)
+    p = np.arange(1, levels + 1, dtype=np.float64) ** -1.1
+    cdf = np.cumsum(p / p.sum())
+    beta = rng.normal(0, 0.3, fields * levels)
+    ng = fields * levels + 1
+    blocks = []
+    per = (rows + partitions - 1) // partitions
+    for k in range(partitions):
+        l = min(per, rows - k * per)
+        lev = np.minimum(np.searchsorted(cdf, rng.random((l, fields))).astype(np.int32), levels - 1)
+        gid = lev + (np.arange(fields, dtype=np.int32) * levels)[None, :]
+        logit = beta[gid].sum(axis=1) - 3.0
+        y = np.where(rng.random(l) < 1 / (1 + np.exp(-logit)), 1, -1).astype(np.int8)
+        uniq, inv = np.unique(gid.reshape(-1), return_inverse=True)
+        ci = np.sort(inv.reshape(l, fields).astype(np.int32), axis=1).reshape(-1)
+        blocks.append(PartitionBlock(k, l, len(uniq) + 1, np.arange(0, (l + 1) * fields, fields, dtype=np.int64), ci, None, y,
+                                     np.ones(l, np.float32), np.zeros(l, np.float32),
+                                     np.concatenate([uniq.astype(np.int32), [ng - 1]]).astype(np.int32)))
+    return PartitionedData(blocks, [str(i) for i in range(ng - 1)], partitions)
+
+
+def permute_rows(b, seed=0):
+    """Same partition, rows in another order (the reference's row order within a reducer key is unspecified)."""
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(b.l)
+    lens = np.diff(b.row_ptr)
+    rp = np.concatenate([[0], np.cumsum(lens[perm])]).astype(np.int64)
+    starts = np.repeat(b.row_ptr[:-1][perm] - rp[:-1], lens[perm])
+    idx = np.arange(rp[-1], dtype=np.int64) + starts
+    return PartitionBlock(b.partition_id, b.l, b.n_local, rp, b.col_idx[idx], None if b.val is None else b.val[idx],
+                          b.y[perm], b.weight[perm], b.offset[perm], b.local_to_global)

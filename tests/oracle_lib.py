@@ -49,6 +49,7 @@ def lib():
         L.orc_admm_create.argtypes = [i32, i32, i32, i32, vp, vp, i32]
         L.orc_admm_destroy.argtypes = [vp]
         L.orc_admm_set_partition.argtypes = [vp, i32, vp, vp]
+        L.orc_admm_set_options.argtypes = [vp, i32, vp]
         L.orc_admm_solve_local.argtypes = [vp, f64, f32, i32]
         L.orc_admm_xbar.restype = C.POINTER(C.c_double)
         L.orc_admm_xbar.argtypes = [vp]
@@ -118,7 +119,8 @@ class OracleAdmm:
     """The reference ADMM loop over in-memory partition blocks (CPU oracle)."""
 
     def __init__(self, blocks: Sequence, n_global: int, lambdas: Sequence[float], rhos: Sequence[float],
-                 num_blocks: Optional[int] = None, penalize_intercept: bool = False):
+                 num_blocks: Optional[int] = None, penalize_intercept: bool = False, regularizer: int = 2,
+                 lambda_map: Optional[np.ndarray] = None):
         order = np.argsort(np.asarray(lambdas, dtype=np.float32), kind="stable")
         self.lambdas = np.ascontiguousarray(np.asarray(lambdas, dtype=np.float32)[order])
         self.rhos = np.ascontiguousarray(np.asarray(rhos, dtype=np.float32)[order])
@@ -127,6 +129,9 @@ class OracleAdmm:
         self.ng, self.nl = int(n_global), len(lambdas)
         self.h = lib().orc_admm_create(self.N, self.nlocal, self.ng, self.nl, _p(self.lambdas), _p(self.rhos),
                                        int(penalize_intercept))
+        if regularizer != 2 or lambda_map is not None:
+            lm = None if lambda_map is None else np.ascontiguousarray(lambda_map, np.float32)
+            lib().orc_admm_set_options(self.h, int(regularizer), _p(lm))
         self.ds: List[OracleDataset] = []
         for k, b in enumerate(blocks):
             d = OracleDataset.from_block(b)
