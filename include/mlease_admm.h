@@ -158,6 +158,17 @@ int mlx_get_partition_model(mlx_handle h, int32_t local_index, int32_t lambda_in
  * x_passes_ref for q = local_index*n_lambda + lambda_index. */
 int mlx_get_solve_counters(mlx_handle h, int32_t *out);
 
+/* ---- test log-likelihood per iteration (jobs/RegressionAdmmTrain.java:766-811, updateLogLikBestModel :812-845) ----
+ * Upload the test rows once (the reference re-reads the first file under test.path, <= 1 000 000 rows, every
+ * iteration): CSR with GLOBAL feature ids (-1 = name absent from the model: skipped as LinearModel.eval does,
+ * models/LinearModel.java:251), val NULL for binary.feature, response[l] as read (1 / 0 / -1), weight[l] and
+ * offset[l] as the doubles Util.getDoubleAvro yields (NULL = 1 / 0). */
+int mlx_set_test_data(mlx_handle h, int32_t l, int64_t nnz, const int64_t *row_ptr, const int32_t *global_idx,
+                      const float *val, const int8_t *response, const double *weight, const double *offset);
+/* loglik_sum[n_lambda] = sum_i evalInstanceAvro(record_i, loglik=true, 1, ignore_value) with the CURRENT driver z
+ * (double); the caller divides by its sum of weights n (:792-807). */
+int mlx_test_loglik(mlx_handle h, double *loglik_sum);
+
 /* ---- unit-test seam S2 == LibLinear.train (liblinearfunc/LibLinear.java:200-228) ---------------
  * Solve ONE problem on local partition `local_index` with explicit dense arrays in the partition's
  * LOCAL index space: w[n_local] holds initParam on entry and the TRON result on exit;

@@ -154,6 +154,7 @@ class IterationRecord:
     maxdiff: float
     mindiff: float
     stats: Any = None
+    test_loglik: Optional[Dict[str, float]] = None      # lambda key -> mean weighted test log-likelihood
 
 
 class AdmmTrain:
@@ -172,6 +173,28 @@ class AdmmTrain:
         self.engine = engine
         self.all_reduce = all_reduce
         self.history: List[IterationRecord] = []
+        self.test_n: Optional[float] = None             # sum of test weights; set by attach_test_rows
+        self.best_test_loglik = np.float32(-9999999)    # MutableFloat(-9999999), :234
+        self.best_model = None                          # (iteration, lambda key, float32 z) like best-model/best-iteration-i.avro
+
+    def attach_test_rows(self, rows) -> None:
+        """test.path handling (:203-232): upload the first file's rows once; loglik is then drawn every iteration."""
+        self.engine.set_test_data(rows.row_ptr, rows.global_idx, rows.val, rows.response, rows.weight, rows.offset)
+        self.test_n = float(rows.n)
+
+    def _update_loglik_best_model(self, niter: int) -> Dict[str, float]:
+        """updateLogLikBestModel (:812-845): loglik[lambda] = sum / n; best model when loglik > best (float compare), niter > 0."""
+        lam, _ = self.cfg.sorted_lambda_rho()
+        sums = self.engine.test_loglik_sums()
+        out: Dict[str, float] = {}
+        for li, l in enumerate(lam):
+            key = java_float_to_string(l)
+            ll = float(sums[li]) / self.test_n
+            out[key] = ll
+            if ll > float(self.best_test_loglik) and niter > 0:
+                self.best_model = (niter, key, self.engine.z()[1][li].copy())
+                self.best_test_loglik = np.float32(ll)
+        return out
 
     def rho_adapt_rate(self, i: int) -> float:
         """conf RHO_ADAPT_RATE for iteration i (:313-317,323-327); once set it stays in the conf."""
@@ -200,6 +223,8 @@ class AdmmTrain:
             fin = self.engine.consensus_finish()
             maxdiff, mindiff = float(fin.maxdiff), float(fin.mindiff)
             rec = IterationRecord(i, eps, rate, maxdiff, mindiff, st)
+            if self.test_n is not None:
+                rec.test_loglik = self._update_loglik_best_model(i)
             self.history.append(rec)
             if callback is not None:
                 callback(rec)
@@ -231,6 +256,15 @@ def write_linear_models(path: str, models: Dict[str, np.ndarray], feature_names:
     """utils/LinearModelUtils.java:39-53 (``final-model/part-r-00000.avro``, ``iter-i/init-value`` ...)."""
     recs = [{"key": k, "model": model_to_avro(v, feature_names)} for k, v in models.items()]
     avro_io.write_container(path, avro_io.LINEAR_MODEL_SCHEMA, recs)
+
+
+def sample_test_loglik_records(history: Sequence[IterationRecord]) -> List[Dict[str, Any]]:
+    """sample-test-loglik/iteration-i.avro records (avro/SampleTestLoglik.avsc; testLoglik stored as float, :828)."""
+    out = []
+    for h in history:
+        for key, ll in (h.test_loglik or {}).items():
+            out.append({"lambda": key, "iter": h.iteration, "testLoglik": float(np.float32(ll))})
+    return out
 
 
 def read_linear_models(path: str, feature_names: Sequence[str]) -> Dict[str, np.ndarray]:

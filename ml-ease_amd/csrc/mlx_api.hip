@@ -77,6 +77,11 @@ struct mlx_context {
     // scratch vectors of the solve_one problem
     double *sc_vec[8] = {nullptr}, *sc_pinv = nullptr;
 
+    // test set (K15)
+    int test_l = 0;
+    int64_t *t_rp = nullptr; int32_t *t_gi = nullptr; float *t_val = nullptr; int8_t *t_y = nullptr;
+    double *t_wt = nullptr, *t_off = nullptr, *t_part = nullptr;
+
     ncclComm_t comm = nullptr;
     int comm_nranks = 1;
 
@@ -773,6 +778,52 @@ int mlx_get_partition_model(mlx_handle h, int32_t local_index, int32_t lambda_in
     if (beta) HIPCHECK(h, hipMemcpy(beta, h->d_B + off, sizeof(float) * ng, hipMemcpyDeviceToHost));
     if (uplusx) HIPCHECK(h, hipMemcpy(uplusx, h->d_UPX + off, sizeof(float) * ng, hipMemcpyDeviceToHost));
     if (u_next) HIPCHECK(h, hipMemcpy(u_next, h->d_u + off, sizeof(float) * ng, hipMemcpyDeviceToHost));
+    return MLX_OK;
+}
+
+int mlx_set_test_data(mlx_handle h, int32_t l, int64_t nnz, const int64_t *row_ptr, const int32_t *global_idx,
+                      const float *val, const int8_t *response, const double *weight, const double *offset)
+{
+    if (!h || !h->problem_set) return fail(h, MLX_ERR_INVALID, "mlx_set_problem first");
+    if (l <= 0 || !row_ptr || (nnz > 0 && !global_idx) || !response) return fail(h, MLX_ERR_INVALID, "bad test data");
+    if (row_ptr[0] != 0 || row_ptr[l] != nnz) return fail(h, MLX_ERR_INVALID, "row_ptr[0] must be 0 and row_ptr[l] == nnz");
+    hipSetDevice(h->device);
+    for (int64_t k = 0; k < nnz; k++)
+        if (global_idx[k] >= h->n_global - 1) return fail(h, MLX_ERR_INVALID, "test feature id %d out of range", global_idx[k]);
+    for (int i = 0; i < l; i++)
+        if (response[i] != 1 && response[i] != 0 && response[i] != -1) return fail(h, MLX_ERR_MODEL_FITTING, "response = %d", (int)response[i]);
+    int rc;
+    std::vector<double> w(l, 1.0), o(l, 0.0);
+    if (weight) w.assign(weight, weight + l);
+    if (offset) o.assign(offset, offset + l);
+    if ((rc = dev_upload(h, &h->t_rp, row_ptr, (size_t)l + 1))) return rc;
+    if ((rc = dev_upload(h, &h->t_gi, global_idx, (size_t)nnz))) return rc;
+    h->t_val = nullptr;
+    if (val && (rc = dev_upload(h, &h->t_val, val, (size_t)nnz))) return rc;
+    if ((rc = dev_upload(h, &h->t_y, response, (size_t)l))) return rc;
+    if ((rc = dev_upload(h, &h->t_wt, w.data(), (size_t)l))) return rc;
+    if ((rc = dev_upload(h, &h->t_off, o.data(), (size_t)l))) return rc;
+    if ((rc = dev_alloc(h, &h->t_part, (size_t)((l + 31) / 32) * h->n_lambda))) return rc;
+    h->test_l = l;
+    return MLX_OK;
+}
+
+int mlx_test_loglik(mlx_handle h, double *loglik_sum)
+{
+    if (!h || !h->finalized || !loglik_sum) return fail(h, MLX_ERR_INVALID, "mlx_finalize first");
+    if (h->test_l <= 0) return fail(h, MLX_ERR_INVALID, "no test data (mlx_set_test_data)");
+    hipSetDevice(h->device);
+    const int nb = (h->test_l + 31) / 32, nl = h->n_lambda;
+    mlxk_test_loglik(h->stream, h->test_l, nl, h->n_global, h->t_rp, h->t_gi, h->t_val, h->t_y, h->t_wt, h->t_off, h->d_Z, h->t_part);
+    std::vector<double> part((size_t)nb * nl);
+    HIPCHECK(h, hipMemcpyAsync(part.data(), h->t_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    HIPCHECK(h, hipGetLastError());
+    for (int li = 0; li < nl; li++) {
+        double acc = 0.0;
+        for (int b = 0; b < nb; b++) acc += part[(size_t)b * nl + li];      // rows in file order, block by block
+        loglik_sum[li] = acc;
+    }
     return MLX_OK;
 }
 

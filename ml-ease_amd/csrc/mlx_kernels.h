@@ -27,4 +27,6 @@ void mlxk_z_update(hipStream_t st, int n_lambda, int n_global, int regularizer, 
                    const double *weight_l, const double *cmap, const double *xbar, const double *ubar, double *Z,
                    float *z32, unsigned long long *diffbits);
 void mlxk_u_update(hipStream_t st, int nlocal, int n_lambda, int n_global, const float *UPX, const double *Z, float *u);
+void mlxk_test_loglik(hipStream_t st, int l, int n_lambda, int n_global, const int64_t *rp, const int32_t *gi,
+                      const float *val, const int8_t *y, const double *wt, const double *off, const double *Z, double *part);
 void mlxk_round_z(hipStream_t st, int64_t n, const double *Z, float *z32);

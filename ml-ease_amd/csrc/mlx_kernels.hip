@@ -823,6 +823,45 @@ k_u_update(int nlocal, int n_lambda, int n_global, const float *__restrict__ UPX
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// test log-likelihood of the consensus model z (jobs/RegressionAdmmTrain.java:766-811 ->
+// models/LinearModel.java:491-554, eval :241-257 with num_click_replicates = 1): per row
+//   xbeta = offset + ( -log(0 + 1*exp(-intercept)) + sum_j z[j] * x_j ),
+//   ll = -log1p(exp(-xbeta)) * weight  if y == 1 else  -log1p(exp(xbeta)) * weight.
+// 8 lanes per row (global feature ids, -1 = feature not in the model), every lambda in one pass.
+// ------------------------------------------------------------------------------------------------
+template <bool HASVAL>
+__global__ void __launch_bounds__(256)
+k_test_loglik(int l, int n_lambda, int n_global, const int64_t *__restrict__ rp, const int32_t *__restrict__ gi,
+              const float *__restrict__ val, const int8_t *__restrict__ y, const double *__restrict__ wt,
+              const double *__restrict__ off, const double *__restrict__ Z, double *__restrict__ part)
+{
+    __shared__ double scratch[48];
+    constexpr int G = 8, GPB = 256 / G;
+    const int gid = threadIdx.x / G, gl = threadIdx.x % G;
+    const int row = blockIdx.x * GPB + gid;
+    const bool valid = row < l;
+    const int rowc = min(row, l - 1);
+    const int64_t k0 = rp[rowc], k1 = valid ? rp[rowc + 1] : k0;
+    for (int li = 0; li < n_lambda; li++) {
+        const double *__restrict__ z = Z + (int64_t)li * n_global;
+        double a = 0.0;
+        for (int64_t k = k0 + gl; k < k1; k += G) {
+            const int g = gi[k];
+            if (g >= 0) a += z[g] * (HASVAL ? (double)val[k] : 1.0);
+        }
+        a = group_allreduce_sum<G>(a);
+        double ll[1] = {0.0};
+        if (valid && gl == 0) {
+            const double base = -log(0.0 + 1.0 * exp(-z[n_global - 1]));
+            const double xbeta = off[row] + (base + a);
+            ll[0] = (y[row] == 1) ? -log1p(exp(-xbeta)) * wt[row] : -log1p(exp(xbeta)) * wt[row];
+        }
+        block_allreduce_sum<1>(ll, scratch);
+        if (threadIdx.x == 0) part[(int64_t)blockIdx.x * n_lambda + li] = ll[0];
+    }
+}
+
 __global__ void k_round_z(int64_t n, const double *__restrict__ Z, float *__restrict__ z32)
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) z32[i] = (float)Z[i];
@@ -940,6 +979,14 @@ void mlxk_u_update(hipStream_t st, int nlocal, int n_lambda, int n_global, const
     const int64_t all = (int64_t)nlocal * n_lambda * n_global;
     const int gx = (int)max((int64_t)1, min((int64_t)4096, (all + 255) / 256));
     hipLaunchKernelGGL(k_u_update, dim3(gx), dim3(256), 0, st, nlocal, n_lambda, n_global, UPX, Z, u);
+}
+
+void mlxk_test_loglik(hipStream_t st, int l, int n_lambda, int n_global, const int64_t *rp, const int32_t *gi,
+                      const float *val, const int8_t *y, const double *wt, const double *off, const double *Z, double *part)
+{
+    const int gx = (l + 31) / 32;
+    if (val) hipLaunchKernelGGL((k_test_loglik<true>), dim3(gx), dim3(256), 0, st, l, n_lambda, n_global, rp, gi, val, y, wt, off, Z, part);
+    else hipLaunchKernelGGL((k_test_loglik<false>), dim3(gx), dim3(256), 0, st, l, n_lambda, n_global, rp, gi, val, y, wt, off, Z, part);
 }
 
 void mlxk_round_z(hipStream_t st, int64_t n, const double *Z, float *z32)

@@ -248,3 +248,54 @@ def dense_partitions(X: np.ndarray, y01: np.ndarray, num_blocks: int, weight: Op
             (np.zeros(l, np.float32) if offset is None else offset[sel].astype(np.float32)),
             np.arange(nf + 1, dtype=np.int32)))
     return PartitionedData(blocks, [str(j + 1) for j in range(nf)], num_blocks)
+
+
+@dataclass
+class TestRows:
+    """Test rows of the per-iteration test-loglik (jobs/RegressionAdmmTrain.java:766-811) in GLOBAL feature ids."""
+    __test__ = False
+    row_ptr: np.ndarray          # int64 [l+1]
+    global_idx: np.ndarray       # int32 [nnz]; -1 = feature name not in the training dictionary (skipped by eval)
+    val: Optional[np.ndarray]    # float32 [nnz] or None (binary.feature -> value 1.0, models/LinearModel.java:532-534)
+    response: np.ndarray         # int8 [l] as read (1 / 0 / -1)
+    weight: np.ndarray           # float64 [l]  Util.getDoubleAvro(record, "weight"), default 1
+    offset: np.ndarray           # float64 [l]
+    n: float                     # sum of Double.parseDouble(record.get("weight").toString()) (:792-798)
+
+
+def build_test_rows(records: Iterable[Dict[str, Any]], feature_names: Sequence[str], binary_feature: bool = False,
+                    max_rows: int = 1000000) -> TestRows:
+    """RAW test records (same format as the training input) -> arrays; at most MAX_NTEST_EVENTS rows (:122,:799)."""
+    from .admm import java_float_to_string
+    index = {k: j for j, k in enumerate(feature_names)}
+    rp, gi, vv, ys, ws, os_ = [0], [], [], [], [], []
+    n = 0.0
+    for rec in records:
+        y = get_response(rec)
+        if y not in (1, 0, -1):
+            raise IOError("response = %d" % y)
+        feats = rec.get("features")
+        if feats is None:
+            raise IOError("features is null")
+        for f in feats:
+            name = str(f["name"])
+            term = "" if f.get("term") is None else str(f["term"])
+            gi.append(index.get(feature_key(name, term), -1))
+            if not binary_feature:
+                vv.append(np.float32(f["value"]))
+        rp.append(len(gi))
+        ys.append(y)
+        w = rec.get("weight")
+        ws.append(1.0 if w is None else float(w))
+        if w is None:
+            n += 1.0
+        elif isinstance(w, (int, np.integer)):
+            n += float(int(w))
+        else:       # a Float prints as the shortest float32 string, a Double as itself
+            n += float(java_float_to_string(w)) if float(np.float32(w)) == float(w) else float(w)
+        o = rec.get("offset")
+        os_.append(0.0 if o is None else float(o))
+        if len(ys) >= max_rows:
+            break
+    return TestRows(np.asarray(rp, np.int64), np.asarray(gi, np.int32), None if binary_feature else np.asarray(vv, np.float32),
+                    np.asarray(ys, np.int8), np.asarray(ws, np.float64), np.asarray(os_, np.float64), n)

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "mlx_create", "mlx_destroy", "mlx_last_error", "mlx_set_stream", "mlx_set_profiling", "mlx_set_problem",
     "mlx_set_regularizer", "mlx_add_partition_csr", "mlx_add_partition_dense", "mlx_finalize", "mlx_set_state",
     "mlx_admm_iterate", "mlx_admm_solve_local", "mlx_consensus_buffer", "mlx_admm_consensus_finish", "mlx_get_z",
-    "mlx_get_partition_model", "mlx_get_solve_counters", "mlx_solve_one", "mlx_comm_get_unique_id", "mlx_comm_init",
+    "mlx_get_partition_model", "mlx_get_solve_counters", "mlx_set_test_data", "mlx_test_loglik", "mlx_solve_one", "mlx_comm_get_unique_id", "mlx_comm_init",
     "mlx_version",
 ]
 
@@ -71,6 +71,8 @@ def load_library():
     L.mlx_get_z.argtypes = [vp, vp, vp]
     L.mlx_get_partition_model.argtypes = [vp, i32, i32, vp, vp, vp]
     L.mlx_get_solve_counters.argtypes = [vp, vp]
+    L.mlx_set_test_data.argtypes = [vp, i32, i64, vp, vp, vp, vp, vp, vp]
+    L.mlx_test_loglik.argtypes = [vp, vp]
     L.mlx_solve_one.argtypes = [vp, i32, vp, vp, vp, f64, i32, vp, vp, vp, vp]
     L.mlx_comm_get_unique_id.argtypes = [vp]
     L.mlx_comm_init.argtypes = [vp, vp, i32, i32]
@@ -204,6 +206,21 @@ class HipAdmmEngine:
         un = np.empty(self.n_global, np.float32)
         self._ck(self.L.mlx_get_partition_model(self.h, int(local_index), int(lambda_index), _p(b), _p(upx), _p(un)))
         return b, upx, un
+
+    def set_test_data(self, row_ptr, global_idx, val, response, weight=None, offset=None):
+        """Test rows in GLOBAL feature ids (-1 = not in the model); see mlx_set_test_data."""
+        rp = np.ascontiguousarray(row_ptr, np.int64)
+        gi = np.ascontiguousarray(global_idx, np.int32)
+        v = None if val is None else np.ascontiguousarray(val, np.float32)
+        y = np.ascontiguousarray(response, np.int8)
+        w = None if weight is None else np.ascontiguousarray(weight, np.float64)
+        o = None if offset is None else np.ascontiguousarray(offset, np.float64)
+        self._ck(self.L.mlx_set_test_data(self.h, len(rp) - 1, int(rp[-1]), _p(rp), _p(gi), _p(v), _p(y), _p(w), _p(o)))
+
+    def test_loglik_sums(self) -> np.ndarray:
+        out = np.zeros(self.n_lambda, np.float64)
+        self._ck(self.L.mlx_test_loglik(self.h, _p(out)))
+        return out
 
     def solve_counters(self) -> np.ndarray:
         out = np.zeros((self.nlocal * self.n_lambda, 4), np.int32)

@@ -611,6 +611,25 @@ void orc_admm_get_stats(const orc_admm *a, orc_tron_stats *out)
     memcpy(out, a->stats, sizeof(orc_tron_stats) * (size_t)a->nlocal * (size_t)a->nlambda);
 }
 
+/* Sum over test rows of LinearModel.evalInstanceAvro(record, loglik=true, num_click_replicates=1, ignore_value)
+ * for one model z (global index, intercept last): models/LinearModel.java:491-554 with eval :241-257;
+ * called per record by testloglik, jobs/RegressionAdmmTrain.java:779-791. gidx < 0 = name not in the model. */
+double orc_test_loglik_sum(int n_global, const double *z, int l, const int64_t *row_ptr, const int32_t *gidx,
+                           const float *val, const int8_t *response, const double *weight, const double *offset)
+{
+    double total = 0.0;
+    for (int i = 0; i < l; i++) {
+        double result = -log(1 - 1 + 1 * exp(-z[n_global - 1]));          /* :243-244 */
+        for (int64_t k = row_ptr[i]; k < row_ptr[i + 1]; k++)
+            if (gidx[k] >= 0) result += z[gidx[k]] * (val ? (double)val[k] : 1.0);   /* :249-255 */
+        double xbeta = (offset ? offset[i] : 0.0) + result;                /* :544 */
+        double w = weight ? weight[i] : 1.0;
+        if (response[i] == 1) total += -log1p(exp(-xbeta)) * w;            /* :545-552 */
+        else total += -log1p(exp(xbeta)) * w;
+    }
+    return total;
+}
+
 /* String.valueOf(float) -> Double.parseDouble round trip of liblinear.epsilon
  * (jobs/RegressionAdmmTrain.java:346,620,702 ; llf/LibLinear.java:128-131 ; utils/Util.java:145-155).
  * Shortest decimal that round-trips the float (== Float.toString digits for the

@@ -41,3 +41,10 @@ class OracleEngine:
 
     def z(self):
         return self.o.z()
+
+    def set_test_data(self, row_ptr, global_idx, val, response, weight=None, offset=None):
+        self._test = (row_ptr, global_idx, val, response, weight, offset)
+
+    def test_loglik_sums(self):
+        Z, _ = self.o.z()
+        return np.array([ol.test_loglik_sum(Z[li], *self._test) for li in range(Z.shape[0])])

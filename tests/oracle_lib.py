@@ -63,6 +63,8 @@ def lib():
         L.orc_admm_get_stats.argtypes = [vp, vp]
         L.orc_float_to_string_to_double.restype = f64
         L.orc_float_to_string_to_double.argtypes = [f32]
+        L.orc_test_loglik_sum.restype = f64
+        L.orc_test_loglik_sum.argtypes = [i32, vp, i32, vp, vp, vp, vp, vp, vp]
         L.orc_admm_run.restype = i32
         L.orc_admm_run.argtypes = [vp, i32, f64, i32, i32, vp, vp]
         _lib = L
@@ -193,6 +195,20 @@ class OracleAdmm:
             lib().orc_admm_destroy(self.h)
         except Exception:
             pass
+
+
+def test_loglik_sum(z, row_ptr, gidx, val, response, weight=None, offset=None) -> float:
+    z = np.ascontiguousarray(z, np.float64)
+    rp = np.ascontiguousarray(row_ptr, np.int64)
+    gi = np.ascontiguousarray(gidx, np.int32)
+    v = None if val is None else np.ascontiguousarray(val, np.float32)
+    y = np.ascontiguousarray(response, np.int8)
+    w = None if weight is None else np.ascontiguousarray(weight, np.float64)
+    o = None if offset is None else np.ascontiguousarray(offset, np.float64)
+    return lib().orc_test_loglik_sum(len(z), _p(z), len(rp) - 1, _p(rp), _p(gi), _p(v), _p(y), _p(w), _p(o))
+
+
+test_loglik_sum.__test__ = False
 
 
 def float_to_string_to_double(e) -> float:

@@ -322,3 +322,29 @@ def test_onehot_sparse_within_reference_order_spread():
     wo, _ = od.train(z, z, one, 0.01)
     wp, _ = odp.train(z, z, one, 0.01)
     assert np.max(np.abs(w - wo)) <= 4 * np.max(np.abs(wp - wo))
+
+
+def test_test_loglik_kernel_vs_oracle(c1):
+    """K15 on the GPU: sum_i evalInstanceAvro(..., loglik=true) for every lambda in one pass vs the oracle."""
+    from mlease_amd import dataset as ds
+    rng = np.random.default_rng(1)
+    b = c1.blocks[7]
+    gi = b.local_to_global[b.col_idx].astype(np.int32)
+    gi[rng.random(len(gi)) < 0.05] = -1                       # features the model does not know
+    resp = np.where(b.y == 1, 1, rng.integers(-1, 1, b.l)).astype(np.int8)
+    wt = rng.uniform(0.5, 3.0, b.l)
+    off = rng.normal(0, 0.3, b.l)
+    lam, rho = [1.0, 10.0, 100.0], [1.0, 1.0, 1.0]
+    eng = make_engine(c1, lam, rho)
+    eng.set_test_data(b.row_ptr, gi, b.val, resp, wt, off)
+    for it in range(3):
+        eng.iterate(0.01)
+        Z, _ = eng.z()
+        got = eng.test_loglik_sums()
+        for li in range(3):
+            want = ol.test_loglik_sum(Z[li], b.row_ptr, gi, b.val, resp, wt, off)
+            assert abs(got[li] - want) <= 1e-11 * abs(want)
+    eng.set_test_data(b.row_ptr, gi, None, resp, None, None)   # binary.feature, default weight / offset
+    got = eng.test_loglik_sums()
+    want = ol.test_loglik_sum(eng.z()[0][1], b.row_ptr, gi, None, resp, None, None)
+    assert abs(got[1] - want) <= 1e-11 * abs(want)

@@ -222,3 +222,47 @@ def test_two_rank_gloo_sharded_consensus(tmp_path):
     done, diffs, _ = oc.run(4)
     assert np.array_equal(z0.astype(np.float32), oc.z()[1])
     assert np.allclose(np.load(tmp_path / "d0.npy"), diffs, rtol=1e-12, atol=0)
+
+
+def _raw_records_from_block(b, names):
+    """Turn a partition block back into raw avro-like records (for test-set plumbing tests)."""
+    recs = []
+    for i in range(b.l):
+        sl = slice(b.row_ptr[i], b.row_ptr[i + 1])
+        feats = [{"name": names[b.local_to_global[c]], "term": "", "value": float(v)} for c, v in zip(b.col_idx[sl], b.val[sl])]
+        recs.append({"features": feats, "response": 1 if b.y[i] == 1 else 0, "weight": 1, "offset": 0})
+    return recs
+
+
+def test_test_loglik_per_iteration_and_best_model():
+    """N3: per-iteration test loglik (jobs/RegressionAdmmTrain.java:766-845) through the driver, checked against a
+    direct NumPy evaluation of the same formula; unknown test features are skipped; best-model tracking."""
+    c1 = load_c1()
+    train = [b for b in c1.blocks if b.partition_id < 6]
+    for k, b in enumerate(train):
+        b.partition_id = k
+    recs = _raw_records_from_block(c1.blocks[7], c1.feature_names)
+    recs[0]["features"].append({"name": "never-seen", "term": "x", "value": 3.0})
+    recs[1]["weight"] = 2.5
+    recs[2]["offset"] = 0.25
+    rows = dataset.build_test_rows(recs, c1.feature_names)
+    assert rows.global_idx[rows.row_ptr[1] - 1] == -1 and abs(rows.n - (len(recs) + 1.5)) < 1e-12
+    cfg = admm.AdmmConfig(num_blocks=6, lambdas=[1.0, 100.0], num_iters=4)
+    lam, rho = cfg.sorted_lambda_rho()
+    eng = OracleEngine(train, c1.n_global, lam, rho, 6)
+    tr = admm.AdmmTrain(cfg, eng)
+    tr.attach_test_rows(rows)
+    hist = tr.run()
+    Z, _ = eng.z()
+    for li, key in enumerate(("1.0", "100.0")):
+        tot = 0.0
+        for i, r in enumerate(recs):
+            xb = Z[li][-1] + sum(Z[li][c1.feature_names.index(f["name"])] * np.float32(f["value"]) for f in r["features"] if f["name"] in c1.feature_names)
+            xb += r["offset"]
+            tot += (-np.log1p(np.exp(-xb)) if r["response"] == 1 else -np.log1p(np.exp(xb))) * r["weight"]
+        assert abs(hist[-1].test_loglik[key] - tot / rows.n) < 1e-10
+    assert tr.best_model is not None and tr.best_model[1] in ("1.0", "100.0")
+    best_ll = max(max(h.test_loglik.values()) for h in hist)
+    assert abs(float(tr.best_test_loglik) - best_ll) < 1e-6
+    recs_out = admm.sample_test_loglik_records(hist)
+    assert len(recs_out) == 8 and recs_out[0]["iter"] == 1 and set(r["lambda"] for r in recs_out) == {"1.0", "100.0"}
