@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=32, help="partitions in the CPU-baseline sample")
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events")
+    ap.add_argument("--loglik-iters", type=int, default=20, help="ADMM iterations of the time-to-reference-loglik run (0 = skip)")
+    ap.add_argument("--test-rows", type=int, default=100000)
     args = ap.parse_args()
 
     import torch
@@ -172,6 +174,41 @@ def main():
     else:
         tot_solves, tot_pref, tot_pdev, tot_cg, tot_newton = acc["solves"], acc["passes_ref"], acc["passes_dev"], acc["cg"], acc["newton"]
 
+    # ---- metric (ii): ADMM wall-clock to the reference test log-likelihood. A full run from z = u = 0:
+    # num.iters iterations with the per-iteration test loglik (jobs/RegressionAdmmTrain.java:766-845) on fresh test
+    # rows from the same generator. "Reference loglik" = the loglik of the final iteration of that same algorithm
+    # (what the reference run ends with; by parity the same iterates). Outside the timed region above.
+    loglik = None
+    if args.loglik_iters > 0:
+        tpid = 1_000_000 + rank                      # a partition id no training partition uses -> fresh rows
+        tparts = []
+        for c in range((args.test_rows + rows - 1) // rows):
+            Xt, yt = gen_partition(torch, dev, tpid + 1000 * c, rows, nf, beta, -1.0)
+            tparts.append((Xt.cpu().numpy(), yt.cpu().numpy()))
+            del Xt, yt
+        Xt = np.concatenate([p[0] for p in tparts])[:args.test_rows]
+        yt = np.concatenate([p[1] for p in tparts])[:args.test_rows]
+        lt = Xt.shape[0]
+        eng.set_test_data(np.arange(0, (lt + 1) * nf, nf, dtype=np.int64), np.tile(np.arange(nf, dtype=np.int32), lt),
+                          Xt.reshape(-1), np.where(yt == 1, 1, 0).astype(np.int8))
+        del Xt, tparts
+        eng.set_state(np.zeros((1, nf + 1)), np.zeros((P, 1, nf + 1), np.float32))
+        e = np.float32(0.01)
+        mindiff = 99999999.0
+        it = 0
+        lls, walls = [], []
+        barrier()
+        tl0 = time.perf_counter()
+        for _ in range(args.loglik_iters):
+            step(False)
+            lls.append(float(eng.test_loglik_sums()[0]) / lt)
+            walls.append(time.perf_counter() - tl0)
+        ref = lls[-1]
+        reached = next(i for i, v in enumerate(lls) if v >= ref - 1e-12 * abs(ref))
+        loglik = {"test_rows": lt, "iterations": args.loglik_iters, "ref_loglik": ref, "reached_at_iteration": reached + 1,
+                  "seconds_to_ref_loglik": round(walls[reached], 4), "seconds_all_iterations": round(walls[-1], 4),
+                  "loglik_by_iteration": [round(v, 6) for v in lls]}
+
     out = None
     if rank == 0:
         value = tot_solves / dt
@@ -206,6 +243,7 @@ def main():
                         "passes_dev_per_solve": round(tot_pdev / max(1.0, tot_solves), 2), "ticks": acc["ticks"],
                         "last_maxdiff": fin.maxdiff},
                "roofline": roof,
+               "time_to_ref_loglik": loglik,
                "all_launches": {"xpass_launches_incl_c0_and_warmup": allrun["launches"], "alg_bytes": allrun["alg_bytes"]}}
         if sample:
             threads = os.cpu_count() or 1

@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline"
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --loglik-iters 0"
 python $R/bench.py --steps 5 --warmup 2 > $OUT/bench_default.json 2> $OUT/bench_default.err
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o bench -- python $R/bench.py $ARGS > $OUT/bench_kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o bench -- python $R/bench.py $ARGS --no-profile > $OUT/bench_pmc_fetch.log 2>&1
