@@ -179,6 +179,11 @@ def build_partitions(rows: Sequence[PreparedRow], num_blocks: int, binary_featur
         if k < 0 or k >= num_blocks:
             raise RuntimeError("Map key is wrong! key has to be in the range of [0,numPartitions-1].")
         per[k].append(r)
+        for name, term, _ in r.features:          # global ids in input-stream order (same as the native host)
+            key = feature_key(name, term)
+            if key not in gindex and key != INTERCEPT_NAME:
+                gindex[key] = len(gnames)
+                gnames.append(key)
     blocks: List[PartitionBlock] = []
     for k, prow in enumerate(per):
         findex: Dict[str, int] = {}

@@ -1,0 +1,308 @@
+// admm_train_main.cpp -- `mlease_admm_train <job file>`: the native host of the drop-in.
+//
+// Mirrors the flow of jobs/Regression.java:37-80 for the ADMM path on local files:
+//   Prepare (jobs/RegressionPrepare.java:96-191, in memory; `write.tmp.data=true` also writes <out>/tmp-data)
+//   -> AdmmTrain (jobs/RegressionAdmmTrain.java:130-522) with the per-iteration body behind the C-ABI
+//      (include/mlease_admm.h): rows are indexed and uploaded ONCE, every iteration is one mlx_admm_iterate.
+// Same .job keys and defaults, same output files: <out>/lambda-rho, <out>/sample-test-loglik/iteration-i.avro,
+// <out>/best-model/best-iteration-i.avro, <out>/final-model/part-r-00000.avro.
+// Extra keys (not in the reference): `gpus` (device list, default "0"), `prepared.input=true` (input.paths already
+// holds RegressionPrepareOutput rows = what AdmmTrain alone consumes), `random.seed`, `write.tmp.data`.
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mlease_admm.h"
+#include "avro_io.h"
+#include "dataset_builder.h"
+#include "java_compat.h"
+
+using namespace mlh;
+
+namespace {
+
+struct Fail : std::runtime_error { using std::runtime_error::runtime_error; };
+
+void ck(mlx_handle h, int rc, const char *what)
+{
+    if (rc != MLX_OK) throw Fail(std::string("Model fitting error! ") + what + ": " + mlx_last_error(h));   // jobs/...:713-716
+}
+
+void write_model_record(AvroFileWriter &w, const std::string &key, const float *z, const Dataset &ds)
+{
+    // LinearModel.toAvro (models/LinearModel.java:697-720): intercept first, then name / term split on U+0001
+    w.put_string(key);
+    w.array_start(ds.n_global());
+    w.put_string("(INTERCEPT)"); w.put_string(""); w.put_float(z[ds.n_global() - 1]);
+    for (int32_t j = 0; j + 1 < ds.n_global(); j++) {
+        const std::string &nm = ds.names[(size_t)j];
+        size_t sep = nm.find('\x01');
+        w.put_string(sep == std::string::npos ? nm : nm.substr(0, sep));
+        w.put_string(sep == std::string::npos ? "" : nm.substr(sep + 1));
+        w.put_float(z[j]);
+    }
+    w.array_end();
+    w.end_record();
+}
+
+void write_tmp_data(const std::string &path, const Dataset &ds)
+{
+    AvroFileWriter w(path, kPrepareOutputSchemaJson);
+    for (auto &p : ds.parts)
+        for (int32_t i = 0; i < p.rows(); i++) {
+            w.put_string(std::to_string(p.pid));
+            w.put_long(p.y[(size_t)i] == 1 ? 1 : 0);
+            const int64_t k0 = p.row_ptr[(size_t)i], k1 = p.row_ptr[(size_t)i + 1];
+            w.array_start(k1 - k0);
+            for (int64_t k = k0; k < k1; k++) {
+                const std::string &nm = ds.names[(size_t)p.local_global[(size_t)p.col[(size_t)k]]];
+                size_t sep = nm.find('\x01');
+                w.put_string(sep == std::string::npos ? nm : nm.substr(0, sep));
+                w.put_string(sep == std::string::npos ? "" : nm.substr(sep + 1));
+                w.put_float(ds.binary ? 1.0f : p.val[(size_t)k]);
+            }
+            w.array_end();
+            w.put_float(p.weight[(size_t)i]);
+            w.put_float(p.offset[(size_t)i]);
+            w.end_record();
+        }
+    w.close();
+}
+
+std::vector<float> read_lambda_map(const std::string &path, const Dataset &ds)
+{
+    // consumers/ReadLambdaMapConsumer.java:33-53 -> dense per-feature lambda, NaN = not listed
+    std::vector<float> lm((size_t)ds.n_global(), std::nanf(""));
+    for (auto &file : list_avro_files(path)) {
+        AvroFileReader rd(file);
+        const AvroSchema &top = rd.schema();
+        rd.for_each([&](AvroCursor &c) {
+            std::string name, term;
+            bool hn = false, hv = false;
+            double v = 0;
+            for (auto &f : top.fields) {
+                const AvroSchema *r = c.resolve(*f.second);
+                if (!r) continue;
+                if (f.first == "name" && r->type == AvroType::String) { c.read_string(name); hn = true; }
+                else if (f.first == "term" && r->type == AvroType::String) c.read_string(term);
+                else if (f.first == "value") { v = c.read_number(*r); hv = true; }
+                else c.skip(*r);
+            }
+            if (hn && hv) {
+                if (!term.empty()) name += '\x01' + term;
+                auto g = ds.gindex.find(name);
+                if (g != ds.gindex.end()) lm[(size_t)g->second] = (float)v;
+            }
+        });
+    }
+    return lm;
+}
+
+bool path_exists(const std::string &p) { struct stat st; return !p.empty() && stat(p.c_str(), &st) == 0; }
+
+}  // namespace
+
+int run_job(const JobConfig &props)
+{
+    using clk = std::chrono::steady_clock;
+    auto t_start = clk::now();
+    const std::string out = props.get_string("output.base.path");
+    const int nblocks = props.get_int("num.blocks");
+    const int niter = props.get_int("num.iters", 10);                                       // :139
+    const bool aggressive = props.get_bool("aggressive.liblinear.epsilon.decay", false);
+    const int reg = props.get_int("regularizer");
+    if (reg != 1 && reg != 2) throw Fail("Only L1 and L2 regularization supported!");       // :143-147
+    const int nrep = props.get_int("num.click.replicates", 1);
+    const bool binary = props.get_bool("binary.feature", false);
+    const float boost = props.get_float("initialize.boost.rate", 0);
+    const float rho_adapt = props.get_float("rho.adapt.coefficient", 0);
+    if (boost > 0 && reg == 2)
+        throw Fail("initialize.boost.rate > 0 (NaiveTrain warm start, jobs/RegressionAdmmTrain.java:236-276) is not supported by this build");
+    // lambda -> rho (:153-185); a HashMap<Float,Float>: duplicates collapse; sorted ascending for the solver (:636-638)
+    std::vector<std::string> lstr = props.get_list("lambda", ','), rstr = props.get_list("rho", ',');
+    if (lstr.empty()) throw Fail("Undefined property: lambda");
+    if (!rstr.empty() && rstr.size() != lstr.size())
+        throw Fail("The number of rho's should be exactly the same as the number of lambda's. OR: don't claim rho!");
+    std::map<float, float> lr;
+    for (size_t j = 0; j < lstr.size(); j++) {
+        const float l = strtof(lstr[j].c_str(), nullptr);
+        lr[l] = rstr.empty() ? (l <= 100 ? 1.0f : 10.0f) : strtof(rstr[j].c_str(), nullptr);
+    }
+    std::vector<float> lam, rho;
+    for (auto &kv : lr) { lam.push_back(kv.first); rho.push_back(kv.second); }
+    const int nl = (int)lam.size();
+
+    // ---- rows: Prepare + indexing, once
+    PrepareOptions po;
+    po.num_blocks = nblocks;
+    po.map_key = props.get_string("map.key", "");
+    po.binary_feature = binary;
+    po.num_click_replicates = nrep;
+    po.seed = (uint64_t)props.get_long("random.seed", 0);
+    po.short_feature_index = props.get_bool("short.feature.index", false);
+    const bool prepared = props.get_bool("prepared.input", false);
+    DatasetBuilder builder(po);
+    const std::string input = props.get_string("input.paths");
+    if (prepared) read_input_rows(input, "key", true, [&](InputRow &r) { builder.add_prepared(r); });
+    else read_input_rows(input, po.map_key, !binary, [&](InputRow &r) { builder.add_raw(r); });
+    Dataset ds = builder.finish();
+    const int ng = ds.n_global();
+    auto t_indexed = clk::now();
+    fprintf(stderr, "[mlease] %lld rows, %d features, %d partitions indexed in %.2f s\n", (long long)ds.total_rows(), ng - 1,
+            nblocks, std::chrono::duration<double>(t_indexed - t_start).count());
+    if (props.get_bool("write.tmp.data", false)) write_tmp_data(out + "/tmp-data/part-00000.avro", ds);
+
+    std::vector<float> lambda_map;
+    const std::string lm_path = props.get_string("lambda.map", "");
+    if (!lm_path.empty()) lambda_map = read_lambda_map(lm_path, ds);
+
+    {   // lambda-rho file (:200-201,721-734)
+        AvroFileWriter w(out + "/lambda-rho/part-r-00000.avro",
+                         "{\"type\":\"record\",\"doc\":\"The map of lambda values to rho values\",\"name\":\"LambdaRhoMap\","
+                         "\"namespace\":\"com.linkedin.mlease.regression.avro\",\"fields\":[{\"name\":\"lambda\",\"type\":\"float\"},"
+                         "{\"name\":\"rho\",\"type\":\"float\"}]}");
+        for (int i = 0; i < nl; i++) { w.put_float(lam[(size_t)i]); w.put_float(rho[(size_t)i]); w.end_record(); }
+        w.close();
+    }
+
+    // ---- devices: partition k -> device k mod G
+    std::vector<int> devs;
+    for (auto &s : props.get_list("gpus", ',')) devs.push_back(atoi(s.c_str()));
+    if (devs.empty()) devs.push_back(0);
+    const int G = (int)devs.size();
+    std::vector<mlx_handle> hs((size_t)G, nullptr);
+    char uid[MLX_UNIQUE_ID_BYTES];
+    if (G > 1 && mlx_comm_get_unique_id(uid) != MLX_OK) throw Fail(std::string("RCCL: ") + mlx_last_error(nullptr));
+    for (int g = 0; g < G; g++) {
+        if (mlx_create(devs[(size_t)g], &hs[(size_t)g]) != MLX_OK) throw Fail(std::string("mlx_create: ") + mlx_last_error(nullptr));
+        mlx_handle h = hs[(size_t)g];
+        ck(h, mlx_set_problem(h, ng, nl, lam.data(), rho.data(), nblocks, props.get_bool("penalize.intercept", false) ? 1 : 0,
+                              lambda_map.empty() ? nullptr : lambda_map.data()), "mlx_set_problem");
+        ck(h, mlx_set_regularizer(h, reg), "mlx_set_regularizer");
+        for (auto &p : ds.parts) {
+            if (p.pid % G != g) continue;
+            if (p.rows() == 0) throw Fail("Some models failed! partition " + std::to_string(p.pid) + " received no rows");   // utils/LinearModelUtils.java:80-83
+            ck(h, mlx_add_partition_csr(h, p.pid, p.rows(), p.n_local(), (int64_t)p.col.size(), p.row_ptr.data(), p.col.data(),
+                                        ds.binary ? nullptr : p.val.data(), p.y.data(), p.weight.data(), p.offset.data(), p.l2g.data()),
+               "mlx_add_partition_csr");
+        }
+        ck(h, mlx_finalize(h), "mlx_finalize");
+    }
+    if (G > 1) {
+        std::vector<std::thread> th;
+        std::vector<int> rcs((size_t)G, 0);
+        for (int g = 0; g < G; g++) th.emplace_back([&, g] { rcs[(size_t)g] = mlx_comm_init(hs[(size_t)g], uid, G, g); });
+        for (auto &t : th) t.join();
+        for (int g = 0; g < G; g++) ck(hs[(size_t)g], rcs[(size_t)g], "mlx_comm_init");
+    }
+
+    // ---- test rows (:203-232): first file under test.path
+    bool test_loglik = false;
+    double test_n = 0;
+    const std::string test_path = props.get_string("test.path", "");
+    if (path_exists(test_path)) {
+        auto files = list_avro_files(test_path);
+        if (!files.empty()) {
+            TestRowsData t = build_test_rows(files[0], ds, binary);
+            if (!t.response.empty()) {
+                ck(hs[0], mlx_set_test_data(hs[0], (int32_t)t.response.size(), (int64_t)t.gidx.size(), t.row_ptr.data(), t.gidx.data(),
+                                            binary ? nullptr : t.val.data(), t.response.data(), t.weight.data(), t.offset.data()),
+                   "mlx_set_test_data");
+                test_loglik = true;
+                test_n = t.n;
+            }
+        }
+    }
+    auto t_uploaded = clk::now();
+
+    // ---- the loop (:278-497)
+    double mindiff = 99999999;
+    float liblinear_eps = 0.01f;                                                            // :279
+    float best_loglik = -9999999;                                                           // :234
+    const double epsilon = props.get_double("epsilon", 0.0001);
+    std::vector<double> zd((size_t)nl * ng), lls((size_t)nl);
+    std::vector<float> zf((size_t)nl * ng);
+    int i;
+    double solve_s = 0;
+    for (i = 1; i <= niter; i++) {
+        float rate = 1.0f;
+        if (i > 1 && rho_adapt > 0) rate = (float)std::exp((double)(-(i - 1) * rho_adapt)); // :323-327 (float product, double exp)
+        if (i > 1 && mindiff < 0.001 && !aggressive) liblinear_eps = liblinear_eps / 10;     // :338-341
+        else if (aggressive && i > 5) liblinear_eps = liblinear_eps / 10;                    // :342-345
+        const double eps = float_string_roundtrip(liblinear_eps);                            // :346,:620,:702
+        auto t0 = clk::now();
+        std::vector<mlx_stats> st((size_t)G);
+        if (G == 1) ck(hs[0], mlx_admm_iterate(hs[0], eps, rate, &st[0]), "mlx_admm_iterate");
+        else {
+            std::vector<std::thread> th;
+            std::vector<int> rcs((size_t)G, 0);
+            for (int g = 0; g < G; g++) th.emplace_back([&, g] { rcs[(size_t)g] = mlx_admm_iterate(hs[(size_t)g], eps, rate, &st[(size_t)g]); });
+            for (auto &t : th) t.join();
+            for (int g = 0; g < G; g++) ck(hs[(size_t)g], rcs[(size_t)g], "mlx_admm_iterate");
+        }
+        solve_s += std::chrono::duration<double>(clk::now() - t0).count();
+        const double maxdiff = st[0].maxdiff;
+        mindiff = st[0].mindiff;
+        fprintf(stderr, "[mlease] iteration %d: liblinear epsilon %s, max |z - z_prev| = %.6g, min = %.6g\n", i,
+                java_float_to_string(liblinear_eps).c_str(), maxdiff, mindiff);
+        if (test_loglik) {                                                                   // updateLogLikBestModel :812-845
+            ck(hs[0], mlx_test_loglik(hs[0], lls.data()), "mlx_test_loglik");
+            AvroFileWriter w(out + "/sample-test-loglik/iteration-" + std::to_string(i) + ".avro", kSampleTestLoglikSchemaJson);
+            for (int li = 0; li < nl; li++) {
+                const double ll = lls[(size_t)li] / test_n;
+                const std::string key = java_float_to_string(lam[(size_t)li]);
+                w.put_string(key); w.put_long(i); w.put_float((float)ll);
+                w.end_record();
+                fprintf(stderr, "[mlease] Sample test loglik for lambda=%s is: %.10g\n", key.c_str(), ll);
+                if (ll > (double)best_loglik && i > 0) {
+                    ck(hs[0], mlx_get_z(hs[0], nullptr, zf.data()), "mlx_get_z");
+                    AvroFileWriter bw(out + "/best-model/best-iteration-" + std::to_string(i) + ".avro", kLinearModelSchemaJson);
+                    write_model_record(bw, key, zf.data() + (size_t)li * ng, ds);
+                    bw.close();
+                    best_loglik = (float)ll;
+                }
+            }
+            w.close();
+        }
+        if (maxdiff < epsilon && liblinear_eps <= 0.00001) break;                            // :493-496
+    }
+    // final-model (:499-501)
+    ck(hs[0], mlx_get_z(hs[0], zd.data(), zf.data()), "mlx_get_z");
+    {
+        AvroFileWriter w(out + "/final-model/part-r-00000.avro", kLinearModelSchemaJson);
+        for (int li = 0; li < nl; li++) write_model_record(w, java_float_to_string(lam[(size_t)li]), zf.data() + (size_t)li * ng, ds);
+        w.close();
+    }
+    for (auto h : hs) mlx_destroy(h);
+    fprintf(stderr, "[mlease] done: index %.2f s, upload %.2f s, %d ADMM iterations in %.3f s, total %.2f s\n",
+            std::chrono::duration<double>(t_indexed - t_start).count(), std::chrono::duration<double>(t_uploaded - t_indexed).count(),
+            std::min(i, niter), solve_s, std::chrono::duration<double>(clk::now() - t_start).count());
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) {
+        fprintf(stderr, "[Usage]: mlease_admm_train <Job config path> [key=value ...]\n");    // jobs/Regression.java:90-94
+        return 2;
+    }
+    try {
+        JobConfig cfg = JobConfig::from_file(argv[1]);
+        for (int a = 2; a < argc; a++) {
+            const char *eq = strchr(argv[a], '=');
+            if (eq) cfg.put(std::string(argv[a], (size_t)(eq - argv[a])), eq + 1);
+        }
+        return run_job(cfg);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "[mlease] ERROR: %s\n", e.what());
+        return 1;
+    }
+}

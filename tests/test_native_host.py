@@ -1,0 +1,220 @@
+"""Native host (ml-ease_amd/host: C++ avro reader, RegressionPrepare + LibLinearDataset indexing, .job parsing, CLI)
+checked against the Python mirror and, end to end on the GPU, against the committed C1 golden."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import mlease_amd  # noqa: F401
+from mlease_amd import admm, avro_io, dataset
+from fixtures import load_c1, load_c1_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "ml-ease_amd", "host")
+
+PIG_SCHEMA = {  # the writer schema shape of examples/sample-data.avro (Pig: everything nullable) + a partition key field
+    "type": "record", "name": "TUPLE_0", "fields": [
+        {"name": "features", "type": ["null", {"type": "array", "items": ["null", {
+            "type": "record", "name": "TUPLE_1", "fields": [
+                {"name": "name", "type": ["null", "string"]}, {"name": "term", "type": ["null", "string"]},
+                {"name": "value", "type": ["null", "float"]}]}]}]},
+        {"name": "offset", "type": ["null", "int"]}, {"name": "response", "type": ["null", "int"]},
+        {"name": "weight", "type": ["null", "int"]}, {"name": "pkey", "type": ["null", "int"]},
+        {"name": "unused", "type": ["null", {"type": "map", "values": "double"}]}]}
+
+
+def lib():
+    subprocess.check_call(["make", "-C", HOST, "-s", "libmlease_host.so"])
+    L = C.CDLL(os.path.join(HOST, "libmlease_host.so"))
+    L.mlh_last_error.restype = C.c_char_p
+    L.mlh_build.restype = C.c_void_p
+    L.mlh_build.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_ulonglong, C.c_int, C.c_int]
+    L.mlh_free.argtypes = [C.c_void_p]
+    L.mlh_n_global.argtypes = [C.c_void_p]
+    L.mlh_feature_name.restype = C.c_char_p
+    L.mlh_feature_name.argtypes = [C.c_void_p, C.c_int]
+    L.mlh_part_sizes.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    for nme, ty in (("rowptr", C.c_longlong), ("col", C.c_int), ("val", C.c_float), ("y", C.c_byte), ("weight", C.c_float),
+                    ("offset", C.c_float), ("l2g", C.c_int)):
+        f = getattr(L, "mlh_part_" + nme)
+        f.restype = C.POINTER(ty)
+        f.argtypes = [C.c_void_p, C.c_int]
+    L.mlh_test_rows.restype = C.c_void_p
+    L.mlh_test_rows.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_longlong]
+    L.mlh_test_free.argtypes = [C.c_void_p]
+    L.mlh_test_sizes.restype = C.c_double
+    L.mlh_test_sizes.argtypes = [C.c_void_p, C.c_void_p]
+    for nme, ty in (("rowptr", C.c_longlong), ("gidx", C.c_int), ("val", C.c_float), ("response", C.c_byte),
+                    ("weight", C.c_double), ("offset", C.c_double)):
+        f = getattr(L, "mlh_test_" + nme)
+        f.restype = C.POINTER(ty)
+        f.argtypes = [C.c_void_p]
+    L.mlh_float_to_string.argtypes = [C.c_float, C.c_char_p, C.c_int]
+    L.mlh_float_string_roundtrip.restype = C.c_double
+    L.mlh_float_string_roundtrip.argtypes = [C.c_float]
+    return L
+
+
+def native_blocks(L, h, nb):
+    out = []
+    for k in range(nb):
+        sz = (C.c_longlong * 3)()
+        L.mlh_part_sizes(h, k, sz)
+        l, nloc, nnz = [int(x) for x in sz]
+        arr = lambda f, n, dt: np.ctypeslib.as_array(f(h, k), shape=(n,)).astype(dt).copy() if n else np.zeros(0, dt)
+        vp = L.mlh_part_val(h, k)
+        out.append(dict(l=l, n_local=nloc, row_ptr=arr(L.mlh_part_rowptr, l + 1, np.int64), col=arr(L.mlh_part_col, nnz, np.int32),
+                        val=(np.ctypeslib.as_array(vp, shape=(nnz,)).copy() if vp and nnz else None),
+                        y=arr(L.mlh_part_y, l, np.int8), weight=arr(L.mlh_part_weight, l, np.float32),
+                        offset=arr(L.mlh_part_offset, l, np.float32), l2g=arr(L.mlh_part_l2g, nloc, np.int32)))
+    return out
+
+
+def c1_raw_records(c1, with_key=True):
+    """The C1 fixture back as raw Pig-style records, rows interleaved across partitions like the original file."""
+    recs = []
+    maxl = max(b.l for b in c1.blocks)
+    for i in range(maxl):
+        for b in c1.blocks:
+            if i >= b.l:
+                continue
+            sl = slice(b.row_ptr[i], b.row_ptr[i + 1])
+            feats = [{"name": c1.feature_names[b.local_to_global[c]], "term": "", "value": float(v)}
+                     for c, v in zip(b.col_idx[sl], b.val[sl])]
+            recs.append({"features": feats, "offset": 0, "response": 1 if b.y[i] == 1 else 0, "weight": 1,
+                         "pkey": b.partition_id if with_key else None, "unused": None})
+    return recs
+
+
+@pytest.fixture(scope="module")
+def c1():
+    return load_c1()
+
+
+def test_native_indexing_equals_python_mirror(tmp_path, c1):
+    L = lib()
+    recs = c1_raw_records(c1)
+    p = str(tmp_path / "raw" / "part-00000.avro")
+    avro_io.write_container(p, PIG_SCHEMA, recs[:600], codec="deflate", block_records=97)
+    avro_io.write_container(str(tmp_path / "raw" / "part-00001.avro"), PIG_SCHEMA, recs[600:], codec="null")
+    h = L.mlh_build(str(tmp_path / "raw").encode(), 8, b"pkey", 0, 1, 0, 0, 0)
+    assert h, L.mlh_last_error()
+    nat = native_blocks(L, h, 8)
+    rows = dataset.prepare_rows(avro_io.read_records(str(tmp_path / "raw")), 8, map_key="pkey")
+    py = dataset.build_partitions(rows, 8)
+    assert L.mlh_n_global(h) == py.n_global
+    assert [L.mlh_feature_name(h, j).decode() for j in range(py.n_global - 1)] == py.feature_names
+    for a, b in zip(nat, py.blocks):
+        assert (a["l"], a["n_local"]) == (b.l, b.n_local)
+        for k, v in (("row_ptr", b.row_ptr), ("col", b.col_idx), ("val", b.val), ("y", b.y), ("weight", b.weight),
+                     ("offset", b.offset), ("l2g", b.local_to_global)):
+            assert np.array_equal(a[k], v), k
+    # test rows: first file only, unknown features -> -1, n = sum of weights as strings
+    t = L.mlh_test_rows(p.encode(), h, 0, 250)
+    assert t, L.mlh_last_error()
+    sz = (C.c_longlong * 2)()
+    n = L.mlh_test_sizes(t, sz)
+    tr = dataset.build_test_rows(recs[:250], py.feature_names)
+    assert int(sz[0]) == 250 and n == tr.n
+    assert np.array_equal(np.ctypeslib.as_array(L.mlh_test_gidx(t), shape=(int(sz[1]),)), tr.global_idx)
+    assert np.array_equal(np.ctypeslib.as_array(L.mlh_test_val(t), shape=(int(sz[1]),)), tr.val)
+    L.mlh_test_free(t)
+    L.mlh_free(h)
+
+
+def test_native_prepare_semantics(tmp_path):
+    L = lib()
+    schema = {"type": "record", "name": "R", "fields": [
+        {"name": "response", "type": "int"}, {"name": "click", "type": ["null", "boolean"]},
+        {"name": "weight", "type": ["null", "double"]}, {"name": "offset", "type": ["null", "float"]},
+        {"name": "features", "type": {"type": "array", "items": {"type": "record", "name": "F", "fields": [
+            {"name": "name", "type": "string"}, {"name": "term", "type": ["null", "string"]}, {"name": "value", "type": "double"}]}}}]}
+    recs = [{"response": 1, "click": None, "weight": 4.0, "offset": 1.5, "features": [{"name": "b", "term": None, "value": 0.1}, {"name": "a", "term": "t", "value": 2.0}]},
+            {"response": 0, "click": True, "weight": None, "offset": None, "features": [{"name": "a", "term": "t", "value": -1.0}]},
+            {"response": 1, "click": None, "weight": 1.0, "offset": None, "features": []}]
+    p = str(tmp_path / "in.avro")
+    avro_io.write_container(p, schema, recs, codec="null")
+    # no map.key: seeded random key; positives divided by / replicated over num.click.replicates consecutive partitions
+    h = L.mlh_build(p.encode(), 4, b"", 0, 2, 7, 0, 0)
+    assert h, L.mlh_last_error()
+    nat = native_blocks(L, h, 4)
+    assert sum(b["l"] for b in nat) == 2 + 1 + 2          # two positives x2 replicas, one negative once
+    pos_parts = [k for k, b in enumerate(nat) for w in b["weight"] if w == np.float32(2.0)]
+    assert len(pos_parts) == 2 and (pos_parts[1] - pos_parts[0]) % 4 in (1, 3)        # consecutive (with wrap)
+    for b in nat:
+        for i in range(b["l"]):
+            seg = b["col"][b["row_ptr"][i]:b["row_ptr"][i + 1]]
+            assert np.all(np.diff(seg) > 0)
+    names = [L.mlh_feature_name(h, j).decode() for j in range(L.mlh_n_global(h) - 1)]
+    assert set(names) == {"b", "a" + dataset.TERM_SEP + "t"}
+    L.mlh_free(h)
+    # binary.feature ignores values; a prepared file written by the Python mirror reads back identically
+    h = L.mlh_build(p.encode(), 4, b"", 1, 1, 7, 0, 0)
+    assert h and native_blocks(L, h, 4)[0]["val"] is None
+    L.mlh_free(h)
+    for bad, msg in ((dict(recs[0], response=2), b"only 1, 0, -1"), (dict(recs[0], weight=-1.0), b"weight cannot")):
+        avro_io.write_container(p, schema, [bad], codec="null")
+        assert not L.mlh_build(p.encode(), 4, b"", 0, 1, 0, 0, 0) and msg in L.mlh_last_error()
+    avro_io.write_container(p, schema, recs, codec="null")
+    assert not L.mlh_build(p.encode(), 4, b"nokey", 0, 1, 0, 0, 0) and b"map.key is wrongly specified" in L.mlh_last_error()
+
+
+def test_native_prepared_input_and_java_strings(tmp_path, c1):
+    L = lib()
+    rows = dataset.prepare_rows(c1_raw_records(c1), 8, map_key="pkey")
+    p = str(tmp_path / "tmp-data" / "part-00000.avro")
+    avro_io.write_container(p, avro_io.PREPARE_OUTPUT_SCHEMA, [r.to_avro() for r in rows])
+    h = L.mlh_build(p.encode(), 8, b"", 0, 1, 0, 1, 0)
+    assert h, L.mlh_last_error()
+    nat = native_blocks(L, h, 8)
+    py = dataset.build_partitions(rows, 8)
+    for a, b in zip(nat, py.blocks):
+        assert np.array_equal(a["col"], b.col_idx) and np.array_equal(a["val"], b.val) and np.array_equal(a["y"], b.y)
+    L.mlh_free(h)
+    buf = C.create_string_buffer(64)
+    e = np.float32(0.01)
+    for _ in range(60):
+        L.mlh_float_to_string(float(e), buf, 64)
+        assert buf.value.decode() == admm.java_float_to_string(e)
+        assert L.mlh_float_string_roundtrip(float(e)) == admm.float_string_roundtrip(e)
+        e = np.float32(e / np.float32(10))
+    for v in (1.0, 10.0, 100.0, 1000.0, 0.3, 1e7, 123456.7, 5e-5):
+        L.mlh_float_to_string(v, buf, 64)
+        assert buf.value.decode() == admm.java_float_to_string(v)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/examples/sample-data.avro"), reason="reference checkout not present")
+def test_native_reads_the_reference_sample_file():
+    L = lib()
+    h = L.mlh_build(b"/root/reference/examples/sample-data.avro", 8, b"", 0, 1, 3, 0, 0)
+    assert h, L.mlh_last_error()
+    nat = native_blocks(L, h, 8)
+    assert sum(b["l"] for b in nat) == 1000 + 299 * 0 and L.mlh_n_global(h) == 201      # 1000 rows, 200 features
+    assert sum(len(b["col"]) for b in nat) == 100326
+    L.mlh_free(h)
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end_matches_golden(tmp_path, c1):
+    """`mlease_admm_train sample.job` on the C1 rows (raw Pig-style avro, map.key) -> final-model avro equals the
+    committed golden z of iteration 20 (float32), sample-test-loglik files written."""
+    subprocess.check_call(["make", "-C", HOST, "-s"])
+    recs = c1_raw_records(c1)
+    avro_io.write_container(str(tmp_path / "in" / "part-00000.avro"), PIG_SCHEMA, recs, codec="deflate")
+    avro_io.write_container(str(tmp_path / "test" / "part-00000.avro"), PIG_SCHEMA, recs[:200], codec="null")
+    job = tmp_path / "sample.job"
+    job.write_text("# sample\ninput.paths=%s\noutput.base.path=%s\ntest.path=%s\nnum.blocks=8\nlambda=1.0\nnum.iters=20\n"
+                   "regularizer=2\nmap.key=pkey\nforce.output.overwrite=true\n" % (tmp_path / "in", tmp_path / "out", tmp_path / "test"))
+    r = subprocess.run([os.path.join(HOST, "mlease_admm_train"), str(job)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    gold = load_c1_golden()
+    models = admm.read_linear_models(str(tmp_path / "out" / "final-model" / "part-r-00000.avro"), c1.feature_names)
+    assert list(models) == ["1.0"]
+    want = gold["Z"][-1][0].astype(np.float32)
+    err = np.abs(models["1.0"].astype(np.float64) - want) / np.maximum(np.abs(want), 1e-2 * np.max(np.abs(want)))
+    assert np.max(err) <= 1e-5
+    ll = avro_io.read_records(str(tmp_path / "out" / "sample-test-loglik" / "iteration-20.avro"))
+    assert ll[0]["lambda"] == "1.0" and ll[0]["iter"] == 20 and -1.0 < ll[0]["testLoglik"] < 0.0
+    assert os.path.isdir(tmp_path / "out" / "best-model") and os.path.exists(tmp_path / "out" / "lambda-rho" / "part-r-00000.avro")
