@@ -469,10 +469,7 @@ int mlx_add_partition_dense(mlx_handle h, int32_t partition_id, int32_t l, int32
     int fine = l >= 4096 ? 512 : std::max(16, ((l + 7) / 8 + 15) / 16 * 16);
     if ((l + fine - 1) / fine > 1024) fine = ((l + 1023) / 1024 + 15) / 16 * 16;
     int coarse = fine;
-    if (const char *e = getenv("MLX_DENSE_RPB")) fine = coarse = std::max(16, atoi(e) / 16 * 16);   // A/B knobs
-    if (const char *e = getenv("MLX_DENSE_RPB_FINE")) fine = std::max(16, atoi(e) / 16 * 16);
-    if (const char *e = getenv("MLX_DENSE_RPB_COARSE")) coarse = std::max(fine, atoi(e) / 16 * 16);
-    if (const char *e = getenv("MLX_TARGET_WGS")) h->target_wgs = std::max(1, atoi(e));
+    if (const char *e = getenv("MLX_DENSE_RPB")) fine = coarse = std::max(16, atoi(e) / 16 * 16);   // A/B knob (profiles/r1_notes.md)
     ph.rows_per_blk = fine;
     ph.nblk = (l + fine - 1) / fine;
     ph.nblk_min = (l + coarse - 1) / coarse;
