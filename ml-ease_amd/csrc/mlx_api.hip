@@ -29,6 +29,9 @@ struct PartHost {
     bool dense = false, hasval = false, all_present = false;
     int64_t nnz = 0, ld = 0;
     int n_short = 0, n_long = 0;
+    bool sell = false;
+    std::vector<int32_t> new2old;          // CSR partitions: library local id -> caller's local id (features only)
+    int n_rslices = 0, n_cslices = 0;
     int nblk = 0, nblk_min = 1, rows_per_blk = 0, n_items = 0, rowgroup = 64, pos = 0, neg = 0;
     PartDev dev{};
     double *c0 = nullptr;
@@ -57,7 +60,8 @@ struct mlx_context {
     int nq_dense = 0, nq_csr = 0;
     int maxblk_dense = 0, maxblk_csr = 0, max_nfeat_dense = 0, max_items = 0, max_short = 0, max_long = 0, rowgroup = 64, max_nlocal = 0, max_l = 0;
     int64_t max_parts_len = 0;
-    bool csr_hasval = false, any_absent = false;
+    bool csr_hasval = false, any_absent = false, csr_sell = false;
+    int max_cslices = 0;
     int step_threads = 256;
     int target_wgs = 1024;                 // dense pass: workgroups wanted per launch (chunk-granularity policy)
 
@@ -199,7 +203,7 @@ int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
     if (h->profiling) { e0 = next_event(h); e1 = next_event(h); hipEventRecord(e0, h->stream); }
     if (nqd > 0 && mlxk_xpass_dense(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->maxblk_dense, h->max_nfeat_dense, nrun, h->d_done, h->target_wgs))
         return fail(h, MLX_ERR_INVALID, "dense tile wider than 2048 features is not supported; use the CSR form");
-    if (nqc > 0) mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_short, h->max_long, h->rowgroup, h->csr_hasval);
+    if (nqc > 0) mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_short, h->max_long, h->rowgroup, h->csr_hasval, h->csr_sell, h->max_cslices);
     if (h->profiling) hipEventRecord(e1, h->stream);
     return MLX_OK;
 }
@@ -371,11 +375,41 @@ int mlx_add_partition_csr(mlx_handle h, int32_t partition_id, int32_t l, int32_t
         if (i && row_ptr[i] < row_ptr[i - 1]) return fail(h, MLX_ERR_INVALID, "row_ptr not monotone at %d", i);
         rp[i] = (int32_t)row_ptr[i];
     }
-    for (int64_t k = 0; k < nnz; k++) {
+    for (int64_t k = 0; k < nnz; k++)
         if (col_idx[k] < 0 || col_idx[k] >= nf) return fail(h, MLX_ERR_INVALID, "col_idx[%lld]=%d out of [0,%d)", (long long)k, col_idx[k], nf);
-        colcnt[col_idx[k] + 1]++;
+    // Library-internal relabelling of the local ids: most frequent feature first (stable). The caller's local order
+    // only matters at mlx_solve_one, which maps through new2old. Frequent columns first means (a) column segments come
+    // out ordered by length, so 64 consecutive segments form a well-filled slice, and (b) the hot head of the dense
+    // vectors is a contiguous prefix.
+    std::vector<int32_t> new2old((size_t)nf), newid((size_t)nf);
+    {
+        std::vector<int32_t> cnt((size_t)nf, 0);
+        for (int64_t k = 0; k < nnz; k++) cnt[(size_t)col_idx[k]]++;
+        for (int j = 0; j < nf; j++) new2old[(size_t)j] = j;
+        std::stable_sort(new2old.begin(), new2old.end(), [&](int32_t a, int32_t b) { return cnt[(size_t)a] > cnt[(size_t)b]; });
+        for (int j = 0; j < nf; j++) newid[(size_t)new2old[(size_t)j]] = j;
     }
+    std::vector<int32_t> pcol((size_t)nnz), l2g_perm((size_t)n_local);
+    std::vector<float> pvalv(val ? (size_t)nnz : 0);
+    for (int j = 0; j < nf; j++) l2g_perm[(size_t)j] = local_to_global[new2old[(size_t)j]];
+    l2g_perm[(size_t)nf] = local_to_global[nf];
+    {
+        std::vector<std::pair<int32_t, float>> rowbuf;
+        for (int i = 0; i < l; i++) {
+            rowbuf.clear();
+            for (int32_t k = rp[i]; k < rp[i + 1]; k++) rowbuf.emplace_back(newid[(size_t)col_idx[k]], val ? val[k] : 1.0f);
+            std::stable_sort(rowbuf.begin(), rowbuf.end(), [](const std::pair<int32_t, float> &a, const std::pair<int32_t, float> &b) { return a.first < b.first; });
+            for (size_t t = 0; t < rowbuf.size(); t++) {
+                pcol[(size_t)rp[i] + t] = rowbuf[t].first;
+                if (val) pvalv[(size_t)rp[i] + t] = rowbuf[t].second;
+            }
+        }
+    }
+    const int32_t *col_idx_p = pcol.data();            // from here on: permuted ids
+    const float *val_p = val ? pvalv.data() : nullptr;
+    for (int64_t k = 0; k < nnz; k++) colcnt[(size_t)col_idx_p[k] + 1]++;
     PartHost ph;
+    ph.new2old = new2old;
     ph.pid = partition_id; ph.l = l; ph.n_local = n_local; ph.n_feat = nf; ph.dense = false; ph.hasval = (val != nullptr);
     ph.nnz = nnz; ph.all_present = (n_local == h->n_global);
     // CSC (rows ascending inside a column = the order XTv accumulates in, llf/LogisticRegressionL2.java:140-145)
@@ -385,9 +419,9 @@ int mlx_add_partition_csr(mlx_handle h, int32_t partition_id, int32_t l, int32_t
     std::vector<float> cval(val ? (size_t)nnz : 0);
     for (int i = 0; i < l; i++)
         for (int32_t k = rp[i]; k < rp[i + 1]; k++) {
-            const int32_t dst = fill[col_idx[k]]++;
+            const int32_t dst = fill[col_idx_p[k]]++;
             cri[dst] = i;
-            if (val) cval[dst] = val[k];
+            if (val) cval[dst] = val_p[k];
         }
     // column segments of <= CSC_SEG entries
     std::vector<int32_t> item_ptr, col_item(nf + 1);
@@ -418,21 +452,93 @@ int mlx_add_partition_csr(mlx_handle h, int32_t partition_id, int32_t l, int32_t
     ph.rows_per_blk = rpb;
     ph.nblk = (l + rpb - 1) / rpb;
 
+    // Sliced-ELL copies for the thread-per-item passes (k_rowpass_sell / k_colpass_sell): built when padding the rows of a
+    // 64-row slice to the slice's longest row costs <= 1.5x the non-zeros (uniform-ish rows: one-hot data pads nothing).
+    std::vector<int32_t> rs_ptr, rs_idx, cs_ptr, cs_idx, cs_item;
+    std::vector<float> rs_val, cs_val;
+    {
+        const int nrs = (l + 63) / 64;
+        rs_ptr.assign((size_t)nrs + 1, 0);
+        for (int s = 0; s < nrs; s++) {
+            int mx = 0;
+            for (int r = s * 64; r < std::min(l, s * 64 + 64); r++) mx = std::max(mx, rp[r + 1] - rp[r]);
+            rs_ptr[(size_t)s + 1] = rs_ptr[(size_t)s] + mx * 64;
+        }
+        const int64_t padded = rs_ptr[(size_t)nrs];
+        ph.sell = nnz > 0 && (double)padded <= 1.5 * (double)nnz + 4096.0 && getenv("MLX_NO_SELL") == nullptr;
+        if (ph.sell) {
+            ph.n_rslices = nrs;
+            rs_idx.assign((size_t)padded, 0);
+            if (val) rs_val.assign((size_t)padded, 0.f);
+            for (int r = 0; r < l; r++) {
+                const int32_t base = rs_ptr[(size_t)(r >> 6)], lane = r & 63;
+                for (int32_t k = rp[r]; k < rp[r + 1]; k++) {
+                    const size_t dst = (size_t)base + (size_t)(k - rp[r]) * 64 + (size_t)lane;
+                    rs_idx[dst] = col_idx_p[k];
+                    if (val) rs_val[dst] = val_p[k];
+                }
+            }
+            // column segments in natural order: columns are already sorted by frequency, so 64 consecutive segments
+            // have similar lengths; natural order keeps the per-segment result writes and their later reads contiguous
+            std::vector<int32_t> order((size_t)ph.n_items);
+            for (int it = 0; it < ph.n_items; it++) order[(size_t)it] = it;
+            const int ncs = (ph.n_items + 63) / 64;
+            ph.n_cslices = ncs;
+            cs_ptr.assign((size_t)ncs + 1, 0);
+            cs_item.assign((size_t)ncs * 64, -1);
+            for (int s = 0; s < ncs; s++) {
+                int32_t mx = 0;
+                for (int t = s * 64; t < std::min(ph.n_items, s * 64 + 64); t++) mx = std::max(mx, item_ptr[(size_t)t + 1] - item_ptr[(size_t)t]);
+                cs_ptr[(size_t)s + 1] = cs_ptr[(size_t)s] + mx * 64;
+            }
+            cs_idx.assign((size_t)cs_ptr[(size_t)ncs], 0);
+            if (val) cs_val.assign((size_t)cs_ptr[(size_t)ncs], 0.f);
+            for (int slot = 0; slot < ph.n_items; slot++) {
+                const int32_t it = order[(size_t)slot];
+                cs_item[(size_t)slot] = it;
+                const int32_t base = cs_ptr[(size_t)(slot >> 6)], lane = slot & 63;
+                for (int32_t k = item_ptr[(size_t)it]; k < item_ptr[(size_t)it + 1]; k++) {
+                    const size_t dst = (size_t)base + (size_t)(k - item_ptr[(size_t)it]) * 64 + (size_t)lane;
+                    cs_idx[dst] = cri[(size_t)k];
+                    if (val) cs_val[dst] = cval[(size_t)k];
+                }
+            }
+            ph.rows_per_blk = l >= 4096 ? 512 : 256;
+            ph.nblk = (l + ph.rows_per_blk - 1) / ph.rows_per_blk;
+        }
+    }
+
     int32_t *d_rp, *d_ci, *d_cri, *d_item, *d_colitem, *d_l2g, *d_ishort, *d_ilong;
     float *d_val = nullptr, *d_cval = nullptr;
     if ((rc = dev_upload(h, &d_rp, rp.data(), rp.size()))) return rc;
-    if ((rc = dev_upload(h, &d_ci, col_idx, (size_t)nnz))) return rc;
+    if ((rc = dev_upload(h, &d_ci, col_idx_p, (size_t)nnz))) return rc;
     if ((rc = dev_upload(h, &d_cri, cri.data(), cri.size()))) return rc;
     if (val) {
-        if ((rc = dev_upload(h, &d_val, val, (size_t)nnz))) return rc;
+        if ((rc = dev_upload(h, &d_val, val_p, (size_t)nnz))) return rc;
         if ((rc = dev_upload(h, &d_cval, cval.data(), cval.size()))) return rc;
     }
     if ((rc = dev_upload(h, &d_item, item_ptr.data(), item_ptr.size()))) return rc;
     if ((rc = dev_upload(h, &d_colitem, col_item.data(), col_item.size()))) return rc;
     if ((rc = dev_upload(h, &d_ishort, ishort.data(), ishort.size()))) return rc;
     if ((rc = dev_upload(h, &d_ilong, ilong.data(), ilong.size()))) return rc;
-    if ((rc = dev_upload(h, &d_l2g, local_to_global, (size_t)n_local))) return rc;
+    if ((rc = dev_upload(h, &d_l2g, l2g_perm.data(), (size_t)n_local))) return rc;
     ph.dev.rp = d_rp; ph.dev.ci = d_ci; ph.dev.val = d_val; ph.dev.cri = d_cri; ph.dev.cval = d_cval;
+    ph.dev.sell = ph.sell ? 1 : 0; ph.dev.n_rslices = ph.n_rslices; ph.dev.n_cslices = ph.n_cslices;
+    if (ph.sell) {
+        int32_t *d_a, *d_b, *d_c, *d_d, *d_e;
+        float *d_f = nullptr, *d_g = nullptr;
+        if ((rc = dev_upload(h, &d_a, rs_ptr.data(), rs_ptr.size()))) return rc;
+        if ((rc = dev_upload(h, &d_b, rs_idx.data(), rs_idx.size()))) return rc;
+        if ((rc = dev_upload(h, &d_c, cs_ptr.data(), cs_ptr.size()))) return rc;
+        if ((rc = dev_upload(h, &d_d, cs_idx.data(), cs_idx.size()))) return rc;
+        if ((rc = dev_upload(h, &d_e, cs_item.data(), cs_item.size()))) return rc;
+        if (val) {
+            if ((rc = dev_upload(h, &d_f, rs_val.data(), rs_val.size()))) return rc;
+            if ((rc = dev_upload(h, &d_g, cs_val.data(), cs_val.size()))) return rc;
+        }
+        ph.dev.rs_ptr = d_a; ph.dev.rs_idx = d_b; ph.dev.cs_ptr = d_c; ph.dev.cs_idx = d_d; ph.dev.cs_item = d_e;
+        ph.dev.rs_val = d_f; ph.dev.cs_val = d_g;
+    }
     ph.dev.items_short = d_ishort; ph.dev.items_long = d_ilong; ph.dev.n_short = ph.n_short; ph.dev.n_long = ph.n_long;
     ph.dev.item_ptr = d_item; ph.dev.col_item = d_colitem; ph.dev.l2g = d_l2g; ph.dev.X = nullptr;
     if ((rc = upload_row_meta(h, ph, l, y, weight, offset, false))) return rc;
@@ -508,6 +614,9 @@ int mlx_finalize(mlx_handle h)
         for (int li = 0; li < nl; li++) (p.dense ? qd : qc).push_back(k * nl + li);
     }
     // a single row-group width / value mode for all CSR partitions of the handle
+    h->csr_sell = true;
+    for (auto &p : h->parts) if (!p.dense) { h->csr_sell = h->csr_sell && p.sell; h->max_cslices = std::max(h->max_cslices, p.n_cslices); }
+    // (if any CSR partition could not be sliced, all of them run the lane-group kernels; those accept any row chunking)
     bool first_csr = true;
     for (auto &p : h->parts) if (!p.dense) {
         if (first_csr) { h->rowgroup = p.rowgroup; first_csr = false; }
@@ -845,11 +954,16 @@ int mlx_solve_one(mlx_handle h, int32_t local_index, double *w, const double *pr
     const int n = p.n_local;
     ProbDev pr = h->h_probs[h->nprob];
     pr.part = local_index; pr.lambda_idx = 0;
-    std::vector<double> pinv(n), pm(n, 0.0);
-    for (int j = 0; j < n; j++) pinv[j] = 1.0 / prior_var[j];              // llf/LogisticRegressionL2.java:107-109
-    if (prior_mean) memcpy(pm.data(), prior_mean, sizeof(double) * n);
-    HIPCHECK(h, hipMemcpy(pr.w, w, sizeof(double) * n, hipMemcpyHostToDevice));
-    HIPCHECK(h, hipMemcpy(pr.w_new, w, sizeof(double) * n, hipMemcpyHostToDevice));
+    // caller's local order -> the library's (frequency-sorted) local order for CSR partitions
+    auto old_of = [&](int j) { return (!p.dense && j < n - 1) ? p.new2old[(size_t)j] : j; };
+    std::vector<double> pinv(n), pm(n, 0.0), w0(n);
+    for (int j = 0; j < n; j++) {
+        pinv[j] = 1.0 / prior_var[old_of(j)];                               // llf/LogisticRegressionL2.java:107-109
+        if (prior_mean) pm[j] = prior_mean[old_of(j)];
+        w0[j] = w[old_of(j)];
+    }
+    HIPCHECK(h, hipMemcpy(pr.w, w0.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    HIPCHECK(h, hipMemcpy(pr.w_new, w0.data(), sizeof(double) * n, hipMemcpyHostToDevice));
     HIPCHECK(h, hipMemcpy(pr.m, pm.data(), sizeof(double) * n, hipMemcpyHostToDevice));
     HIPCHECK(h, hipMemcpy(h->sc_pinv, pinv.data(), sizeof(double) * n, hipMemcpyHostToDevice));
     pr.pinv_vec = h->sc_pinv; pr.pinv = 0;
@@ -866,7 +980,8 @@ int mlx_solve_one(mlx_handle h, int32_t local_index, double *w, const double *pr
     if (rc) return rc;
     HIPCHECK(h, hipMemcpy(&pr, h->d_probs + h->nprob, sizeof(ProbDev), hipMemcpyDeviceToHost));
     if (pr.status != ST_OK) return fail(h, MLX_ERR_MODEL_FITTING, "Model fitting error! status %d", pr.status);
-    HIPCHECK(h, hipMemcpy(w, pr.w, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIPCHECK(h, hipMemcpy(w0.data(), pr.w, sizeof(double) * n, hipMemcpyDeviceToHost));
+    for (int j = 0; j < n; j++) w[old_of(j)] = w0[j];
     if (counters4) {
         counters4[0] = pr.newton; counters4[1] = pr.accepted; counters4[2] = pr.cg_total;
         counters4[3] = 3 + 2 * pr.cg_total + pr.newton + pr.accepted;

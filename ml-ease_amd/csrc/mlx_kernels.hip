@@ -79,11 +79,11 @@ __device__ __forceinline__ double block_allreduce_max(double x, double *scratch)
 __device__ __forceinline__ double block_norm(const double *__restrict__ v, int n, double *scratch)
 {
     double mx = 0;
-    for (int j = threadIdx.x; j < n; j += blockDim.x) mx = fmax(mx, fabs(v[j]));
+    _Pragma("unroll 4") for (int j = threadIdx.x; j < n; j += blockDim.x) mx = fmax(mx, fabs(v[j]));
     mx = block_allreduce_max(mx, scratch);
     if (!(mx > 0)) return (mx == 0) ? 0.0 : mx;   // 0, or NaN propagates
     double a[1] = {0};
-    for (int j = threadIdx.x; j < n; j += blockDim.x) { double t = fabs(v[j]) / mx; a[0] += t * t; }
+    _Pragma("unroll 4") for (int j = threadIdx.x; j < n; j += blockDim.x) { double t = fabs(v[j]) / mx; a[0] += t * t; }
     block_allreduce_sum<1>(a, scratch);
     return mx * sqrt(a[0]);
 }
@@ -252,6 +252,18 @@ k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     }
 }
 
+// XCD-aware work mapping of the sparse passes. Workgroup L of a 1-D grid is dispatched to XCD L % 8 (observed order;
+// used for speed only, never for correctness). All chunks of one problem are given to ONE XCD (problem index % 8), so
+// the randomly gathered fp64 vectors of the 1-3 problems an XCD works on at a time (d / w_new: 8*n_local bytes, coef:
+// 8*l bytes) stay in that XCD's 4 MiB L2 instead of being re-fetched through the fabric by all eight L2s.
+__device__ __forceinline__ bool xcd_map(int nq, int gx, int &pi, int &bx)
+{
+    const int L = blockIdx.x, xcd = L & 7, s = L >> 3;
+    pi = (s / gx) * 8 + xcd;
+    bx = s % gx;
+    return pi < nq;
+}
+
 // ------------------------------------------------------------------------------------------------
 // sparse X pass, part 1: CSR rows -> row coefficients (gather of v)
 // ------------------------------------------------------------------------------------------------
@@ -261,15 +273,17 @@ k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
 #define RU 4
 template <int G, bool HASVAL>
 __global__ void __launch_bounds__(256)
-k_rowpass_csr(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist)
+k_rowpass_csr(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx)
 {
     __shared__ double scratch[48];
-    const int q = qlist[blockIdx.y];
+    int pi_, bx_;
+    if (!xcd_map(nq, gx, pi_, bx_)) return;
+    const int q = qlist[pi_];
     ProbDev &pr = probs[q];
     const int phase = pr.phase;
     if (phase == PH_DONE) return;
     const PartDev &pa = parts[pr.part];
-    const int b = blockIdx.x;
+    const int b = bx_;
     if (b >= pa.nblk) return;
     const bool cg = (phase == PH_CG);
     const double *__restrict__ v = cg ? pr.d : pr.w_new;
@@ -344,18 +358,20 @@ k_rowpass_csr(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
 #define CU 8
 template <int G, bool HASVAL>
 __global__ void __launch_bounds__(256)
-k_colpass_items(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist)
+k_colpass_items(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx)
 {
-    const int q = qlist[blockIdx.y];
+    int pi_, bx_;
+    if (!xcd_map(nq, gx, pi_, bx_)) return;
+    const int q = qlist[pi_];
     ProbDev &pr = probs[q];
     if (pr.phase == PH_DONE) return;
     const PartDev &pa = parts[pr.part];
     constexpr bool LONG = (G == 64);
     const int nlist = LONG ? pa.n_long : pa.n_short;
     const int32_t *__restrict__ list = LONG ? pa.items_long : pa.items_short;
-    const int slot = blockIdx.x * (256 / G) + threadIdx.x / G;
+    const int slot = bx_ * (256 / G) + threadIdx.x / G;
     const int gl = threadIdx.x % G;
-    if (blockIdx.x * (256 / G) >= nlist) return;
+    if (bx_ * (256 / G) >= nlist) return;
     const bool valid = slot < nlist;
     const int item = list[min(slot, nlist - 1)];
     const double *__restrict__ coef = pr.coef;
@@ -385,6 +401,139 @@ k_colpass_items(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, 
     }
     a = group_allreduce_sum<G>(a);
     if (valid && gl == 0) pr.parts[item] = a;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sparse X pass on the sliced-ELL copies: one THREAD per row / per column segment.
+// Measured (tools/sparse_probe.hip, profiles/r1_notes.md): the lane-group kernels above are bound by the texture
+// addresser (~1 divergent lane address per clock per CU) and by their semi-coalesced 32-byte index reads; in the
+// sliced layout entry k of 64 consecutive work items is one contiguous 256-byte load, every lane has SU
+// independent index loads + gathers in flight and there is no cross-lane reduction. Each sum runs in the
+// reference's own order (entries by ascending index, intercept last; XTv by ascending row inside a segment) with
+// contraction off, so a row's z_i is bit-identical to LogisticRegressionL2.Xv's (llf/LogisticRegressionL2.java:115-129).
+// ------------------------------------------------------------------------------------------------
+#define SU 8
+template <bool HASVAL>
+__global__ void __launch_bounds__(256)
+k_rowpass_sell(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx)
+{
+#pragma clang fp contract(off)
+    __shared__ double scratch[48];
+    int pi_, bx_;
+    if (!xcd_map(nq, gx, pi_, bx_)) return;
+    const int q = qlist[pi_];
+    ProbDev &pr = probs[q];
+    const int phase = pr.phase;
+    if (phase == PH_DONE) return;
+    const PartDev &pa = parts[pr.part];
+    const int b = bx_;
+    if (b >= pa.nblk) return;
+    const bool cg = (phase == PH_CG);
+    const double *__restrict__ v = cg ? pr.d : pr.w_new;
+    const double *__restrict__ wdcur = pr.wd[pr.dsel];
+    double *__restrict__ wdnew = pr.wd[pr.dsel ^ 1];
+    double *__restrict__ coef = pr.coef;
+    const int32_t *__restrict__ rp = pa.rp;
+    const int32_t *__restrict__ rs_ptr = pa.rs_ptr;
+    const int32_t *__restrict__ rs_idx = pa.rs_idx;
+    const float *__restrict__ rs_val = pa.rs_val;
+    const double vb = v[pa.n_feat];
+    const int l = pa.l;
+    const int r0 = b * pa.rows_per_blk;
+    const int r1 = min(l, r0 + pa.rows_per_blk);
+    double red[2] = {0.0, 0.0};          // loss, sum of coef
+    for (int rowb = r0; rowb < r1; rowb += 256) {
+        const int row = rowb + threadIdx.x;
+        const bool valid = row < r1;
+        const int rowc = min(row, l - 1);
+        const int slice = rowc >> 6, lane = rowc & 63;
+        const int base = rs_ptr[slice];
+        const int L = (rs_ptr[slice + 1] - base) >> 6;
+        const int len = valid ? rp[rowc + 1] - rp[rowc] : 0;
+        const double wdv0 = cg ? wdcur[rowc] : 0.0;
+        const float offv = cg ? 0.f : pa.off[rowc];
+        const float wtv = cg ? 0.f : pa.wt[rowc];
+        const int yv = cg ? 0 : (int)pa.y[rowc];
+        double a = 0.0;
+        for (int k = 0; k < L; k += SU) {
+            int idx[SU];
+            float xv[SU];
+#pragma unroll
+            for (int u = 0; u < SU; u++) {
+                const int kk = min(k + u, L - 1);
+                idx[u] = rs_idx[base + kk * 64 + lane];
+                if (HASVAL) xv[u] = rs_val[base + kk * 64 + lane];
+            }
+            double vv[SU];
+#pragma unroll
+            for (int u = 0; u < SU; u++) vv[u] = v[idx[u]];
+#pragma unroll
+            for (int u = 0; u < SU; u++) {
+                const double term = HASVAL ? vv[u] * (double)xv[u] : vv[u];
+                if (k + u < len) a = a + term;
+            }
+        }
+        if (valid) {
+            const double t = a + vb;
+            double cf;
+            if (cg) {
+                cf = wdv0 * t;
+            } else {
+                double loss, wdv;
+                row_eval(t + (double)offv, yv, (double)wtv, loss, wdv, cf);
+                wdnew[row] = wdv;
+                red[0] += loss;
+            }
+            coef[row] = cf;
+            red[1] += cf;
+        }
+    }
+    block_allreduce_sum<2>(red, scratch);
+    if (threadIdx.x == 0) { pr.lossp[b] = red[0]; pr.csump[b] = red[1]; }
+}
+
+template <bool HASVAL>
+__global__ void __launch_bounds__(256)
+k_colpass_sell(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx)
+{
+#pragma clang fp contract(off)
+    int pi_, bx_;
+    if (!xcd_map(nq, gx, pi_, bx_)) return;
+    const int q = qlist[pi_];
+    ProbDev &pr = probs[q];
+    if (pr.phase == PH_DONE) return;
+    const PartDev &pa = parts[pr.part];
+    const int slot = bx_ * 256 + threadIdx.x;
+    const int slice = slot >> 6, lane = slot & 63;
+    if (slice >= pa.n_cslices) return;                 // wave-uniform
+    const int item = pa.cs_item[slot];
+    const int32_t *__restrict__ cs_idx = pa.cs_idx;
+    const float *__restrict__ cs_val = pa.cs_val;
+    const double *__restrict__ coef = pr.coef;
+    const int base = pa.cs_ptr[slice];
+    const int L = (pa.cs_ptr[slice + 1] - base) >> 6;
+    const int itc = max(item, 0);
+    const int len = item >= 0 ? pa.item_ptr[itc + 1] - pa.item_ptr[itc] : 0;
+    double a = 0.0;
+    for (int k = 0; k < L; k += SU) {
+        int idx[SU];
+        float xv[SU];
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+            const int kk = min(k + u, L - 1);
+            idx[u] = cs_idx[base + kk * 64 + lane];
+            if (HASVAL) xv[u] = cs_val[base + kk * 64 + lane];
+        }
+        double cc[SU];
+#pragma unroll
+        for (int u = 0; u < SU; u++) cc[u] = coef[idx[u]];
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+            const double term = HASVAL ? cc[u] * (double)xv[u] : cc[u];
+            if (k + u < len) a = a + term;
+        }
+    }
+    if (item >= 0) pr.parts[item] = a;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -526,14 +675,14 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
     if (phase == PH_CG) {
         // ---- one CG step (bw/Tron.java:145-175)
         double a1[1] = {0.0};
-        for (int j = tid; j < n; j += nt) {
+        _Pragma("unroll 4") for (int j = tid; j < n; j += nt) {
             const double hd = d[j] * pinv_at(pr, j) + Hd[j];      // Hs[i] = (s[i]*priorVar_inv[i] + Hs[i]) * 1
             Hd[j] = hd;
             a1[0] += d[j] * hd;
         }
         block_allreduce_sum<1>(a1, scratch);
         double alpha = rTr0 / a1[0];
-        for (int j = tid; j < n; j += nt) s[j] += alpha * d[j];    // daxpy(alpha, d, s)
+        _Pragma("unroll 4") for (int j = tid; j < n; j += nt) s[j] += alpha * d[j];    // daxpy(alpha, d, s)
         __syncthreads();
         const double snorm = block_norm(s, n, scratch);
         bool end_cg = false;
@@ -541,7 +690,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
             // cg reaches trust region boundary (:150-168)
             alpha = -alpha;
             double a3[3] = {0.0, 0.0, 0.0};
-            for (int j = tid; j < n; j += nt) {
+            _Pragma("unroll 4") for (int j = tid; j < n; j += nt) {
                 const double sj = s[j] + alpha * d[j];
                 s[j] = sj;
                 a3[0] += sj * d[j];
@@ -555,7 +704,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
             if (std_ >= 0) alpha = (dsq - sts) / (std_ + rad);
             else alpha = (rad - std_) / dtd;
             const double nalpha = -alpha;
-            for (int j = tid; j < n; j += nt) {
+            _Pragma("unroll 4") for (int j = tid; j < n; j += nt) {
                 s[j] += alpha * d[j];
                 r[j] += nalpha * Hd[j];
             }
@@ -563,7 +712,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
         } else {
             alpha = -alpha;
             double a2[1] = {0.0};
-            for (int j = tid; j < n; j += nt) {
+            _Pragma("unroll 4") for (int j = tid; j < n; j += nt) {
                 const double rj = r[j] + alpha * Hd[j];
                 r[j] = rj;
                 a2[0] += rj * rj;
@@ -571,7 +720,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
             block_allreduce_sum<1>(a2, scratch);
             const double rnew = a2[0];
             const double beta = rnew / rTr0;
-            for (int j = tid; j < n; j += nt) {
+            _Pragma("unroll 4") for (int j = tid; j < n; j += nt) {
                 double dj = d[j];
                 if (beta != 1.0) dj = dj * beta;                   // scale(beta, d)
                 d[j] = dj + 1.0 * r[j];                            // daxpy(one, r, d)
@@ -586,7 +735,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
         if (end_cg) {
             // back in tron(): w_new = w + s, gs, prered (:69-73)
             double a2[2] = {0.0, 0.0};
-            for (int j = tid; j < n; j += nt) {
+            _Pragma("unroll 4") for (int j = tid; j < n; j += nt) {
                 w_new[j] = w[j] + 1.0 * s[j];
                 a2[0] += g[j] * s[j];
                 a2[1] += s[j] * r[j];
@@ -605,7 +754,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
 
     // ---- PH_EVAL0 / PH_EVAL: objective and gradient at w_new
     double a1[1] = {0.0};
-    for (int j = tid; j < n; j += nt) {
+    _Pragma("unroll 4") for (int j = tid; j < n; j += nt) {
         const double t = w_new[j] - m[j];
         const double pj = pinv_at(pr, j);
         a1[0] += t * t * pj;                                        // fun :187-188
@@ -620,7 +769,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
 
     if (phase == PH_EVAL0) {
         // Tron prologue (:47-62): gnorm1 = ||grad(0)||, f, g, delta at the warm start
-        for (int j = tid; j < n; j += nt) {
+        _Pragma("unroll 4") for (int j = tid; j < n; j += nt) {
             g[j] = Hd[j];
             s[j] = (0.0 - m[j]) * pinv_at(pr, j) + pa.c0[j];        // grad(0) staged in s[]
         }
@@ -655,7 +804,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
         const bool accept = actred > eta0 * prered;
         if (accept) {
             iter++;
-            for (int j = tid; j < n; j += nt) { w[j] = w_new[j]; g[j] = Hd[j]; }
+            _Pragma("unroll 4") for (int j = tid; j < n; j += nt) { w[j] = w_new[j]; g[j] = Hd[j]; }
             f = fnew;
             __syncthreads();
             gnorm = block_norm(g, n, scratch);
@@ -680,7 +829,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
     if (start_trcg) {
         // trcg prologue (:133-141): s = 0, r = -g, d = r, cgtol = 0.1||g||, rTr = r.r
         double a2[1] = {0.0};
-        for (int j = tid; j < n; j += nt) {
+        _Pragma("unroll 4") for (int j = tid; j < n; j += nt) {
             const double rj = -g[j];
             s[j] = 0.0; r[j] = rj; d[j] = rj;
             a2[0] += rj * rj;
@@ -694,7 +843,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
         }
         if (gn <= 0.1 * gn) {
             // CG loop exits at once (:144) with s = 0: evaluate the (null) step like the reference does
-            for (int j = tid; j < n; j += nt) w_new[j] = w[j] + 1.0 * 0.0;
+            _Pragma("unroll 4") for (int j = tid; j < n; j += nt) w_new[j] = w[j] + 1.0 * 0.0;
             if (tid == 0) { pr.gs = 0.0; pr.prered = -0.5 * (0.0 - 0.0); pr.newton += 1; pr.phase = PH_EVAL; }
         } else if (tid == 0) {
             pr.phase = PH_CG;
@@ -894,18 +1043,31 @@ int mlxk_xpass_dense(hipStream_t st, const PartDev *parts, ProbDev *probs, const
     return 0;
 }
 
+#define XGRID(nq, gx) ((unsigned)(((nq) + 7) / 8 * 8) * (unsigned)(gx))
+
 template <int G>
 static void launch_rowpass(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq,
                            int maxblk, bool hasval)
 {
-    if (hasval) hipLaunchKernelGGL((k_rowpass_csr<G, true>), dim3(maxblk, nq), dim3(256), 0, st, parts, probs, qlist);
-    else hipLaunchKernelGGL((k_rowpass_csr<G, false>), dim3(maxblk, nq), dim3(256), 0, st, parts, probs, qlist);
+    if (hasval) hipLaunchKernelGGL((k_rowpass_csr<G, true>), dim3(XGRID(nq, maxblk)), dim3(256), 0, st, parts, probs, qlist, nq, maxblk);
+    else hipLaunchKernelGGL((k_rowpass_csr<G, false>), dim3(XGRID(nq, maxblk)), dim3(256), 0, st, parts, probs, qlist, nq, maxblk);
 }
 
 int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
-                   int max_short, int max_long, int rowgroup, bool hasval)
+                   int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cslices)
 {
     if (nq <= 0) return 0;
+    if (sell) {
+        const int gc = (max_cslices * 64 + 255) / 256;
+        if (hasval) {
+            hipLaunchKernelGGL((k_rowpass_sell<true>), dim3(XGRID(nq, maxblk)), dim3(256), 0, st, parts, probs, qlist, nq, maxblk);
+            if (gc > 0) hipLaunchKernelGGL((k_colpass_sell<true>), dim3(XGRID(nq, gc)), dim3(256), 0, st, parts, probs, qlist, nq, gc);
+        } else {
+            hipLaunchKernelGGL((k_rowpass_sell<false>), dim3(XGRID(nq, maxblk)), dim3(256), 0, st, parts, probs, qlist, nq, maxblk);
+            if (gc > 0) hipLaunchKernelGGL((k_colpass_sell<false>), dim3(XGRID(nq, gc)), dim3(256), 0, st, parts, probs, qlist, nq, gc);
+        }
+        return 0;
+    }
     switch (rowgroup) {
     case 8: launch_rowpass<8>(st, parts, probs, qlist, nq, maxblk, hasval); break;
     case 16: launch_rowpass<16>(st, parts, probs, qlist, nq, maxblk, hasval); break;
@@ -914,12 +1076,12 @@ int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const i
     }
     const int gs = (max_short + 31) / 32, gl = (max_long + 3) / 4;
     if (gl > 0) {
-        if (hasval) hipLaunchKernelGGL((k_colpass_items<64, true>), dim3(gl, nq), dim3(256), 0, st, parts, probs, qlist);
-        else hipLaunchKernelGGL((k_colpass_items<64, false>), dim3(gl, nq), dim3(256), 0, st, parts, probs, qlist);
+        if (hasval) hipLaunchKernelGGL((k_colpass_items<64, true>), dim3(XGRID(nq, gl)), dim3(256), 0, st, parts, probs, qlist, nq, gl);
+        else hipLaunchKernelGGL((k_colpass_items<64, false>), dim3(XGRID(nq, gl)), dim3(256), 0, st, parts, probs, qlist, nq, gl);
     }
     if (gs > 0) {
-        if (hasval) hipLaunchKernelGGL((k_colpass_items<8, true>), dim3(gs, nq), dim3(256), 0, st, parts, probs, qlist);
-        else hipLaunchKernelGGL((k_colpass_items<8, false>), dim3(gs, nq), dim3(256), 0, st, parts, probs, qlist);
+        if (hasval) hipLaunchKernelGGL((k_colpass_items<8, true>), dim3(XGRID(nq, gs)), dim3(256), 0, st, parts, probs, qlist, nq, gs);
+        else hipLaunchKernelGGL((k_colpass_items<8, false>), dim3(XGRID(nq, gs)), dim3(256), 0, st, parts, probs, qlist, nq, gs);
     }
     return 0;
 }

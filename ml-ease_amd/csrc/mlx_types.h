@@ -32,6 +32,17 @@ struct PartDev {
     const int32_t *items_short;  // item ids with <= 64 entries (8-lane groups)
     const int32_t *items_long;   // item ids with 65..512 entries (one wave each)
     int32_t n_short, n_long;
+    // Sliced-ELL copies (slices of 64 work items, entry k of the 64 items contiguous): coalesced index streams for
+    // thread-per-row / thread-per-column-segment passes. sell != 0 when built (row padding <= 1.5x nnz).
+    int32_t sell;
+    int32_t n_rslices, n_cslices;
+    const int32_t *rs_ptr;     // [n_rslices+1] entry offset of each row slice (rows 64s .. 64s+63)
+    const int32_t *rs_idx;     // [rs_ptr[n_rslices]] local column ids, slot (slice, k, lane) at rs_ptr[s] + k*64 + lane
+    const float *rs_val;       // values in the same layout or nullptr (binary.feature)
+    const int32_t *cs_ptr;     // [n_cslices+1] same for CSC items ordered by length (longest first)
+    const int32_t *cs_idx;     // row ids
+    const float *cs_val;
+    const int32_t *cs_item;    // [n_cslices*64] item id of each slot (-1 = padding slot)
     int32_t rowgroup;      // lanes per row in the CSR row pass (8..64)
     const int8_t *y;       // +1/-1
     const float *wt;       // instance weight

@@ -84,6 +84,49 @@ __global__ void __launch_bounds__(NT) k_A4(Args a) {
     }
 }
 
+// B4: A4's row-group ILP + LDS-staged hot prefix (cold entries from global)
+template <int RB, int NT, int ABL = 0>
+__global__ void __launch_bounds__(NT) k_B4(Args a) {
+    extern __shared__ double vh[];
+    constexpr int G = 8, RU = 3, GPB = NT / G;
+    const int p = blockIdx.y, b = blockIdx.x;
+    const int *rp = a.rp, *ci = a.ci + (long)p * a.cistride;
+    const double *v = a.v + (long)p * a.vstride, *wd = a.wd + (long)p * a.lstride;
+    double *coef = a.coef + (long)p * a.lstride;
+    const int hot = min(a.hot, a.n);
+    for (int j = threadIdx.x; j < hot; j += NT) vh[j] = v[j];
+    __syncthreads();
+    const int gid = threadIdx.x / G, gl = threadIdx.x % G;
+    const int r0 = b * a.rows_per_blk, r1 = min(a.l, r0 + a.rows_per_blk);
+    for (int base = r0; base < r1; base += GPB * RB) {
+        int k0[RB], k1[RB]; double w[RB], s[RB];
+#pragma unroll
+        for (int q = 0; q < RB; q++) { const int row = base + q * GPB + gid; const int rowc = min(row, r1 - 1);
+            k0[q] = rp[rowc]; k1[q] = row < r1 ? rp[rowc + 1] : k0[q]; w[q] = wd[rowc]; s[q] = 0; }
+        int idx[RB][RU]; double vv[RB][RU];
+#pragma unroll
+        for (int q = 0; q < RB; q++)
+#pragma unroll
+            for (int u = 0; u < RU; u++) {
+                if (ABL == 2) { unsigned hsh = (unsigned)(k0[q] + gl + u * G) * 2654435761u; idx[q][u] = (hsh >> 8) % (unsigned)((hsh & 7) ? 8192 : a.n); }
+                else idx[q][u] = ci[min(k0[q] + gl + u * G, max(k1[q] - 1, k0[q]))];
+            }
+#pragma unroll
+        for (int q = 0; q < RB; q++)
+#pragma unroll
+            for (int u = 0; u < RU; u++) vv[q][u] = (ABL == 1) ? (double)idx[q][u] : ((idx[q][u] < hot) ? vh[idx[q][u]] : v[idx[q][u]]);
+#pragma unroll
+        for (int q = 0; q < RB; q++) {
+#pragma unroll
+            for (int u = 0; u < RU; u++) s[q] += (k0[q] + gl + u * G) < k1[q] ? vv[q][u] : 0.0;
+            for (int kb = k0[q] + G * RU; kb < k1[q]; kb += G) { const int k = kb + gl; if (k < k1[q]) s[q] += v[ci[k]]; }
+            s[q] = group_sum<G>(s[q]);
+            const int row = base + q * GPB + gid;
+            if (row < r1 && gl == 0) coef[row] = w[q] * s[q];
+        }
+    }
+}
+
 // B: 1024 threads, hot prefix of v staged in LDS (HOT doubles), cold entries from global
 template <int G>
 __global__ void __launch_bounds__(1024) k_B(Args a) {
@@ -200,6 +243,12 @@ int main(int argc, char **argv) {
     const double bytes = (double)NP * (nnz * 4.0 + 8.0 * L + 8.0 * N);
     struct V { const char *name; int id; int rpb; int hot; };
     std::vector<V> vs = {{"A 8 lanes/row, global gathers, 128 rows/blk (r1)", 0, 128, 0},
+                         {"B4 LDS hot 8192 + 4 row-groups, 512 thr, 2048 rows/blk", 7, 2048, 8192},
+                         {"B4 ablation: index loads only (no gathers)", 9, 2048, 8192},
+                         {"B4 ablation: gathers only (synthetic indices)", 10, 2048, 8192},
+                         {"B4 LDS hot 16384 + 4 row-groups, 512 thr, 4096 rows/blk", 7, 4096, 16384},
+                         {"B8 LDS hot 8192 + 8 row-groups, 256 thr, 2048 rows/blk", 8, 2048, 8192},
+                         {"B4 LDS hot 4096 + 4 row-groups, 512 thr, 2048 rows/blk", 7, 2048, 4096},
                          {"B G=8 LDS hot 16384, 4096 rows/blk", 1, 4096, 16384}, {"B G=8 LDS hot 16384, 8192 rows/blk", 1, 8192, 16384},
                          {"B G=8 LDS hot 18000, 4096 rows/blk", 1, 4096, 18000}, {"B G=8 hot 0 (global only), 4096 rows/blk", 1, 4096, 0},
                          {"C thread/row LDS hot 16384, 4096 rows/blk", 2, 4096, 16384}, {"C thread/row LDS hot 16384, 8192 rows/blk", 2, 8192, 16384},
@@ -213,6 +262,10 @@ int main(int argc, char **argv) {
     std::vector<double> ref((long)L), got((long)L);
     CK(hipFuncSetAttribute((const void *)k_B<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
     CK(hipFuncSetAttribute((const void *)k_C, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    CK(hipFuncSetAttribute((const void *)k_B4<4, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    CK(hipFuncSetAttribute((const void *)k_B4<8, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    CK(hipFuncSetAttribute((const void *)k_B4<4, 512, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    CK(hipFuncSetAttribute((const void *)k_B4<4, 512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
     CK(hipFuncSetAttribute((const void *)k_D<24, true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
     for (int r = 0; r < reps + 1; r++) for (size_t i = 0; i < vs.size(); i++) {
         Args a{d_rp, d_ci, d_v, d_wd, d_coef, L, N, K, vs[i].rpb, vs[i].hot, nnz, N, L};
@@ -223,6 +276,10 @@ int main(int argc, char **argv) {
         else if (vs[i].id == 2) hipLaunchKernelGGL(k_C, g, dim3(1024), sizeof(double) * std::max(1, vs[i].hot), 0, a);
         else if (vs[i].id == 3) hipLaunchKernelGGL((k_D<24, true, 1024>), g, dim3(1024), sizeof(double) * std::max(1, vs[i].hot), 0, a);
         else if (vs[i].id == 4) hipLaunchKernelGGL((k_D<24, false, 256>), g, dim3(256), 8, 0, a);
+        else if (vs[i].id == 7) hipLaunchKernelGGL((k_B4<4, 512>), g, dim3(512), sizeof(double) * vs[i].hot, 0, a);
+        else if (vs[i].id == 8) hipLaunchKernelGGL((k_B4<8, 256>), g, dim3(256), sizeof(double) * vs[i].hot, 0, a);
+        else if (vs[i].id == 9) hipLaunchKernelGGL((k_B4<4, 512, 1>), g, dim3(512), sizeof(double) * vs[i].hot, 0, a);
+        else if (vs[i].id == 10) hipLaunchKernelGGL((k_B4<4, 512, 2>), g, dim3(512), sizeof(double) * vs[i].hot, 0, a);
         else if (vs[i].id == 5) hipLaunchKernelGGL((k_A4<4, 256>), g, dim3(256), 0, 0, a);
         else hipLaunchKernelGGL((k_A4<8, 256>), g, dim3(256), 0, 0, a);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
