@@ -348,3 +348,55 @@ def test_test_loglik_kernel_vs_oracle(c1):
     got = eng.test_loglik_sums()
     want = ol.test_loglik_sum(eng.z()[0][1], b.row_ptr, gi, None, resp, None, None)
     assert abs(got[1] - want) <= 1e-11 * abs(want)
+
+
+def _ragged_partitions():
+    """Ragged inputs: rows without any feature (intercept only), duplicate feature entries inside a row (kept as separate
+    FeatureNodes, llf/LibLinearDataset.java:479), zero-weight rows, a partition that has no feature at all (n_local = 1),
+    one very long row."""
+    from mlease_amd.dataset import PartitionBlock, PartitionedData
+    rng = np.random.default_rng(17)
+    nfeat, blocks = 40, []
+    for k in range(3):
+        rp, ci, vv, ys, ws, os_ = [0], [], [], [], [], []
+        lidx = {}
+        for i in range(150):
+            m = 0 if (k == 2 or i % 7 == 0) else int(rng.integers(1, 6))
+            if k == 0 and i == 5:
+                m = 30
+            cols = list(rng.integers(0, nfeat, m))
+            if m >= 2 and i % 5 == 0:
+                cols[1] = cols[0]                      # duplicate entry
+            ent = []
+            for c in cols:
+                lidx.setdefault(int(c), len(lidx))
+                ent.append((lidx[int(c)], np.float32(rng.normal())))
+            ent.sort(key=lambda e: e[0])
+            ci += [e[0] for e in ent]
+            vv += [e[1] for e in ent]
+            rp.append(len(ci))
+            ys.append(1 if rng.random() < 0.4 else -1)
+            ws.append(np.float32(0.0 if i % 11 == 0 else rng.uniform(0.5, 2)))
+            os_.append(np.float32(rng.normal(0, 0.2)))
+        blocks.append((k, rp, ci, vv, ys, ws, os_, [c for c, _ in sorted(lidx.items(), key=lambda kv: kv[1])]))
+    out = []
+    for k, rp, ci, vv, ys, ws, os_, lcols in blocks:
+        l2g = np.asarray(lcols + [nfeat], np.int32)
+        out.append(PartitionBlock(k, len(ys), len(l2g), np.asarray(rp, np.int64), np.asarray(ci, np.int32),
+                                  np.asarray(vv, np.float32), np.asarray(ys, np.int8), np.asarray(ws, np.float32),
+                                  np.asarray(os_, np.float32), l2g))
+    return PartitionedData(out, ["f%d" % j for j in range(nfeat)], 3)
+
+
+def test_ragged_inputs():
+    pd = _ragged_partitions()
+    assert pd.blocks[2].n_local == 1 and pd.blocks[2].nnz == 0
+    oc = ol.OracleAdmm(pd.blocks, pd.n_global, [1.0, 30.0], [1.0, 1.0])
+    eng = make_engine(pd, [1.0, 30.0], [1.0, 1.0])
+    for it in range(5):
+        oc.iterate(0.01, 1.0, nthreads=2)
+        eng.iterate(0.01)
+        cnt = np.array([(s.newton_iters, s.accepted, s.cg_iters, s.x_passes) for s in oc.stats()])
+        assert np.array_equal(eng.solve_counters(), cnt)
+        for li in range(2):
+            assert_coef_close(eng.z()[1][li], oc.z()[1][li], "ragged it %d" % it)
