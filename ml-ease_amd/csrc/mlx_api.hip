@@ -623,6 +623,20 @@ int mlx_finalize(mlx_handle h)
         else h->rowgroup = std::max(h->rowgroup, p.rowgroup);
         if (p.hasval != h->csr_hasval) return fail(h, MLX_ERR_INVALID, "binary.feature and valued CSR partitions cannot be mixed in one handle");
     }
+    // Order of the CSR work list = XCD placement (xcd_map in mlx_kernels.hip puts list position i on XCD i % 8):
+    // the n_lambda problems of one partition share its index streams, so they go to the SAME XCD, back to back:
+    // CSR partition number c (c-th in add order) -> XCD c % 8, and within that XCD the sequence (c / 8, lambda).
+    if (nl > 1 && !qc.empty()) {
+        const int ncp = (int)qc.size() / nl;             // qc holds, per CSR partition in add order, its nl problems
+        const int rounds = (ncp + 7) / 8;
+        std::vector<int> ordered((size_t)rounds * nl * 8, -1);
+        for (int c = 0; c < ncp; c++)
+            for (int li = 0; li < nl; li++)
+                ordered[((size_t)(c / 8) * nl + li) * 8 + (size_t)(c % 8)] = qc[(size_t)c * nl + li];
+        // holes (when ncp is not a multiple of 8) are dropped: placement is a speed matter only
+        qc.clear();
+        for (int q : ordered) if (q >= 0) qc.push_back(q);
+    }
     h->nq_dense = (int)qd.size(); h->nq_csr = (int)qc.size();
     if ((rc = dev_upload(h, &h->d_qdense, qd.data(), qd.size()))) return rc;
     if ((rc = dev_upload(h, &h->d_qcsr, qc.data(), qc.size()))) return rc;

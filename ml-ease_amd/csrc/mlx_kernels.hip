@@ -88,6 +88,16 @@ __device__ __forceinline__ double block_norm(const double *__restrict__ v, int n
     return mx * sqrt(a[0]);
 }
 
+// Norm from a sum of squares gathered inside an update loop (saves two passes over the vector). For every vector whose
+// squares neither overflow nor vanish, sqrt(sum v^2) equals euclideanNorm's scale*sqrt(sum (v/scale)^2) up to the last bits
+// (a power-of-two scale makes them identical); outside that range fall back to the scaled two-pass form.
+__device__ __forceinline__ double norm_from_sumsq(double ss, const double *__restrict__ v, int n, double *scratch)
+{
+    if (ss > 1e-280 && ss < 1e280) return sqrt(ss);
+    __syncthreads();
+    return block_norm(v, n, scratch);
+}
+
 // ------------------------------------------------------------------------------------------------
 // row-wise scalar maps
 // ------------------------------------------------------------------------------------------------
@@ -665,8 +675,24 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
     double *__restrict__ s = pr.s, *__restrict__ r = pr.r, *__restrict__ d = pr.d, *__restrict__ Hd = pr.Hd;
     const double *__restrict__ m = pr.m;
 
-    assemble_out(pa, pr, Hd, scratch, stage);
+    // X'c of this tick: dense partitions assemble their per-block partial vectors into Hd[] first; CSR partitions read
+    // their column-segment sums inline in the first update loop (one write + one read of Hd[] less per tick).
+    const bool inl = !pa.dense;
+    const int nf = pa.n_feat;
+    double csum_icpt = 0.0;
+    if (inl) csum_icpt = block_sum_array(pr.csump, pa.nblk, scratch);
+    else assemble_out(pa, pr, Hd, scratch, stage);
     __syncthreads();
+    const double *__restrict__ segsum = pr.parts;
+    const int32_t *__restrict__ col_item = pa.col_item;
+    auto xtc = [&](int j) -> double {
+        if (!inl) return Hd[j];
+        if (j >= nf) return csum_icpt;
+        double a = 0.0;
+        const int i0 = col_item[j], i1 = col_item[j + 1];
+        for (int it = i0; it < i1; it++) a += segsum[it];
+        return a;
+    };
 
     const double rTr0 = pr.rTr, delta0 = pr.delta, cgtol0 = pr.cgtol, eps0 = pr.eps, gnorm1_0 = pr.gnorm1;
     double gnorm_cur = pr.gnorm;
@@ -676,15 +702,20 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
         // ---- one CG step (bw/Tron.java:145-175)
         double a1[1] = {0.0};
         _Pragma("unroll 4") for (int j = tid; j < n; j += nt) {
-            const double hd = d[j] * pinv_at(pr, j) + Hd[j];      // Hs[i] = (s[i]*priorVar_inv[i] + Hs[i]) * 1
+            const double hd = d[j] * pinv_at(pr, j) + xtc(j);     // Hs[i] = (s[i]*priorVar_inv[i] + Hs[i]) * 1
             Hd[j] = hd;
             a1[0] += d[j] * hd;
         }
         block_allreduce_sum<1>(a1, scratch);
         double alpha = rTr0 / a1[0];
-        _Pragma("unroll 4") for (int j = tid; j < n; j += nt) s[j] += alpha * d[j];    // daxpy(alpha, d, s)
-        __syncthreads();
-        const double snorm = block_norm(s, n, scratch);
+        double ss1[1] = {0.0};
+        _Pragma("unroll 4") for (int j = tid; j < n; j += nt) {
+            const double sj = s[j] + alpha * d[j];                  // daxpy(alpha, d, s)
+            s[j] = sj;
+            ss1[0] += sj * sj;
+        }
+        block_allreduce_sum<1>(ss1, scratch);
+        const double snorm = norm_from_sumsq(ss1[0], s, n, scratch);
         bool end_cg = false;
         if (snorm > delta0) {
             // cg reaches trust region boundary (:150-168)
@@ -725,8 +756,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
                 if (beta != 1.0) dj = dj * beta;                   // scale(beta, d)
                 d[j] = dj + 1.0 * r[j];                            // daxpy(one, r, d)
             }
-            __syncthreads();
-            const double rnorm = block_norm(r, n, scratch);
+            const double rnorm = norm_from_sumsq(rnew, r, n, scratch);
             if (tid == 0) pr.rTr = rnew;
             if (rnorm <= cgtol0) end_cg = true;                  // loop-top test of the next trip (:144)
         }
@@ -758,7 +788,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
         const double t = w_new[j] - m[j];
         const double pj = pinv_at(pr, j);
         a1[0] += t * t * pj;                                        // fun :187-188
-        Hd[j] = t * pj + Hd[j];                                     // grad :224 (multiplier 1)
+        Hd[j] = t * pj + xtc(j);                                    // grad :224 (multiplier 1)
     }
     block_allreduce_sum<1>(a1, scratch);
     const double loss = block_sum_array(pr.lossp, pa.dense ? pr.cur_nblk : pa.nblk, scratch);
