@@ -701,7 +701,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
     if (phase == PH_CG) {
         // ---- one CG step (bw/Tron.java:145-175)
         double a1[1] = {0.0};
-        _Pragma("unroll 4") for (int j = tid; j < n; j += nt) {
+        _Pragma("unroll 8") for (int j = tid; j < n; j += nt) {
             const double hd = d[j] * pinv_at(pr, j) + xtc(j);     // Hs[i] = (s[i]*priorVar_inv[i] + Hs[i]) * 1
             Hd[j] = hd;
             a1[0] += d[j] * hd;
@@ -709,7 +709,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
         block_allreduce_sum<1>(a1, scratch);
         double alpha = rTr0 / a1[0];
         double ss1[1] = {0.0};
-        _Pragma("unroll 4") for (int j = tid; j < n; j += nt) {
+        _Pragma("unroll 8") for (int j = tid; j < n; j += nt) {
             const double sj = s[j] + alpha * d[j];                  // daxpy(alpha, d, s)
             s[j] = sj;
             ss1[0] += sj * sj;
@@ -721,7 +721,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
             // cg reaches trust region boundary (:150-168)
             alpha = -alpha;
             double a3[3] = {0.0, 0.0, 0.0};
-            _Pragma("unroll 4") for (int j = tid; j < n; j += nt) {
+            _Pragma("unroll 8") for (int j = tid; j < n; j += nt) {
                 const double sj = s[j] + alpha * d[j];
                 s[j] = sj;
                 a3[0] += sj * d[j];
@@ -735,7 +735,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
             if (std_ >= 0) alpha = (dsq - sts) / (std_ + rad);
             else alpha = (rad - std_) / dtd;
             const double nalpha = -alpha;
-            _Pragma("unroll 4") for (int j = tid; j < n; j += nt) {
+            _Pragma("unroll 8") for (int j = tid; j < n; j += nt) {
                 s[j] += alpha * d[j];
                 r[j] += nalpha * Hd[j];
             }
@@ -743,7 +743,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
         } else {
             alpha = -alpha;
             double a2[1] = {0.0};
-            _Pragma("unroll 4") for (int j = tid; j < n; j += nt) {
+            _Pragma("unroll 8") for (int j = tid; j < n; j += nt) {
                 const double rj = r[j] + alpha * Hd[j];
                 r[j] = rj;
                 a2[0] += rj * rj;
@@ -751,7 +751,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
             block_allreduce_sum<1>(a2, scratch);
             const double rnew = a2[0];
             const double beta = rnew / rTr0;
-            _Pragma("unroll 4") for (int j = tid; j < n; j += nt) {
+            _Pragma("unroll 8") for (int j = tid; j < n; j += nt) {
                 double dj = d[j];
                 if (beta != 1.0) dj = dj * beta;                   // scale(beta, d)
                 d[j] = dj + 1.0 * r[j];                            // daxpy(one, r, d)
@@ -765,7 +765,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
         if (end_cg) {
             // back in tron(): w_new = w + s, gs, prered (:69-73)
             double a2[2] = {0.0, 0.0};
-            _Pragma("unroll 4") for (int j = tid; j < n; j += nt) {
+            _Pragma("unroll 8") for (int j = tid; j < n; j += nt) {
                 w_new[j] = w[j] + 1.0 * s[j];
                 a2[0] += g[j] * s[j];
                 a2[1] += s[j] * r[j];
@@ -784,7 +784,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
 
     // ---- PH_EVAL0 / PH_EVAL: objective and gradient at w_new
     double a1[1] = {0.0};
-    _Pragma("unroll 4") for (int j = tid; j < n; j += nt) {
+    _Pragma("unroll 8") for (int j = tid; j < n; j += nt) {
         const double t = w_new[j] - m[j];
         const double pj = pinv_at(pr, j);
         a1[0] += t * t * pj;                                        // fun :187-188
@@ -799,7 +799,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
 
     if (phase == PH_EVAL0) {
         // Tron prologue (:47-62): gnorm1 = ||grad(0)||, f, g, delta at the warm start
-        _Pragma("unroll 4") for (int j = tid; j < n; j += nt) {
+        _Pragma("unroll 8") for (int j = tid; j < n; j += nt) {
             g[j] = Hd[j];
             s[j] = (0.0 - m[j]) * pinv_at(pr, j) + pa.c0[j];        // grad(0) staged in s[]
         }
@@ -834,7 +834,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
         const bool accept = actred > eta0 * prered;
         if (accept) {
             iter++;
-            _Pragma("unroll 4") for (int j = tid; j < n; j += nt) { w[j] = w_new[j]; g[j] = Hd[j]; }
+            _Pragma("unroll 8") for (int j = tid; j < n; j += nt) { w[j] = w_new[j]; g[j] = Hd[j]; }
             f = fnew;
             __syncthreads();
             gnorm = block_norm(g, n, scratch);
@@ -859,7 +859,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
     if (start_trcg) {
         // trcg prologue (:133-141): s = 0, r = -g, d = r, cgtol = 0.1||g||, rTr = r.r
         double a2[1] = {0.0};
-        _Pragma("unroll 4") for (int j = tid; j < n; j += nt) {
+        _Pragma("unroll 8") for (int j = tid; j < n; j += nt) {
             const double rj = -g[j];
             s[j] = 0.0; r[j] = rj; d[j] = rj;
             a2[0] += rj * rj;
@@ -873,7 +873,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
         }
         if (gn <= 0.1 * gn) {
             // CG loop exits at once (:144) with s = 0: evaluate the (null) step like the reference does
-            _Pragma("unroll 4") for (int j = tid; j < n; j += nt) w_new[j] = w[j] + 1.0 * 0.0;
+            _Pragma("unroll 8") for (int j = tid; j < n; j += nt) w_new[j] = w[j] + 1.0 * 0.0;
             if (tid == 0) { pr.gs = 0.0; pr.prered = -0.5 * (0.0 - 0.0); pr.newton += 1; pr.phase = PH_EVAL; }
         } else if (tid == 0) {
             pr.phase = PH_CG;
