@@ -146,6 +146,23 @@ int mlx_admm_solve_local(mlx_handle h, double liblinear_epsilon, float rho_adapt
 int mlx_consensus_buffer(mlx_handle h, void **device_ptr, size_t *count_doubles);
 int mlx_admm_consensus_finish(mlx_handle h, mlx_stats *stats);
 
+/* ---- mean-model warm start (initialize.boost.rate > 0 and regularizer == 2) -----------------
+ * Replaces the RegressionNaiveTrain job that jobs/RegressionAdmmTrain.java:236-276 launches before iteration 1
+ * and the meanModel call that turns its part files into the initial z:
+ *   per (lambda, partition): LibLinear.train(dataset, null, null, priorVarMap, prior.mean, 1/lambda,
+ *   "epsilon=<liblinear.epsilon>") from w = 0 (jobs/RegressionNaiveTrain.java:318-404; priorVarMap = 1/lambda.map[k]
+ *   where mapped, 100000 for the intercept unless penalize.intercept, :311-320), model stored as float32, then
+ *   z = sum_k (1/num.blocks) model_k (utils/LinearModelUtils.java:68-86).
+ * mlx_naive_init == mlx_naive_solve_local + (RCCL all-reduce if mlx_comm_init was called) + mlx_naive_finish;
+ * the split form leaves this shard's partial mean in the xbar half of mlx_consensus_buffer (ubar half = 0) for
+ * the caller's own all-reduce. Afterwards z = the mean (double), u = 0; run iteration 1 with
+ * rho_adapt_rate = initialize.boost.rate (:313-317).
+ *   liblinear_epsilon = Double.parseDouble(String.valueOf(conf float liblinear.epsilon)), 0.01 when the job
+ *   file does not set it (:246-249);  prior_mean = (double)(float) prior.mean (default 0). */
+int mlx_naive_init(mlx_handle h, double liblinear_epsilon, double prior_mean, mlx_stats *stats);
+int mlx_naive_solve_local(mlx_handle h, double liblinear_epsilon, double prior_mean, mlx_stats *stats);
+int mlx_naive_finish(mlx_handle h);
+
 /* ---- results ------------------------------------------------------------------------------- */
 /* Driver z in double and as the float32 the final-model file holds (models/LinearModel.java:703,716). */
 int mlx_get_z(mlx_handle h, double *z_double /* may be NULL */, float *z_float /* may be NULL */);

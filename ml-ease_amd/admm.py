@@ -166,9 +166,6 @@ class AdmmTrain:
     """
 
     def __init__(self, config: AdmmConfig, engine, all_reduce=None):
-        if config.initialize_boost_rate > 0 and config.regularizer == 2:
-            raise NotImplementedError("initialize.boost.rate > 0 (mean-model warm start via NaiveTrain, "
-                                      "jobs/RegressionAdmmTrain.java:236-276) is outside the hot path of this round")
         self.cfg = config
         self.engine = engine
         self.all_reduce = all_reduce
@@ -197,19 +194,40 @@ class AdmmTrain:
         return out
 
     def rho_adapt_rate(self, i: int) -> float:
-        """conf RHO_ADAPT_RATE for iteration i (:313-317,323-327); once set it stays in the conf."""
+        """conf RHO_ADAPT_RATE for iteration i (:313-317,323-327) (the JobConf is rebuilt every iteration)."""
         c = np.float32(self.cfg.rho_adapt_coefficient)
         if i > 1 and c > 0:
             x = -(np.float32(i - 1) * c)                                  # int*float in float, :325
             return float(np.float32(math.exp(float(x))))
         return 1.0
 
+    def mean_model_init(self) -> None:
+        """Initialize z by the mean model (:236-276): the RegressionNaiveTrain job on the same partitions
+        (liblinear.epsilon from the job file, else 0.01, :246-249; prior.mean) and z = meanModel(...); with
+        test.loglik.per.iter the loglik of that z is drawn as iteration 0 (:271-274; never the best model)."""
+        p = self.cfg.extras
+        eps = float_string_roundtrip(np.float32(p.get("liblinear.epsilon", 0.01)))
+        prior_mean = float(np.float32(p.get("prior.mean", 0.0)))
+        self.init_stats = self.engine.naive_solve_local(eps, prior_mean)
+        if self.all_reduce is not None:
+            self.all_reduce(self.engine.consensus_tensor())
+        self.engine.naive_finish()
+        if self.test_n is not None:
+            self.init_test_loglik = self._update_loglik_best_model(0)
+
     def run(self, callback=None) -> List[IterationRecord]:
         cfg = self.cfg
+        boost = cfg.initialize_boost_rate > 0 and cfg.regularizer == 2
+        if boost:
+            self.mean_model_init()
         mindiff = 99999999.0
         e = np.float32(0.01)                                              # :279
-        rate = 1.0
         for i in range(1, cfg.num_iters + 1):
+            # RHO_ADAPT_RATE lives in the per-iteration JobConf (:287-291): the boost rate at i == 1 (:313-317),
+            # exp(-(i-1)c) from i == 2 on when rho.adapt.coefficient > 0 (:323-327), else the reducer default 1
+            rate = 1.0
+            if i == 1 and boost:
+                rate = float(np.float32(cfg.initialize_boost_rate))
             if i > 1 and cfg.rho_adapt_coefficient > 0:
                 rate = self.rho_adapt_rate(i)
             if i > 1 and mindiff < 0.001 and not cfg.aggressive_liblinear_epsilon_decay:

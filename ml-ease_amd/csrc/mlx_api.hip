@@ -80,6 +80,8 @@ struct mlx_context {
     size_t ev_used = 0;
     // scratch vectors of the solve_one problem
     double *sc_vec[8] = {nullptr}, *sc_pinv = nullptr;
+    // mean-model warm start: per-problem prior precision [nprob][max_nlocal], global overrides [n_global]
+    double *d_naive_pinv = nullptr, *d_pinv_ovr = nullptr;
 
     // test set (K15)
     int test_l = 0;
@@ -766,6 +768,8 @@ int mlx_set_state(mlx_handle h, const double *z, const float *u)
     return MLX_OK;
 }
 
+static int collect_solve_stats(mlx_handle h, int64_t ticks, mlx_stats *stats);
+
 int mlx_admm_solve_local(mlx_handle h, double liblinear_epsilon, float rho_adapt_rate, mlx_stats *stats)
 {
     if (!h || !h->finalized) return fail(h, MLX_ERR_INVALID, "mlx_finalize first");
@@ -791,6 +795,12 @@ int mlx_admm_solve_local(mlx_handle h, double liblinear_epsilon, float rho_adapt
     mlxk_outputs(h->stream, h->d_parts, h->d_probs, h->nprob, nl, ng, h->max_nlocal, h->any_absent, h->d_z32, h->d_u,
                  h->d_B, h->d_UPX);
     mlxk_partial_means(h->stream, np, nl, ng, 1.0 / h->num_blocks, h->d_B, h->d_u, h->d_cons, h->d_cons + (size_t)nl * ng);
+    return collect_solve_stats(h, ticks, stats);
+}
+
+// Common tail of the batched solves: wait for the stream, check every problem, fill the counters.
+static int collect_solve_stats(mlx_handle h, int64_t ticks, mlx_stats *stats)
+{
     HIPCHECK(h, hipEventRecord(h->ev_t1, h->stream));
     HIPCHECK(h, hipMemcpyAsync(h->h_probs.data(), h->d_probs, sizeof(ProbDev) * h->nprob, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
@@ -874,6 +884,73 @@ int mlx_admm_iterate(mlx_handle h, double liblinear_epsilon, float rho_adapt_rat
                     h->parts.size(), h->num_blocks);
     }
     return mlx_admm_consensus_finish(h, stats);
+}
+
+// ---- mean-model warm start: jobs/RegressionAdmmTrain.java:236-276 running jobs/RegressionNaiveTrain.java ----
+int mlx_naive_solve_local(mlx_handle h, double liblinear_epsilon, double prior_mean, mlx_stats *stats)
+{
+    if (!h || !h->finalized) return fail(h, MLX_ERR_INVALID, "mlx_finalize first");
+    hipSetDevice(h->device);
+    const int nl = h->n_lambda, ng = h->n_global, np = (int)h->parts.size();
+    int rc;
+    if (!h->d_naive_pinv) {
+        if ((rc = dev_alloc(h, &h->d_naive_pinv, (size_t)h->nprob * h->max_nlocal))) return rc;
+        if ((rc = dev_alloc(h, &h->d_pinv_ovr, (size_t)ng))) return rc;
+    }
+    // prior variance: 1/lambda per key (RegressionNaiveTrain.java:380 `1.0 / lambda`), 1/lambda.map[k] where mapped
+    // (:311-316), 100000 for the intercept unless penalize.intercept (:317-320); precision = 1/var
+    // (llf/LogisticRegressionL2.java:107-109)
+    std::vector<double> pinv(nl), ovr((size_t)ng, std::nan(""));
+    for (int li = 0; li < nl; li++) pinv[li] = 1.0 / (1.0 / (double)h->lambda[li]);
+    if (!h->lambda_map.empty())
+        for (int j = 0; j < ng; j++)
+            if (!std::isnan(h->lambda_map[j])) ovr[j] = 1.0 / (1.0 / (double)h->lambda_map[j]);
+    if (!h->penalize_intercept) ovr[ng - 1] = 1.0 / 100000.0;
+    HIPCHECK(h, hipMemcpyAsync(h->d_pinv_l, pinv.data(), sizeof(double) * nl, hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(h->d_pinv_ovr, ovr.data(), sizeof(double) * ng, hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    h->ev_used = 0;
+    HIPCHECK(h, hipEventRecord(h->ev_t0, h->stream));
+    mlxk_setup_naive(h->stream, h->d_parts, h->d_probs, h->nprob, h->max_nlocal, h->d_pinv_l, h->d_pinv_ovr,
+                     h->d_naive_pinv, prior_mean, liblinear_epsilon, DEFAULT_MAX_ITER);
+    int64_t ticks = 0;
+    rc = run_ticks(h, 0, h->nprob, h->d_qdense, h->nq_dense, h->d_qcsr, h->nq_csr, &ticks);
+    if (rc) return rc;
+    const size_t zl = (size_t)nl * ng;
+    HIPCHECK(h, hipMemsetAsync(h->d_B, 0, sizeof(float) * zl * np, h->stream));
+    mlxk_outputs_naive(h->stream, h->d_parts, h->d_probs, h->nprob, nl, ng, h->max_nlocal, h->d_B);
+    mlxk_partial_means(h->stream, np, nl, ng, 1.0 / h->num_blocks, h->d_B, h->d_B, h->d_cons, h->d_cons + zl);
+    HIPCHECK(h, hipMemsetAsync(h->d_cons + zl, 0, sizeof(double) * zl, h->stream));
+    return collect_solve_stats(h, ticks, stats);
+}
+
+int mlx_naive_finish(mlx_handle h)
+{
+    if (!h || !h->finalized) return fail(h, MLX_ERR_INVALID, "mlx_finalize first");
+    hipSetDevice(h->device);
+    const size_t zl = (size_t)h->n_lambda * h->n_global;
+    // z = meanModel(...) kept in double by the driver (:267); iteration 1 starts from an empty u file (:310-312)
+    HIPCHECK(h, hipMemcpyAsync(h->d_Z, h->d_cons, sizeof(double) * zl, hipMemcpyDeviceToDevice, h->stream));
+    mlxk_round_z(h->stream, (int64_t)zl, h->d_Z, h->d_z32);
+    HIPCHECK(h, hipMemsetAsync(h->d_u, 0, sizeof(float) * zl * h->parts.size(), h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    HIPCHECK(h, hipGetLastError());
+    return MLX_OK;
+}
+
+int mlx_naive_init(mlx_handle h, double liblinear_epsilon, double prior_mean, mlx_stats *stats)
+{
+    int rc = mlx_naive_solve_local(h, liblinear_epsilon, prior_mean, stats);
+    if (rc) return rc;
+    if (h->comm && h->comm_nranks > 1) {
+        const size_t cnt = 2 * (size_t)h->n_lambda * h->n_global;
+        ncclResult_t r = ncclAllReduce(h->d_cons, h->d_cons, cnt, ncclDouble, ncclSum, h->comm, h->stream);
+        if (r != ncclSuccess) return fail(h, MLX_ERR_COMM, "ncclAllReduce failed: %s", ncclGetErrorString(r));
+    } else if ((int)h->parts.size() != h->num_blocks) {
+        return fail(h, MLX_ERR_MISSING_MODELS, "Some models failed! this handle holds %zu of %d partitions and no communicator is set",
+                    h->parts.size(), h->num_blocks);
+    }
+    return mlx_naive_finish(h);
 }
 
 int mlx_get_z(mlx_handle h, double *z_double, float *z_float)

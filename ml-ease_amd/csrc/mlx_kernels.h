@@ -19,6 +19,11 @@ void mlxk_collect_c0(hipStream_t st, const PartDev *parts, const ProbDev *probs,
                      double *const *c0_ptrs);
 void mlxk_setup(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int n_lambda, int n_global,
                 int max_nlocal, const float *z32, const float *u, const double *pinv_l, double epsilon, int max_iter);
+void mlxk_setup_naive(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int max_nlocal,
+                      const double *pinv_l, const double *pinv_ovr, double *pinv_buf, double prior_mean,
+                      double epsilon, int max_iter);
+void mlxk_outputs_naive(hipStream_t st, const PartDev *parts, const ProbDev *probs, int nprob, int n_lambda,
+                        int n_global, int max_nlocal, float *B);
 void mlxk_outputs(hipStream_t st, const PartDev *parts, const ProbDev *probs, int nprob, int n_lambda, int n_global,
                   int max_nlocal, bool any_absent, const float *z32, const float *u, float *B, float *UPX);
 void mlxk_partial_means(hipStream_t st, int nlocal, int n_lambda, int n_global, double invN, const float *B,

@@ -584,6 +584,57 @@ k_setup(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int npro
     }
 }
 
+// Mean-model warm start (initialize.boost.rate): the per-key solve of jobs/RegressionNaiveTrain.java:380
+// `liblinear.train(dataset, null, null, priorVarMap, prior.mean, 1/lambda, option)`: w0 = 0, prior mean constant,
+// prior precision per coordinate (default 1/(1/lambda); lambda.map / intercept overrides in pinv_ovr, NaN = none).
+__global__ void __launch_bounds__(256)
+k_setup_naive(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int nprob, int max_nlocal,
+              const double *__restrict__ pinv_l, const double *__restrict__ pinv_ovr, double *__restrict__ pinv_buf,
+              double prior_mean, double epsilon, int max_iter)
+{
+    const int q = blockIdx.y;
+    if (q >= nprob) return;
+    ProbDev &pr = probs[q];
+    const PartDev &pa = parts[pr.part];
+    const int n = pa.n_local;
+    double *__restrict__ pv = pinv_buf + (int64_t)q * max_nlocal;
+    const double dflt = pinv_l[pr.lambda_idx];
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+        const double o = pinv_ovr[pa.l2g[j]];
+        pv[j] = (o != o) ? dflt : o;
+        pr.w[j] = 0.0;
+        pr.w_new[j] = 0.0;
+        pr.m[j] = prior_mean;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        pr.pinv = 0.0;
+        pr.pinv_vec = pv;
+        const int mn = pa.pos < pa.neg ? pa.pos : pa.neg;
+        pr.eps = epsilon * (double)mn / (double)pa.l;     // llf/LibLinear.java:310-311
+        pr.max_iter = max_iter;
+        pr.phase = PH_EVAL0;
+        pr.iter = 1;
+        pr.cg_iter = 0;
+        pr.newton = pr.accepted = pr.cg_total = pr.ticks = 0;
+        pr.status = ST_OK;
+        pr.f = pr.delta = pr.gnorm = pr.gnorm1 = pr.rTr = pr.cgtol = pr.prered = pr.gs = 0.0;
+    }
+}
+
+// models/part files of the naive job: every feature of the partition's dataset, float32 (models/LinearModel.java:697-720);
+// B was zeroed first, so features absent from the partition add nothing to the mean (LinearModel.java:181-201).
+__global__ void __launch_bounds__(256)
+k_outputs_naive(const PartDev *__restrict__ parts, const ProbDev *__restrict__ probs, int nprob, int n_lambda,
+                int n_global, float *__restrict__ B)
+{
+    const int q = blockIdx.y;
+    if (q >= nprob) return;
+    const ProbDev &pr = probs[q];
+    const PartDev &pa = parts[pr.part];
+    const int64_t base = ((int64_t)pr.part * n_lambda + pr.lambda_idx) * n_global;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < pa.n_local; j += gridDim.x * 256) B[base + pa.l2g[j]] = (float)pr.w[j];
+}
+
 // ------------------------------------------------------------------------------------------------
 // TRON / CG control flow: one workgroup per problem, one call per tick (bw/Tron.java:30-179).
 // Elementwise updates mirror the Java statement by statement with contraction OFF (Java never
@@ -1134,6 +1185,22 @@ void mlxk_setup(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob,
     const int gx = max(1, min(64, (max_nlocal + 255) / 256));
     hipLaunchKernelGGL(k_setup, dim3(gx, nprob), dim3(256), 0, st, parts, probs, nprob, n_lambda, n_global, z32, u,
                        pinv_l, epsilon, max_iter);
+}
+
+void mlxk_setup_naive(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int max_nlocal,
+                      const double *pinv_l, const double *pinv_ovr, double *pinv_buf, double prior_mean,
+                      double epsilon, int max_iter)
+{
+    const int gx = max(1, min(64, (max_nlocal + 255) / 256));
+    hipLaunchKernelGGL(k_setup_naive, dim3(gx, nprob), dim3(256), 0, st, parts, probs, nprob, max_nlocal, pinv_l,
+                       pinv_ovr, pinv_buf, prior_mean, epsilon, max_iter);
+}
+
+void mlxk_outputs_naive(hipStream_t st, const PartDev *parts, const ProbDev *probs, int nprob, int n_lambda,
+                        int n_global, int max_nlocal, float *B)
+{
+    const int gx = max(1, min(64, (max_nlocal + 255) / 256));
+    hipLaunchKernelGGL(k_outputs_naive, dim3(gx, nprob), dim3(256), 0, st, parts, probs, nprob, n_lambda, n_global, B);
 }
 
 void mlxk_outputs(hipStream_t st, const PartDev *parts, const ProbDev *probs, int nprob, int n_lambda, int n_global,

@@ -21,7 +21,7 @@ UNIQUE_ID_BYTES = 128
 ABI_SYMBOLS = [
     "mlx_create", "mlx_destroy", "mlx_last_error", "mlx_set_stream", "mlx_set_profiling", "mlx_set_problem",
     "mlx_set_regularizer", "mlx_add_partition_csr", "mlx_add_partition_dense", "mlx_finalize", "mlx_set_state",
-    "mlx_admm_iterate", "mlx_admm_solve_local", "mlx_consensus_buffer", "mlx_admm_consensus_finish", "mlx_get_z",
+    "mlx_admm_iterate", "mlx_admm_solve_local", "mlx_naive_init", "mlx_naive_solve_local", "mlx_naive_finish", "mlx_consensus_buffer", "mlx_admm_consensus_finish", "mlx_get_z",
     "mlx_get_partition_model", "mlx_get_solve_counters", "mlx_set_test_data", "mlx_test_loglik", "mlx_solve_one", "mlx_comm_get_unique_id", "mlx_comm_init",
     "mlx_version",
 ]
@@ -66,6 +66,9 @@ def load_library():
     L.mlx_set_state.argtypes = [vp, vp, vp]
     L.mlx_admm_iterate.argtypes = [vp, f64, f32, C.POINTER(MlxStats)]
     L.mlx_admm_solve_local.argtypes = [vp, f64, f32, C.POINTER(MlxStats)]
+    L.mlx_naive_init.argtypes = [vp, f64, f64, C.POINTER(MlxStats)]
+    L.mlx_naive_solve_local.argtypes = [vp, f64, f64, C.POINTER(MlxStats)]
+    L.mlx_naive_finish.argtypes = [vp]
     L.mlx_consensus_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.mlx_admm_consensus_finish.argtypes = [vp, C.POINTER(MlxStats)]
     L.mlx_get_z.argtypes = [vp, vp, vp]
@@ -171,6 +174,20 @@ class HipAdmmEngine:
         st = MlxStats()
         self._ck(self.L.mlx_admm_solve_local(self.h, float(epsilon), float(rho_adapt_rate), C.byref(st)))
         return st
+
+    # -- mean-model warm start (initialize.boost.rate; jobs/RegressionAdmmTrain.java:236-276) ---------
+    def naive_init(self, epsilon: float, prior_mean: float = 0.0) -> MlxStats:
+        st = MlxStats()
+        self._ck(self.L.mlx_naive_init(self.h, float(epsilon), float(prior_mean), C.byref(st)))
+        return st
+
+    def naive_solve_local(self, epsilon: float, prior_mean: float = 0.0) -> MlxStats:
+        st = MlxStats()
+        self._ck(self.L.mlx_naive_solve_local(self.h, float(epsilon), float(prior_mean), C.byref(st)))
+        return st
+
+    def naive_finish(self) -> None:
+        self._ck(self.L.mlx_naive_finish(self.h))
 
     def consensus_buffer(self) -> Tuple[int, int]:
         ptr, cnt = C.c_void_p(), C.c_size_t()

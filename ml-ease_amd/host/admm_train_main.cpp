@@ -124,8 +124,6 @@ int run_job(const JobConfig &props)
     const bool binary = props.get_bool("binary.feature", false);
     const float boost = props.get_float("initialize.boost.rate", 0);
     const float rho_adapt = props.get_float("rho.adapt.coefficient", 0);
-    if (boost > 0 && reg == 2)
-        throw Fail("initialize.boost.rate > 0 (NaiveTrain warm start, jobs/RegressionAdmmTrain.java:236-276) is not supported by this build");
     // lambda -> rho (:153-185); a HashMap<Float,Float>: duplicates collapse; sorted ascending for the solver (:636-638)
     std::vector<std::string> lstr = props.get_list("lambda", ','), rstr = props.get_list("rho", ',');
     if (lstr.empty()) throw Fail("Undefined property: lambda");
@@ -232,46 +230,61 @@ int run_job(const JobConfig &props)
     std::vector<float> zf((size_t)nl * ng);
     int i;
     double solve_s = 0;
+    auto update_loglik_best_model = [&](int it) {                                            // :812-845
+        ck(hs[0], mlx_test_loglik(hs[0], lls.data()), "mlx_test_loglik");
+        AvroFileWriter w(out + "/sample-test-loglik/iteration-" + std::to_string(it) + ".avro", kSampleTestLoglikSchemaJson);
+        for (int li = 0; li < nl; li++) {
+            const double ll = lls[(size_t)li] / test_n;
+            const std::string key = java_float_to_string(lam[(size_t)li]);
+            w.put_string(key); w.put_long(it); w.put_float((float)ll);
+            w.end_record();
+            fprintf(stderr, "[mlease] Sample test loglik for lambda=%s is: %.10g\n", key.c_str(), ll);
+            if (ll > (double)best_loglik && it > 0) {
+                ck(hs[0], mlx_get_z(hs[0], nullptr, zf.data()), "mlx_get_z");
+                AvroFileWriter bw(out + "/best-model/best-iteration-" + std::to_string(it) + ".avro", kLinearModelSchemaJson);
+                write_model_record(bw, key, zf.data() + (size_t)li * ng, ds);
+                bw.close();
+                best_loglik = (float)ll;
+            }
+        }
+        w.close();
+    };
+    auto on_all_devices = [&](const char *what, const std::function<int(int)> &call) {
+        if (G == 1) { ck(hs[0], call(0), what); return; }
+        std::vector<std::thread> th;
+        std::vector<int> rcs((size_t)G, 0);
+        for (int g = 0; g < G; g++) th.emplace_back([&, g] { rcs[(size_t)g] = call(g); });
+        for (auto &t : th) t.join();
+        for (int g = 0; g < G; g++) ck(hs[(size_t)g], rcs[(size_t)g], what);
+    };
+    const bool warm_start = boost > 0 && reg == 2;
+    if (warm_start) {
+        // Initialize z by the mean model (:236-276): RegressionNaiveTrain on the same partitions with the job's
+        // liblinear.epsilon (0.01 when unset, :246-249) and prior.mean, then z = meanModel(...)
+        const double ieps = float_string_roundtrip(props.get_float("liblinear.epsilon", 0.01f));
+        const double pmean = (double)props.get_float("prior.mean", 0.0f);
+        auto t0 = clk::now();
+        on_all_devices("mlx_naive_init", [&](int g) { return mlx_naive_init(hs[(size_t)g], ieps, pmean, nullptr); });
+        solve_s += std::chrono::duration<double>(clk::now() - t0).count();
+        fprintf(stderr, "[mlease] mean model initialised (liblinear epsilon %g)\n", ieps);
+        if (test_loglik) update_loglik_best_model(0);                                        // :271-274
+    }
     for (i = 1; i <= niter; i++) {
         float rate = 1.0f;
+        if (i == 1 && warm_start) rate = boost;                                              // :313-317
         if (i > 1 && rho_adapt > 0) rate = (float)std::exp((double)(-(i - 1) * rho_adapt)); // :323-327 (float product, double exp)
         if (i > 1 && mindiff < 0.001 && !aggressive) liblinear_eps = liblinear_eps / 10;     // :338-341
         else if (aggressive && i > 5) liblinear_eps = liblinear_eps / 10;                    // :342-345
         const double eps = float_string_roundtrip(liblinear_eps);                            // :346,:620,:702
         auto t0 = clk::now();
         std::vector<mlx_stats> st((size_t)G);
-        if (G == 1) ck(hs[0], mlx_admm_iterate(hs[0], eps, rate, &st[0]), "mlx_admm_iterate");
-        else {
-            std::vector<std::thread> th;
-            std::vector<int> rcs((size_t)G, 0);
-            for (int g = 0; g < G; g++) th.emplace_back([&, g] { rcs[(size_t)g] = mlx_admm_iterate(hs[(size_t)g], eps, rate, &st[(size_t)g]); });
-            for (auto &t : th) t.join();
-            for (int g = 0; g < G; g++) ck(hs[(size_t)g], rcs[(size_t)g], "mlx_admm_iterate");
-        }
+        on_all_devices("mlx_admm_iterate", [&](int g) { return mlx_admm_iterate(hs[(size_t)g], eps, rate, &st[(size_t)g]); });
         solve_s += std::chrono::duration<double>(clk::now() - t0).count();
         const double maxdiff = st[0].maxdiff;
         mindiff = st[0].mindiff;
         fprintf(stderr, "[mlease] iteration %d: liblinear epsilon %s, max |z - z_prev| = %.6g, min = %.6g\n", i,
                 java_float_to_string(liblinear_eps).c_str(), maxdiff, mindiff);
-        if (test_loglik) {                                                                   // updateLogLikBestModel :812-845
-            ck(hs[0], mlx_test_loglik(hs[0], lls.data()), "mlx_test_loglik");
-            AvroFileWriter w(out + "/sample-test-loglik/iteration-" + std::to_string(i) + ".avro", kSampleTestLoglikSchemaJson);
-            for (int li = 0; li < nl; li++) {
-                const double ll = lls[(size_t)li] / test_n;
-                const std::string key = java_float_to_string(lam[(size_t)li]);
-                w.put_string(key); w.put_long(i); w.put_float((float)ll);
-                w.end_record();
-                fprintf(stderr, "[mlease] Sample test loglik for lambda=%s is: %.10g\n", key.c_str(), ll);
-                if (ll > (double)best_loglik && i > 0) {
-                    ck(hs[0], mlx_get_z(hs[0], nullptr, zf.data()), "mlx_get_z");
-                    AvroFileWriter bw(out + "/best-model/best-iteration-" + std::to_string(i) + ".avro", kLinearModelSchemaJson);
-                    write_model_record(bw, key, zf.data() + (size_t)li * ng, ds);
-                    bw.close();
-                    best_loglik = (float)ll;
-                }
-            }
-            w.close();
-        }
+        if (test_loglik) update_loglik_best_model(i);
         if (maxdiff < epsilon && liblinear_eps <= 0.00001) break;                            // :493-496
     }
     // final-model (:499-501)

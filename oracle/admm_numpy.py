@@ -271,6 +271,33 @@ class AdmmNumpy:
         self.UPX[k, li] = f32(u + beta)                                    # :709-711
         self.stats[(k, li)] = st
 
+    def mean_model_init(self, epsilon: float = 0.01, prior_mean: float = 0.0,
+                        lambda_map: Optional[np.ndarray] = None) -> None:
+        """initialize.boost.rate branch, jobs/RegressionAdmmTrain.java:236-276: one RegressionNaiveTrain reducer per
+        (lambda, partition) (jobs/RegressionNaiveTrain.java:318-404) and z = meanModel (MeanLinearModelConsumer:61)."""
+        b = 1.0 / self.N
+        for li, l in enumerate(self.lam):
+            zbar = np.zeros(self.ng)
+            for k, p in enumerate(self.parts):
+                n = p.X.shape[1]
+                pv = np.full(n, 1.0 / float(l))                            # `1.0 / lambda`, :380
+                if lambda_map is not None:                                 # 1/lambda.map[k], :311-316
+                    lm = np.asarray(lambda_map, np.float32)[p.l2g].astype(np.float64)
+                    pv = np.where(np.isnan(lm), pv, 1.0 / lm)
+                if not self.pen:
+                    pv[p.l2g == self.ng - 1] = 100000.0                    # :317-320
+                st = TronStats()
+                fo = LogisticL2(p.X, p.y, p.weight, p.offset, np.full(n, float(prior_mean)), pv, st)
+                pos = int(np.sum(p.y == 1))
+                neg = p.X.shape[0] - pos
+                w = tron(fo, np.zeros(n), epsilon * min(pos, neg) / p.X.shape[0])
+                model = np.zeros(self.ng)
+                model[p.l2g] = f32(w)                                      # part file float32, LinearModel.java:703,716
+                zbar = zbar + b * model
+                self.stats[(k, li)] = st
+            self.Z[li] = zbar
+        self.u[:] = 0.0
+
     def iterate(self, epsilon: float, rho_adapt_rate: float = 1.0) -> Tuple[float, float]:
         nl = len(self.lam)
         for k in range(len(self.parts)):

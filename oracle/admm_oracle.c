@@ -581,6 +581,64 @@ void orc_admm_iterate(orc_admm *a, double epsilon, float rho_adapt_rate, int nth
     orc_admm_finish(a, maxdiff_out, mindiff_out);
 }
 
+/* Mean-model warm start, jobs/RegressionAdmmTrain.java:236-276: the RegressionNaiveTrain job per (lambda, partition)
+ * (jobs/RegressionNaiveTrain.java:318-404: initParam null, priorMean map null, priorVar map = 1/lambda.map[k] with
+ * the intercept forced to 100000 unless penalize.intercept :311-320, default prior mean = prior.mean, default prior
+ * var = 1.0/lambda, "epsilon=" option) and this shard's part of meanModel (utils/LinearModelUtils.java:68-86 ->
+ * consumers/MeanLinearModelConsumer.java:61: model files are float32, mean accumulates (1/nblocks) * value). */
+static void naive_one(orc_admm *a, int k, int li, double epsilon, double prior_mean)
+{
+    const orc_dataset *d = a->ds[k];
+    int n = d->n, ng = a->n_global;
+    size_t off = ((size_t)k * (size_t)a->nlambda + (size_t)li) * (size_t)ng;
+    float *B = a->B + off;
+    const int *l2g = a->l2g[k];
+    double *w = (double *)malloc(sizeof(double) * (size_t)n);
+    double *pm = (double *)malloc(sizeof(double) * (size_t)n);
+    double *pv = (double *)malloc(sizeof(double) * (size_t)n);
+    for (int j = 0; j < n; j++) {
+        int gj = l2g[j];
+        w[j] = 0.0;
+        pm[j] = prior_mean;
+        pv[j] = 1.0 / (double)a->lambda[li];                                   /* :380 `1.0 / lambda` */
+        if (a->lambda_map && !isnan(a->lambda_map[gj])) pv[j] = 1.0 / (double)a->lambda_map[gj];   /* :311-316 */
+        if (gj == ng - 1 && !a->penalize_intercept) pv[j] = 100000.0;          /* :317-320 */
+    }
+    orc_train(d, w, pm, pv, epsilon, 10000, &a->stats[(size_t)k * (size_t)a->nlambda + (size_t)li]);
+    for (int gj = 0; gj < ng; gj++) B[gj] = 0.0f;          /* features the partition never saw are not in its model */
+    for (int j = 0; j < n; j++) B[l2g[j]] = (float)w[j];   /* models/LinearModel.java:703,716 */
+    free(w); free(pm); free(pv);
+}
+
+void orc_admm_naive_solve_local(orc_admm *a, double epsilon, double prior_mean, int nthreads)
+{
+    int np = a->nlocal * a->nlambda;
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+#endif
+    for (int q = 0; q < np; q++) naive_one(a, q / a->nlambda, q % a->nlambda, epsilon, prior_mean);
+    (void)nthreads;
+    size_t ng = (size_t)a->n_global;
+    double b = 1.0 / a->nblocks;
+    for (int li = 0; li < a->nlambda; li++) {
+        double *xb = a->xbar + (size_t)li * ng, *ub = a->ubar + (size_t)li * ng;
+        for (size_t j = 0; j < ng; j++) { xb[j] = 0; ub[j] = 0; }
+        for (int k = 0; k < a->nlocal; k++) {
+            size_t off = ((size_t)k * (size_t)a->nlambda + (size_t)li) * ng;
+            for (size_t j = 0; j < ng; j++) xb[j] = 1.0 * xb[j] + b * (double)a->B[off + j];
+        }
+    }
+}
+
+/* z = the mean model, kept in double by the driver (:267); the u file of iteration 1 is empty (:310-312). */
+void orc_admm_naive_finish(orc_admm *a)
+{
+    size_t zl = (size_t)a->nlambda * (size_t)a->n_global;
+    memcpy(a->Z, a->xbar, sizeof(double) * zl);
+    memset(a->u, 0, sizeof(float) * zl * (size_t)a->nlocal);
+}
+
 void orc_admm_get_z(const orc_admm *a, double *Z_out, float *z32_out)
 {
     size_t n = (size_t)a->nlambda * (size_t)a->n_global;

@@ -14,9 +14,10 @@ class _Fin:
 
 
 class OracleEngine:
-    def __init__(self, blocks, n_global, lambdas, rhos, num_blocks, penalize_intercept=False, nthreads=2):
+    def __init__(self, blocks, n_global, lambdas, rhos, num_blocks, penalize_intercept=False, nthreads=2,
+                 regularizer=2, lambda_map=None):
         self.o = ol.OracleAdmm(blocks, n_global, lambdas, rhos, num_blocks=num_blocks,
-                               penalize_intercept=penalize_intercept)
+                               penalize_intercept=penalize_intercept, regularizer=regularizer, lambda_map=lambda_map)
         self.nthreads = nthreads
         n = self.o.nl * self.o.ng
         self._buf = np.zeros(2 * n)
@@ -28,6 +29,20 @@ class OracleEngine:
         self._buf[:n] = xb
         self._buf[n:] = ub
         return None
+
+    def naive_solve_local(self, eps, prior_mean=0.0):
+        self.o.naive_solve_local(eps, prior_mean, self.nthreads)
+        xb, ub = self.o.partial_means()
+        n = len(xb)
+        self._buf[:n] = xb
+        self._buf[n:] = ub
+
+    def naive_finish(self):
+        xb, ub = self.o.partial_means()
+        n = len(xb)
+        xb[:] = self._buf[:n]
+        ub[:] = self._buf[n:]
+        self.o.naive_finish()
 
     def consensus_tensor(self):
         return torch.from_numpy(self._buf)

@@ -51,6 +51,8 @@ def lib():
         L.orc_admm_set_partition.argtypes = [vp, i32, vp, vp]
         L.orc_admm_set_options.argtypes = [vp, i32, vp]
         L.orc_admm_solve_local.argtypes = [vp, f64, f32, i32]
+        L.orc_admm_naive_solve_local.argtypes = [vp, f64, f64, i32]
+        L.orc_admm_naive_finish.argtypes = [vp]
         L.orc_admm_xbar.restype = C.POINTER(C.c_double)
         L.orc_admm_xbar.argtypes = [vp]
         L.orc_admm_ubar.restype = C.POINTER(C.c_double)
@@ -143,6 +145,12 @@ class OracleAdmm:
 
     def solve_local(self, epsilon, rho_adapt_rate=1.0, nthreads=1):
         lib().orc_admm_solve_local(self.h, float(epsilon), float(rho_adapt_rate), int(nthreads))
+
+    def naive_solve_local(self, epsilon, prior_mean=0.0, nthreads=1):
+        lib().orc_admm_naive_solve_local(self.h, float(epsilon), float(prior_mean), int(nthreads))
+
+    def naive_finish(self):
+        lib().orc_admm_naive_finish(self.h)
 
     def partial_means(self):
         n = self.nl * self.ng

@@ -400,3 +400,51 @@ def test_ragged_inputs():
         assert np.array_equal(eng.solve_counters(), cnt)
         for li in range(2):
             assert_coef_close(eng.z()[1][li], oc.z()[1][li], "ragged it %d" % it)
+
+
+@pytest.mark.parametrize("variant", ["plain", "lambda_map", "penalize_intercept", "dense"])
+def test_mean_model_warm_start(c1, variant):
+    """N4 initialize.boost.rate (jobs/RegressionAdmmTrain.java:236-276): the batched NaiveTrain solves
+    (jobs/RegressionNaiveTrain.java:318-404), z = meanModel, then iteration 1 with the boost rate -- against
+    the oracle's restatement, counters equal."""
+    kw = {}
+    pd = c1
+    if variant == "lambda_map":
+        lm = np.full(c1.n_global, np.nan, np.float32)
+        lm[::5] = 40.0
+        lm[2] = 0.25
+        lm[-1] = 3.0                                   # overridden by the intercept's 100000 (not penalized)
+        kw = dict(lambda_map=lm)
+    elif variant == "penalize_intercept":
+        kw = dict(penalize_intercept=True)
+    elif variant == "plain":
+        pd = synth_sparse(77, 3000, 2500, 6, 5, weights=True, offsets=True)    # absent features add 0 to the mean
+    lam, rho = [0.5, 30.0], [1.0, 1.0]
+    if variant == "dense":
+        rng = np.random.default_rng(5)
+        X = rng.normal(0, 1, (4000, 24)).astype(np.float32)
+        y01 = (rng.random(4000) < 0.3).astype(np.int8)
+        pd = dataset.dense_partitions(X, y01, 4)
+        eng = HipAdmmEngine(pd.n_global, lam, rho, 4)
+        for k in range(4):
+            sel = np.arange(k, 4000, 4)
+            eng.add_partition_dense(k, X[sel], np.where(y01[sel] == 1, 1, -1))
+        eng.finalize()
+    else:
+        eng = make_engine(pd, lam, rho, **kw)
+    oc = ol.OracleAdmm(pd.blocks, pd.n_global, lam, rho, **kw)
+    prior_mean = 0.125 if variant == "plain" else 0.0
+    oc.naive_solve_local(0.01, prior_mean, nthreads=4)
+    oc.naive_finish()
+    eng.naive_init(0.01, prior_mean)
+    cnt = np.array([(s.newton_iters, s.accepted, s.cg_iters, s.x_passes) for s in oc.stats()])
+    assert np.array_equal(eng.solve_counters(), cnt)
+    Zg, Zo = eng.z()[0], oc.z()[0]
+    for li in range(2):
+        assert_coef_close(Zg[li], Zo[li], "mean model %s" % variant)
+    for it in range(2):
+        rate = 2.5 if it == 0 else 1.0
+        oc.iterate(0.01, rate, nthreads=4)
+        eng.iterate(0.01, rate)
+        for li in range(2):
+            assert_coef_close(eng.z()[1][li], oc.z()[1][li], "z after warm start it %d" % it)

@@ -201,6 +201,12 @@ hist = tr.run()
 Z, z32 = eng.z()
 np.save({out!r} + "/z%d.npy" % rank, Z)
 np.save({out!r} + "/d%d.npy" % rank, np.array([[h.maxdiff, h.mindiff] for h in hist]))
+# the mean-model warm start shards the same way (initialize.boost.rate)
+cfg2 = admm.AdmmConfig(num_blocks=8, lambdas=[1.0, 10.0], num_iters=2, initialize_boost_rate=1.5)
+eng2 = OracleEngine(mine, c1.n_global, lam, rho, 8)
+tr2 = admm.AdmmTrain(cfg2, eng2, all_reduce=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+tr2.run()
+np.save({out!r} + "/zb%d.npy" % rank, eng2.z()[0])
 dist.destroy_process_group()
 """
 
@@ -222,6 +228,52 @@ def test_two_rank_gloo_sharded_consensus(tmp_path):
     done, diffs, _ = oc.run(4)
     assert np.array_equal(z0.astype(np.float32), oc.z()[1])
     assert np.allclose(np.load(tmp_path / "d0.npy"), diffs, rtol=1e-12, atol=0)
+    zb0, zb1 = np.load(tmp_path / "zb0.npy"), np.load(tmp_path / "zb1.npy")
+    assert np.array_equal(zb0, zb1)
+    eng = OracleEngine(c1.blocks, c1.n_global, [1.0, 10.0], [1.0, 1.0], 8)
+    admm.AdmmTrain(admm.AdmmConfig(num_blocks=8, lambdas=[1.0, 10.0], num_iters=2, initialize_boost_rate=1.5), eng).run()
+    assert np.array_equal(zb0.astype(np.float32), eng.z()[1])
+
+
+def test_mean_model_warm_start_driver_flow():
+    """initialize.boost.rate > 0 (jobs/RegressionAdmmTrain.java:236-276,313-317): NaiveTrain mean model first (with
+    liblinear.epsilon / prior.mean from the job file), the boost rate in iteration 1 only, the test loglik of the
+    mean model drawn as iteration 0 without touching the best model; ignored for L1 (`reg==2` guard)."""
+    pd = synth_sparse(9, 800, 120, 5, 4)
+    lam, rho = [1.0, 10.0], [1.0, 1.0]
+    props = {"output.base.path": "x", "num.blocks": "4", "lambda": "1,10", "regularizer": "2", "num.iters": "3",
+             "initialize.boost.rate": "2.5", "liblinear.epsilon": "0.001", "prior.mean": "0.5"}
+    cfg = admm.AdmmConfig.from_properties(props)
+    eng = OracleEngine(pd.blocks, pd.n_global, lam, rho, 4)
+    tr = admm.AdmmTrain(cfg, eng)
+    names = pd.feature_names
+    recs = _raw_records_from_block(pd.blocks[0], names + ["(INTERCEPT)"])
+    rows = dataset.build_test_rows(recs, names)
+    tr.attach_test_rows(rows)
+    seen = {}
+    orig = eng.naive_solve_local
+    eng.naive_solve_local = lambda eps, pm=0.0: (seen.update(eps=eps, pm=pm), orig(eps, pm))[1]
+    hist = tr.run()
+    assert seen == {"eps": admm.float_string_roundtrip(np.float32(0.001)), "pm": 0.5}
+    assert [h.rho_adapt_rate for h in hist] == [2.5, 1.0, 1.0]
+    assert set(tr.init_test_loglik) == {"1.0", "10.0"} and tr.best_model[0] >= 1
+    # same thing by hand on a second oracle
+    oc = ol.OracleAdmm(pd.blocks, pd.n_global, lam, rho)
+    oc.naive_solve_local(admm.float_string_roundtrip(np.float32(0.001)), 0.5, nthreads=2)
+    oc.naive_finish()
+    for i, h in enumerate(hist):
+        oc.iterate(h.liblinear_epsilon, 2.5 if i == 0 else 1.0, nthreads=2)
+    assert np.array_equal(oc.z()[1], eng.z()[1])
+    # rho.adapt.coefficient takes over from iteration 2
+    cfg2 = admm.AdmmConfig.from_properties(dict(props, **{"rho.adapt.coefficient": "0.1"}))
+    tr2 = admm.AdmmTrain(cfg2, OracleEngine(pd.blocks, pd.n_global, lam, rho, 4))
+    r = [h.rho_adapt_rate for h in tr2.run()]
+    assert r[0] == 2.5 and r[1] == float(np.float32(np.exp(float(-(np.float32(1) * np.float32(0.1))))))
+    # L1: the warm start is skipped
+    cfg3 = admm.AdmmConfig.from_properties(dict(props, regularizer="1"))
+    eng3 = OracleEngine(pd.blocks, pd.n_global, lam, rho, 4, regularizer=1)
+    eng3.naive_solve_local = None
+    assert [h.rho_adapt_rate for h in admm.AdmmTrain(cfg3, eng3).run()] == [1.0, 1.0, 1.0]
 
 
 def _raw_records_from_block(b, names):

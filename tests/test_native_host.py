@@ -218,3 +218,30 @@ def test_cli_end_to_end_matches_golden(tmp_path, c1):
     ll = avro_io.read_records(str(tmp_path / "out" / "sample-test-loglik" / "iteration-20.avro"))
     assert ll[0]["lambda"] == "1.0" and ll[0]["iter"] == 20 and -1.0 < ll[0]["testLoglik"] < 0.0
     assert os.path.isdir(tmp_path / "out" / "best-model") and os.path.exists(tmp_path / "out" / "lambda-rho" / "part-r-00000.avro")
+
+
+@pytest.mark.gpu
+def test_cli_mean_model_warm_start(tmp_path, c1):
+    """initialize.boost.rate in the job file: CLI (native host + HIP) == the Python driver loop over the oracle."""
+    subprocess.check_call(["make", "-C", HOST, "-s"])
+    recs = c1_raw_records(c1)
+    avro_io.write_container(str(tmp_path / "in" / "part-00000.avro"), PIG_SCHEMA, recs, codec="deflate")
+    avro_io.write_container(str(tmp_path / "test" / "part-00000.avro"), PIG_SCHEMA, recs[:200], codec="null")
+    job = tmp_path / "boost.job"
+    job.write_text("input.paths=%s\noutput.base.path=%s\ntest.path=%s\nnum.blocks=8\nlambda=1.0,10\nnum.iters=3\nregularizer=2\n"
+                   "map.key=pkey\ninitialize.boost.rate=2.0\nliblinear.epsilon=0.001\n" % (tmp_path / "in", tmp_path / "out", tmp_path / "test"))
+    r = subprocess.run([os.path.join(HOST, "mlease_admm_train"), str(job)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "mean model initialised" in r.stderr
+    models = admm.read_linear_models(str(tmp_path / "out" / "final-model" / "part-r-00000.avro"), c1.feature_names)
+    cfg = admm.AdmmConfig.from_properties(admm.parse_job_file(str(job)))
+    from engines import OracleEngine
+    lam, rho = cfg.sorted_lambda_rho()
+    eng = OracleEngine(c1.blocks, c1.n_global, lam, rho, 8)
+    tr = admm.AdmmTrain(cfg, eng)
+    tr.run()
+    for key, want in tr.final_models().items():
+        err = np.abs(models[key].astype(np.float64) - want) / np.maximum(np.abs(want), 1e-2 * np.max(np.abs(want)))
+        assert np.max(err) <= 1e-5, key
+    ll0 = avro_io.read_records(str(tmp_path / "out" / "sample-test-loglik" / "iteration-0.avro"))
+    assert [x["iter"] for x in ll0] == [0, 0] and not os.path.exists(tmp_path / "out" / "best-model" / "best-iteration-0.avro")

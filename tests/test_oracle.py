@@ -258,3 +258,46 @@ def test_reference_algorithm_is_order_sensitive_on_onehot_data():
     w_e, _ = ol.OracleDataset.from_block(b).train(z, z, one, 1e-9)
     w_f, _ = ol.OracleDataset.from_block(permute_rows(b)).train(z, z, one, 1e-9)
     assert np.max(np.abs(w_e - w_f)) < 1e-6
+
+
+def test_mean_model_warm_start_c_vs_numpy_and_seam(c1):
+    """initialize.boost.rate (jobs/RegressionAdmmTrain.java:236-276): the C restatement of the NaiveTrain + meanModel
+    step equals (a) its own LibLinear.train seam composed by hand and (b) the independent numpy restatement."""
+    pd = synth_sparse(5, 900, 350, 5, 4, weights=True)
+    assert any(b.n_local < pd.n_global for b in pd.blocks)
+    lm = np.full(pd.n_global, np.nan, np.float32)
+    lm[::9] = 12.0
+    lam = [0.5, 8.0]
+    for kw, pmean in ((dict(), 0.0), (dict(lambda_map=lm), 0.0), (dict(penalize_intercept=True), 0.25)):
+        oc = ol.OracleAdmm(pd.blocks, pd.n_global, lam, [1.0, 1.0], **kw)
+        oc.naive_solve_local(0.01, pmean, nthreads=2)
+        oc.naive_finish()
+        Z = oc.z()[0]
+        # (a) composition through the S2 seam
+        for li, l in enumerate(lam):
+            want = np.zeros(pd.n_global)
+            for b in pd.blocks:
+                pv = np.full(b.n_local, 1.0 / float(np.float32(l)))
+                if "lambda_map" in kw:
+                    m = lm[b.local_to_global].astype(np.float64)
+                    pv = np.where(np.isnan(m), pv, 1.0 / m)
+                if not kw.get("penalize_intercept"):
+                    pv[-1] = 100000.0
+                w, _ = ol.OracleDataset.from_block(b).train(np.zeros(b.n_local), np.full(b.n_local, pmean), pv, 0.01)
+                model = np.zeros(pd.n_global)
+                model[b.local_to_global] = w.astype(np.float32)
+                want = want + (1.0 / len(pd.blocks)) * model
+            assert np.array_equal(Z[li], want)
+        # (b) numpy restatement: same float32 mean model
+        na = an.AdmmNumpy(np_parts(pd), pd.n_global, lam, penalize_intercept=bool(kw.get("penalize_intercept")))
+        na.mean_model_init(0.01, pmean, kw.get("lambda_map"))
+        assert np.array_equal(na.Z.astype(np.float32), Z.astype(np.float32))
+        assert np.max(np.abs(na.Z - Z)) <= 1e-12 * np.max(np.abs(Z))
+    # the warm start is a sensible start: mean of the per-partition fits is far closer to the consensus than 0
+    oc0 = ol.OracleAdmm(pd.blocks, pd.n_global, lam, [1.0, 1.0])
+    oc0.run(30)
+    zfin = oc0.z()[0]
+    oc = ol.OracleAdmm(pd.blocks, pd.n_global, lam, [1.0, 1.0])
+    oc.naive_solve_local(0.01, 0.0)
+    oc.naive_finish()
+    assert np.linalg.norm(oc.z()[0] - zfin) < 0.8 * np.linalg.norm(zfin)
