@@ -20,7 +20,9 @@
 
 namespace {
 
-constexpr int CSC_SEG = 512;          // max entries of one CSC work item (8 lanes)
+constexpr int CSC_SEG = 256;          // max entries of one column work item
+constexpr int RBLK_MAX_ROWS = 20224;  // rows of one row block: 20224 fp64 coefficients = 158 KiB of the 160 KiB LDS
+constexpr int CUNIT_ENTRIES = 262144; // padded entries per work unit of the LDS column pass
 constexpr int DEFAULT_MAX_ITER = 10000;   // llf/LibLinear.java:97
 constexpr int64_t TICK_CAP = 2000000;
 
@@ -31,7 +33,7 @@ struct PartHost {
     int n_short = 0, n_long = 0;
     bool sell = false;
     std::vector<int32_t> new2old;          // CSR partitions: library local id -> caller's local id (features only)
-    int n_rslices = 0, n_cslices = 0;
+    int n_rslices = 0, n_cslices = 0, n_rblk = 1, rblk_rows = 0, n_cunits = 0;
     int nblk = 0, nblk_min = 1, rows_per_blk = 0, n_items = 0, rowgroup = 64, pos = 0, neg = 0;
     PartDev dev{};
     double *c0 = nullptr;
@@ -61,7 +63,8 @@ struct mlx_context {
     int maxblk_dense = 0, maxblk_csr = 0, max_nfeat_dense = 0, max_items = 0, max_short = 0, max_long = 0, rowgroup = 64, max_nlocal = 0, max_l = 0;
     int64_t max_parts_len = 0;
     bool csr_hasval = false, any_absent = false, csr_sell = false;
-    int max_cslices = 0;
+    int max_cunits = 0, max_rblk_rows = 0;
+    int row_hot = 4096;                     // SELL row pass: most frequent columns staged in LDS (0, 2048, 4096, 8192)
     int step_threads = 256;
     int target_wgs = 1024;                 // dense pass: workgroups wanted per launch (chunk-granularity policy)
 
@@ -205,7 +208,7 @@ int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
     if (h->profiling) { e0 = next_event(h); e1 = next_event(h); hipEventRecord(e0, h->stream); }
     if (nqd > 0 && mlxk_xpass_dense(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->maxblk_dense, h->max_nfeat_dense, nrun, h->d_done, h->target_wgs))
         return fail(h, MLX_ERR_INVALID, "dense tile wider than 2048 features is not supported; use the CSR form");
-    if (nqc > 0) mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_short, h->max_long, h->rowgroup, h->csr_hasval, h->csr_sell, h->max_cslices);
+    if (nqc > 0) mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_short, h->max_long, h->rowgroup, h->csr_hasval, h->csr_sell, h->max_cunits, h->max_rblk_rows, h->row_hot);
     if (h->profiling) hipEventRecord(e1, h->stream);
     return MLX_OK;
 }
@@ -257,7 +260,7 @@ int finish_part(mlx_handle h, PartHost &ph)
 {
     ph.dev.l = ph.l; ph.dev.n_local = ph.n_local; ph.dev.n_feat = ph.n_feat; ph.dev.dense = ph.dense ? 1 : 0;
     ph.dev.nblk = ph.nblk; ph.dev.nblk_min = ph.nblk_min; ph.dev.rows_per_blk = ph.rows_per_blk; ph.dev.pos = ph.pos; ph.dev.neg = ph.neg;
-    ph.dev.ld = ph.ld; ph.dev.nnz = ph.nnz; ph.dev.n_items = ph.n_items; ph.dev.rowgroup = ph.rowgroup;
+    ph.dev.ld = ph.ld; ph.dev.nnz = ph.nnz; ph.dev.n_items = ph.n_items; ph.dev.n_rblk = ph.n_rblk; ph.dev.rblk_rows = ph.rblk_rows; ph.dev.rowgroup = ph.rowgroup;
     int rc = dev_alloc(h, &ph.c0, (size_t)ph.n_local);
     if (rc) return rc;
     ph.dev.c0 = ph.c0;
@@ -425,23 +428,52 @@ int mlx_add_partition_csr(mlx_handle h, int32_t partition_id, int32_t l, int32_t
             cri[dst] = i;
             if (val) cval[dst] = val_p[k];
         }
-    // column segments of <= CSC_SEG entries
-    std::vector<int32_t> item_ptr, col_item(nf + 1);
-    item_ptr.reserve(nf + nnz / CSC_SEG + 2);
-    for (int j = 0; j < nf; j++) {
-        col_item[j] = (int32_t)item_ptr.size();
-        int32_t b = cp[j];
-        const int32_t e = cp[j + 1];
-        do {
-            item_ptr.push_back(b);
-            b = std::min(e, b + CSC_SEG);
-        } while (b < e);
+    // Row blocks (the LDS column pass stages one block of the row coefficients) and work items: the entries of column j
+    // inside block b, rows ascending, cut into segments of <= CSC_SEG entries; items numbered block-major, each block
+    // padded to a multiple of 64 items. cri/cval are re-ordered into item order so item_ptr is monotone.
+    const int seg = getenv("MLX_SEG") ? atoi(getenv("MLX_SEG")) : CSC_SEG;
+    const int rbmax = getenv("MLX_RBMAX") ? atoi(getenv("MLX_RBMAX")) : RBLK_MAX_ROWS;
+    const int nb = std::max(1, (l + rbmax - 1) / rbmax);
+    const int RB = std::max(64, ((l + nb - 1) / nb + 63) / 64 * 64);
+    ph.n_rblk = nb; ph.rblk_rows = RB;
+    std::vector<int32_t> item_ptr, col_item((size_t)nb * (nf + 1)), blk_item0((size_t)nb + 1);
+    std::vector<int32_t> cri_b((size_t)nnz);
+    std::vector<float> cval_b(val ? (size_t)nnz : 0);
+    {
+        std::vector<int32_t> pos(cp.begin(), cp.end() - 1);      // next unconsumed entry of each column
+        item_ptr.reserve((size_t)nf + (size_t)(nnz / CSC_SEG) + 64 * (size_t)nb + 2);
+        int32_t w = 0;                                           // write position in item order
+        for (int bk = 0; bk < nb; bk++) {
+            blk_item0[(size_t)bk] = (int32_t)item_ptr.size();
+            const int32_t rend = (int32_t)std::min<int64_t>(l, (int64_t)(bk + 1) * RB);
+            for (int j = 0; j < nf; j++) {
+                col_item[(size_t)bk * (nf + 1) + j] = (int32_t)item_ptr.size();
+                int32_t q = pos[(size_t)j];
+                const int32_t e = cp[(size_t)j + 1];
+                int32_t cnt = 0;
+                while (q < e && cri[(size_t)q] < rend) {
+                    if (cnt % seg == 0) item_ptr.push_back(w);
+                    cri_b[(size_t)w] = cri[(size_t)q];
+                    if (val) cval_b[(size_t)w] = cval[(size_t)q];
+                    w++; q++; cnt++;
+                }
+                pos[(size_t)j] = q;
+            }
+            col_item[(size_t)bk * (nf + 1) + nf] = (int32_t)item_ptr.size();
+            while (item_ptr.size() % 64 != 0) item_ptr.push_back(w);          // empty padding items
+        }
+        blk_item0[(size_t)nb] = (int32_t)item_ptr.size();
+        ph.n_items = (int)item_ptr.size();
+        item_ptr.push_back(w);
     }
-    col_item[nf] = (int32_t)item_ptr.size();
-    ph.n_items = (int)item_ptr.size();
-    item_ptr.push_back((int32_t)nnz);
+    cri.swap(cri_b);
+    cval.swap(cval_b);
     std::vector<int32_t> ishort, ilong;
-    for (int it = 0; it < ph.n_items; it++) (item_ptr[it + 1] - item_ptr[it] > 64 ? ilong : ishort).push_back(it);
+    for (int it = 0; it < ph.n_items; it++) {
+        const int32_t len = item_ptr[(size_t)it + 1] - item_ptr[(size_t)it];
+        if (len > 64) ilong.push_back(it);
+        else if (len > 0) ishort.push_back(it);
+    }
     ph.n_short = (int)ishort.size(); ph.n_long = (int)ilong.size();
     // row pass geometry
     const double avg = l ? (double)nnz / l : 0.0;
@@ -456,7 +488,8 @@ int mlx_add_partition_csr(mlx_handle h, int32_t partition_id, int32_t l, int32_t
 
     // Sliced-ELL copies for the thread-per-item passes (k_rowpass_sell / k_colpass_sell): built when padding the rows of a
     // 64-row slice to the slice's longest row costs <= 1.5x the non-zeros (uniform-ish rows: one-hot data pads nothing).
-    std::vector<int32_t> rs_ptr, rs_idx, cs_ptr, cs_idx, cs_item;
+    std::vector<int32_t> rs_ptr, rs_idx, cs_ptr, cs_idx, cw_blk, cw_slice;
+    const int32_t cunit_entries = getenv("MLX_CUNIT") ? atoi(getenv("MLX_CUNIT")) : CUNIT_ENTRIES;
     std::vector<float> rs_val, cs_val;
     {
         const int nrs = (l + 63) / 64;
@@ -480,31 +513,41 @@ int mlx_add_partition_csr(mlx_handle h, int32_t partition_id, int32_t l, int32_t
                     if (val) rs_val[dst] = val_p[k];
                 }
             }
-            // column segments in natural order: columns are already sorted by frequency, so 64 consecutive segments
-            // have similar lengths; natural order keeps the per-segment result writes and their later reads contiguous
-            std::vector<int32_t> order((size_t)ph.n_items);
-            for (int it = 0; it < ph.n_items; it++) order[(size_t)it] = it;
-            const int ncs = (ph.n_items + 63) / 64;
+            // item slices: slice s = items 64s..64s+63 (blocks are padded to 64 items, so a slice lies in one block);
+            // columns are already sorted by frequency, so the 64 items of a slice have similar lengths. Row ids are
+            // stored relative to the block: they index the block's coefficients in LDS.
+            const int ncs = ph.n_items / 64;
             ph.n_cslices = ncs;
             cs_ptr.assign((size_t)ncs + 1, 0);
-            cs_item.assign((size_t)ncs * 64, -1);
-            for (int s = 0; s < ncs; s++) {
+            for (int s2 = 0; s2 < ncs; s2++) {
                 int32_t mx = 0;
-                for (int t = s * 64; t < std::min(ph.n_items, s * 64 + 64); t++) mx = std::max(mx, item_ptr[(size_t)t + 1] - item_ptr[(size_t)t]);
-                cs_ptr[(size_t)s + 1] = cs_ptr[(size_t)s] + mx * 64;
+                for (int t = s2 * 64; t < s2 * 64 + 64; t++) mx = std::max(mx, item_ptr[(size_t)t + 1] - item_ptr[(size_t)t]);
+                cs_ptr[(size_t)s2 + 1] = cs_ptr[(size_t)s2] + mx * 64;
             }
             cs_idx.assign((size_t)cs_ptr[(size_t)ncs], 0);
             if (val) cs_val.assign((size_t)cs_ptr[(size_t)ncs], 0.f);
-            for (int slot = 0; slot < ph.n_items; slot++) {
-                const int32_t it = order[(size_t)slot];
-                cs_item[(size_t)slot] = it;
-                const int32_t base = cs_ptr[(size_t)(slot >> 6)], lane = slot & 63;
-                for (int32_t k = item_ptr[(size_t)it]; k < item_ptr[(size_t)it + 1]; k++) {
-                    const size_t dst = (size_t)base + (size_t)(k - item_ptr[(size_t)it]) * 64 + (size_t)lane;
-                    cs_idx[dst] = cri[(size_t)k];
-                    if (val) cs_val[dst] = cval[(size_t)k];
+            for (int bk = 0; bk < nb; bk++) {
+                for (int it = blk_item0[(size_t)bk]; it < blk_item0[(size_t)bk + 1]; it++) {
+                    const int32_t base = cs_ptr[(size_t)(it >> 6)], lane = it & 63;
+                    for (int32_t k = item_ptr[(size_t)it]; k < item_ptr[(size_t)it + 1]; k++) {
+                        const size_t dst = (size_t)base + (size_t)(k - item_ptr[(size_t)it]) * 64 + (size_t)lane;
+                        cs_idx[dst] = cri[(size_t)k] - bk * RB;
+                        if (val) cs_val[dst] = cval[(size_t)k];
+                    }
+                }
+                // work units of ~CUNIT_ENTRIES padded entries, never across blocks
+                const int sb0 = blk_item0[(size_t)bk] / 64, sb1 = blk_item0[(size_t)bk + 1] / 64;
+                int s0 = sb0;
+                while (s0 < sb1) {
+                    int s1 = s0 + 1;
+                    while (s1 < sb1 && cs_ptr[(size_t)s1 + 1] - cs_ptr[(size_t)s0] <= cunit_entries) s1++;
+                    cw_blk.push_back(bk);
+                    cw_slice.push_back(s0);
+                    s0 = s1;
                 }
             }
+            cw_slice.push_back(ncs);
+            ph.n_cunits = (int)cw_blk.size();
             ph.rows_per_blk = l >= 4096 ? 512 : 256;
             ph.nblk = (l + ph.rows_per_blk - 1) / ph.rows_per_blk;
         }
@@ -533,12 +576,14 @@ int mlx_add_partition_csr(mlx_handle h, int32_t partition_id, int32_t l, int32_t
         if ((rc = dev_upload(h, &d_b, rs_idx.data(), rs_idx.size()))) return rc;
         if ((rc = dev_upload(h, &d_c, cs_ptr.data(), cs_ptr.size()))) return rc;
         if ((rc = dev_upload(h, &d_d, cs_idx.data(), cs_idx.size()))) return rc;
-        if ((rc = dev_upload(h, &d_e, cs_item.data(), cs_item.size()))) return rc;
+        if ((rc = dev_upload(h, &d_e, cw_blk.data(), cw_blk.size()))) return rc;
+        int32_t *d_h;
+        if ((rc = dev_upload(h, &d_h, cw_slice.data(), cw_slice.size()))) return rc;
         if (val) {
             if ((rc = dev_upload(h, &d_f, rs_val.data(), rs_val.size()))) return rc;
             if ((rc = dev_upload(h, &d_g, cs_val.data(), cs_val.size()))) return rc;
         }
-        ph.dev.rs_ptr = d_a; ph.dev.rs_idx = d_b; ph.dev.cs_ptr = d_c; ph.dev.cs_idx = d_d; ph.dev.cs_item = d_e;
+        ph.dev.rs_ptr = d_a; ph.dev.rs_idx = d_b; ph.dev.cs_ptr = d_c; ph.dev.cs_idx = d_d; ph.dev.cw_blk = d_e; ph.dev.cw_slice = d_h; ph.dev.n_cunits = ph.n_cunits;
         ph.dev.rs_val = d_f; ph.dev.cs_val = d_g;
     }
     ph.dev.items_short = d_ishort; ph.dev.items_long = d_ilong; ph.dev.n_short = ph.n_short; ph.dev.n_long = ph.n_long;
@@ -617,7 +662,8 @@ int mlx_finalize(mlx_handle h)
     }
     // a single row-group width / value mode for all CSR partitions of the handle
     h->csr_sell = true;
-    for (auto &p : h->parts) if (!p.dense) { h->csr_sell = h->csr_sell && p.sell; h->max_cslices = std::max(h->max_cslices, p.n_cslices); }
+    for (auto &p : h->parts) if (!p.dense) { h->csr_sell = h->csr_sell && p.sell; h->max_cunits = std::max(h->max_cunits, p.n_cunits); h->max_rblk_rows = std::max(h->max_rblk_rows, p.rblk_rows); }
+    if (const char *e = getenv("MLX_ROW_HOT")) h->row_hot = atoi(e);
     // (if any CSR partition could not be sliced, all of them run the lane-group kernels; those accept any row chunking)
     bool first_csr = true;
     for (auto &p : h->parts) if (!p.dense) {

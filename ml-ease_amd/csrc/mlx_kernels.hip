@@ -423,7 +423,7 @@ k_colpass_items(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, 
 // contraction off, so a row's z_i is bit-identical to LogisticRegressionL2.Xv's (llf/LogisticRegressionL2.java:115-129).
 // ------------------------------------------------------------------------------------------------
 #define SU 8
-template <bool HASVAL>
+template <bool HASVAL, int HOT>
 __global__ void __launch_bounds__(256)
 k_rowpass_sell(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx)
 {
@@ -451,6 +451,14 @@ k_rowpass_sell(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, c
     const int l = pa.l;
     const int r0 = b * pa.rows_per_blk;
     const int r1 = min(l, r0 + pa.rows_per_blk);
+    // the HOT most frequent columns (library ids are frequency-sorted) are gathered from LDS instead of through
+    // the texture addresser / L2
+    __shared__ double hot[HOT > 0 ? HOT : 1];
+    if (HOT > 0) {
+        const int nh = min(HOT, pa.n_local);
+        for (int j = threadIdx.x; j < nh; j += 256) hot[j] = v[j];
+        __syncthreads();
+    }
     double red[2] = {0.0, 0.0};          // loss, sum of coef
     for (int rowb = r0; rowb < r1; rowb += 256) {
         const int row = rowb + threadIdx.x;
@@ -476,7 +484,10 @@ k_rowpass_sell(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, c
             }
             double vv[SU];
 #pragma unroll
-            for (int u = 0; u < SU; u++) vv[u] = v[idx[u]];
+            for (int u = 0; u < SU; u++) {
+                if (HOT > 0) vv[u] = idx[u] < HOT ? hot[idx[u]] : v[idx[u]];
+                else vv[u] = v[idx[u]];
+            }
 #pragma unroll
             for (int u = 0; u < SU; u++) {
                 const double term = HASVAL ? vv[u] * (double)xv[u] : vv[u];
@@ -502,48 +513,68 @@ k_rowpass_sell(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, c
     if (threadIdx.x == 0) { pr.lossp[b] = red[0]; pr.csump[b] = red[1]; }
 }
 
+// Column pass with the row coefficients in LDS. One workgroup = (problem, work unit): the unit's row block of `coef`
+// (<= 19 456 doubles) is staged once, then every wave walks item slices of that block: one THREAD per item, entry k of
+// the 64 items one coalesced 256-B index load, the gather served by LDS instead of the L2 request path (which is what
+// bounds the global-gather form: ~250 G random 8-byte requests/s chip-wide). Sums run in row order, contraction off.
 template <bool HASVAL>
-__global__ void __launch_bounds__(256)
-k_colpass_sell(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx)
+__global__ void __launch_bounds__(1024)
+k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx)
 {
 #pragma clang fp contract(off)
+    extern __shared__ double cf[];
     int pi_, bx_;
     if (!xcd_map(nq, gx, pi_, bx_)) return;
     const int q = qlist[pi_];
     ProbDev &pr = probs[q];
     if (pr.phase == PH_DONE) return;
     const PartDev &pa = parts[pr.part];
-    const int slot = bx_ * 256 + threadIdx.x;
-    const int slice = slot >> 6, lane = slot & 63;
-    if (slice >= pa.n_cslices) return;                 // wave-uniform
-    const int item = pa.cs_item[slot];
+    if (bx_ >= pa.n_cunits) return;
+    const int blk = pa.cw_blk[bx_];
+    const int s0 = pa.cw_slice[bx_], s1 = pa.cw_slice[bx_ + 1];
+    const int r0 = blk * pa.rblk_rows;
+    const int nr = min(pa.rblk_rows, pa.l - r0);
+    {
+        const double *__restrict__ src = pr.coef + r0;      // r0 is a multiple of 64: 16-byte aligned pairs
+        const int np2 = nr >> 1;
+        for (int i = threadIdx.x; i < np2; i += 1024) {
+            const double2 v2 = reinterpret_cast<const double2 *>(src)[i];
+            cf[2 * i] = v2.x;
+            cf[2 * i + 1] = v2.y;
+        }
+        if ((nr & 1) && threadIdx.x == 0) cf[nr - 1] = src[nr - 1];
+    }
+    __syncthreads();
     const int32_t *__restrict__ cs_idx = pa.cs_idx;
     const float *__restrict__ cs_val = pa.cs_val;
-    const double *__restrict__ coef = pr.coef;
-    const int base = pa.cs_ptr[slice];
-    const int L = (pa.cs_ptr[slice + 1] - base) >> 6;
-    const int itc = max(item, 0);
-    const int len = item >= 0 ? pa.item_ptr[itc + 1] - pa.item_ptr[itc] : 0;
-    double a = 0.0;
-    for (int k = 0; k < L; k += SU) {
-        int idx[SU];
-        float xv[SU];
+    const int32_t *__restrict__ cs_ptr = pa.cs_ptr;
+    const int32_t *__restrict__ item_ptr = pa.item_ptr;
+    double *__restrict__ out = pr.parts;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int s = s0 + wave; s < s1; s += 16) {
+        const int base = cs_ptr[s];
+        const int L = (cs_ptr[s + 1] - base) >> 6;
+        const int item = s * 64 + lane;
+        const int len = item_ptr[item + 1] - item_ptr[item];
+        double a = 0.0;
+        for (int k = 0; k < L; k += SU) {
+            int idx[SU];
+            float xv[SU];
 #pragma unroll
-        for (int u = 0; u < SU; u++) {
-            const int kk = min(k + u, L - 1);
-            idx[u] = cs_idx[base + kk * 64 + lane];
-            if (HASVAL) xv[u] = cs_val[base + kk * 64 + lane];
+            for (int u = 0; u < SU; u++) {
+                const int kk = min(k + u, L - 1);
+                idx[u] = cs_idx[base + kk * 64 + lane];
+                if (HASVAL) xv[u] = cs_val[base + kk * 64 + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < SU; u++) {
+                const double c = cf[idx[u]];
+                const double term = HASVAL ? c * (double)xv[u] : c;
+                if (k + u < len) a = a + term;
+            }
         }
-        double cc[SU];
-#pragma unroll
-        for (int u = 0; u < SU; u++) cc[u] = coef[idx[u]];
-#pragma unroll
-        for (int u = 0; u < SU; u++) {
-            const double term = HASVAL ? cc[u] * (double)xv[u] : cc[u];
-            if (k + u < len) a = a + term;
-        }
+        if (len > 0) out[item] = a;
     }
-    if (item >= 0) pr.parts[item] = a;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -686,10 +717,14 @@ __device__ __forceinline__ void assemble_out(const PartDev &pa, const ProbDev &p
         }
     } else {
         const double *__restrict__ parts = pr.parts;
+        const int nrb = pa.n_rblk;
         for (int j = tid; j < nf; j += nt) {
             double a = 0.0;
-            const int i0 = pa.col_item[j], i1 = pa.col_item[j + 1];
-            for (int it = i0; it < i1; it++) a += parts[it];
+            for (int bk = 0; bk < nrb; bk++) {
+                const int32_t *__restrict__ ci = pa.col_item + (int64_t)bk * (nf + 1);
+                const int i0 = ci[j], i1 = ci[j + 1];
+                for (int it = i0; it < i1; it++) a += parts[it];
+            }
             out[j] = a;
         }
         const double cs = block_sum_array(pr.csump, pa.nblk, scratch);
@@ -736,12 +771,24 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
     __syncthreads();
     const double *__restrict__ segsum = pr.parts;
     const int32_t *__restrict__ col_item = pa.col_item;
+    const int nrb = pa.n_rblk;
     auto xtc = [&](int j) -> double {
         if (!inl) return Hd[j];
         if (j >= nf) return csum_icpt;
         double a = 0.0;
-        const int i0 = col_item[j], i1 = col_item[j + 1];
-        for (int it = i0; it < i1; it++) a += segsum[it];
+        if (nrb <= 2) {                 // the common shapes: both blocks' item ranges are fetched before any partial
+            const int i0 = col_item[j], i1 = col_item[j + 1];
+            int k0 = 0, k1 = 0;
+            if (nrb == 2) { k0 = col_item[(nf + 1) + j]; k1 = col_item[(nf + 1) + j + 1]; }
+            for (int it = i0; it < i1; it++) a += segsum[it];
+            for (int it = k0; it < k1; it++) a += segsum[it];
+            return a;
+        }
+        for (int bk = 0; bk < nrb; bk++) {
+            const int32_t *__restrict__ ci = col_item + (int64_t)bk * (nf + 1);
+            const int i0 = ci[j], i1 = ci[j + 1];
+            for (int it = i0; it < i1; it++) a += segsum[it];
+        }
         return a;
     };
 
@@ -1135,18 +1182,36 @@ static void launch_rowpass(hipStream_t st, const PartDev *parts, ProbDev *probs,
 }
 
 int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
-                   int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cslices)
+                   int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cunits, int max_rblk_rows, int hot)
 {
     if (nq <= 0) return 0;
     if (sell) {
-        const int gc = (max_cslices * 64 + 255) / 256;
-        if (hasval) {
-            hipLaunchKernelGGL((k_rowpass_sell<true>), dim3(XGRID(nq, maxblk)), dim3(256), 0, st, parts, probs, qlist, nq, maxblk);
-            if (gc > 0) hipLaunchKernelGGL((k_colpass_sell<true>), dim3(XGRID(nq, gc)), dim3(256), 0, st, parts, probs, qlist, nq, gc);
-        } else {
-            hipLaunchKernelGGL((k_rowpass_sell<false>), dim3(XGRID(nq, maxblk)), dim3(256), 0, st, parts, probs, qlist, nq, maxblk);
-            if (gc > 0) hipLaunchKernelGGL((k_colpass_sell<false>), dim3(XGRID(nq, gc)), dim3(256), 0, st, parts, probs, qlist, nq, gc);
+        const size_t lds = (size_t)max_rblk_rows * sizeof(double);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_colpass_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_colpass_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
         }
+#define LAUNCH_ROWSELL(HV, H) hipLaunchKernelGGL((k_rowpass_sell<HV, H>), dim3(XGRID(nq, maxblk)), dim3(256), 0, st, parts, probs, qlist, nq, maxblk)
+        if (hasval) {
+            switch (hot) {
+            case 2048: LAUNCH_ROWSELL(true, 2048); break;
+            case 4096: LAUNCH_ROWSELL(true, 4096); break;
+            case 8192: LAUNCH_ROWSELL(true, 8192); break;
+            default: LAUNCH_ROWSELL(true, 0); break;
+            }
+            if (max_cunits > 0) hipLaunchKernelGGL((k_colpass_lds<true>), dim3(XGRID(nq, max_cunits)), dim3(1024), lds, st, parts, probs, qlist, nq, max_cunits);
+        } else {
+            switch (hot) {
+            case 2048: LAUNCH_ROWSELL(false, 2048); break;
+            case 4096: LAUNCH_ROWSELL(false, 4096); break;
+            case 8192: LAUNCH_ROWSELL(false, 8192); break;
+            default: LAUNCH_ROWSELL(false, 0); break;
+            }
+            if (max_cunits > 0) hipLaunchKernelGGL((k_colpass_lds<false>), dim3(XGRID(nq, max_cunits)), dim3(1024), lds, st, parts, probs, qlist, nq, max_cunits);
+        }
+#undef LAUNCH_ROWSELL
         return 0;
     }
     switch (rowgroup) {

@@ -24,25 +24,31 @@ struct PartDev {
     const int32_t *rp;     // CSR row pointer [l+1] (intercept excluded)
     const int32_t *ci;     // CSR local column ids [nnz]
     const float *val;      // CSR values [nnz] or nullptr (binary.feature)
-    const int32_t *cri;    // CSC row ids [nnz] (column-major order)
-    const float *cval;     // CSC values [nnz] or nullptr
-    const int32_t *item_ptr;   // [n_items+1] CSC segments (<= SEG entries each), columns in order
-    const int32_t *col_item;   // [n_feat+1] first item of each column
-    int32_t n_items;
-    const int32_t *items_short;  // item ids with <= 64 entries (8-lane groups)
-    const int32_t *items_long;   // item ids with 65..512 entries (one wave each)
+    // Column side (X'c). Rows are cut into n_rblk row blocks of rblk_rows rows (one block's slice of the row
+    // coefficients fits in LDS); the entries of column j inside block b form 0+ work items of <= SEG entries, rows
+    // ascending. Items are numbered block-major, each block padded to a multiple of 64 items (padding items are empty).
+    const int32_t *cri;        // [nnz] row ids in item order (block-major, column-major inside a block)
+    const float *cval;         // [nnz] values in the same order, or nullptr
+    const int32_t *item_ptr;   // [n_items+1] entry offsets of the items
+    const int32_t *col_item;   // [n_rblk][n_feat+1] first item of (block, column); [b][n_feat] = end of block b's real items
+    int32_t n_items;           // incl. padding items
+    int32_t n_rblk, rblk_rows;
+    const int32_t *items_short;  // real item ids with <= 64 entries (8-lane groups; fallback kernels)
+    const int32_t *items_long;   // real item ids with 65..SEG entries (one wave each)
     int32_t n_short, n_long;
     // Sliced-ELL copies (slices of 64 work items, entry k of the 64 items contiguous): coalesced index streams for
-    // thread-per-row / thread-per-column-segment passes. sell != 0 when built (row padding <= 1.5x nnz).
+    // thread-per-row / thread-per-item passes. sell != 0 when built (row padding <= 1.5x nnz).
     int32_t sell;
     int32_t n_rslices, n_cslices;
     const int32_t *rs_ptr;     // [n_rslices+1] entry offset of each row slice (rows 64s .. 64s+63)
     const int32_t *rs_idx;     // [rs_ptr[n_rslices]] local column ids, slot (slice, k, lane) at rs_ptr[s] + k*64 + lane
     const float *rs_val;       // values in the same layout or nullptr (binary.feature)
-    const int32_t *cs_ptr;     // [n_cslices+1] same for CSC items ordered by length (longest first)
-    const int32_t *cs_idx;     // row ids
+    const int32_t *cs_ptr;     // [n_cslices+1] same for the items: slice s = items 64s .. 64s+63 (one block each)
+    const int32_t *cs_idx;     // row ids RELATIVE to the item's row block (index into the LDS-staged coefficients)
     const float *cs_val;
-    const int32_t *cs_item;    // [n_cslices*64] item id of each slot (-1 = padding slot)
+    int32_t n_cunits;          // work units of the LDS column pass: unit u = slices [cw_slice[u], cw_slice[u+1]) of block cw_blk[u]
+    const int32_t *cw_blk;     // [n_cunits]
+    const int32_t *cw_slice;   // [n_cunits+1]
     int32_t rowgroup;      // lanes per row in the CSR row pass (8..64)
     const int8_t *y;       // +1/-1
     const float *wt;       // instance weight

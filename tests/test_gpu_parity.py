@@ -448,3 +448,34 @@ def test_mean_model_warm_start(c1, variant):
         eng.iterate(0.01, rate)
         for li in range(2):
             assert_coef_close(eng.z()[1][li], oc.z()[1][li], "z after warm start it %d" % it)
+
+
+@pytest.mark.parametrize("binary", [False, True])
+def test_row_blocked_column_pass_layouts(binary, monkeypatch):
+    """The LDS column pass on forced-small geometry: several row blocks (generic n_rblk > 2 assembly), short column
+    segments, many work units, the LDS hot prefix of the row pass smaller than n_local -- all against the oracle, and
+    the two-block / default layouts against each other."""
+    pd = synth_sparse(31 + binary, 6000, 5000, 12, 3, binary=binary, weights=True, offsets=True)
+    assert max(b.n_local for b in pd.blocks) > 4096           # the row pass's LDS prefix does not cover every column
+    lam, rho = [0.3, 30.0], [1.0, 1.0]
+    oc = ol.OracleAdmm(pd.blocks, pd.n_global, lam, rho)
+    engines = []
+    for env in ({}, {"MLX_RBMAX": "1024"}, {"MLX_RBMAX": "320", "MLX_SEG": "8", "MLX_CUNIT": "512"},
+                {"MLX_RBMAX": "640", "MLX_SEG": "3", "MLX_ROW_HOT": "2048"}):
+        for k in ("MLX_RBMAX", "MLX_SEG", "MLX_CUNIT", "MLX_ROW_HOT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        engines.append(make_engine(pd, lam, rho))
+    for k in ("MLX_RBMAX", "MLX_SEG", "MLX_CUNIT", "MLX_ROW_HOT"):
+        monkeypatch.delenv(k, raising=False)
+    for it in range(4):
+        oc.iterate(0.01, 1.0, nthreads=3)
+        cnt = np.array([(s.newton_iters, s.accepted, s.cg_iters, s.x_passes) for s in oc.stats()])
+        for e, eng in enumerate(engines):
+            eng.iterate(0.01)
+            assert np.array_equal(eng.solve_counters(), cnt), "layout %d it %d" % (e, it)
+            for li in range(2):
+                assert_coef_close(eng.z()[1][li], oc.z()[1][li], "layout %d z it %d" % (e, it))
+                # z is a mean of float32 models: layouts may differ by a few float32 ulps of single coefficients
+                assert np.max(np.abs(eng.z()[0][li] - engines[0].z()[0][li])) <= 1e-6 * np.max(np.abs(oc.z()[0][li]))
