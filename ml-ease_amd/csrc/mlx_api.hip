@@ -25,6 +25,9 @@ constexpr int RBLK_MAX_ROWS = 20224;  // rows of one row block: 20224 fp64 coeff
 constexpr int CUNIT_ENTRIES = 262144; // padded entries per work unit of the LDS column pass
 constexpr int DEFAULT_MAX_ITER = 10000;   // llf/LibLinear.java:97
 constexpr int64_t TICK_CAP = 2000000;
+constexpr int SMALL_TICKS_PER_LAUNCH = 16384;
+constexpr int64_t SMALL_MAX_NNZ = 65536;   // k_solve_small: partitions up to this many non-zeros / SMALL_MAX_DIM rows and columns
+constexpr int SMALL_MAX_DIM = 16384;
 
 struct PartHost {
     int pid = 0, l = 0, n_local = 0, n_feat = 0;
@@ -62,7 +65,7 @@ struct mlx_context {
     int nq_dense = 0, nq_csr = 0;
     int maxblk_dense = 0, maxblk_csr = 0, max_nfeat_dense = 0, max_items = 0, max_short = 0, max_long = 0, rowgroup = 64, max_nlocal = 0, max_l = 0;
     int64_t max_parts_len = 0;
-    bool csr_hasval = false, any_absent = false, csr_sell = false;
+    bool csr_hasval = false, any_absent = false, csr_sell = false, csr_small = false;
     int max_cunits = 0, max_rblk_rows = 0;
     int row_hot = 4096;                     // SELL row pass: most frequent columns staged in LDS (0, 2048, 4096, 8192)
     int step_threads = 256;
@@ -218,6 +221,27 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
 {
     HIPCHECK(h, hipMemsetAsync(h->d_done, 0, sizeof(int), h->stream));
     h->h_done[0] = h->h_done[1] = 0;
+    if (h->csr_small && nqd == 0 && nqc == count && !h->profiling) {
+        // small CSR problems: the whole solve in one launch (k_solve_small), relaunched only if a problem needs more
+        // than SMALL_TICKS_PER_LAUNCH ticks
+        int64_t ticks = 0;
+        for (;;) {
+            mlxk_solve_small(h->stream, h->d_parts, h->d_probs, count, first, h->csr_hasval, SMALL_TICKS_PER_LAUNCH, h->d_done);
+            ticks += SMALL_TICKS_PER_LAUNCH;
+            HIPCHECK(h, hipMemcpyAsync(&h->h_done[0], h->d_done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHECK(h, hipStreamSynchronize(h->stream));
+            HIPCHECK(h, hipGetLastError());
+            if (h->h_done[0] >= count) break;
+            if (ticks > TICK_CAP) return fail(h, MLX_ERR_MODEL_FITTING, "Model fitting error! solve did not terminate within %lld ticks", (long long)TICK_CAP);
+        }
+        if (ticks_out) {                  // report the longest problem's tick count
+            HIPCHECK(h, hipMemcpy(h->h_probs.data() + first, h->d_probs + first, sizeof(ProbDev) * count, hipMemcpyDeviceToHost));
+            int mx = 0;
+            for (int q = first; q < first + count; q++) mx = std::max(mx, h->h_probs[(size_t)q].ticks);
+            *ticks_out = mx;
+        }
+        return MLX_OK;
+    }
     const int batch = 4;
     int64_t ticks = 0;
     int slot = 0;
@@ -664,6 +688,9 @@ int mlx_finalize(mlx_handle h)
     h->csr_sell = true;
     for (auto &p : h->parts) if (!p.dense) { h->csr_sell = h->csr_sell && p.sell; h->max_cunits = std::max(h->max_cunits, p.n_cunits); h->max_rblk_rows = std::max(h->max_rblk_rows, p.rblk_rows); }
     if (const char *e = getenv("MLX_ROW_HOT")) h->row_hot = atoi(e);
+    h->csr_small = getenv("MLX_NO_SMALL") == nullptr;
+    for (auto &p : h->parts)
+        if (!p.dense && (p.nnz > SMALL_MAX_NNZ || p.l > SMALL_MAX_DIM || p.n_local > SMALL_MAX_DIM)) h->csr_small = false;
     // (if any CSR partition could not be sliced, all of them run the lane-group kernels; those accept any row chunking)
     bool first_csr = true;
     for (auto &p : h->parts) if (!p.dense) {

@@ -743,18 +743,12 @@ k_collect_c0(const PartDev *__restrict__ parts, const ProbDev *__restrict__ prob
     assemble_out(parts[pr.part], pr, c0_ptrs[blockIdx.x], scratch, stage);
 }
 
-__global__ void __launch_bounds__(1024)
-k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int nprob, int *__restrict__ done_counter)
+__device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, double *scratch, double *stage,
+                                               int *__restrict__ done_counter)
 {
 #pragma clang fp contract(off)
-    __shared__ double scratch[64];
-    __shared__ double stage[1024];
-    const int q = blockIdx.x;
-    if (q >= nprob) return;
-    ProbDev &pr = probs[q];
     const int phase = pr.phase;
     if (phase == PH_DONE) return;
-    const PartDev &pa = parts[pr.part];
     const int n = pa.n_local;
     const int tid = threadIdx.x, nt = blockDim.x;
     double *__restrict__ w = pr.w, *__restrict__ w_new = pr.w_new, *__restrict__ g = pr.g;
@@ -980,6 +974,122 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
     if (finished && tid == 0) {
         pr.phase = PH_DONE;
         atomicAdd(done_counter, 1);
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int nprob, int *__restrict__ done_counter)
+{
+    __shared__ double scratch[64];
+    __shared__ double stage[1024];
+    const int q = blockIdx.x;
+    if (q >= nprob) return;
+    ProbDev &pr = probs[q];
+    tron_step_body(parts[pr.part], pr, scratch, stage, done_counter);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Whole solve in one launch for SMALL CSR partitions (config #1: 125 rows x 200 features): at that size a tick of three
+// kernels costs ~30 us of launch/dependent-load latency for ~1 us of work, so one workgroup per problem runs the tick
+// loop itself -- row pass, column pass and the same TRON step body, separated by workgroup barriers -- until its problem
+// is DONE (or max_ticks, then the host relaunches). Row sums run in the same entry order as the sliced kernels; the
+// loss / coefficient sums are one block reduction instead of per-chunk partials.
+// ------------------------------------------------------------------------------------------------
+template <bool HASVAL>
+__global__ void __launch_bounds__(1024)
+k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int nprob, int max_ticks,
+              int *__restrict__ done_counter)
+{
+#pragma clang fp contract(off)
+    constexpr int G = 8, U = 8;             // 8 lanes per row / per column item, 8 loads in flight per lane
+    __shared__ double scratch[64];
+    __shared__ double stage[1024];
+    const int q = blockIdx.x;
+    if (q >= nprob) return;
+    ProbDev &pr = probs[q];
+    const PartDev &pa = parts[pr.part];
+    const int tid = threadIdx.x, nt = 1024;
+    const int gid = tid / G, gl = tid % G, ng = nt / G;
+    const int l = pa.l, nitems = pa.n_items;
+    const int32_t *__restrict__ rp = pa.rp;
+    const int32_t *__restrict__ ci = pa.ci;
+    const float *__restrict__ val = pa.val;
+    const int32_t *__restrict__ item_ptr = pa.item_ptr;
+    const int32_t *__restrict__ cri = pa.cri;
+    const float *__restrict__ cval = pa.cval;
+    double *__restrict__ coef = pr.coef;
+    double *__restrict__ segsum = pr.parts;
+    for (int b = 1 + tid; b < pa.nblk; b += nt) { pr.lossp[b] = 0.0; pr.csump[b] = 0.0; }
+    // lane-group sum of sparse dot products: lane gl takes entries k0+gl, k0+gl+G, ...; fixed xor tree inside the group
+    auto group_dot = [&](const int32_t *__restrict__ idxs, const float *__restrict__ vals, const double *__restrict__ vec,
+                         int k0, int k1) -> double {
+        double a = 0.0;
+        for (int kb = k0 + gl; kb < k1; kb += G * U) {
+            int idx[U];
+            float xv[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int kk = min(kb + u * G, k1 - 1);
+                idx[u] = idxs[kk];
+                if (HASVAL) xv[u] = vals[kk];
+            }
+            double vv[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) vv[u] = vec[idx[u]];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const double term = HASVAL ? vv[u] * (double)xv[u] : vv[u];
+                if (kb + u * G < k1) a = a + term;
+            }
+        }
+#pragma unroll
+        for (int m = G / 2; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
+        return a;
+    };
+    for (int tick = 0; tick < max_ticks; tick++) {
+        __syncthreads();
+        const int phase = pr.phase;
+        if (phase == PH_DONE) return;
+        const bool cg = (phase == PH_CG);
+        const double *__restrict__ v = cg ? pr.d : pr.w_new;
+        const double *__restrict__ wdcur = pr.wd[pr.dsel];
+        double *__restrict__ wdnew = pr.wd[pr.dsel ^ 1];
+        const double vb = v[pa.n_feat];
+        double red[2] = {0.0, 0.0};
+        for (int rowb = 0; rowb < l; rowb += ng) {
+            const int row = rowb + gid;
+            const bool valid = row < l;
+            const int rowc = min(row, l - 1);
+            const int k0 = rp[rowc], k1 = valid ? rp[rowc + 1] : k0;
+            const double a = group_dot(ci, val, v, k0, k1);
+            if (valid && gl == 0) {
+                const double t = a + vb;
+                double cf;
+                if (cg) {
+                    cf = wdcur[row] * t;
+                } else {
+                    double loss, wdv;
+                    row_eval(t + (double)pa.off[row], (int)pa.y[row], (double)pa.wt[row], loss, wdv, cf);
+                    wdnew[row] = wdv;
+                    red[0] += loss;
+                }
+                coef[row] = cf;
+                red[1] += cf;
+            }
+        }
+        block_allreduce_sum<2>(red, scratch);
+        if (tid == 0) { pr.lossp[0] = red[0]; pr.csump[0] = red[1]; }
+        __syncthreads();
+        for (int itb = 0; itb < nitems; itb += ng) {
+            const int it = itb + gid;
+            const bool valid = it < nitems;
+            const int itc = min(it, nitems - 1);
+            const int k0 = item_ptr[itc], k1 = valid ? item_ptr[itc + 1] : k0;
+            const double a = group_dot(cri, cval, coef, k0, k1);
+            if (valid && gl == 0 && k1 > k0) segsum[it] = a;
+        }
+        __syncthreads();
+        tron_step_body(pa, pr, scratch, stage, done_counter);
     }
 }
 
@@ -1236,6 +1346,13 @@ void mlxk_tron_step(hipStream_t st, const PartDev *parts, ProbDev *probs, int np
                     int *done_counter)
 {
     hipLaunchKernelGGL(k_tron_step, dim3(nprob), dim3(threads), 0, st, parts, probs + first, nprob, done_counter);
+}
+
+void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int first, bool hasval,
+                      int max_ticks, int *done_counter)
+{
+    if (hasval) hipLaunchKernelGGL((k_solve_small<true>), dim3(nprob), dim3(1024), 0, st, parts, probs + first, nprob, max_ticks, done_counter);
+    else hipLaunchKernelGGL((k_solve_small<false>), dim3(nprob), dim3(1024), 0, st, parts, probs + first, nprob, max_ticks, done_counter);
 }
 
 void mlxk_collect_c0(hipStream_t st, const PartDev *parts, const ProbDev *probs, const int *qlist, int nq,

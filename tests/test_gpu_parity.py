@@ -40,12 +40,23 @@ def c1():
     return load_c1()
 
 
+@pytest.fixture(params=["one_launch", "ticks"])
+def csr_path(request, monkeypatch):
+    """Small CSR partitions are solved by k_solve_small (one launch per solve) unless MLX_NO_SMALL is set (then by the
+    lock-step tick kernels every larger problem uses): the parity tests on small data run on both."""
+    if request.param == "ticks":
+        monkeypatch.setenv("MLX_NO_SMALL", "1")
+    else:
+        monkeypatch.delenv("MLX_NO_SMALL", raising=False)
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def gold():
     return load_c1_golden()
 
 
-def test_solve_one_matches_oracle_train(c1):
+def test_solve_one_matches_oracle_train(c1, csr_path):
     """S2 seam == LibLinear.train: same TRON trajectory, w equal to ~1e-12."""
     eng = make_engine(c1, [1.0], [1.0])
     rng = np.random.default_rng(0)
@@ -62,7 +73,7 @@ def test_solve_one_matches_oracle_train(c1):
             assert abs(f - st.f) <= 1e-11 * abs(st.f) and abs(gn1 - st.gnorm1) <= 1e-11 * st.gnorm1
 
 
-def test_c1_admm_20_iterations_vs_golden(c1, gold):
+def test_c1_admm_20_iterations_vs_golden(c1, gold, csr_path):
     """BASELINE config #1: sample data, lambda=1.0, num.blocks=8, 20 iterations, every iteration checked."""
     cfg = admm.AdmmConfig(num_blocks=8, lambdas=[1.0], num_iters=20)
     lam, rho = cfg.sorted_lambda_rho()
@@ -91,7 +102,7 @@ def test_c1_admm_20_iterations_vs_golden(c1, gold):
     assert st.x_passes_dev == 2 * (st.solves + st.cg_iters + st.newton_iters)      # CSR: 2 passes per tick
 
 
-def test_c1_multilambda_vs_golden(c1, gold):
+def test_c1_multilambda_vs_golden(c1, gold, csr_path):
     lam, rho = [float(x) for x in gold["lambdas_m"]], [float(x) for x in gold["rhos_m"]]
     eng = make_engine(c1, lam, rho)
     for i in range(6):
@@ -137,7 +148,7 @@ def test_dense_tile_path_equals_csr_path_and_oracle():
 
 
 @pytest.mark.parametrize("binary", [False, True])
-def test_sparse_absent_features_weights_offsets(binary):
+def test_sparse_absent_features_weights_offsets(binary, csr_path):
     """Partition-local feature spaces (absent features keep z-u), instance weights, offsets, binary.feature."""
     pd = synth_sparse(21 + binary, 3000, 2500, 6, 5, binary=binary, weights=True, offsets=True)
     assert any(b.n_local < pd.n_global for b in pd.blocks)
@@ -177,7 +188,7 @@ def test_rho_adapt_rate_penalize_intercept_and_resume(c1):
     assert np.array_equal(eng.z()[0], eng2.z()[0])
 
 
-def test_run_to_run_determinism(c1):
+def test_run_to_run_determinism(c1, csr_path):
     """No atomics-ordered fp64 sums anywhere: two handles give bit-identical doubles."""
     outs = []
     for _ in range(2):
@@ -188,7 +199,7 @@ def test_run_to_run_determinism(c1):
     assert np.array_equal(outs[0], outs[1])
 
 
-def test_degenerate_single_class_partition_terminates():
+def test_degenerate_single_class_partition_terminates(csr_path):
     """min(pos,neg)=0 -> eps_tron=0 (llf/LibLinear.java:311): TRON exits through the 1e-12 tests, as in the oracle."""
     pd = synth_sparse(9, 400, 30, 4, 2)
     pd.blocks[1].y[:] = -1
@@ -282,7 +293,7 @@ def test_split_api_with_torch_alias_tensor(c1):
     assert np.array_equal(a.z()[0], b.z()[0])
 
 
-def test_l1_regularizer_and_lambda_map(c1):
+def test_l1_regularizer_and_lambda_map(c1, csr_path):
     """R12 remaining branches: L1 iterative thresholding (jobs/RegressionAdmmTrain.java:406-451) and per-feature
     lambda.map weights (:383-386), against the oracle's restatement of the same lines."""
     lm = np.full(c1.n_global, np.nan, np.float32)
@@ -388,7 +399,7 @@ def _ragged_partitions():
     return PartitionedData(out, ["f%d" % j for j in range(nfeat)], 3)
 
 
-def test_ragged_inputs():
+def test_ragged_inputs(csr_path):
     pd = _ragged_partitions()
     assert pd.blocks[2].n_local == 1 and pd.blocks[2].nnz == 0
     oc = ol.OracleAdmm(pd.blocks, pd.n_global, [1.0, 30.0], [1.0, 1.0])
@@ -403,7 +414,7 @@ def test_ragged_inputs():
 
 
 @pytest.mark.parametrize("variant", ["plain", "lambda_map", "penalize_intercept", "dense"])
-def test_mean_model_warm_start(c1, variant):
+def test_mean_model_warm_start(c1, variant, csr_path):
     """N4 initialize.boost.rate (jobs/RegressionAdmmTrain.java:236-276): the batched NaiveTrain solves
     (jobs/RegressionNaiveTrain.java:318-404), z = meanModel, then iteration 1 with the boost rate -- against
     the oracle's restatement, counters equal."""
@@ -460,6 +471,7 @@ def test_row_blocked_column_pass_layouts(binary, monkeypatch):
     lam, rho = [0.3, 30.0], [1.0, 1.0]
     oc = ol.OracleAdmm(pd.blocks, pd.n_global, lam, rho)
     engines = []
+    monkeypatch.setenv("MLX_NO_SMALL", "1")                   # the tick kernels are what this test is about
     for env in ({}, {"MLX_RBMAX": "1024"}, {"MLX_RBMAX": "320", "MLX_SEG": "8", "MLX_CUNIT": "512"},
                 {"MLX_RBMAX": "640", "MLX_SEG": "3", "MLX_ROW_HOT": "2048"}):
         for k in ("MLX_RBMAX", "MLX_SEG", "MLX_CUNIT", "MLX_ROW_HOT"):
