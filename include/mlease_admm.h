@@ -194,6 +194,20 @@ int mlx_solve_one(mlx_handle h, int32_t local_index, double *w, const double *pr
                   const double *prior_var, double epsilon, int32_t max_iter, int32_t *counters4,
                   double *f_out, double *gnorm_out, double *gnorm1_out);
 
+/* ---- posterior variance at the mode: the computePosteriorVar tail of LibLinear.train ----------
+ * (liblinearfunc/LibLinear.java:221-228 with computePosteriorVar = true, body :314-337; the ADMM reducer passes false,
+ * jobs/ItemModelTrain.java:269 is the reference's caller). On local partition `local_index`, arrays in the
+ * partition's LOCAL index space like mlx_solve_one:
+ *   full == 0: post_var[j] = 1 / hessianDiagonal(w)[j]          (liblinearfunc/LogisticRegressionL2.java:304-327)
+ *   full != 0: H = diag(1/prior_var) + X' D X                   (:258-297; D_ii = weight_i p_i (1 - p_i)), built on the
+ *              GPU as an fp64-MFMA Gram matrix, then commons-math3 3.2 CholeskyDecomposition + getInverse():
+ *              post_var_matrix[n_local * n_local] (row-major, may be NULL) and post_var = its diagonal.
+ * Errors: MLX_ERR_MODEL_FITTING when the Cholesky checks fail (the reference throws NonPositiveDefiniteMatrixException);
+ * MLX_ERR_INVALID for CSR partitions too large to densify (n_local > 8192). gram_ms (may be NULL) receives the HIP-event
+ * time of the Gram kernel when full != 0. */
+int mlx_posterior_variance(mlx_handle h, int32_t local_index, const double *w, const double *prior_var, int32_t full,
+                           double *post_var, double *post_var_matrix, double *gram_ms);
+
 /* ---- multi-GPU exchange inside the library (RCCL over xGMI) ---------------------------------
  * Replaces the gather of iter-i/model + iter-i/u files to the driver (SURVEY 2a collective table). */
 #define MLX_UNIQUE_ID_BYTES 128

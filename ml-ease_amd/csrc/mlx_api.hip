@@ -1156,6 +1156,154 @@ int mlx_solve_one(mlx_handle h, int32_t local_index, double *w, const double *pr
     return MLX_OK;
 }
 
+namespace {
+// org.apache.commons:commons-math3:3.2 CholeskyDecomposition (default thresholds: relative symmetry 1e-15, absolute
+// positivity 1e-10) + getSolver().getInverse(), the call sequence of llf/LibLinear.java:321-325, from the published
+// algorithm. A (n x n, row-major) is overwritten by L^T; X receives the inverse. 0 ok, -1 not symmetric, -2 not SPD.
+int cholesky_inverse(int n, std::vector<double> &A, std::vector<double> &X)
+{
+    const size_t N = (size_t)n;
+    for (size_t i = 0; i < N; i++)
+        for (size_t j = i + 1; j < N; j++) {
+            const double lIJ = A[i * N + j], lJI = A[j * N + i];
+            if (std::fabs(lIJ - lJI) > 1.0e-15 * std::max(std::fabs(lIJ), std::fabs(lJI))) return -1;
+            A[j * N + i] = 0;
+        }
+    for (size_t i = 0; i < N; i++) {
+        double *ltI = &A[i * N];
+        if (ltI[i] <= 1.0e-10) return -2;
+        ltI[i] = std::sqrt(ltI[i]);
+        const double inverse = 1.0 / ltI[i];
+        for (size_t q = N - 1; q > i; q--) {
+            ltI[q] *= inverse;
+            double *ltQ = &A[q * N];
+            const double f = ltI[q];
+            for (size_t p = q; p < N; p++) ltQ[p] -= f * ltI[p];
+        }
+    }
+    X.assign(N * N, 0.0);
+    for (size_t i = 0; i < N; i++) X[i * N + i] = 1.0;
+    for (size_t j = 0; j < N; j++) {                          // L Y = I
+        const double *lJ = &A[j * N];
+        const double lJJ = lJ[j];
+        double *xJ = &X[j * N];
+        for (size_t k = 0; k < N; k++) xJ[k] /= lJJ;
+        for (size_t i = j + 1; i < N; i++) {
+            double *xI = &X[i * N];
+            const double lJI = lJ[i];
+            for (size_t k = 0; k < N; k++) xI[k] -= xJ[k] * lJI;
+        }
+    }
+    for (size_t jj = N; jj-- > 0;) {                          // L^T X = Y
+        const double lJJ = A[jj * N + jj];
+        double *xJ = &X[jj * N];
+        for (size_t k = 0; k < N; k++) xJ[k] /= lJJ;
+        for (size_t i = 0; i < jj; i++) {
+            double *xI = &X[i * N];
+            const double lIJ = A[i * N + jj];
+            for (size_t k = 0; k < N; k++) xI[k] -= xJ[k] * lIJ;
+        }
+    }
+    return 0;
+}
+}  // namespace
+
+int mlx_posterior_variance(mlx_handle h, int32_t local_index, const double *w, const double *prior_var, int32_t full,
+                           double *post_var, double *post_var_matrix, double *gram_ms)
+{
+    if (!h || !h->finalized) return fail(h, MLX_ERR_INVALID, "mlx_finalize first");
+    if (local_index < 0 || local_index >= (int)h->parts.size() || !w || !prior_var || !post_var) return fail(h, MLX_ERR_INVALID, "bad arguments");
+    hipSetDevice(h->device);
+    const PartHost &p = h->parts[local_index];
+    const int n = p.n_local, nf = p.n_feat, l = p.l;
+    if (!p.dense && (n > 8192 || (int64_t)l * ((nf + 3) / 4 * 4) > ((int64_t)1 << 30)))
+        return fail(h, MLX_ERR_INVALID, "posterior variance of a CSR partition needs a temporary dense tile: n_local <= 8192 and l*n_local <= 2^30");
+    if (full && n > 8192) return fail(h, MLX_ERR_INVALID, "full posterior covariance is limited to n_local <= 8192 (the reference allocates double[n][n])");
+    auto old_of = [&](int j) { return (!p.dense && j < n - 1) ? p.new2old[(size_t)j] : j; };
+    int rc;
+    // D_ii at w: one EVAL pass of the scratch problem leaves weight_i p_i (1 - p_i) in wd[dsel ^ 1]
+    ProbDev pr = h->h_probs[h->nprob];
+    pr.part = local_index; pr.lambda_idx = 0; pr.phase = PH_EVAL; pr.dsel = 0; pr.status = ST_OK; pr.pinv_vec = nullptr; pr.pinv = 0;
+    std::vector<double> wl(n), pinv(n);
+    for (int j = 0; j < n; j++) { wl[j] = w[old_of(j)]; pinv[j] = 1.0 / prior_var[old_of(j)]; }   // llf/LogisticRegressionL2.java:107-109
+    HIPCHECK(h, hipMemcpy(pr.w_new, wl.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    HIPCHECK(h, hipMemcpy(h->d_probs + h->nprob, &pr, sizeof(ProbDev), hipMemcpyHostToDevice));
+    const bool prof = h->profiling;
+    h->profiling = false;
+    rc = launch_xpass(h, h->d_qscratch, p.dense ? 1 : 0, h->d_qscratch, p.dense ? 0 : 1, 1);
+    h->profiling = prof;
+    if (rc) return rc;
+    const double *d_wd = pr.wd[1];
+
+    // the partition as a dense tile
+    const float *X = p.dev.X;
+    int64_t ld = p.ld;
+    float *Xtmp = nullptr;
+    std::vector<void *> tmp;
+    auto cleanup = [&]() { for (void *q : tmp) hipFree(q); };
+    auto talloc = [&](void **q, size_t bytes) -> int {
+        if (hipMalloc(q, std::max<size_t>(bytes, 8)) != hipSuccess) { cleanup(); return fail(h, MLX_ERR_HIP, "hipMalloc(%zu) failed", bytes); }
+        tmp.push_back(*q);
+        return MLX_OK;
+    };
+    if (!p.dense) {
+        ld = (nf + 3) / 4 * 4;
+        if (ld == 0) ld = 4;
+        if ((rc = talloc((void **)&Xtmp, sizeof(float) * (size_t)l * ld))) return rc;
+        hipMemsetAsync(Xtmp, 0, sizeof(float) * (size_t)l * ld, h->stream);
+        mlxk_densify(h->stream, l, p.dev.rp, p.dev.ci, p.dev.val, Xtmp, ld);
+        X = Xtmp;
+    }
+    const int rows_per_chunk = 128, nchunk = (l + rows_per_chunk - 1) / rows_per_chunk;
+    double *d_part, *d_cs, *d_pinv;
+    if ((rc = talloc((void **)&d_part, sizeof(double) * 2 * ld * nchunk))) return rc;
+    if ((rc = talloc((void **)&d_cs, sizeof(double) * (2 * ld + 1)))) return rc;
+    if ((rc = talloc((void **)&d_pinv, sizeof(double) * n))) return rc;
+    hipMemcpyAsync(d_pinv, pinv.data(), sizeof(double) * n, hipMemcpyHostToDevice, h->stream);
+    mlxk_hess_colsums(h->stream, X, ld, l, d_wd, d_part, nchunk, rows_per_chunk, d_cs);
+    std::vector<double> out((size_t)n);
+    if (!full) {
+        // hessianDiagonal + 1/H (llf/LogisticRegressionL2.java:304-327, llf/LibLinear.java:331-334)
+        std::vector<double> cs((size_t)(2 * ld + 1));
+        hipMemcpyAsync(cs.data(), d_cs, sizeof(double) * cs.size(), hipMemcpyDeviceToHost, h->stream);
+        if (hipStreamSynchronize(h->stream) != hipSuccess || hipGetLastError() != hipSuccess) { cleanup(); return fail(h, MLX_ERR_HIP, "posterior variance kernels failed"); }
+        for (int j = 0; j < nf; j++) out[(size_t)j] = 1.0 / (pinv[(size_t)j] + cs[(size_t)(ld + j)]);
+        out[(size_t)nf] = 1.0 / (pinv[(size_t)nf] + cs[(size_t)(2 * ld)]);
+    } else {
+        const int nb = (nf + 127) / 128 > 0 ? (nf + 127) / 128 : 1, npad = nb * 128;
+        std::vector<int> blocks;
+        for (int bi = 0; bi < nb; bi++) for (int bj = 0; bj <= bi; bj++) { blocks.push_back(bi); blocks.push_back(bj); }
+        const int nblocks = (int)blocks.size() / 2;
+        const int wgs = 512;                                  // row splits in total: two per 8-wave workgroup, one workgroup per CU
+        int ksplit = std::max(1, std::min(wgs / nblocks, (l + 255) / 256));
+        ksplit = (ksplit + 1) / 2 * 2;                       // two row splits per 8-wave workgroup
+        const int rows_per_split = ((l + ksplit - 1) / ksplit + 3) / 4 * 4;
+        int *d_blocks;
+        double *d_P, *d_H;
+        if ((rc = talloc((void **)&d_blocks, sizeof(int) * blocks.size()))) return rc;
+        if ((rc = talloc((void **)&d_P, sizeof(double) * (size_t)ksplit * npad * npad))) return rc;
+        if ((rc = talloc((void **)&d_H, sizeof(double) * (size_t)n * n))) return rc;
+        hipMemcpyAsync(d_blocks, blocks.data(), sizeof(int) * blocks.size(), hipMemcpyHostToDevice, h->stream);
+        hipEventRecord(h->ev_t0, h->stream);
+        mlxk_gram_f64(h->stream, X, ld, l, d_wd, d_blocks, nblocks, ksplit, rows_per_split, d_P, npad);
+        hipEventRecord(h->ev_t1, h->stream);
+        mlxk_gram_finish(h->stream, d_P, ksplit, npad, nf, d_cs, ld, d_pinv, d_H);
+        std::vector<double> H((size_t)n * n), V;
+        hipMemcpyAsync(H.data(), d_H, sizeof(double) * H.size(), hipMemcpyDeviceToHost, h->stream);
+        if (hipStreamSynchronize(h->stream) != hipSuccess || hipGetLastError() != hipSuccess) { cleanup(); return fail(h, MLX_ERR_HIP, "posterior variance kernels failed"); }
+        if (gram_ms) { float ms = 0; hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1); *gram_ms = ms; }
+        const int cr = cholesky_inverse(n, H, V);
+        if (cr != 0) { cleanup(); return fail(h, MLX_ERR_MODEL_FITTING, cr == -1 ? "Hessian is not symmetric (NonSymmetricMatrixException)" : "Hessian is not positive definite (NonPositiveDefiniteMatrixException)"); }
+        for (int j = 0; j < n; j++) out[(size_t)j] = V[(size_t)j * n + j];
+        if (post_var_matrix)
+            for (int a = 0; a < n; a++)
+                for (int b = 0; b < n; b++) post_var_matrix[(size_t)old_of(a) * n + old_of(b)] = V[(size_t)a * n + b];
+    }
+    for (int j = 0; j < n; j++) post_var[old_of(j)] = out[(size_t)j];
+    cleanup();
+    return MLX_OK;
+}
+
 int mlx_comm_get_unique_id(char out[MLX_UNIQUE_ID_BYTES])
 {
     static_assert(sizeof(ncclUniqueId) <= MLX_UNIQUE_ID_BYTES, "unique id size");

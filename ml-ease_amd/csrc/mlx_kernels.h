@@ -38,3 +38,12 @@ void mlxk_u_update(hipStream_t st, int nlocal, int n_lambda, int n_global, const
 void mlxk_test_loglik(hipStream_t st, int l, int n_lambda, int n_global, const int64_t *rp, const int32_t *gi,
                       const float *val, const int8_t *y, const double *wt, const double *off, const double *Z, double *part);
 void mlxk_round_z(hipStream_t st, int64_t n, const double *Z, float *z32);
+
+// posterior variance (LibLinear.train computePosteriorVar): densify a CSR partition, weighted column sums, fp64-MFMA Gram
+void mlxk_densify(hipStream_t st, int l, const int32_t *rp, const int32_t *ci, const float *val, float *X, int64_t ld);
+void mlxk_hess_colsums(hipStream_t st, const float *X, int64_t ld, int l, const double *wd, double *part, int nchunk,
+                       int rows_per_chunk, double *out /* [2*ld + 1]: s1, s2, sum wd */);
+void mlxk_gram_f64(hipStream_t st, const float *X, int64_t ld, int l, const double *wd, const int *blocks_xy, int nblocks,
+                   int ksplit, int rows_per_split, double *P, int npad);
+void mlxk_gram_finish(hipStream_t st, const double *P, int ksplit, int npad, int nf, const double *colsums, int64_t ld,
+                      const double *pinv, double *H);

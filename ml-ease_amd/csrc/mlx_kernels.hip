@@ -12,6 +12,7 @@
 //   * fun and grad share one pass; after a rejected step the trial D is discarded (wd double buffer);
 //   * grad(0)'s data term X' t0 is a per-partition constant (c0), computed once at upload.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 
 #include "mlx_kernels.h"
@@ -1134,6 +1135,159 @@ k_outputs_present(const PartDev *__restrict__ parts, const ProbDev *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// Posterior variance at the mode (LibLinear.train with computePosteriorVar, llf/LibLinear.java:314-337):
+// H = diag(1/priorVar) + X' D X (llf/LogisticRegressionL2.java:258-297), D_ii = weight_i p_i (1 - p_i) = the wd[] an EVAL
+// pass leaves behind. The n x n Gram build is the one GEMM-shaped piece of this code base: fp64 MFMA.
+// ------------------------------------------------------------------------------------------------
+// CSR partition -> temporary dense tile (zero-initialised by the caller), duplicates accumulate like the reference's loops
+template <bool HASVAL>
+__global__ void __launch_bounds__(256)
+k_densify(int l, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci, const float *__restrict__ val,
+          float *__restrict__ X, int64_t ld)
+{
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= l) return;
+    for (int k = rp[row]; k < rp[row + 1]; k++) X[(int64_t)row * ld + ci[k]] += HASVAL ? val[k] : 1.0f;
+}
+
+// per row chunk: s1[c] = sum_i wd_i x_ic (the intercept's Hessian row), s2[c] = sum_i wd_i x_ic^2 (hessianDiagonal,
+// llf/LogisticRegressionL2.java:304-327). part[chunk][2][ld]; thread = column, rows of the chunk in order.
+__global__ void __launch_bounds__(256)
+k_hess_colsums(const float *__restrict__ X, int64_t ld, int l, int rows_per_chunk, const double *__restrict__ wd,
+               double *__restrict__ part)
+{
+#pragma clang fp contract(off)
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= ld) return;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(l, r0 + rows_per_chunk);
+    double a1 = 0.0, a2 = 0.0;
+    for (int r = r0; r < r1; r++) {
+        const double x = (double)X[(int64_t)r * ld + c], q = wd[r];
+        a1 += q * x;
+        a2 += q * x * x;
+    }
+    part[((int64_t)blockIdx.y * 2 + 0) * ld + c] = a1;
+    part[((int64_t)blockIdx.y * 2 + 1) * ld + c] = a2;
+}
+
+// out[0][c] = sum_chunks part[.][0][c], out[1][c] likewise (fixed chunk order); out[2][0] = sum_i wd_i
+__global__ void __launch_bounds__(256)
+k_hess_colsums_reduce(const double *__restrict__ part, int nchunk, int64_t ld, const double *__restrict__ wd, int l,
+                      double *__restrict__ out)
+{
+    __shared__ double scratch[16];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < ld) {
+        double a1 = 0.0, a2 = 0.0;
+        for (int k = 0; k < nchunk; k++) { a1 += part[((int64_t)k * 2) * ld + c]; a2 += part[((int64_t)k * 2 + 1) * ld + c]; }
+        out[c] = a1;
+        out[ld + c] = a2;
+    }
+    if (blockIdx.x == 0) {
+        double v[1] = {0.0};
+        for (int i = threadIdx.x; i < l; i += 256) v[0] += wd[i];
+        block_allreduce_sum<1>(v, scratch);
+        if (threadIdx.x == 0) out[2 * ld] = v[0];
+    }
+}
+
+// X' D X, lower-triangle 128 x 128 blocks, rows split in `ksplit` ranges: P[ks][npad][npad] partial Gram matrices.
+// One wave = 64 x 64 outputs = 4 x 4 tiles of v_mfma_f64_16x16x4_f64 (A[i][k] = wd_row x[row][m0+i], B[k][j] = x[row][n0+j],
+// lane = (i|j = lane & 15, k = lane >> 4); C/D: col = lane & 15, row = (lane >> 4) + 4 reg). The operands of the next 4 rows
+// are fetched while the 16 MFMAs of the current rows run.
+typedef double d4_t __attribute__((ext_vector_type(4)));
+// Column mapping of the 4 tiles of a wave side: tile t, lane index ii <-> matrix column base + 4 ii + t, so that a lane's
+// four A (and four B) operands of one row are ONE 16-byte load and a 16-lane group reads 256 contiguous bytes of the row.
+// KU k-steps (4 rows each) are fetched ahead while the 16 KU MFMAs of the current rows run.
+template <int KU>
+__global__ void __launch_bounds__(512)
+k_gram_f64(const float *__restrict__ X, int64_t ld, int l, const double *__restrict__ wd, const int2 *__restrict__ blocks,
+           int rows_per_split, double *__restrict__ P, int npad)
+{
+    // 8 waves = two groups of 4: each group owns one row split of the same 128 x 128 block, so that two waves share every
+    // SIMD (one wave per SIMD reaches only ~45 % of the f64 MFMA rate, two reach 98 %: tools/mfma_f64_probe.hip)
+    const int2 bb = blocks[blockIdx.x];
+    const int wave = (threadIdx.x >> 6) & 3, lane = threadIdx.x & 63;
+    const int split = blockIdx.y * 2 + (threadIdx.x >> 8);
+    const int ii = lane & 15, kk = lane >> 4;
+    const int m0 = bb.x * 128 + (wave >> 1) * 64, n0 = bb.y * 128 + (wave & 1) * 64;
+    const int r0 = min(l, split * rows_per_split), r1 = min(l, r0 + rows_per_split);
+    d4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    // ld is a multiple of 4: a 4-column group is either entirely inside the tile or entirely padding
+    const int cma = m0 + 4 * ii, cna = n0 + 4 * ii;
+    const bool vm = cma < ld, vn = cna < ld;
+    const int cm = vm ? cma : 0, cn = vn ? cna : 0;
+    float4 ca[KU], cb[KU], na[KU], nb[KU];      // operands of the current / the next 4 KU rows
+    double cq[KU], nq[KU];
+    auto fetch = [&](int r) {
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const int row = r + 4 * u + kk;
+            const int rc = min(row, l - 1);
+            nq[u] = (row < r1 && vm) ? wd[rc] : 0.0;
+            const float *__restrict__ xr = X + (int64_t)rc * ld;
+            na[u] = *reinterpret_cast<const float4 *>(xr + cm);
+            nb[u] = *reinterpret_cast<const float4 *>(xr + cn);
+        }
+    };
+    if (r0 < r1) fetch(r0);
+    for (int r = r0; r < r1; r += 4 * KU) {
+#pragma unroll
+        for (int u = 0; u < KU; u++) { ca[u] = na[u]; cb[u] = nb[u]; cq[u] = nq[u]; }
+        if (r + 4 * KU < r1) fetch(r + 4 * KU);
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const double qq = cq[u];
+            const double a[4] = {qq * (double)ca[u].x, qq * (double)ca[u].y, qq * (double)ca[u].z, qq * (double)ca[u].w};
+            const double b[4] = {vn ? (double)cb[u].x : 0.0, vn ? (double)cb[u].y : 0.0, vn ? (double)cb[u].z : 0.0,
+                                 vn ? (double)cb[u].w : 0.0};
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+    double *__restrict__ out = P + (int64_t)split * npad * npad;
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int row = m0 + 4 * (kk + 4 * reg) + mt, col = n0 + 4 * ii + nt;
+                out[(int64_t)row * npad + col] = acc[mt][nt][reg];
+            }
+}
+
+// H[n][n] (n = nf + 1, row-major): feature block from the partial Gram matrices (lower triangle, mirrored), the intercept's
+// row/column from the column sums, 1/priorVar on the diagonal (llf/LogisticRegressionL2.java:259,293-296)
+__global__ void __launch_bounds__(256)
+k_gram_finish(const double *__restrict__ P, int ksplit, int npad, int nf, const double *__restrict__ colsums, int64_t ld,
+              const double *__restrict__ pinv, double *__restrict__ H)
+{
+    const int n = nf + 1;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)n * n) return;
+    const int m = (int)(idx / n), c = (int)(idx % n);
+    double v;
+    if (m == nf && c == nf) v = colsums[2 * ld];
+    else if (m == nf) v = colsums[c];
+    else if (c == nf) v = colsums[m];
+    else {
+        const int hi = max(m, c), lo = min(m, c);
+        v = 0.0;
+        for (int k = 0; k < ksplit; k++) v += P[((int64_t)k * npad + hi) * npad + lo];
+    }
+    if (m == c) v = pinv[m] + v;
+    H[idx] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
 // consensus
 // ------------------------------------------------------------------------------------------------
 // partial means of this shard, sequential over local partitions in add order:
@@ -1434,4 +1588,33 @@ void mlxk_round_z(hipStream_t st, int64_t n, const double *Z, float *z32)
 {
     const int gx = (int)max((int64_t)1, min((int64_t)1024, (n + 255) / 256));
     hipLaunchKernelGGL(k_round_z, dim3(gx), dim3(256), 0, st, n, Z, z32);
+}
+
+void mlxk_densify(hipStream_t st, int l, const int32_t *rp, const int32_t *ci, const float *val, float *X, int64_t ld)
+{
+    const int gx = (l + 255) / 256;
+    if (val) hipLaunchKernelGGL((k_densify<true>), dim3(gx), dim3(256), 0, st, l, rp, ci, val, X, ld);
+    else hipLaunchKernelGGL((k_densify<false>), dim3(gx), dim3(256), 0, st, l, rp, ci, val, X, ld);
+}
+
+void mlxk_hess_colsums(hipStream_t st, const float *X, int64_t ld, int l, const double *wd, double *part, int nchunk,
+                       int rows_per_chunk, double *out)
+{
+    const int gx = (int)((ld + 255) / 256);
+    hipLaunchKernelGGL(k_hess_colsums, dim3(gx, nchunk), dim3(256), 0, st, X, ld, l, rows_per_chunk, wd, part);
+    hipLaunchKernelGGL(k_hess_colsums_reduce, dim3(gx), dim3(256), 0, st, part, nchunk, ld, wd, l, out);
+}
+
+void mlxk_gram_f64(hipStream_t st, const float *X, int64_t ld, int l, const double *wd, const int *blocks_xy, int nblocks,
+                   int ksplit, int rows_per_split, double *P, int npad)
+{
+    hipLaunchKernelGGL((k_gram_f64<4>), dim3(nblocks, ksplit / 2), dim3(512), 0, st, X, ld, l, wd,
+                       reinterpret_cast<const int2 *>(blocks_xy), rows_per_split, P, npad);
+}
+
+void mlxk_gram_finish(hipStream_t st, const double *P, int ksplit, int npad, int nf, const double *colsums, int64_t ld,
+                      const double *pinv, double *H)
+{
+    const int64_t tot = (int64_t)(nf + 1) * (nf + 1);
+    hipLaunchKernelGGL(k_gram_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, P, ksplit, npad, nf, colsums, ld, pinv, H);
 }

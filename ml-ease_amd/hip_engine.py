@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "mlx_create", "mlx_destroy", "mlx_last_error", "mlx_set_stream", "mlx_set_profiling", "mlx_set_problem",
     "mlx_set_regularizer", "mlx_add_partition_csr", "mlx_add_partition_dense", "mlx_finalize", "mlx_set_state",
     "mlx_admm_iterate", "mlx_admm_solve_local", "mlx_naive_init", "mlx_naive_solve_local", "mlx_naive_finish", "mlx_consensus_buffer", "mlx_admm_consensus_finish", "mlx_get_z",
-    "mlx_get_partition_model", "mlx_get_solve_counters", "mlx_set_test_data", "mlx_test_loglik", "mlx_solve_one", "mlx_comm_get_unique_id", "mlx_comm_init",
+    "mlx_get_partition_model", "mlx_get_solve_counters", "mlx_set_test_data", "mlx_test_loglik", "mlx_solve_one", "mlx_posterior_variance", "mlx_comm_get_unique_id", "mlx_comm_init",
     "mlx_version",
 ]
 
@@ -77,6 +77,7 @@ def load_library():
     L.mlx_set_test_data.argtypes = [vp, i32, i64, vp, vp, vp, vp, vp, vp]
     L.mlx_test_loglik.argtypes = [vp, vp]
     L.mlx_solve_one.argtypes = [vp, i32, vp, vp, vp, f64, i32, vp, vp, vp, vp]
+    L.mlx_posterior_variance.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp]
     L.mlx_comm_get_unique_id.argtypes = [vp]
     L.mlx_comm_init.argtypes = [vp, vp, i32, i32]
     _lib = L
@@ -255,6 +256,18 @@ class HipAdmmEngine:
         self._ck(self.L.mlx_solve_one(self.h, int(local_index), _p(w), _p(pm), _p(pv), float(epsilon), int(max_iter),
                                       _p(cnt), C.byref(f), C.byref(gn), C.byref(gn1)))
         return w, cnt, (f.value, gn.value, gn1.value)
+
+    def posterior_variance(self, local_index: int, w: np.ndarray, prior_var: np.ndarray, full: bool = False):
+        """LibLinear.train's computePosteriorVar tail (llf/LibLinear.java:314-337) at the mode w:
+        -> (post_var[n_local], post_var_matrix[n_local, n_local] or None, Gram-kernel ms or None)."""
+        w_ = np.ascontiguousarray(w, np.float64)
+        pv = np.ascontiguousarray(prior_var, np.float64)
+        out = np.empty(len(w_))
+        M = np.empty((len(w_), len(w_))) if full else None
+        ms = C.c_double(0.0)
+        self._ck(self.L.mlx_posterior_variance(self.h, int(local_index), _p(w_), _p(pv), int(bool(full)), _p(out), _p(M),
+                                               C.byref(ms)))
+        return out, M, (ms.value if full else None)
 
     # -- RCCL -------------------------------------------------------------------------------------
     @staticmethod

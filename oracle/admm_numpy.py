@@ -190,6 +190,22 @@ def tron(fo: LogisticL2, w: np.ndarray, eps: float, max_iter: int = 10000) -> np
 
 
 # ----------------------------------------------------------------------------- partitions
+def posterior_variance(X: sp.csr_matrix, y: np.ndarray, weight: np.ndarray, offset: np.ndarray, w: np.ndarray,
+                       prior_var: np.ndarray, full: bool):
+    """llf/LibLinear.java:314-337 on llf/LogisticRegressionL2.java:258-327: H = diag(1/priorVar) + X'DX with
+    D_ii = weight_i p_i (1-p_i); full -> inverse(H) (dense solve instead of commons-math3's Cholesky), else 1/diag(H).
+    X includes the intercept column."""
+    score = X @ w + offset
+    p = 1.0 / (1.0 + np.exp(-y * score))
+    q = weight * p * (1 - p)
+    if not full:
+        return 1.0 / (1.0 / prior_var + np.asarray(X.multiply(X).T @ q).ravel()), None
+    Xd = X.toarray()
+    H = np.diag(1.0 / prior_var) + Xd.T @ (q[:, None] * Xd)
+    V = np.linalg.inv(H)
+    return np.diag(V).copy(), V
+
+
 @dataclass
 class Partition:
     X: sp.csr_matrix          # l x n_local (intercept column last, value 1.0)

@@ -377,6 +377,136 @@ void orc_train(const orc_dataset *d, double *w, const double *priorMean, const d
     func_destroy(fo);
 }
 
+/* ------------------------------------------------- posterior variance (LibLinear.train with computePosteriorVar) */
+
+/* llf/LogisticRegressionL2.java:258-297 `hessian` (binary: llf/LogisticRegressionL2BinaryFeature.java:134-178):
+ * H = diag(1/priorVar) + X' D X with D_ii = weight_i p_i (1 - p_i), p_i = 1/(1+exp(-y_i (w.x_i + offset_i))); the lower
+ * triangle is accumulated row by row, then mirrored. H is n x n row-major (zeroed here: Java's new double[n][n]). */
+static double row_q(const orc_func *f, const double *w, int i)
+{
+    const orc_dataset *d = f->data;
+    double score = 0;
+    for (int64_t k = d->rp[i]; k < d->rp[i + 1]; k++)
+        score += d->binary ? w[d->idx[k] - 1] : w[d->nodes[k].index - 1] * d->nodes[k].value;
+    score += d->offset[i];
+    double p = 1.0 / (1.0 + exp(-d->y[i] * score));
+    return f->weight[i] * p * (1 - p);
+}
+
+static void hessian(orc_func *f, const double *w, double *H)
+{
+    const orc_dataset *d = f->data;
+    int n = d->n;
+    memset(H, 0, sizeof(double) * (size_t)n * (size_t)n);
+    for (int k = 0; k < n; k++) H[(size_t)k * n + k] = f->priorVar_inv[k];
+    for (int i = 0; i < d->l; i++) {
+        double D_ii = row_q(f, w, i);
+        for (int64_t a = d->rp[i]; a < d->rp[i + 1]; a++) {
+            int m = (d->binary ? d->idx[a] : d->nodes[a].index) - 1;
+            double vm = d->binary ? 1.0 : d->nodes[a].value;
+            for (int64_t b = d->rp[i]; b < d->rp[i + 1]; b++) {
+                int nn = (d->binary ? d->idx[b] : d->nodes[b].index) - 1;
+                if (d->binary) H[(size_t)m * n + nn] += D_ii;
+                else H[(size_t)m * n + nn] += D_ii * vm * d->nodes[b].value;
+                if (m == nn) break;
+            }
+        }
+    }
+    for (int m = 0; m < n; m++)
+        for (int nn = m + 1; nn < n; nn++) H[(size_t)m * n + nn] = H[(size_t)nn * n + m];
+}
+
+/* llf/LogisticRegressionL2.java:304-327 `hessianDiagonal` */
+static void hessianDiagonal(orc_func *f, const double *w, double *H)
+{
+    const orc_dataset *d = f->data;
+    for (int k = 0; k < d->n; k++) H[k] = f->priorVar_inv[k];
+    for (int i = 0; i < d->l; i++) {
+        double q = row_q(f, w, i);
+        for (int64_t a = d->rp[i]; a < d->rp[i + 1]; a++) {
+            if (d->binary) H[d->idx[a] - 1] += q;      /* the binary class inherits the same loop with value 1 */
+            else H[d->nodes[a].index - 1] += q * d->nodes[a].value * d->nodes[a].value;
+        }
+    }
+}
+
+/* org.apache.commons:commons-math3:3.2 (pom.xml:113-117; not vendored in the reference tree), restated from its
+ * published algorithm: CholeskyDecomposition(matrix) with the default thresholds (relative symmetry 1e-15, absolute
+ * positivity 1e-10) followed by getSolver().getInverse() = solve(identity). A is n x n row-major and is overwritten
+ * by L^T (upper triangle); X receives the inverse. Returns 0, or -1 not symmetric / -2 not positive definite. */
+static int cholesky_inverse(int n, double *A, double *X)
+{
+    for (int i = 0; i < n; i++)
+        for (int j = i + 1; j < n; j++) {
+            double lIJ = A[(size_t)i * n + j], lJI = A[(size_t)j * n + i];
+            double maxDelta = 1.0e-15 * fmax(fabs(lIJ), fabs(lJI));
+            if (fabs(lIJ - lJI) > maxDelta) return -1;
+            A[(size_t)j * n + i] = 0;
+        }
+    for (int i = 0; i < n; i++) {
+        double *ltI = A + (size_t)i * n;
+        if (ltI[i] <= 1.0e-10) return -2;
+        ltI[i] = sqrt(ltI[i]);
+        double inverse = 1.0 / ltI[i];
+        for (int q = n - 1; q > i; q--) {
+            ltI[q] *= inverse;
+            double *ltQ = A + (size_t)q * n;
+            for (int p = q; p < n; p++) ltQ[p] -= ltI[q] * ltI[p];
+        }
+    }
+    memset(X, 0, sizeof(double) * (size_t)n * (size_t)n);
+    for (int i = 0; i < n; i++) X[(size_t)i * n + i] = 1.0;
+    for (int j = 0; j < n; j++) {                      /* L Y = I */
+        const double *lJ = A + (size_t)j * n;
+        double lJJ = lJ[j];
+        double *xJ = X + (size_t)j * n;
+        for (int k = 0; k < n; k++) xJ[k] /= lJJ;
+        for (int i = j + 1; i < n; i++) {
+            double *xI = X + (size_t)i * n;
+            double lJI = lJ[i];
+            for (int k = 0; k < n; k++) xI[k] -= xJ[k] * lJI;
+        }
+    }
+    for (int j = n - 1; j >= 0; j--) {                 /* L^T X = Y */
+        double lJJ = A[(size_t)j * n + j];
+        double *xJ = X + (size_t)j * n;
+        for (int k = 0; k < n; k++) xJ[k] /= lJJ;
+        for (int i = 0; i < j; i++) {
+            double *xI = X + (size_t)i * n;
+            double lIJ = A[(size_t)i * n + j];
+            for (int k = 0; k < n; k++) xI[k] -= xJ[k] * lIJ;
+        }
+    }
+    return 0;
+}
+
+/* llf/LibLinear.java:314-337: posterior variance at the mode w. full == 0: postVar = 1 / hessianDiagonal;
+ * full != 0: postVarMatrix = inverse(hessian) (n x n, may be NULL if only the diagonal is wanted), postVar = its diagonal.
+ * hess_out (n x n, optional) receives the Hessian itself for tests. */
+int orc_posterior_variance(const orc_dataset *d, const double *w, const double *priorVar, int full,
+                           double *post_var, double *post_var_matrix, double *hess_out)
+{
+    int n = d->n, rc = 0;
+    double *zero = (double *)calloc((size_t)n, sizeof(double));
+    orc_func *fo = func_create(d, zero, priorVar, 1.0, 1.0, 1.0, NULL);
+    if (!full) {
+        hessianDiagonal(fo, w, post_var);
+        for (int i = 0; i < n; i++) post_var[i] = 1.0 / post_var[i];
+    } else {
+        double *H = (double *)malloc(sizeof(double) * (size_t)n * (size_t)n);
+        double *V = post_var_matrix ? post_var_matrix : (double *)malloc(sizeof(double) * (size_t)n * (size_t)n);
+        hessian(fo, w, H);
+        if (hess_out) memcpy(hess_out, H, sizeof(double) * (size_t)n * (size_t)n);
+        rc = cholesky_inverse(n, H, V);
+        if (rc == 0) for (int i = 0; i < n; i++) post_var[i] = V[(size_t)i * n + i];
+        if (!post_var_matrix) free(V);
+        free(H);
+    }
+    func_destroy(fo);
+    free(zero);
+    return rc;
+}
+
 /* ------------------------------------------------------------- ADMM driver */
 
 typedef struct orc_admm {

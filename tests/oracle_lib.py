@@ -45,6 +45,8 @@ def lib():
         L.orc_dataset_destroy.argtypes = [vp]
         L.orc_eval.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
         L.orc_train.argtypes = [vp, vp, vp, vp, f64, i32, vp]
+        L.orc_posterior_variance.argtypes = [vp, vp, vp, i32, vp, vp, vp]
+        L.orc_posterior_variance.restype = i32
         L.orc_admm_create.restype = vp
         L.orc_admm_create.argtypes = [i32, i32, i32, i32, vp, vp, i32]
         L.orc_admm_destroy.argtypes = [vp]
@@ -111,6 +113,18 @@ class OracleDataset:
         st = TronStats()
         lib().orc_train(self.h, _p(w), _p(pm), _p(pv), float(epsilon), int(max_iter), C.byref(st))
         return w, st
+
+    def posterior_variance(self, w, prior_var, full):
+        """LibLinear.train's computePosteriorVar tail (llf/LibLinear.java:314-337): -> (post_var, matrix or None, H or None)."""
+        w = np.ascontiguousarray(w, np.float64)
+        pv = np.ascontiguousarray(prior_var, np.float64)
+        out = np.empty(self.n)
+        M = np.empty((self.n, self.n)) if full else None
+        H = np.empty((self.n, self.n)) if full else None
+        rc = lib().orc_posterior_variance(self.h, _p(w), _p(pv), int(bool(full)), _p(out), _p(M), _p(H))
+        if rc != 0:
+            raise ArithmeticError("CholeskyDecomposition failed (%d)" % rc)
+        return out, M, H
 
     def __del__(self):
         try:

@@ -491,3 +491,53 @@ def test_row_blocked_column_pass_layouts(binary, monkeypatch):
                 assert_coef_close(eng.z()[1][li], oc.z()[1][li], "layout %d z it %d" % (e, it))
                 # z is a mean of float32 models: layouts may differ by a few float32 ulps of single coefficients
                 assert np.max(np.abs(eng.z()[0][li] - engines[0].z()[0][li])) <= 1e-6 * np.max(np.abs(oc.z()[0][li]))
+
+
+def test_posterior_variance_vs_oracle(c1):
+    """N4: LibLinear.train's computePosteriorVar tail (llf/LibLinear.java:314-337). hessianDiagonal and the full Hessian
+    (fp64-MFMA Gram kernel) + Cholesky inverse against the oracle: CSR partition (densified, library column order mapped
+    back), dense-tile partition whose width is not a multiple of the 128-column MFMA blocks, binary rows."""
+    rng = np.random.default_rng(11)
+    # (a) C1 partitions through the CSR upload
+    eng = make_engine(c1, [1.0], [1.0])
+    for k in (0, 3):
+        b = c1.blocks[k]
+        od = ol.OracleDataset.from_block(b)
+        pv = rng.uniform(0.3, 3.0, b.n_local)
+        w, _ = od.train(np.zeros(b.n_local), np.zeros(b.n_local), pv, 1e-4)
+        dv, _, _ = od.posterior_variance(w, pv, False)
+        gv, _, _ = eng.posterior_variance(k, w, pv, False)
+        assert np.max(np.abs(gv - dv) / dv) < 1e-12
+        fv, V, _ = od.posterior_variance(w, pv, True)
+        gf, GV, ms = eng.posterior_variance(k, w, pv, True)
+        assert np.max(np.abs(GV - V)) <= 1e-9 * np.max(np.abs(V)) and np.max(np.abs(gf - fv) / fv) < 1e-9
+        assert np.array_equal(gf, np.diag(GV)) and ms > 0
+    # (b) dense tile, 300 features (3 column blocks, the last one partial), weights and offsets
+    nrow, nf = 3000, 300
+    X = rng.normal(0, 1, (nrow, nf)).astype(np.float32)
+    y01 = (rng.random(nrow) < 0.4).astype(np.int8)
+    wt = rng.uniform(0.5, 1.5, nrow).astype(np.float32)
+    off = rng.normal(0, 0.2, nrow).astype(np.float32)
+    pd = dataset.dense_partitions(X, y01, 1, wt, off)
+    eng2 = HipAdmmEngine(pd.n_global, [1.0], [1.0], 1)
+    eng2.add_partition_dense(0, X, np.where(y01 == 1, 1, -1), wt, off)
+    eng2.finalize()
+    od = ol.OracleDataset.from_block(pd.blocks[0])
+    pv = rng.uniform(0.5, 2.0, nf + 1)
+    w = rng.normal(0, 0.3, nf + 1)
+    fv, V, H = od.posterior_variance(w, pv, True)
+    gf, GV, _ = eng2.posterior_variance(0, w, pv, True)
+    assert np.max(np.abs(GV - V)) <= 1e-9 * np.max(np.abs(V))
+    dv, _, _ = od.posterior_variance(w, pv, False)
+    gv, _, _ = eng2.posterior_variance(0, w, pv, False)
+    assert np.max(np.abs(gv - dv) / dv) < 1e-12
+    # (c) binary rows
+    pb = synth_sparse(8, 500, 60, 5, 2, binary=True, weights=True, offsets=True)
+    eng3 = make_engine(pb, [1.0], [1.0])
+    b = pb.blocks[1]
+    od = ol.OracleDataset.from_block(b)
+    pv = rng.uniform(0.3, 3.0, b.n_local)
+    w = rng.normal(0, 0.3, b.n_local)
+    fv, V, _ = od.posterior_variance(w, pv, True)
+    gf, GV, _ = eng3.posterior_variance(1, w, pv, True)
+    assert np.max(np.abs(GV - V)) <= 1e-9 * np.max(np.abs(V))

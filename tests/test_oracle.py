@@ -301,3 +301,25 @@ def test_mean_model_warm_start_c_vs_numpy_and_seam(c1):
     oc.naive_solve_local(0.01, 0.0)
     oc.naive_finish()
     assert np.linalg.norm(oc.z()[0] - zfin) < 0.8 * np.linalg.norm(zfin)
+
+
+def test_posterior_variance_c_vs_numpy(c1):
+    """LibLinear.train's computePosteriorVar tail (llf/LibLinear.java:314-337; hessian / hessianDiagonal
+    llf/LogisticRegressionL2.java:258-327; commons-math3 3.2 CholeskyDecomposition + inverse restated): the C oracle vs
+    the numpy restatement (dense inverse), on valued and binary rows."""
+    rng = np.random.default_rng(3)
+    for pd_, binary in ((c1, False), (synth_sparse(8, 500, 60, 5, 2, binary=True, weights=True, offsets=True), True)):
+        b = pd_.blocks[0]
+        p = np_parts(pd_)[0]
+        od = ol.OracleDataset.from_block(b)
+        pv = rng.uniform(0.3, 3.0, b.n_local)
+        w, _ = od.train(np.zeros(b.n_local), np.zeros(b.n_local), pv, 1e-3)
+        dv, _, _ = od.posterior_variance(w, pv, False)
+        dn, _ = an.posterior_variance(p.X, p.y, p.weight, p.offset, w, pv, False)
+        assert np.max(np.abs(dv - dn) / dn) < 1e-13
+        fv, V, H = od.posterior_variance(w, pv, True)
+        fn, Vn = an.posterior_variance(p.X, p.y, p.weight, p.offset, w, pv, True)
+        assert np.array_equal(H, H.T) and np.all(np.diag(H) > 1.0 / pv - 1e-15)
+        assert np.max(np.abs(V - Vn)) <= 1e-10 * np.max(np.abs(Vn))
+        assert np.array_equal(fv, np.diag(V)) and np.max(np.abs(V @ H - np.eye(b.n_local))) < 1e-9
+        assert np.all(fv >= dv * (1 - 1e-12))        # (H^-1)_kk >= 1/H_kk for SPD H
