@@ -194,6 +194,15 @@ int mlx_solve_one(mlx_handle h, int32_t local_index, double *w, const double *pr
                   const double *prior_var, double epsilon, int32_t max_iter, int32_t *counters4,
                   double *f_out, double *gnorm_out, double *gnorm1_out);
 
+/* ---- RegressionTest scoring (jobs/RegressionTest.java:147-175, the AdmmTestMapper) -----------------------------
+ * pred[i] = (float) model.evalInstanceAvro(record_i, loglik = false, ignore_value) = (float)(offset_i + eval(features_i))
+ * (models/LinearModel.java:241-257,491-541) for l rows in CSR form with GLOBAL feature ids (-1 = a name the model does
+ * not hold: skipped), val NULL for binary.feature, offset NULL = 0. `model` is one record of the final-model /
+ * best-model file as dense float32 [n_global] (intercept last), exactly the values LinearModel reads back from avro.
+ * Needs only mlx_create (no training partitions); sums run in record order, one thread per row. */
+int mlx_score_rows(mlx_handle h, int32_t n_global, const float *model, int32_t l, int64_t nnz, const int64_t *row_ptr,
+                   const int32_t *global_idx, const float *val, const double *offset, float *pred);
+
 /* ---- posterior variance at the mode: the computePosteriorVar tail of LibLinear.train ----------
  * (liblinearfunc/LibLinear.java:221-228 with computePosteriorVar = true, body :314-337; the ADMM reducer passes false,
  * jobs/ItemModelTrain.java:269 is the reference's caller). On local partition `local_index`, arrays in the

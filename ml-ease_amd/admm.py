@@ -10,6 +10,7 @@ same small protocol to check the host logic and the sharded exchange on CPU/gloo
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional, Sequence
 
@@ -299,3 +300,80 @@ def read_linear_models(path: str, feature_names: Sequence[str]) -> Dict[str, np.
                 v[index[name]] = np.float32(f["value"])
         out[rec["key"]] = v
     return out
+
+
+# ------------------------------------------------------------------------------- RegressionTest (scoring job)
+def read_model_file(path: str) -> Dict[str, Tuple[List[str], np.ndarray]]:
+    """ReadLinearModelConsumer over a model file or directory: key -> (feature keys in file order, float32 vector with the
+    intercept last). A later record with the same key replaces an earlier one (HashMap.put)."""
+    out: Dict[str, Tuple[List[str], np.ndarray]] = {}
+    for rec in avro_io.read_records(path):
+        names: List[str] = []
+        vals: List[float] = []
+        icpt = np.float32(0)
+        for f in rec["model"]:
+            name = f["name"] if f["term"] in ("", None) else f["name"] + TERM_SEP + f["term"]
+            if name == INTERCEPT_NAME:
+                icpt = np.float32(f["value"])
+            else:
+                names.append(name)
+                vals.append(f["value"])
+        out[str(rec["key"])] = (names, np.asarray(vals + [icpt], np.float32))
+    return out
+
+
+def test_output_schema(input_schema: Any) -> Dict[str, Any]:
+    """jobs/RegressionTest.java:201-232: record AdmmTestOutput = the input fields (Util.removeUnion of the top level) +
+    `pred` float."""
+    sch = input_schema
+    if isinstance(sch, list):                                             # top-level union: the record branch
+        sch = next(s for s in sch if isinstance(s, dict) and s.get("type") == "record")
+    fields = [{"name": f["name"], "type": f["type"], **({"doc": f["doc"]} if "doc" in f else {})} for f in sch["fields"]]
+    fields.append({"name": "pred", "type": "float", "doc": ""})
+    return {"type": "record", "name": "AdmmTestOutput", "namespace": "com.linkedin.lab.regression.avro",
+            "doc": "Test output for AdmmTest", "fields": fields}
+
+
+test_output_schema.__test__ = False
+
+
+def regression_test(props: Dict[str, str], scorer) -> List[str]:
+    """jobs/RegressionTest.java:64-112 for local files: for every lambda of the job, score input.paths with the
+    final-model record of that lambda (key String.valueOf(Float.parseFloat(lambda))) and write
+    output.base.path/lambda-<lambda as written>/part-r-00000.avro = input fields + pred, ordered by pred like the
+    shuffle on the Float key orders them (ties keep input order here; Hadoop leaves them unspecified); then the same with
+    model.base.path/best-model if it exists (the first model of the directory). `scorer.score_rows(model32, row_ptr,
+    global_idx, val, offset)` is HipScorer in the product. Returns the files written."""
+    from . import dataset
+    in_path = props.get("input.paths", "")
+    if in_path == "":
+        return []                                                          # "test.input.paths is empty!" :109-111
+    out_base, model_base = props["output.base.path"], props["model.base.path"]
+    binary = _get_bool(props, "binary.feature", False)
+    files = sorted(os.path.join(in_path, n) for n in os.listdir(in_path) if n.endswith(".avro")) if os.path.isdir(in_path) else [in_path]
+    schema, _ = avro_io.read_container(files[0])
+    records = [r for f in files for r in avro_io.read_container(f)[1]]
+    out_schema = test_output_schema(schema)
+    written: List[str] = []
+
+    def run(model_names: List[str], model: np.ndarray, out_dir: str) -> None:
+        rows = dataset.build_test_rows(records, model_names, binary, max_rows=len(records) + 1)
+        pred = scorer.score_rows(model, rows.row_ptr, rows.global_idx, rows.val, rows.offset)
+        order = np.argsort(pred, kind="stable")
+        recs = [dict(records[i], pred=float(pred[i])) for i in order]
+        path = os.path.join(out_dir, "part-r-00000.avro")
+        avro_io.write_container(path, out_schema, recs)
+        written.append(path)
+
+    models = read_model_file(os.path.join(model_base, "final-model"))
+    for lam in [s for s in props["lambda"].split(",") if s.strip() != ""]:
+        key = java_float_to_string(np.float32(lam))
+        if key not in models:
+            raise KeyError("no model for lambda %s in %s/final-model" % (key, model_base))    # the reference NPEs in map()
+        run(models[key][0], models[key][1], os.path.join(out_base, "lambda-" + lam))
+    best = os.path.join(model_base, "best-model")
+    if os.path.isdir(best) and any(n.endswith(".avro") for n in os.listdir(best)):
+        bm = read_model_file(best)
+        names, vec = next(iter(bm.values()))
+        run(names, vec, os.path.join(out_base, "best-model"))
+    return written

@@ -1156,6 +1156,42 @@ int mlx_solve_one(mlx_handle h, int32_t local_index, double *w, const double *pr
     return MLX_OK;
 }
 
+int mlx_score_rows(mlx_handle h, int32_t n_global, const float *model, int32_t l, int64_t nnz, const int64_t *row_ptr,
+                   const int32_t *global_idx, const float *val, const double *offset, float *pred)
+{
+    if (!h) return fail(h, MLX_ERR_INVALID, "no handle");
+    if (n_global < 1 || !model || l < 0 || nnz < 0 || !row_ptr || (nnz > 0 && !global_idx) || !pred) return fail(h, MLX_ERR_INVALID, "bad arguments");
+    if (l == 0) return MLX_OK;
+    if (row_ptr[0] != 0 || row_ptr[l] != nnz) return fail(h, MLX_ERR_INVALID, "row_ptr must run from 0 to nnz");
+    for (int64_t k = 0; k < nnz; k++)
+        if (global_idx[k] < -1 || global_idx[k] >= n_global - 1) return fail(h, MLX_ERR_INVALID, "global_idx[%lld]=%d out of range", (long long)k, global_idx[k]);
+    hipSetDevice(h->device);
+    // the model as LinearModel reads it from the final-model file: float32 widened to double (models/LinearModel.java:112-156)
+    std::vector<double> z((size_t)n_global), off((size_t)l, 0.0);
+    for (int j = 0; j < n_global; j++) z[(size_t)j] = (double)model[j];
+    if (offset) off.assign(offset, offset + l);
+    const double base = -std::log(1 - 1 + 1 * std::exp(-z[(size_t)n_global - 1]));   // LinearModel.java:243-244, num_click_replicates = 1
+    std::vector<void *> tmp;
+    auto cleanup = [&]() { for (void *q : tmp) hipFree(q); };
+    auto up = [&](void **q, const void *src, size_t bytes) -> bool {
+        if (hipMalloc(q, std::max<size_t>(bytes, 8)) != hipSuccess) return false;
+        tmp.push_back(*q);
+        return bytes == 0 || !src || hipMemcpyAsync(*q, src, bytes, hipMemcpyHostToDevice, h->stream) == hipSuccess;
+    };
+    int64_t *d_rp; int32_t *d_gi; float *d_val = nullptr, *d_pred; double *d_off, *d_z;
+    bool ok = up((void **)&d_rp, row_ptr, sizeof(int64_t) * ((size_t)l + 1)) && up((void **)&d_gi, global_idx, sizeof(int32_t) * (size_t)nnz) &&
+              up((void **)&d_off, off.data(), sizeof(double) * (size_t)l) && up((void **)&d_z, z.data(), sizeof(double) * (size_t)n_global) &&
+              up((void **)&d_pred, nullptr, sizeof(float) * (size_t)l);
+    if (ok && val) ok = up((void **)&d_val, val, sizeof(float) * (size_t)nnz);
+    if (!ok) { cleanup(); return fail(h, MLX_ERR_HIP, "mlx_score_rows: device allocation/copy failed"); }
+    mlxk_score_rows(h->stream, l, d_rp, d_gi, d_val, d_off, d_z, base, d_pred);
+    ok = hipMemcpyAsync(pred, d_pred, sizeof(float) * (size_t)l, hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
+         hipStreamSynchronize(h->stream) == hipSuccess && hipGetLastError() == hipSuccess;
+    cleanup();
+    if (!ok) return fail(h, MLX_ERR_HIP, "mlx_score_rows: kernel failed");
+    return MLX_OK;
+}
+
 namespace {
 // org.apache.commons:commons-math3:3.2 CholeskyDecomposition (default thresholds: relative symmetry 1e-15, absolute
 // positivity 1e-10) + getSolver().getInverse(), the call sequence of llf/LibLinear.java:321-325, from the published

@@ -47,3 +47,6 @@ void mlxk_gram_f64(hipStream_t st, const float *X, int64_t ld, int l, const doub
                    int ksplit, int rows_per_split, double *P, int npad);
 void mlxk_gram_finish(hipStream_t st, const double *P, int ksplit, int npad, int nf, const double *colsums, int64_t ld,
                       const double *pinv, double *H);
+// RegressionTest scoring: one float prediction per row
+void mlxk_score_rows(hipStream_t st, int l, const int64_t *rp, const int32_t *gi, const float *val, const double *off,
+                     const double *z, double base, float *pred);

@@ -1135,6 +1135,27 @@ k_outputs_present(const PartDev *__restrict__ parts, const ProbDev *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// RegressionTest scoring (jobs/RegressionTest.java:147-175): pred_i = (float)(offset_i + eval(features_i)) with
+// eval = base + sum_k coef[key_k] * value_k in record order, unknown names skipped (models/LinearModel.java:241-257);
+// base = -log(exp(-intercept)) is evaluated once on the host. One thread per row keeps the reference's summation order.
+// ------------------------------------------------------------------------------------------------
+template <bool HASVAL>
+__global__ void __launch_bounds__(256)
+k_score_rows(int l, const int64_t *__restrict__ rp, const int32_t *__restrict__ gi, const float *__restrict__ val,
+             const double *__restrict__ off, const double *__restrict__ z, double base, float *__restrict__ pred)
+{
+#pragma clang fp contract(off)
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= l) return;
+    double result = base;
+    for (int64_t k = rp[row]; k < rp[row + 1]; k++) {
+        const int g = gi[k];
+        if (g >= 0) result += z[g] * (HASVAL ? (double)val[k] : 1.0);
+    }
+    pred[row] = (float)(off[row] + result);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Posterior variance at the mode (LibLinear.train with computePosteriorVar, llf/LibLinear.java:314-337):
 // H = diag(1/priorVar) + X' D X (llf/LogisticRegressionL2.java:258-297), D_ii = weight_i p_i (1 - p_i) = the wd[] an EVAL
 // pass leaves behind. The n x n Gram build is the one GEMM-shaped piece of this code base: fp64 MFMA.
@@ -1617,4 +1638,12 @@ void mlxk_gram_finish(hipStream_t st, const double *P, int ksplit, int npad, int
 {
     const int64_t tot = (int64_t)(nf + 1) * (nf + 1);
     hipLaunchKernelGGL(k_gram_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, P, ksplit, npad, nf, colsums, ld, pinv, H);
+}
+
+void mlxk_score_rows(hipStream_t st, int l, const int64_t *rp, const int32_t *gi, const float *val, const double *off,
+                     const double *z, double base, float *pred)
+{
+    const int gx = (l + 255) / 256;
+    if (val) hipLaunchKernelGGL((k_score_rows<true>), dim3(gx), dim3(256), 0, st, l, rp, gi, val, off, z, base, pred);
+    else hipLaunchKernelGGL((k_score_rows<false>), dim3(gx), dim3(256), 0, st, l, rp, gi, val, off, z, base, pred);
 }

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "mlx_create", "mlx_destroy", "mlx_last_error", "mlx_set_stream", "mlx_set_profiling", "mlx_set_problem",
     "mlx_set_regularizer", "mlx_add_partition_csr", "mlx_add_partition_dense", "mlx_finalize", "mlx_set_state",
     "mlx_admm_iterate", "mlx_admm_solve_local", "mlx_naive_init", "mlx_naive_solve_local", "mlx_naive_finish", "mlx_consensus_buffer", "mlx_admm_consensus_finish", "mlx_get_z",
-    "mlx_get_partition_model", "mlx_get_solve_counters", "mlx_set_test_data", "mlx_test_loglik", "mlx_solve_one", "mlx_posterior_variance", "mlx_comm_get_unique_id", "mlx_comm_init",
+    "mlx_get_partition_model", "mlx_get_solve_counters", "mlx_set_test_data", "mlx_test_loglik", "mlx_solve_one", "mlx_posterior_variance", "mlx_score_rows", "mlx_comm_get_unique_id", "mlx_comm_init",
     "mlx_version",
 ]
 
@@ -78,6 +78,7 @@ def load_library():
     L.mlx_test_loglik.argtypes = [vp, vp]
     L.mlx_solve_one.argtypes = [vp, i32, vp, vp, vp, f64, i32, vp, vp, vp, vp]
     L.mlx_posterior_variance.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp]
+    L.mlx_score_rows.argtypes = [vp, i32, vp, i32, i64, vp, vp, vp, vp, vp]
     L.mlx_comm_get_unique_id.argtypes = [vp]
     L.mlx_comm_init.argtypes = [vp, vp, i32, i32]
     _lib = L
@@ -281,6 +282,40 @@ class HipAdmmEngine:
     def comm_init(self, unique_id: bytes, nranks: int, rank: int):
         buf = C.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
         self._ck(self.L.mlx_comm_init(self.h, buf, int(nranks), int(rank)))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.mlx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipScorer:
+    """RegressionTest's mapper on the GPU (mlx_score_rows): a bare handle, no training partitions."""
+
+    def __init__(self, device: int = 0):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        rc = self.L.mlx_create(int(device), C.byref(self.h))
+        if rc != 0:
+            raise RuntimeError("mlx_create failed (%d): %s" % (rc, (self.L.mlx_last_error(None) or b"").decode()))
+
+    def score_rows(self, model32: np.ndarray, row_ptr, global_idx, val, offset=None) -> np.ndarray:
+        m = np.ascontiguousarray(model32, np.float32)
+        rp = np.ascontiguousarray(row_ptr, np.int64)
+        gi = np.ascontiguousarray(global_idx, np.int32)
+        v = None if val is None else np.ascontiguousarray(val, np.float32)
+        o = None if offset is None else np.ascontiguousarray(offset, np.float64)
+        out = np.empty(len(rp) - 1, np.float32)
+        rc = self.L.mlx_score_rows(self.h, len(m), _p(m), len(rp) - 1, int(rp[-1]), _p(rp), _p(gi), _p(v), _p(o), _p(out))
+        if rc != 0:
+            raise RuntimeError("mlx_score_rows failed (%d): %s" % (rc, (self.L.mlx_last_error(self.h) or b"").decode()))
+        return out
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:

@@ -818,6 +818,21 @@ double orc_test_loglik_sum(int n_global, const double *z, int l, const int64_t *
     return total;
 }
 
+/* RegressionTest's mapper, jobs/RegressionTest.java:147-175: pred = (float) evalInstanceAvro(record, loglik=false,
+ * ignore_value) = (float)(offset + eval(keys, values, 1)) with eval of models/LinearModel.java:241-257 (result starts at
+ * -log(1-1+1*exp(-intercept)), then += coef*value in record order; names the model does not hold, gidx < 0, are skipped).
+ * z = the model as read from the final-model file (float32 widened), intercept last. */
+void orc_score_rows(int n_global, const double *z, int l, const int64_t *row_ptr, const int32_t *gidx, const float *val,
+                    const double *offset, float *pred)
+{
+    for (int i = 0; i < l; i++) {
+        double result = -log(1 - 1 + 1 * exp(-z[n_global - 1]));
+        for (int64_t k = row_ptr[i]; k < row_ptr[i + 1]; k++)
+            if (gidx[k] >= 0) result += z[gidx[k]] * (val ? (double)val[k] : 1.0);
+        pred[i] = (float)((offset ? offset[i] : 0.0) + result);
+    }
+}
+
 /* String.valueOf(float) -> Double.parseDouble round trip of liblinear.epsilon
  * (jobs/RegressionAdmmTrain.java:346,620,702 ; llf/LibLinear.java:128-131 ; utils/Util.java:145-155).
  * Shortest decimal that round-trips the float (== Float.toString digits for the

@@ -63,3 +63,11 @@ class OracleEngine:
     def test_loglik_sums(self):
         Z, _ = self.o.z()
         return np.array([ol.test_loglik_sum(Z[li], *self._test) for li in range(Z.shape[0])])
+
+
+class OracleScorer:
+    """CPU stand-in of mlease_amd.hip_engine.HipScorer for the host-logic tests."""
+
+    @staticmethod
+    def score_rows(model32, row_ptr, global_idx, val, offset=None):
+        return ol.score_rows(model32, row_ptr, global_idx, val, offset)

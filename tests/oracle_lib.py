@@ -69,6 +69,7 @@ def lib():
         L.orc_float_to_string_to_double.argtypes = [f32]
         L.orc_test_loglik_sum.restype = f64
         L.orc_test_loglik_sum.argtypes = [i32, vp, i32, vp, vp, vp, vp, vp, vp]
+        L.orc_score_rows.argtypes = [i32, vp, i32, vp, vp, vp, vp, vp]
         L.orc_admm_run.restype = i32
         L.orc_admm_run.argtypes = [vp, i32, f64, i32, i32, vp, vp]
         _lib = L
@@ -235,3 +236,15 @@ test_loglik_sum.__test__ = False
 
 def float_to_string_to_double(e) -> float:
     return lib().orc_float_to_string_to_double(float(np.float32(e)))
+
+
+def score_rows(model32, row_ptr, gidx, val, offset=None) -> np.ndarray:
+    """RegressionTest mapper (jobs/RegressionTest.java:147-175) on CSR rows with global ids; model as float32."""
+    z = np.ascontiguousarray(np.asarray(model32, np.float32).astype(np.float64))
+    rp = np.ascontiguousarray(row_ptr, np.int64)
+    gi = np.ascontiguousarray(gidx, np.int32)
+    v = None if val is None else np.ascontiguousarray(val, np.float32)
+    o = None if offset is None else np.ascontiguousarray(offset, np.float64)
+    out = np.empty(len(rp) - 1, np.float32)
+    lib().orc_score_rows(len(z), _p(z), len(rp) - 1, _p(rp), _p(gi), _p(v), _p(o), _p(out))
+    return out

@@ -541,3 +541,26 @@ def test_posterior_variance_vs_oracle(c1):
     fv, V, _ = od.posterior_variance(w, pv, True)
     gf, GV, _ = eng3.posterior_variance(1, w, pv, True)
     assert np.max(np.abs(GV - V)) <= 1e-9 * np.max(np.abs(V))
+
+
+def test_regression_test_scoring_kernel(c1):
+    """N3: RegressionTest's mapper (jobs/RegressionTest.java:147-175) on the GPU == the oracle, float32 predictions
+    bit for bit (same summation order, the intercept's -log(exp(-b)) evaluated on the host): valued and binary rows,
+    unknown names, offsets."""
+    from mlease_amd.hip_engine import HipScorer
+    sc = HipScorer()
+    rng = np.random.default_rng(4)
+    for binary in (False, True):
+        b = c1.blocks[2]
+        gi = b.local_to_global[b.col_idx].astype(np.int32)
+        gi[rng.random(len(gi)) < 0.1] = -1
+        val = None if binary else b.val
+        off = rng.normal(0, 0.5, b.l)
+        model = rng.normal(0, 0.4, c1.n_global).astype(np.float32)
+        got = sc.score_rows(model, b.row_ptr, gi, val, off)
+        want = ol.score_rows(model, b.row_ptr, gi, val, off)
+        assert got.dtype == np.float32 and np.array_equal(got, want)
+        assert np.array_equal(sc.score_rows(model, b.row_ptr, gi, val, None), ol.score_rows(model, b.row_ptr, gi, val, None))
+    with pytest.raises(RuntimeError):
+        sc.score_rows(model, b.row_ptr, np.full(len(gi), c1.n_global, np.int32), None, None)      # id out of range
+    sc.close()

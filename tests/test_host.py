@@ -318,3 +318,44 @@ def test_test_loglik_per_iteration_and_best_model():
     assert abs(float(tr.best_test_loglik) - best_ll) < 1e-6
     recs_out = admm.sample_test_loglik_records(hist)
     assert len(recs_out) == 8 and recs_out[0]["iter"] == 1 and set(r["lambda"] for r in recs_out) == {"1.0", "100.0"}
+
+
+def test_regression_test_job_flow(tmp_path):
+    """jobs/RegressionTest.java:64-175 mirrored for local files: one output per lambda (+ best-model), records = input
+    fields + pred (float), ordered by pred; pred = offset + eval with the float32 model of the final-model file, names
+    the model does not know skipped."""
+    from engines import OracleScorer
+    from test_native_host import PIG_SCHEMA, c1_raw_records
+    c1 = load_c1()
+    recs = c1_raw_records(c1)[:300]
+    recs[5]["features"].append({"name": "never-seen", "term": "x", "value": 3.0})
+    recs[7]["offset"] = 0.25
+    avro_io.write_container(str(tmp_path / "test" / "part-00000.avro"), PIG_SCHEMA, recs, codec="deflate")
+    rng = np.random.default_rng(0)
+    models = {"1.0": rng.normal(0, 0.3, c1.n_global).astype(np.float32), "10.0": rng.normal(0, 0.1, c1.n_global).astype(np.float32)}
+    admm.write_linear_models(str(tmp_path / "model" / "final-model" / "part-r-00000.avro"), models, c1.feature_names)
+    admm.write_linear_models(str(tmp_path / "model" / "best-model" / "best-iteration-3.avro"), {"10.0": models["10.0"]}, c1.feature_names)
+    props = {"input.paths": str(tmp_path / "test"), "output.base.path": str(tmp_path / "out"), "model.base.path": str(tmp_path / "model"),
+             "lambda": "1,10.0"}
+    written = admm.regression_test(props, OracleScorer())
+    assert [os.path.relpath(w, tmp_path / "out") for w in written] == ["lambda-1/part-r-00000.avro", "lambda-10.0/part-r-00000.avro",
+                                                                        "best-model/part-r-00000.avro"]
+    index = {k: j for j, k in enumerate(c1.feature_names)}
+    for path, key in zip(written, ("1.0", "10.0", "10.0")):
+        schema, it = avro_io.read_container(path)
+        out = list(it)
+        assert schema["name"] == "AdmmTestOutput" and [f["name"] for f in schema["fields"]] == [f["name"] for f in PIG_SCHEMA["fields"]] + ["pred"]
+        assert len(out) == len(recs)
+        preds = np.array([o["pred"] for o in out], np.float32)
+        assert np.all(np.diff(preds) >= 0)
+        m = models[key].astype(np.float64)
+        for o in out[::37]:
+            s = -np.log(np.exp(-m[-1]))
+            for f in o["features"]:
+                name = f["name"] if not f["term"] else f["name"] + "\x01" + f["term"]
+                if name in index:
+                    s += m[index[name]] * float(np.float32(f["value"]))
+            want = np.float32((0.0 if o.get("offset") is None else float(o["offset"])) + s)
+            assert abs(np.float32(o["pred"]) - want) <= 2e-7 * max(1.0, abs(want))
+    # empty input.paths: nothing is done (:109-111)
+    assert admm.regression_test(dict(props, **{"input.paths": ""}), OracleScorer()) == []
