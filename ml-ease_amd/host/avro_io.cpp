@@ -311,6 +311,7 @@ void AvroFileWriter::put_long(int64_t v) { put_varint(block_, v); }
 void AvroFileWriter::put_float(float v) { uint8_t b[4]; memcpy(b, &v, 4); block_.insert(block_.end(), b, b + 4); }
 void AvroFileWriter::put_double(double v) { uint8_t b[8]; memcpy(b, &v, 8); block_.insert(block_.end(), b, b + 8); }
 void AvroFileWriter::put_string(const std::string &s) { put_varint(block_, (int64_t)s.size()); block_.insert(block_.end(), s.begin(), s.end()); }
+void AvroFileWriter::put_raw(const uint8_t *p, size_t n) { block_.insert(block_.end(), p, p + n); }
 void AvroFileWriter::array_start(int64_t count) { if (count > 0) put_varint(block_, count); }
 void AvroFileWriter::array_end() { put_varint(block_, 0); }
 void AvroFileWriter::end_record() { if (++block_count_ >= 4096 || block_.size() > (8u << 20)) flush_block(); }

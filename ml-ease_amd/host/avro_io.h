@@ -84,6 +84,7 @@ class AvroFileWriter {
     void put_float(float v);
     void put_double(double v);
     void put_string(const std::string &s);
+    void put_raw(const uint8_t *p, size_t n);   // already-encoded bytes (e.g. the fields of an input record, verbatim)
     void array_start(int64_t count);      // count items follow, then array_end()
     void array_end();
     void end_record();                    // one datum complete

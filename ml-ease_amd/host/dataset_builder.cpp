@@ -108,6 +108,7 @@ void read_input_rows(const std::string &path, const std::string &key_field, bool
         InputRow row;
         rd.for_each([&](AvroCursor &c) {
             row = InputRow();
+            row.raw = c.ptr();
             bool saw_features = false;
             for (int i = 0; i < (int)top.fields.size(); i++) {
                 const AvroSchema &fs = *top.fields[i].second;
@@ -132,6 +133,7 @@ void read_input_rows(const std::string &path, const std::string &key_field, bool
                 } else c.skip(fs);
             }
             if (!saw_features) throw std::runtime_error("features is null");
+            row.raw_len = (size_t)(c.ptr() - row.raw);
             fn(row);
         });
     }

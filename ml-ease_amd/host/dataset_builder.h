@@ -58,6 +58,8 @@ struct InputRow {
     bool has_key = false;
     std::string key;                                      // map.key field or prepared "key"
     std::vector<std::pair<std::string, double>> feats;    // (name key, value as getDoubleAvro yields); value NaN = null
+    const uint8_t *raw = nullptr;                         // the record's avro encoding (valid inside the callback only)
+    size_t raw_len = 0;
 };
 
 // Streams the rows of an avro file / directory; `key_field` = the field to read into InputRow::key ("" = none).

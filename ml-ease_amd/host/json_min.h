@@ -1,6 +1,7 @@
 // json_min.h -- a minimal JSON reader/writer, enough for Avro schemas (avro.schema metadata of container files).
 #pragma once
 #include <cctype>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <memory>
@@ -129,6 +130,48 @@ inline std::string json_escape(const std::string &s)
         else o += c;
     }
     return o + "\"";
+}
+
+// Serialise back to JSON text (schemas only: numbers are printed as integers when integral).
+inline void json_dump(const Json &v, std::string &out)
+{
+    switch (v.kind) {
+    case Json::Null: out += "null"; break;
+    case Json::Bool: out += v.b ? "true" : "false"; break;
+    case Json::Num: {
+        char buf[40];
+        if (v.num == (double)(long long)v.num) snprintf(buf, sizeof buf, "%lld", (long long)v.num);
+        else snprintf(buf, sizeof buf, "%.17g", v.num);
+        out += buf;
+        break;
+    }
+    case Json::Str: {
+        out += '"';
+        for (unsigned char c : v.str) {
+            if (c == '"' || c == '\\') { out += '\\'; out += (char)c; }
+            else if (c < 0x20) { char buf[8]; snprintf(buf, sizeof buf, "\\u%04x", c); out += buf; }
+            else out += (char)c;
+        }
+        out += '"';
+        break;
+    }
+    case Json::Arr:
+        out += '[';
+        for (size_t i = 0; i < v.arr.size(); i++) { if (i) out += ','; json_dump(v.arr[i], out); }
+        out += ']';
+        break;
+    case Json::Obj:
+        out += '{';
+        for (size_t i = 0; i < v.obj.size(); i++) {
+            if (i) out += ',';
+            Json k; k.kind = Json::Str; k.str = v.obj[i].first;
+            json_dump(k, out);
+            out += ':';
+            json_dump(v.obj[i].second, out);
+        }
+        out += '}';
+        break;
+    }
 }
 
 }  // namespace mlh

@@ -245,3 +245,37 @@ def test_cli_mean_model_warm_start(tmp_path, c1):
         assert np.max(err) <= 1e-5, key
     ll0 = avro_io.read_records(str(tmp_path / "out" / "sample-test-loglik" / "iteration-0.avro"))
     assert [x["iter"] for x in ll0] == [0, 0] and not os.path.exists(tmp_path / "out" / "best-model" / "best-iteration-0.avro")
+
+
+@pytest.mark.gpu
+def test_cli_regression_test_matches_python_mirror(tmp_path, c1):
+    """`mlease_regression_test job` (native host + mlx_score_rows) == admm.regression_test over the oracle scorer: same
+    files, same schema, same float32 predictions in the same order; input records copied through unchanged."""
+    from engines import OracleScorer
+    subprocess.check_call(["make", "-C", HOST, "-s"])
+    recs = c1_raw_records(c1)[:400]
+    recs[3]["features"].append({"name": "never-seen", "term": "", "value": 2.5})
+    recs[9]["offset"] = -0.5
+    avro_io.write_container(str(tmp_path / "test" / "part-00000.avro"), PIG_SCHEMA, recs[:250], codec="deflate")
+    avro_io.write_container(str(tmp_path / "test" / "part-00001.avro"), PIG_SCHEMA, recs[250:], codec="null")
+    rng = np.random.default_rng(2)
+    models = {"1.0": rng.normal(0, 0.3, c1.n_global).astype(np.float32), "0.5": rng.normal(0, 0.2, c1.n_global).astype(np.float32)}
+    admm.write_linear_models(str(tmp_path / "model" / "final-model" / "part-r-00000.avro"), models, c1.feature_names)
+    admm.write_linear_models(str(tmp_path / "model" / "best-model" / "best-iteration-2.avro"), {"0.5": models["0.5"]}, c1.feature_names)
+    job = tmp_path / "test.job"
+    job.write_text("input.paths=%s\noutput.base.path=%s\nmodel.base.path=%s\nlambda=1,0.5\n" % (tmp_path / "test", tmp_path / "out", tmp_path / "model"))
+    r = subprocess.run([os.path.join(HOST, "mlease_regression_test"), str(job)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    props = admm.parse_job_file(str(job))
+    props["output.base.path"] = str(tmp_path / "pyout")
+    written = admm.regression_test(props, OracleScorer())
+    assert len(written) == 3
+    for w in written:
+        rel = os.path.relpath(w, tmp_path / "pyout")
+        s1, it1 = avro_io.read_container(str(tmp_path / "out" / rel))
+        s2, it2 = avro_io.read_container(w)
+        a, b = list(it1), list(it2)
+        assert s1["name"] == s2["name"] == "AdmmTestOutput" and [f["name"] for f in s1["fields"]] == [f["name"] for f in s2["fields"]]
+        assert len(a) == len(b) == 400
+        assert np.array_equal(np.array([x["pred"] for x in a], np.float32), np.array([x["pred"] for x in b], np.float32))
+        assert a == b                                            # every input field survived the byte-level copy
