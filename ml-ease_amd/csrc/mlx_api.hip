@@ -518,13 +518,15 @@ int mlx_add_partition_csr(mlx_handle h, int32_t partition_id, int32_t l, int32_t
     {
         const int nrs = (l + 63) / 64;
         rs_ptr.assign((size_t)nrs + 1, 0);
+        int64_t padded = 0;                                 // in 64 bits: the slice offsets themselves are int32
         for (int s = 0; s < nrs; s++) {
             int mx = 0;
             for (int r = s * 64; r < std::min(l, s * 64 + 64); r++) mx = std::max(mx, rp[r + 1] - rp[r]);
-            rs_ptr[(size_t)s + 1] = rs_ptr[(size_t)s] + mx * 64;
+            padded += (int64_t)mx * 64;
+            rs_ptr[(size_t)s + 1] = (int32_t)std::min<int64_t>(padded, std::numeric_limits<int32_t>::max());
         }
-        const int64_t padded = rs_ptr[(size_t)nrs];
-        ph.sell = nnz > 0 && (double)padded <= 1.5 * (double)nnz + 4096.0 && getenv("MLX_NO_SELL") == nullptr;
+        ph.sell = nnz > 0 && (double)padded <= 1.5 * (double)nnz + 4096.0 && padded < (int64_t)std::numeric_limits<int32_t>::max() &&
+                  (int64_t)nnz + 64LL * ph.n_items < (int64_t)std::numeric_limits<int32_t>::max() / 2 && getenv("MLX_NO_SELL") == nullptr;
         if (ph.sell) {
             ph.n_rslices = nrs;
             rs_idx.assign((size_t)padded, 0);

@@ -473,13 +473,14 @@ def test_row_blocked_column_pass_layouts(binary, monkeypatch):
     engines = []
     monkeypatch.setenv("MLX_NO_SMALL", "1")                   # the tick kernels are what this test is about
     for env in ({}, {"MLX_RBMAX": "1024"}, {"MLX_RBMAX": "320", "MLX_SEG": "8", "MLX_CUNIT": "512"},
-                {"MLX_RBMAX": "640", "MLX_SEG": "3", "MLX_ROW_HOT": "2048"}):
-        for k in ("MLX_RBMAX", "MLX_SEG", "MLX_CUNIT", "MLX_ROW_HOT"):
+                {"MLX_RBMAX": "640", "MLX_SEG": "3", "MLX_ROW_HOT": "2048"},
+                {"MLX_NO_SELL": "1", "MLX_RBMAX": "640", "MLX_SEG": "100"}):      # lane-group fallback kernels on blocked items
+        for k in ("MLX_RBMAX", "MLX_SEG", "MLX_CUNIT", "MLX_ROW_HOT", "MLX_NO_SELL"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         engines.append(make_engine(pd, lam, rho))
-    for k in ("MLX_RBMAX", "MLX_SEG", "MLX_CUNIT", "MLX_ROW_HOT"):
+    for k in ("MLX_RBMAX", "MLX_SEG", "MLX_CUNIT", "MLX_ROW_HOT", "MLX_NO_SELL"):
         monkeypatch.delenv(k, raising=False)
     for it in range(4):
         oc.iterate(0.01, 1.0, nthreads=3)
@@ -564,3 +565,35 @@ def test_regression_test_scoring_kernel(c1):
     with pytest.raises(RuntimeError):
         sc.score_rows(model, b.row_ptr, np.full(len(gi), c1.n_global, np.int32), None, None)      # id out of range
     sc.close()
+
+
+def test_dense_partition_beyond_2g_elements_equals_weighted_small_problem():
+    """Maximum-size edge: one dense tile of 2.2 M rows x 1000 columns (2.2e9 elements, 8.8 GB: every row*ld product needs
+    64 bits). Built on the device as R copies of a 10 000-row block, it must solve like the block itself with instance
+    weight R (the objective is identical; only summation order differs)."""
+    import torch
+    nf, B, R = 1000, 10000, 220
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    Xs = torch.randn((B, nf), generator=g, device=dev, dtype=torch.float32)
+    beta = 0.1 * torch.randn(nf, generator=g, device=dev, dtype=torch.float64)
+    ys = torch.where(torch.rand(B, generator=g, device=dev) < torch.sigmoid(Xs.double() @ beta - 1.0), 1, -1).to(torch.int8)
+    big = HipAdmmEngine(nf + 1, [1.0], [1.0], 1)
+    X = Xs.repeat(R, 1)
+    y = ys.repeat(R)
+    assert X.numel() > 2 ** 31
+    torch.cuda.synchronize()
+    big.add_partition_dense_device(0, X.data_ptr(), B * R, nf, nf, y.data_ptr())
+    del X, y
+    big.finalize()
+    small = HipAdmmEngine(nf + 1, [1.0], [1.0], 1)
+    small.add_partition_dense(0, Xs.cpu().numpy(), ys.cpu().numpy(), np.full(B, float(R), np.float32))
+    small.finalize()
+    for it in range(2):
+        sb, ss = big.iterate(0.01), small.iterate(0.01)
+        assert np.array_equal(big.solve_counters(), small.solve_counters())
+        zb, zs = big.z()[0][0], small.z()[0][0]
+        assert np.max(np.abs(zb - zs)) <= 1e-7 * np.max(np.abs(zs))
+    big.close()
+    small.close()
