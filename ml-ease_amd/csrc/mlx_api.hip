@@ -37,7 +37,7 @@ struct PartHost {
     bool sell = false;
     std::vector<int32_t> new2old;          // CSR partitions: library local id -> caller's local id (features only)
     int n_rslices = 0, n_cslices = 0, n_rblk = 1, rblk_rows = 0, n_cunits = 0;
-    int nblk = 0, nblk_min = 1, rows_per_blk = 0, n_items = 0, rowgroup = 64, pos = 0, neg = 0;
+    int nblk = 0, rows_per_blk = 0, n_items = 0, rowgroup = 64, pos = 0, neg = 0;
     PartDev dev{};
     double *c0 = nullptr;
 };
@@ -69,7 +69,6 @@ struct mlx_context {
     int max_cunits = 0, max_rblk_rows = 0;
     int row_hot = 4096;                     // SELL row pass: most frequent columns staged in LDS (0, 2048, 4096, 8192)
     int step_threads = 256;
-    int target_wgs = 1024;                 // dense pass: workgroups wanted per launch (chunk-granularity policy)
 
     double *d_Z = nullptr;
     float *d_z32 = nullptr, *d_u = nullptr, *d_B = nullptr, *d_UPX = nullptr;
@@ -205,11 +204,11 @@ hipEvent_t next_event(mlx_handle h)
 }
 
 // One X pass over every unfinished problem of the given lists (+ optional event bracket).
-int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int nqc, int nrun)
+int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int nqc)
 {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) { e0 = next_event(h); e1 = next_event(h); hipEventRecord(e0, h->stream); }
-    if (nqd > 0 && mlxk_xpass_dense(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->maxblk_dense, h->max_nfeat_dense, nrun, h->d_done, h->target_wgs))
+    if (nqd > 0 && mlxk_xpass_dense(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->maxblk_dense, h->max_nfeat_dense))
         return fail(h, MLX_ERR_INVALID, "dense tile wider than 2048 features is not supported; use the CSR form");
     if (nqc > 0) mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_short, h->max_long, h->rowgroup, h->csr_hasval, h->csr_sell, h->max_cunits, h->max_rblk_rows, h->row_hot);
     if (h->profiling) hipEventRecord(e1, h->stream);
@@ -249,7 +248,7 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
     int rc;
     for (;;) {
         for (int i = 0; i < batch; i++) {
-            if ((rc = launch_xpass(h, qdense, nqd, qcsr, nqc, count))) return rc;
+            if ((rc = launch_xpass(h, qdense, nqd, qcsr, nqc))) return rc;
             mlxk_tron_step(h->stream, h->d_parts, h->d_probs, count, first, h->step_threads, h->d_done);
             ticks++;
         }
@@ -283,7 +282,7 @@ double alg_bytes_per_tick(const PartHost &p)
 int finish_part(mlx_handle h, PartHost &ph)
 {
     ph.dev.l = ph.l; ph.dev.n_local = ph.n_local; ph.dev.n_feat = ph.n_feat; ph.dev.dense = ph.dense ? 1 : 0;
-    ph.dev.nblk = ph.nblk; ph.dev.nblk_min = ph.nblk_min; ph.dev.rows_per_blk = ph.rows_per_blk; ph.dev.pos = ph.pos; ph.dev.neg = ph.neg;
+    ph.dev.nblk = ph.nblk; ph.dev.rows_per_blk = ph.rows_per_blk; ph.dev.pos = ph.pos; ph.dev.neg = ph.neg;
     ph.dev.ld = ph.ld; ph.dev.nnz = ph.nnz; ph.dev.n_items = ph.n_items; ph.dev.n_rblk = ph.n_rblk; ph.dev.rblk_rows = ph.rblk_rows; ph.dev.rowgroup = ph.rowgroup;
     int rc = dev_alloc(h, &ph.c0, (size_t)ph.n_local);
     if (rc) return rc;
@@ -642,16 +641,12 @@ int mlx_add_partition_dense(mlx_handle h, int32_t partition_id, int32_t l, int32
     if ((rc = dev_upload(h, &d_l2g, local_to_global, (size_t)n_local))) return rc;
     ph.dev.X = dX; ph.dev.l2g = d_l2g;
     // Row chunk per workgroup. Measured on 64 x (15625 x 1000) (profiles/r1_notes.md): 512 rows/chunk is the
-    // optimum (5.9 TB/s); finer chunks pay per-block prologue/epilogue, and a finer launch grid whose surplus
-    // blocks exit at once still costs ~12 ns per no-op block. The pass can pick between a fine and a coarse
-    // chunking from the live count of unfinished problems (dense_rows_per_blk); by default both are equal.
-    int fine = l >= 4096 ? 512 : std::max(16, ((l + 7) / 8 + 15) / 16 * 16);
-    if ((l + fine - 1) / fine > 1024) fine = ((l + 1023) / 1024 + 15) / 16 * 16;
-    int coarse = fine;
-    if (const char *e = getenv("MLX_DENSE_RPB")) fine = coarse = std::max(16, atoi(e) / 16 * 16);   // A/B knob (profiles/r1_notes.md)
-    ph.rows_per_blk = fine;
-    ph.nblk = (l + fine - 1) / fine;
-    ph.nblk_min = (l + coarse - 1) / coarse;
+    // optimum (5.9 TB/s); finer chunks pay per-block prologue/epilogue, coarser ones leave CUs idle in the tail.
+    int rpb = l >= 4096 ? 512 : std::max(16, ((l + 7) / 8 + 15) / 16 * 16);
+    if ((l + rpb - 1) / rpb > 1024) rpb = ((l + 1023) / 1024 + 15) / 16 * 16;
+    if (const char *e = getenv("MLX_DENSE_RPB")) rpb = std::max(16, atoi(e) / 16 * 16);   // A/B knob (profiles/r1_notes.md)
+    ph.rows_per_blk = rpb;
+    ph.nblk = (l + rpb - 1) / rpb;
     if ((rc = upload_row_meta(h, ph, l, y, weight, offset, x_on_device != 0))) return rc;
     return finish_part(h, ph);
 }
@@ -776,7 +771,7 @@ int mlx_finalize(mlx_handle h)
         if ((rc = dev_upload(h, &d_c0, c0ptrs.data(), c0ptrs.size()))) return rc;
         const bool prof = h->profiling;
         h->profiling = false;
-        rc = launch_xpass(h, d_qfd, (int)qfirst_d.size(), d_qfc, (int)qfirst_c.size(), np);
+        rc = launch_xpass(h, d_qfd, (int)qfirst_d.size(), d_qfc, (int)qfirst_c.size());
         h->profiling = prof;
         if (rc) return rc;
         mlxk_collect_c0(h->stream, h->d_parts, h->d_probs, d_qfa, (int)qfirst_all.size(), d_c0);
@@ -1268,7 +1263,7 @@ int mlx_posterior_variance(mlx_handle h, int32_t local_index, const double *w, c
     HIPCHECK(h, hipMemcpy(h->d_probs + h->nprob, &pr, sizeof(ProbDev), hipMemcpyHostToDevice));
     const bool prof = h->profiling;
     h->profiling = false;
-    rc = launch_xpass(h, h->d_qscratch, p.dense ? 1 : 0, h->d_qscratch, p.dense ? 0 : 1, 1);
+    rc = launch_xpass(h, h->d_qscratch, p.dense ? 1 : 0, h->d_qscratch, p.dense ? 0 : 1);
     h->profiling = prof;
     if (rc) return rc;
     const double *d_wd = pr.wd[1];

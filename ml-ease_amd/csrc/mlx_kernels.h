@@ -7,9 +7,8 @@ struct PartDev;
 struct ProbDev;
 
 // One X pass for the problems in qlist (device array of problem indices). Returns -1 if unsupported width.
-// nrun = problems driven by this tick loop, done_counter = device count of finished ones (granularity policy).
 int mlxk_xpass_dense(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
-                     int max_nfeat, int nrun, const int *done_counter, int target_wgs);
+                     int max_nfeat);
 int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
                    int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cunits, int max_rblk_rows, int hot);
 // TRON/CG control flow for problems [first, first+nprob)

@@ -120,21 +120,11 @@ __device__ __forceinline__ void row_eval(double z, int y, double wt, double &los
 // (c < NV), i.e. 16*NV bytes per lane per row, loaded as 1 KiB-per-instruction coalesced reads.
 // Per row: partial dot -> wave all-reduce -> row coefficient -> rank-1 accumulate into the lane's
 // 4*NV fp64 column accumulators. U rows are in flight per wave for ILP.
-//
-// Row-chunk granularity adapts to how many problems are still running (dense_rows_per_blk): with all
-// problems active the chunks are coarse (least per-block prologue/epilogue, measured +5 %), in the tail
-// of a tick sequence the few remaining problems are cut into many chunks so they still fill 256 CUs.
-__device__ __forceinline__ int dense_rows_per_blk(const PartDev &pa, int active, int target_wgs)
-{
-    const int want = (target_wgs + active - 1) / active;
-    const int nb = min(max(want, pa.nblk_min), pa.nblk);
-    return ((pa.l + nb - 1) / nb + 15) & ~15;
-}
-
+// The rows of a partition are cut into fixed chunks of rows_per_blk rows (512: finer chunks cost one no-op-ish
+// prologue each, coarser ones leave CUs idle in the tail; profiles/r1_notes.md).
 template <int NV, int U>
 __global__ void __launch_bounds__(256)
-k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist,
-              int nrun, const int *__restrict__ done_counter, int target_wgs)
+k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int q = qlist[blockIdx.y];
@@ -143,10 +133,8 @@ k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     if (phase == PH_DONE) return;
     const PartDev &pa = parts[pr.part];
     const int b = blockIdx.x;
-    const int rpb = dense_rows_per_blk(pa, max(1, nrun - *done_counter), target_wgs);
-    const int nblk = (pa.l + rpb - 1) / rpb;
-    if (b >= nblk) return;
-    if (b == 0 && threadIdx.x == 0) pr.cur_nblk = nblk;
+    const int rpb = pa.rows_per_blk;
+    if (b >= pa.nblk) return;
     const int nf = pa.n_feat, n = nf + 1;
     const int64_t ld = pa.ld;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -696,7 +684,7 @@ __device__ __forceinline__ void assemble_out(const PartDev &pa, const ProbDev &p
     if (pa.dense) {
         // thread = (slice group g, column c): 256 columns x nt/256 groups; each group walks its slices with
         // several loads in flight (a single thread walking all P slices is latency-bound: 85 us -> ~10 us).
-        const int P = pr.cur_nblk;
+        const int P = pa.nblk;
         const int CW = nt < 256 ? nt : 256, NG = nt / CW;
         const int c = tid % CW, g = tid / CW;
         const double *__restrict__ parts = pr.parts;
@@ -884,7 +872,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
         Hd[j] = t * pj + xtc(j);                                    // grad :224 (multiplier 1)
     }
     block_allreduce_sum<1>(a1, scratch);
-    const double loss = block_sum_array(pr.lossp, pa.dense ? pr.cur_nblk : pa.nblk, scratch);
+    const double loss = block_sum_array(pr.lossp, pa.nblk, scratch);
     double fnew = 2.0 * loss;
     fnew = fnew + a1[0];
     fnew = fnew / 2.0;
@@ -1434,10 +1422,10 @@ __global__ void k_round_z(int64_t n, const double *__restrict__ Z, float *__rest
 // ------------------------------------------------------------------------------------------------
 #define LAUNCH_DENSE(NV, U)                                                                                   \
     hipLaunchKernelGGL((k_xpass_dense<NV, U>), dim3(maxblk, nq), dim3(256), (4 * NV * 256 + 16) * sizeof(double), \
-                       st, parts, probs, qlist, nrun, done_counter, target_wgs)
+                       st, parts, probs, qlist)
 
 int mlxk_xpass_dense(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
-                     int max_nfeat, int nrun, const int *done_counter, int target_wgs)
+                     int max_nfeat)
 {
     if (nq <= 0) return 0;
     if (max_nfeat <= 256) LAUNCH_DENSE(1, 8);

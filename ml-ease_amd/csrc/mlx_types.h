@@ -14,9 +14,8 @@ struct PartDev {
     int32_t n_local;       // features incl. intercept (intercept = local index n_local-1, implicit column of 1.0)
     int32_t n_feat;        // n_local - 1
     int32_t dense;         // 1: X dense tile, 0: CSR+CSC
-    int32_t nblk;          // max workgroups per X pass over this partition (finest row chunks; sizes the partial buffers)
-    int32_t nblk_min;      // dense: coarsest chunking (used while every problem is active)
-    int32_t rows_per_blk;  // CSR: rows per workgroup (fixed)
+    int32_t nblk;          // workgroups (row chunks) per X pass over this partition; sizes the partial buffers
+    int32_t rows_per_blk;  // rows per chunk
     int32_t pos, neg;      // #y==+1, #y==-1 (llf/LibLinear.java:272-276)
     int64_t ld;            // dense row stride in floats (multiple of 4, zero padded)
     int64_t nnz;
@@ -67,7 +66,6 @@ struct ProbDev {
     int32_t cg_iter;       // CG steps of the current trcg call
     int32_t newton, accepted, cg_total, ticks;
     int32_t status;
-    int32_t cur_nblk;      // dense: row chunks used by the last X pass (written by the pass, read by the step)
     double f, delta, gnorm, gnorm1, eps, rTr, cgtol, prered, gs;
     double pinv;           // scalar prior precision 1/(1/rho) (used when pinv_vec == nullptr)
     const double *pinv_vec;    // per-coordinate 1/priorVar (mlx_solve_one) or nullptr
