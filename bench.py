@@ -120,8 +120,12 @@ def main():
     torch.cuda.synchronize()
 
     def all_reduce(t):
+        # The library runs on its own HIP stream and is blocking, so the buffer is complete when we get here; the
+        # collective runs on RCCL's stream, ordered against torch's current stream only. Wait for it on the host
+        # before the library's next kernels (consensus_finish) read the summed buffer.
         if dist is not None:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            torch.cuda.current_stream().synchronize()
 
     def barrier():
         if dist is not None:

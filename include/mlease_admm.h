@@ -141,7 +141,10 @@ int mlx_admm_iterate(mlx_handle h, double liblinear_epsilon, float rho_adapt_rat
  * torch.distributed): solve all local (partition, lambda) problems and leave this shard's partial
  * means  xbar = sum_k (1/num_blocks) f32(beta_k),  ubar = sum_k (1/num_blocks) u_k  in one device
  * buffer of 2*n_lambda*n_global doubles ([xbar | ubar]); the caller sums that buffer over all
- * shards (ncclAllReduce / all_reduce(SUM)) and then calls mlx_admm_consensus_finish. */
+ * shards (ncclAllReduce / all_reduce(SUM)) and then calls mlx_admm_consensus_finish.
+ * Stream ordering: mlx_admm_solve_local has completed on return (the buffer is final). The caller's collective
+ * must in turn be COMPLETE before mlx_admm_consensus_finish is called, unless it was enqueued on the very stream
+ * given to mlx_set_stream: the handle's kernels are ordered only against that stream. */
 int mlx_admm_solve_local(mlx_handle h, double liblinear_epsilon, float rho_adapt_rate, mlx_stats *stats);
 int mlx_consensus_buffer(mlx_handle h, void **device_ptr, size_t *count_doubles);
 int mlx_admm_consensus_finish(mlx_handle h, mlx_stats *stats);

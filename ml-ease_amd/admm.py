@@ -164,6 +164,8 @@ class AdmmTrain:
     Engine protocol: ``solve_local(eps, rate)``, ``consensus_finish() -> obj with maxdiff/mindiff``,
     ``z() -> (Z double, z float32)``; for a sharded run additionally ``consensus_tensor()`` returning a
     torch tensor that aliases the [xbar | ubar] buffer, summed in place over ranks by ``all_reduce``.
+    ``all_reduce(tensor)`` must have COMPLETED when it returns (with torch.distributed on a GPU: issue the collective,
+    then synchronize the stream it was ordered on) -- the engine's next kernels run on the engine's own stream.
     """
 
     def __init__(self, config: AdmmConfig, engine, all_reduce=None):

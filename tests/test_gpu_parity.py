@@ -288,7 +288,8 @@ def test_split_api_with_torch_alias_tensor(c1):
         b.solve_local(0.01)
         t = b.consensus_tensor()
         assert t.is_cuda and t.dtype == torch.float64 and t.numel() == 2 * 2 * c1.n_global
-        t.mul_(1.0)                      # touches the library's buffer in place through torch
+        t.mul_(1.0)                      # touches the library's buffer in place through torch (stands in for all_reduce)
+        torch.cuda.current_stream().synchronize()      # the handle runs on its own stream: finish torch's work first
         b.consensus_finish()
     assert np.array_equal(a.z()[0], b.z()[0])
 
