@@ -78,6 +78,12 @@ def main():
     ap.add_argument("--test-rows", type=int, default=100000)
     args = ap.parse_args()
 
+    # stdout must carry exactly ONE line (the JSON): anything a library prints to fd 1 (RCCL prints a version banner
+    # through C stdio, flushed at exit) is sent to stderr instead; the JSON goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import mlease_amd  # noqa: F401
     from mlease_amd import admm
@@ -259,7 +265,7 @@ def main():
                                              % (len(sample), N, len(sample), args.cpu_iters, cdt),
                                    "x_passes_ref_per_s": round(pps, 2), "host_cores_available": os.cpu_count()}
             out["gpu_over_cpu"] = {"solves_per_s": round(value / v, 2), "x_passes_ref_per_s": round(tot_pref / dt / pps, 2)}
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
