@@ -59,7 +59,28 @@ def cpu_baseline(sample, nfeat, iters, threads):
         oc.iterate(0.01, 1.0, nthreads=threads)
         passes += sum(s.x_passes for s in oc.stats())
     dt = time.perf_counter() - t0
-    return len(blocks) * iters / dt, passes / dt, dt
+    counters = np.array([(st.newton_iters, st.accepted, st.cg_iters, st.x_passes) for st in oc.stats()])
+    return len(blocks) * iters / dt, passes / dt, dt, oc.z()[1][0].copy(), counters
+
+
+def parity_on_sample(HipAdmmEngine, sample, nfeat, iters, device, z_oracle, counters_oracle):
+    """The same job the CPU baseline just ran (the sampled partitions as their own num.blocks ADMM problem, `iters`
+    iterations from z = 0) on the GPU: full-size parity check inside the bench run, outside every timed region."""
+    eng = HipAdmmEngine(nfeat + 1, [1.0], [1.0], len(sample), device=device)
+    for k, (Xh, yh) in enumerate(sample):
+        eng.add_partition_dense(k, Xh, yh)
+    eng.finalize()
+    for _ in range(iters):
+        eng.iterate(0.01, 1.0)
+    z = eng.z()[1][0].astype(np.float64)
+    zo = z_oracle.astype(np.float64)
+    floor = 1e-2 * float(np.max(np.abs(zo)))
+    err = float(np.max(np.abs(z - zo) / np.maximum(np.abs(zo), floor)))
+    same = bool(np.array_equal(eng.solve_counters(), counters_oracle))
+    ident = float(np.mean(z.astype(np.float32) == zo.astype(np.float32)))
+    eng.close()
+    return {"what": "GPU vs oracle on the cpu_baseline job (%d partitions of %d x %d, %d iterations)" % (len(sample), sample[0][0].shape[0], nfeat, iters),
+            "max_rel_err_z": err, "tolerance": 1e-5, "tron_counters_equal": same, "bit_identical_float32_fraction": round(ident, 4)}
 
 
 def main():
@@ -258,13 +279,14 @@ def main():
         if sample:
             threads = os.cpu_count() or 1
             threads = min(threads, len(sample))
-            v, pps, cdt = cpu_baseline(sample, nf, args.cpu_iters, threads)
+            v, pps, cdt, z_orc, cnt_orc = cpu_baseline(sample, nf, args.cpu_iters, threads)
             out["cpu_baseline"] = {"value": round(v, 4), "unit": "solves/s", "cores": threads, "kind": "port",
                                    "sample": "oracle/admm_oracle.c (-O2, fp64, one thread per partition solve) on %d of the %d "
                                              "partitions as its own num.blocks=%d ADMM job, iterations 1..%d from z=0, %.1f s wall"
                                              % (len(sample), N, len(sample), args.cpu_iters, cdt),
                                    "x_passes_ref_per_s": round(pps, 2), "host_cores_available": os.cpu_count()}
             out["gpu_over_cpu"] = {"solves_per_s": round(value / v, 2), "x_passes_ref_per_s": round(tot_pref / dt / pps, 2)}
+            out["parity_check"] = parity_on_sample(HipAdmmEngine, sample, nf, args.cpu_iters, local_rank, z_orc, cnt_orc)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
