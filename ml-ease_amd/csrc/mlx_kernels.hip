@@ -174,7 +174,11 @@ k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
 #pragma unroll
             for (int c = 0; c < NV; c++) {
                 const int col0 = min((c * 64 + lane) * 4, (int)ld - 4);
-                x[u][c] = *reinterpret_cast<const float4 *>(xr + col0);
+                {
+                    typedef float f4v __attribute__((ext_vector_type(4)));
+                    const f4v t4 = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(xr + col0));
+                    x[u][c] = make_float4(t4.x, t4.y, t4.z, t4.w);
+                }
             }
         }
         double t[U];
@@ -468,8 +472,8 @@ k_rowpass_sell(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, c
 #pragma unroll
             for (int u = 0; u < SU; u++) {
                 const int kk = min(k + u, L - 1);
-                idx[u] = rs_idx[base + kk * 64 + lane];
-                if (HASVAL) xv[u] = rs_val[base + kk * 64 + lane];
+                idx[u] = __builtin_nontemporal_load(rs_idx + base + kk * 64 + lane);      // streamed once per pass
+                if (HASVAL) xv[u] = __builtin_nontemporal_load(rs_val + base + kk * 64 + lane);
             }
             double vv[SU];
 #pragma unroll
@@ -552,8 +556,8 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
 #pragma unroll
             for (int u = 0; u < SU; u++) {
                 const int kk = min(k + u, L - 1);
-                idx[u] = cs_idx[base + kk * 64 + lane];
-                if (HASVAL) xv[u] = cs_val[base + kk * 64 + lane];
+                idx[u] = __builtin_nontemporal_load(cs_idx + base + kk * 64 + lane);
+                if (HASVAL) xv[u] = __builtin_nontemporal_load(cs_val + base + kk * 64 + lane);
             }
 #pragma unroll
             for (int u = 0; u < SU; u++) {
