@@ -10,7 +10,7 @@ struct ProbDev;
 int mlxk_xpass_dense(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
                      int max_nfeat);
 int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
-                   int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cunits, int max_rblk_rows, int hot);
+                   int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cunits, int max_rblk_rows, int hot, bool stream_once);
 // TRON/CG control flow for problems [first, first+nprob)
 void mlxk_tron_step(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int first, int threads,
                     int *done_counter);

@@ -416,7 +416,7 @@ k_colpass_items(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, 
 // contraction off, so a row's z_i is bit-identical to LogisticRegressionL2.Xv's (llf/LogisticRegressionL2.java:115-129).
 // ------------------------------------------------------------------------------------------------
 #define SU 8
-template <bool HASVAL, int HOT>
+template <bool HASVAL, int HOT, bool NT>
 __global__ void __launch_bounds__(256)
 k_rowpass_sell(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx)
 {
@@ -472,8 +472,10 @@ k_rowpass_sell(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, c
 #pragma unroll
             for (int u = 0; u < SU; u++) {
                 const int kk = min(k + u, L - 1);
-                idx[u] = __builtin_nontemporal_load(rs_idx + base + kk * 64 + lane);      // streamed once per pass
-                if (HASVAL) xv[u] = __builtin_nontemporal_load(rs_val + base + kk * 64 + lane);
+                // NT: the index stream is read once per tick (single lambda); with several lambdas per partition the
+                // problems of a partition share it through L2 and it must stay cacheable
+                idx[u] = NT ? __builtin_nontemporal_load(rs_idx + base + kk * 64 + lane) : rs_idx[base + kk * 64 + lane];
+                if (HASVAL) xv[u] = NT ? __builtin_nontemporal_load(rs_val + base + kk * 64 + lane) : rs_val[base + kk * 64 + lane];
             }
             double vv[SU];
 #pragma unroll
@@ -510,7 +512,7 @@ k_rowpass_sell(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, c
 // (<= 19 456 doubles) is staged once, then every wave walks item slices of that block: one THREAD per item, entry k of
 // the 64 items one coalesced 256-B index load, the gather served by LDS instead of the L2 request path (which is what
 // bounds the global-gather form: ~250 G random 8-byte requests/s chip-wide). Sums run in row order, contraction off.
-template <bool HASVAL>
+template <bool HASVAL, bool NT>
 __global__ void __launch_bounds__(1024)
 k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx)
 {
@@ -556,8 +558,8 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
 #pragma unroll
             for (int u = 0; u < SU; u++) {
                 const int kk = min(k + u, L - 1);
-                idx[u] = __builtin_nontemporal_load(cs_idx + base + kk * 64 + lane);
-                if (HASVAL) xv[u] = __builtin_nontemporal_load(cs_val + base + kk * 64 + lane);
+                idx[u] = NT ? __builtin_nontemporal_load(cs_idx + base + kk * 64 + lane) : cs_idx[base + kk * 64 + lane];
+                if (HASVAL) xv[u] = NT ? __builtin_nontemporal_load(cs_val + base + kk * 64 + lane) : cs_val[base + kk * 64 + lane];
             }
 #pragma unroll
             for (int u = 0; u < SU; u++) {
@@ -1459,35 +1461,34 @@ static void launch_rowpass(hipStream_t st, const PartDev *parts, ProbDev *probs,
 }
 
 int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
-                   int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cunits, int max_rblk_rows, int hot)
+                   int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cunits, int max_rblk_rows, int hot, bool stream_once)
 {
     if (nq <= 0) return 0;
     if (sell) {
         const size_t lds = (size_t)max_rblk_rows * sizeof(double);
         static bool attr_set = false;
         if (!attr_set) {
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_colpass_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_colpass_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define SETLDS(HV, NTF) hipFuncSetAttribute(reinterpret_cast<const void *>(&k_colpass_lds<HV, NTF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+            SETLDS(true, true); SETLDS(true, false); SETLDS(false, true); SETLDS(false, false);
+#undef SETLDS
             attr_set = true;
         }
-#define LAUNCH_ROWSELL(HV, H) hipLaunchKernelGGL((k_rowpass_sell<HV, H>), dim3(XGRID(nq, maxblk)), dim3(256), 0, st, parts, probs, qlist, nq, maxblk)
-        if (hasval) {
-            switch (hot) {
-            case 2048: LAUNCH_ROWSELL(true, 2048); break;
-            case 4096: LAUNCH_ROWSELL(true, 4096); break;
-            case 8192: LAUNCH_ROWSELL(true, 8192); break;
-            default: LAUNCH_ROWSELL(true, 0); break;
-            }
-            if (max_cunits > 0) hipLaunchKernelGGL((k_colpass_lds<true>), dim3(XGRID(nq, max_cunits)), dim3(1024), lds, st, parts, probs, qlist, nq, max_cunits);
-        } else {
-            switch (hot) {
-            case 2048: LAUNCH_ROWSELL(false, 2048); break;
-            case 4096: LAUNCH_ROWSELL(false, 4096); break;
-            case 8192: LAUNCH_ROWSELL(false, 8192); break;
-            default: LAUNCH_ROWSELL(false, 0); break;
-            }
-            if (max_cunits > 0) hipLaunchKernelGGL((k_colpass_lds<false>), dim3(XGRID(nq, max_cunits)), dim3(1024), lds, st, parts, probs, qlist, nq, max_cunits);
-        }
+#define LAUNCH_ROWSELL(HV, H, NTF) hipLaunchKernelGGL((k_rowpass_sell<HV, H, NTF>), dim3(XGRID(nq, maxblk)), dim3(256), 0, st, parts, probs, qlist, nq, maxblk)
+#define LAUNCH_COLLDS(HV, NTF) hipLaunchKernelGGL((k_colpass_lds<HV, NTF>), dim3(XGRID(nq, max_cunits)), dim3(1024), lds, st, parts, probs, qlist, nq, max_cunits)
+#define LAUNCH_SELL(HV, NTF)                                         \
+        do {                                                         \
+            switch (hot) {                                           \
+            case 2048: LAUNCH_ROWSELL(HV, 2048, NTF); break;         \
+            case 4096: LAUNCH_ROWSELL(HV, 4096, NTF); break;         \
+            case 8192: LAUNCH_ROWSELL(HV, 8192, NTF); break;         \
+            default: LAUNCH_ROWSELL(HV, 0, NTF); break;              \
+            }                                                        \
+            if (max_cunits > 0) LAUNCH_COLLDS(HV, NTF);              \
+        } while (0)
+        if (hasval) { if (stream_once) LAUNCH_SELL(true, true); else LAUNCH_SELL(true, false); }
+        else { if (stream_once) LAUNCH_SELL(false, true); else LAUNCH_SELL(false, false); }
+#undef LAUNCH_SELL
+#undef LAUNCH_COLLDS
 #undef LAUNCH_ROWSELL
         return 0;
     }
