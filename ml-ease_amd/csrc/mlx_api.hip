@@ -208,7 +208,7 @@ int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
 {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) { e0 = next_event(h); e1 = next_event(h); hipEventRecord(e0, h->stream); }
-    if (nqd > 0 && mlxk_xpass_dense(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->maxblk_dense, h->max_nfeat_dense))
+    if (nqd > 0 && mlxk_xpass_dense(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->maxblk_dense, h->max_nfeat_dense, h->n_lambda == 1))
         return fail(h, MLX_ERR_INVALID, "dense tile wider than 2048 features is not supported; use the CSR form");
     if (nqc > 0) mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_short, h->max_long, h->rowgroup, h->csr_hasval, h->csr_sell, h->max_cunits, h->max_rblk_rows, h->row_hot, h->n_lambda == 1);
     if (h->profiling) hipEventRecord(e1, h->stream);

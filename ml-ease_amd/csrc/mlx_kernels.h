@@ -8,7 +8,7 @@ struct ProbDev;
 
 // One X pass for the problems in qlist (device array of problem indices). Returns -1 if unsupported width.
 int mlxk_xpass_dense(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
-                     int max_nfeat);
+                     int max_nfeat, bool stream_once);
 int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
                    int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cunits, int max_rblk_rows, int hot, bool stream_once);
 // TRON/CG control flow for problems [first, first+nprob)

@@ -122,7 +122,7 @@ __device__ __forceinline__ void row_eval(double z, int y, double wt, double &los
 // 4*NV fp64 column accumulators. U rows are in flight per wave for ILP.
 // The rows of a partition are cut into fixed chunks of rows_per_blk rows (512: finer chunks cost one no-op-ish
 // prologue each, coarser ones leave CUs idle in the tail; profiles/r1_notes.md).
-template <int NV, int U>
+template <int NV, int U, bool NT>
 __global__ void __launch_bounds__(256)
 k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist)
 {
@@ -174,10 +174,12 @@ k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
 #pragma unroll
             for (int c = 0; c < NV; c++) {
                 const int col0 = min((c * 64 + lane) * 4, (int)ld - 4);
-                {
+                if (NT) {       // single lambda: the tile is read once per tick and must not displace the vectors in L2/MALL
                     typedef float f4v __attribute__((ext_vector_type(4)));
                     const f4v t4 = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(xr + col0));
                     x[u][c] = make_float4(t4.x, t4.y, t4.z, t4.w);
+                } else {        // several lambdas per partition run side by side and share the tile through the caches
+                    x[u][c] = *reinterpret_cast<const float4 *>(xr + col0);
                 }
             }
         }
@@ -1426,12 +1428,16 @@ __global__ void k_round_z(int64_t n, const double *__restrict__ Z, float *__rest
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-#define LAUNCH_DENSE(NV, U)                                                                                   \
-    hipLaunchKernelGGL((k_xpass_dense<NV, U>), dim3(maxblk, nq), dim3(256), (4 * NV * 256 + 16) * sizeof(double), \
-                       st, parts, probs, qlist)
+#define LAUNCH_DENSE(NV, U)                                                                                               \
+    do {                                                                                                                  \
+        if (stream_once) hipLaunchKernelGGL((k_xpass_dense<NV, U, true>), dim3(maxblk, nq), dim3(256),                    \
+                                            (4 * NV * 256 + 16) * sizeof(double), st, parts, probs, qlist);               \
+        else hipLaunchKernelGGL((k_xpass_dense<NV, U, false>), dim3(maxblk, nq), dim3(256),                               \
+                                (4 * NV * 256 + 16) * sizeof(double), st, parts, probs, qlist);                           \
+    } while (0)
 
 int mlxk_xpass_dense(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
-                     int max_nfeat)
+                     int max_nfeat, bool stream_once)
 {
     if (nq <= 0) return 0;
     if (max_nfeat <= 256) LAUNCH_DENSE(1, 8);
@@ -1440,7 +1446,9 @@ int mlxk_xpass_dense(hipStream_t st, const PartDev *parts, ProbDev *probs, const
     else if (max_nfeat <= 2048) {
         static bool attr_set = false;
         if (!attr_set) {
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xpass_dense<8, 2>),
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xpass_dense<8, 2, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (4 * 8 * 256 + 16) * (int)sizeof(double));
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xpass_dense<8, 2, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (4 * 8 * 256 + 16) * (int)sizeof(double));
             attr_set = true;
         }
