@@ -247,7 +247,7 @@ class AdmmNumpy:
 
     def __init__(self, parts: Sequence[Partition], n_global: int, lambdas: Sequence[float],
                  rhos: Optional[Sequence[float]] = None, penalize_intercept: bool = False,
-                 num_blocks: Optional[int] = None):
+                 num_blocks: Optional[int] = None, regularizer: int = 2, lambda_map: Optional[np.ndarray] = None):
         self.parts = list(parts)
         self.N = num_blocks if num_blocks is not None else len(self.parts)
         self.ng = n_global
@@ -259,6 +259,8 @@ class AdmmNumpy:
             rho = [m[l] for l in lam]
         self.lam, self.rho = lam, rho
         self.pen = penalize_intercept
+        self.reg = regularizer                                             # :143-147
+        self.lambda_map = None if lambda_map is None else np.asarray(lambda_map, np.float32)   # per global feature, NaN = not listed
         nl = len(lam)
         self.Z = np.zeros((nl, n_global))
         self.u = np.zeros((len(self.parts), nl, n_global))                 # float32-valued doubles
@@ -328,10 +330,26 @@ class AdmmNumpy:
                 xbar = xbar + b * self.B[k, li]
                 ubar = ubar + b * self.u[k, li]
             l, r = self.lam[li], self.rho[li]
-            weight = float(np.float32(self.N) * r / (l + np.float32(self.N) * r))   # float arithmetic :381
-            zn = weight * xbar + weight * ubar                             # :387-391
+            nr = np.float32(self.N) * r                                    # int * float in float
+            if self.reg == 2:
+                weight = float(nr / (l + nr))                              # float arithmetic :381
+                wvec = np.full(self.ng, weight)
+                if self.lambda_map is not None:                            # weightmap :383-386: float sum, then + 0.0 in double
+                    lm = self.lambda_map
+                    listed = ~np.isnan(lm)
+                    wvec[listed] = float(nr) / ((lm[listed] + nr).astype(np.float32).astype(np.float64) + 0.0)
+                # thisz = 0; linearCombine(1, weight, xbar, weightmap); linearCombine(1, weight, ubar, weightmap) :387-391;
+                # the intercept always takes the scalar weight (models/LinearModel.java:205)
+                zn = (1.0 * np.zeros(self.ng) + wvec * xbar)
+                zn = 1.0 * zn + wvec * ubar
+                zn[-1] = (0.0 + weight * xbar[-1]) + weight * ubar[-1]
+            else:                                                          # L1 :406-451
+                weight = float(l) / (float(np.float32(r * np.float32(self.N))) + 0.0)
+                zn = (np.zeros(self.ng) + 1.0 * xbar) + 1.0 * ubar
+                coef = zn[:-1]
+                coef[...] = np.where(coef > weight, coef - weight, np.where(coef < -weight, coef + weight, coef))  # :424-436 (the band is kept)
             if not self.pen:
-                zn[-1] = xbar[-1] + ubar[-1]                               # :392-403
+                zn[-1] = xbar[-1] + ubar[-1]                               # :392-403, :438-449
             diff = float(np.max(np.abs(self.Z[li] - zn)))                  # :463-464
             self.Z[li] = zn
             mindiff = min(mindiff, diff)

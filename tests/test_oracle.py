@@ -323,3 +323,27 @@ def test_posterior_variance_c_vs_numpy(c1):
         assert np.max(np.abs(V - Vn)) <= 1e-10 * np.max(np.abs(Vn))
         assert np.array_equal(fv, np.diag(V)) and np.max(np.abs(V @ H - np.eye(b.n_local))) < 1e-9
         assert np.all(fv >= dv * (1 - 1e-12))        # (H^-1)_kk >= 1/H_kk for SPD H
+
+
+def test_l1_and_lambda_map_c_vs_numpy(c1):
+    """The remaining consensus branches (jobs/RegressionAdmmTrain.java:383-386 lambda.map weights, :406-451 L1 iterative
+    thresholding -- including its untouched band |z| <= weight) in the C oracle and in the independent numpy restatement."""
+    lm = np.full(c1.n_global, np.nan, np.float32)
+    lm[::6] = 35.0
+    lm[4] = 0.25
+    lm[-1] = 7.0                                   # an intercept entry in the map is ignored by linearCombine
+    for kw in (dict(lambda_map=lm), dict(regularizer=1), dict(regularizer=1, penalize_intercept=True),
+               dict(lambda_map=lm, penalize_intercept=True)):
+        oc = ol.OracleAdmm(c1.blocks, c1.n_global, [0.5, 20.0], [1.0, 1.0], **kw)
+        na = an.AdmmNumpy(np_parts(c1), c1.n_global, [0.5, 20.0], [1.0, 1.0], **kw)
+        for it in range(4):
+            mo = oc.iterate(0.01, 1.0, nthreads=4)
+            mn = na.iterate(0.01)
+            assert np.array_equal(na.Z.astype(np.float32), oc.z()[1]), (list(kw), it)
+            assert abs(mo[0] - mn[0]) <= 1e-10 * mo[0] and abs(mo[1] - mn[1]) <= 1e-10 * mo[1]
+    # L1: coefficients inside the band are kept, not zeroed (:424-436)
+    oc = ol.OracleAdmm(c1.blocks, c1.n_global, [400.0], [1.0], regularizer=1)
+    oc.iterate(0.01, 1.0, nthreads=4)
+    z = oc.z()[0][0][:-1]
+    w = 400.0 / 8.0
+    assert np.any((np.abs(z) > 0) & (np.abs(z) <= w))
