@@ -716,36 +716,50 @@ int mlx_finalize(mlx_handle h)
 
     // problems (+1 scratch for mlx_solve_one)
     h->h_probs.assign(h->nprob + 1, ProbDev{});
-    auto alloc_vecs = [&](ProbDev &pr, int n_local, int l, int64_t plen, int nblk, bool dense) -> int {
+    // All work vectors of all problems are carved out of ONE allocation (256-byte aligned pieces): thousands of problems
+    // (configs #4/#5: 1024 partitions x 8 lambdas) must not become 10^5 hipMalloc calls of a few hundred KB each.
+    auto carve_size = [](size_t count) { return (count * sizeof(double) + 255) / 256 * 256; };
+    auto vec_bytes = [&](int n_local, int l, int64_t plen, int nblk, bool dense) {
+        return 8 * carve_size((size_t)n_local) + (dense ? 2 : 3) * carve_size((size_t)l) + carve_size((size_t)plen) + 2 * carve_size((size_t)nblk);
+    };
+    const int scratch_blk = std::max(h->maxblk_dense, h->maxblk_csr);
+    size_t slab_bytes = vec_bytes(h->max_nlocal, h->max_l, h->max_parts_len, scratch_blk, false) + carve_size((size_t)h->max_nlocal);
+    for (int k = 0; k < np; k++) {
+        const PartHost &p = h->parts[k];
+        slab_bytes += (size_t)nl * vec_bytes(p.n_local, p.l, p.dense ? (int64_t)p.nblk * p.n_local : (int64_t)p.n_items, p.nblk, p.dense);
+    }
+    uint8_t *slab = nullptr;
+    if ((rc = dev_alloc(h, &slab, slab_bytes))) return rc;
+    HIPCHECK(h, hipMemset(slab, 0, slab_bytes));
+    size_t slab_off = 0;
+    auto carve = [&](size_t count) { double *q = reinterpret_cast<double *>(slab + slab_off); slab_off += carve_size(count); return q; };
+    auto alloc_vecs = [&](ProbDev &pr, int n_local, int l, int64_t plen, int nblk, bool dense) {
         double **vs[8] = {&pr.w, &pr.w_new, &pr.g, &pr.s, &pr.r, &pr.d, &pr.Hd, &pr.m};
-        int r2;
-        for (auto v : vs) if ((r2 = dev_alloc(h, v, (size_t)n_local))) return r2;
-        if ((r2 = dev_alloc(h, &pr.wd[0], (size_t)l))) return r2;
-        if ((r2 = dev_alloc(h, &pr.wd[1], (size_t)l))) return r2;
-        if (!dense && (r2 = dev_alloc(h, &pr.coef, (size_t)l))) return r2;
-        if ((r2 = dev_alloc(h, &pr.parts, (size_t)plen))) return r2;
-        if ((r2 = dev_alloc(h, &pr.lossp, (size_t)nblk))) return r2;
-        if ((r2 = dev_alloc(h, &pr.csump, (size_t)nblk))) return r2;
-        return MLX_OK;
+        for (auto v : vs) *v = carve((size_t)n_local);
+        pr.wd[0] = carve((size_t)l);
+        pr.wd[1] = carve((size_t)l);
+        if (!dense) pr.coef = carve((size_t)l);
+        pr.parts = carve((size_t)plen);
+        pr.lossp = carve((size_t)nblk);
+        pr.csump = carve((size_t)nblk);
     };
     for (int k = 0; k < np; k++) {
         const PartHost &p = h->parts[k];
         for (int li = 0; li < nl; li++) {
             ProbDev &pr = h->h_probs[k * nl + li];
             pr.part = k; pr.lambda_idx = li; pr.phase = PH_DONE;
-            const int64_t plen = p.dense ? (int64_t)p.nblk * p.n_local : (int64_t)p.n_items;
-            if ((rc = alloc_vecs(pr, p.n_local, p.l, plen, p.nblk, p.dense))) return rc;
+            alloc_vecs(pr, p.n_local, p.l, p.dense ? (int64_t)p.nblk * p.n_local : (int64_t)p.n_items, p.nblk, p.dense);
         }
     }
     {
         ProbDev &pr = h->h_probs[h->nprob];
         pr.part = 0; pr.phase = PH_DONE;
-        int maxblk = std::max(h->maxblk_dense, h->maxblk_csr);
-        if ((rc = alloc_vecs(pr, h->max_nlocal, h->max_l, h->max_parts_len, maxblk, false))) return rc;
-        if ((rc = dev_alloc(h, &h->sc_pinv, (size_t)h->max_nlocal))) return rc;
+        alloc_vecs(pr, h->max_nlocal, h->max_l, h->max_parts_len, scratch_blk, false);
+        h->sc_pinv = carve((size_t)h->max_nlocal);
         const int sidx = h->nprob;
         if ((rc = dev_upload(h, &h->d_qscratch, &sidx, 1))) return rc;
     }
+    if (slab_off > slab_bytes) return fail(h, MLX_ERR_INVALID, "internal: work-vector slab overrun");
 
     if ((rc = dev_alloc(h, &h->d_done, 1))) return rc;
     HIPCHECK(h, hipMemset(h->d_done, 0, sizeof(int)));
