@@ -598,3 +598,36 @@ def test_dense_partition_beyond_2g_elements_equals_weighted_small_problem():
         assert np.max(np.abs(zb - zs)) <= 1e-7 * np.max(np.abs(zs))
     big.close()
     small.close()
+
+
+def test_large_csr_partition_equals_weighted_small_problem():
+    """Size-independent property for the CSR path at more than a full config-#3 partition: 1.5 M rows x 16 nnz (24 M
+    non-zeros, 75 row blocks of the LDS column pass, tick kernels) built as 150 copies of a 10 000-row block must solve like
+    the block with instance weight 150."""
+    rng = np.random.default_rng(12)
+    B, R, nf, k = 10000, 150, 2000, 16
+    cols = np.sort(rng.integers(0, nf, (B, k)).astype(np.int32), axis=1)
+    cols[:, 1:][cols[:, 1:] == cols[:, :-1]] = nf - 1 - rng.integers(0, 50)      # few duplicates are fine (kept like the reference)
+    cols = np.sort(cols, axis=1)
+    vals = rng.normal(0, 1, (B, k)).astype(np.float32)
+    beta = rng.normal(0, 0.3, nf)
+    y = np.where(rng.random(B) < 1 / (1 + np.exp(-((vals * beta[cols]).sum(1) - 0.5))), 1, -1).astype(np.int8)
+    l2g = np.arange(nf + 1, dtype=np.int32)
+    small = dataset.PartitionBlock(0, B, nf + 1, np.arange(0, (B + 1) * k, k, dtype=np.int64), cols.reshape(-1), vals.reshape(-1), y,
+                                   np.full(B, float(R), np.float32), np.zeros(B, np.float32), l2g)
+    big = dataset.PartitionBlock(0, B * R, nf + 1, np.arange(0, (B * R + 1) * k, k, dtype=np.int64), np.tile(cols.reshape(-1), R),
+                                 np.tile(vals.reshape(-1), R), np.tile(y, R), np.ones(B * R, np.float32), np.zeros(B * R, np.float32), l2g)
+    eb = HipAdmmEngine(nf + 1, [1.0], [1.0], 1)
+    eb.add_partition(big)
+    eb.finalize()
+    es = HipAdmmEngine(nf + 1, [1.0], [1.0], 1)
+    es.add_partition(small)
+    es.finalize()
+    for it in range(2):
+        eb.iterate(0.01)
+        es.iterate(0.01)
+        assert np.array_equal(eb.solve_counters(), es.solve_counters())
+        zb, zs = eb.z()[0][0], es.z()[0][0]
+        assert np.max(np.abs(zb - zs)) <= 1e-7 * np.max(np.abs(zs))
+    eb.close()
+    es.close()
