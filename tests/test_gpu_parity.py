@@ -231,6 +231,13 @@ def test_error_behaviour(c1):
     # 1 of 8 partitions and no communicator: the reference's count check fails (utils/LinearModelUtils.java:80-83)
     with pytest.raises(dataset.ModelFittingError, match="Some models failed"):
         eng.iterate(0.01)
+    with pytest.raises(dataset.ModelFittingError, match="Some models failed"):
+        eng.naive_init(0.01)                                  # the warm start has the same count check (:80-83)
+    with pytest.raises(RuntimeError, match="bad arguments"):
+        eng.posterior_variance(3, np.zeros(b.n_local), np.ones(b.n_local))
+    unfinal = HipAdmmEngine(c1.n_global, [1.0], [1.0], 8)
+    with pytest.raises(RuntimeError, match="mlx_finalize first"):
+        unfinal.naive_init(0.01)
     with pytest.raises(RuntimeError, match="ascending"):
         HipAdmmEngine(10, [1.0, 1.0], [1.0, 1.0], 1)        # duplicate lambda keys collapse in the reference's HashMap
 
@@ -543,6 +550,21 @@ def test_posterior_variance_vs_oracle(c1):
     fv, V, _ = od.posterior_variance(w, pv, True)
     gf, GV, _ = eng3.posterior_variance(1, w, pv, True)
     assert np.max(np.abs(GV - V)) <= 1e-9 * np.max(np.abs(V))
+    # a Hessian commons-math3 rejects (a column no row uses + a flat prior: diagonal 1e-12 <= its 1e-10 threshold) is
+    # reported like the reference's NonPositiveDefiniteMatrixException, by the oracle and by the library alike
+    rows = 40
+    blk = dataset.PartitionBlock(0, rows, 4, np.arange(0, 2 * rows + 1, 2, dtype=np.int64), np.tile(np.array([0, 1], np.int32), rows),
+                                 rng.normal(0, 1, 2 * rows).astype(np.float32), np.where(rng.random(rows) < 0.5, 1, -1).astype(np.int8),
+                                 np.ones(rows, np.float32), np.zeros(rows, np.float32), np.array([0, 1, 2, 3], np.int32))
+    e4 = HipAdmmEngine(4, [1.0], [1.0], 1)
+    e4.add_partition(blk)
+    e4.finalize()
+    with pytest.raises(ArithmeticError):
+        ol.OracleDataset.from_block(blk).posterior_variance(np.zeros(4), np.full(4, 1e12), True)
+    with pytest.raises(dataset.ModelFittingError, match="positive definite"):
+        e4.posterior_variance(0, np.zeros(4), np.full(4, 1e12), True)
+    dv, _, _ = e4.posterior_variance(0, np.zeros(4), np.full(4, 1e12), False)      # the diagonal form has no such check
+    assert dv[2] == 1.0 / (1.0 / 1e12)
 
 
 def test_regression_test_scoring_kernel(c1):
