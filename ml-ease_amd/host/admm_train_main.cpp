@@ -149,8 +149,8 @@ int run_job(const JobConfig &props)
     const bool prepared = props.get_bool("prepared.input", false);
     DatasetBuilder builder(po);
     const std::string input = props.get_string("input.paths");
-    if (prepared) read_input_rows(input, "key", true, [&](InputRow &r) { builder.add_prepared(r); });
-    else read_input_rows(input, po.map_key, !binary, [&](InputRow &r) { builder.add_raw(r); });
+    if (prepared) read_input_rows(input, "key", true, [&](InputRow &r) { builder.add_prepared(r); }, builder.interner());
+    else read_input_rows(input, po.map_key, !binary, [&](InputRow &r) { builder.add_raw(r); }, builder.interner());
     Dataset ds = builder.finish();
     const int ng = ds.n_global();
     auto t_indexed = clk::now();

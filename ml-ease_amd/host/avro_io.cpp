@@ -231,40 +231,55 @@ AvroFileReader::AvroFileReader(const std::string &path)
     schema_ = parse_schema(schema_json_);
 }
 
-void AvroFileReader::for_each(const std::function<void(AvroCursor &)> &fn)
+std::vector<AvroFileReader::RawBlock> AvroFileReader::blocks() const
 {
-    std::vector<uint8_t> inflated;
+    std::vector<RawBlock> out;
     size_t pos = pos_;
     while (pos < data_.size()) {
         AvroCursor hc(data_.data() + pos, data_.data() + data_.size());
         const int64_t count = hc.read_long(), size = hc.read_long();
         const uint8_t *q = hc.ptr();
         if (size < 0 || q + size + 16 > data_.data() + data_.size()) throw std::runtime_error("avro: bad block size");
-        const uint8_t *bp = q, *be = q + size;
-        if (codec_ == "deflate") {
-            inflated.clear();
-            z_stream zs;
-            memset(&zs, 0, sizeof zs);
-            if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("zlib init failed");
-            zs.next_in = const_cast<Bytef *>(bp);
-            zs.avail_in = (uInt)size;
-            uint8_t buf[1 << 16];
-            int rc;
-            do {
-                zs.next_out = buf;
-                zs.avail_out = sizeof buf;
-                rc = inflate(&zs, Z_NO_FLUSH);
-                if (rc != Z_OK && rc != Z_STREAM_END) { inflateEnd(&zs); throw std::runtime_error("avro: inflate failed"); }
-                inflated.insert(inflated.end(), buf, buf + (sizeof buf - zs.avail_out));
-            } while (rc != Z_STREAM_END);
-            inflateEnd(&zs);
-            bp = inflated.data();
-            be = inflated.data() + inflated.size();
-        }
-        AvroCursor c(bp, be);
-        for (int64_t i = 0; i < count; i++) fn(c);
         if (memcmp(q + size, sync_, 16) != 0) throw std::runtime_error("avro: sync marker mismatch");
+        out.push_back({count, q, q + size});
         pos = (size_t)(q + size + 16 - data_.data());
+    }
+    return out;
+}
+
+void AvroFileReader::inflate(const RawBlock &b, std::vector<uint8_t> &out) const
+{
+    out.clear();
+    if (codec_ != "deflate") { out.assign(b.begin, b.end); return; }
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("zlib init failed");
+    zs.next_in = const_cast<Bytef *>(b.begin);
+    zs.avail_in = (uInt)(b.end - b.begin);
+    out.resize(std::max<size_t>((size_t)(b.end - b.begin) * 4, 1 << 16));
+    size_t have = 0;
+    int rc;
+    do {
+        if (have == out.size()) out.resize(out.size() * 2);
+        zs.next_out = out.data() + have;
+        zs.avail_out = (uInt)std::min<size_t>(out.size() - have, 1u << 30);
+        const size_t before = zs.avail_out;
+        rc = ::inflate(&zs, Z_NO_FLUSH);
+        if (rc != Z_OK && rc != Z_STREAM_END) { inflateEnd(&zs); throw std::runtime_error("avro: inflate failed"); }
+        have += before - zs.avail_out;
+    } while (rc != Z_STREAM_END);
+    inflateEnd(&zs);
+    out.resize(have);
+}
+
+void AvroFileReader::for_each(const std::function<void(AvroCursor &)> &fn)
+{
+    std::vector<uint8_t> inflated;
+    for (const RawBlock &b : blocks()) {
+        const uint8_t *bp = b.begin, *be = b.end;
+        if (deflated()) { inflate(b, inflated); bp = inflated.data(); be = inflated.data() + inflated.size(); }
+        AvroCursor c(bp, be);
+        for (int64_t i = 0; i < b.count; i++) fn(c);
     }
 }
 

@@ -63,6 +63,11 @@ class AvroFileReader {
     const std::string &schema_json() const { return schema_json_; }
     // Calls fn(cursor) once per record; fn must consume exactly one record of schema().
     void for_each(const std::function<void(AvroCursor &)> &fn);
+    // Block-level access for parallel decoding: the (possibly deflated) payload spans in file order, and the inflater.
+    struct RawBlock { int64_t count; const uint8_t *begin, *end; };
+    std::vector<RawBlock> blocks() const;
+    void inflate(const RawBlock &b, std::vector<uint8_t> &out) const;      // out = the block's datum bytes
+    bool deflated() const { return codec_ == "deflate"; }
 
   private:
     std::vector<uint8_t> data_;

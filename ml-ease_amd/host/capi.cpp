@@ -30,8 +30,8 @@ void *mlh_build(const char *path, int num_blocks, const char *map_key, int binar
         po.seed = seed;
         po.short_feature_index = short_index != 0;
         DatasetBuilder b(po);
-        if (prepared) read_input_rows(path, "key", true, [&](InputRow &r) { b.add_prepared(r); });
-        else read_input_rows(path, po.map_key, !po.binary_feature, [&](InputRow &r) { b.add_raw(r); });
+        if (prepared) read_input_rows(path, "key", true, [&](InputRow &r) { b.add_prepared(r); }, b.interner());
+        else read_input_rows(path, po.map_key, !po.binary_feature, [&](InputRow &r) { b.add_raw(r); }, b.interner());
         return new Dataset(b.finish());
     } catch (const std::exception &e) {
         g_err = e.what();
