@@ -114,6 +114,15 @@ int mlx_add_partition_csr(mlx_handle h, int32_t partition_id, int32_t l, int32_t
                           const int8_t *y, const float *weight, const float *offset,
                           const int32_t *local_to_global);
 
+/* `count` partitions in one call: identical in effect to `count` calls of mlx_add_partition_csr in argument order, but the
+ * host-side preparation (frequency relabelling, column items, sliced copies) of different partitions runs on a pool of
+ * threads; uploads follow sequentially. Every argument is an array of `count` entries; val, weight, offset may be NULL
+ * as a whole or per entry. */
+int mlx_add_partitions_csr(mlx_handle h, int32_t count, const int32_t *partition_id, const int32_t *l, const int32_t *n_local,
+                           const int64_t *nnz, const int64_t *const *row_ptr, const int32_t *const *col_idx,
+                           const float *const *val, const int8_t *const *y, const float *const *weight,
+                           const float *const *offset, const int32_t *const *local_to_global);
+
 /* Dense tile form for partitions in which every row carries every feature (BASELINE config #2):
  * X is row-major [l][ld] float32, the first n_feat columns used; n_local = n_feat+1.
  * x_on_device != 0: X, y, weight, offset are DEVICE pointers (synthetic data generated on the GPU). */

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mlease_admm.h"
@@ -386,25 +387,43 @@ int mlx_set_regularizer(mlx_handle h, int32_t regularizer)
     return MLX_OK;
 }
 
-int mlx_add_partition_csr(mlx_handle h, int32_t partition_id, int32_t l, int32_t n_local, int64_t nnz,
-                          const int64_t *row_ptr, const int32_t *col_idx, const float *val, const int8_t *y,
-                          const float *weight, const float *offset, const int32_t *local_to_global)
+// Everything mlx_add_partition_csr derives on the host from one partition's CSR arrays, before any upload. Pure function
+// of its inputs (no handle, no device): partitions can be prepared by several threads (mlx_add_partitions_csr).
+struct CsrPrep {
+    PartHost ph;
+    std::vector<int32_t> rp, pcol, cri, item_ptr, col_item, ishort, ilong, l2g_perm, rs_ptr, rs_idx, cs_ptr, cs_idx, cw_blk, cw_slice;
+    std::vector<float> pvalv, cval, rs_val, cs_val;
+    bool hasval = false;
+    int rc = MLX_OK;
+    std::string error;
+    int fail(int code, const char *fmt, ...)
+    {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        error = buf;
+        rc = code;
+        return code;
+    }
+};
+
+static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t l, int32_t n_local, int64_t nnz,
+                    const int64_t *row_ptr, const int32_t *col_idx, const float *val, const int8_t *y,
+                    const int32_t *local_to_global)
 {
-    if (!h) return MLX_ERR_INVALID;
-    hipSetDevice(h->device);
-    int rc = check_common_rows(h, partition_id, l, local_to_global, n_local);
-    if (rc) return rc;
-    if (!row_ptr || (nnz > 0 && !col_idx) || !y) return fail(h, MLX_ERR_INVALID, "NULL row data");
-    if (row_ptr[0] != 0 || row_ptr[l] != nnz) return fail(h, MLX_ERR_INVALID, "row_ptr[0] must be 0 and row_ptr[l] == nnz");
-    if (nnz >= (int64_t)std::numeric_limits<int32_t>::max()) return fail(h, MLX_ERR_INVALID, "partition nnz must be < 2^31");
+    if (!row_ptr || (nnz > 0 && !col_idx) || !y) return P.fail(MLX_ERR_INVALID, "NULL row data");
+    if (row_ptr[0] != 0 || row_ptr[l] != nnz) return P.fail(MLX_ERR_INVALID, "row_ptr[0] must be 0 and row_ptr[l] == nnz");
+    if (nnz >= (int64_t)std::numeric_limits<int32_t>::max()) return P.fail(MLX_ERR_INVALID, "partition nnz must be < 2^31");
     const int nf = n_local - 1;
     std::vector<int32_t> rp(l + 1), colcnt(nf + 1, 0);
     for (int i = 0; i <= l; i++) {
-        if (i && row_ptr[i] < row_ptr[i - 1]) return fail(h, MLX_ERR_INVALID, "row_ptr not monotone at %d", i);
+        if (i && row_ptr[i] < row_ptr[i - 1]) return P.fail(MLX_ERR_INVALID, "row_ptr not monotone at %d", i);
         rp[i] = (int32_t)row_ptr[i];
     }
     for (int64_t k = 0; k < nnz; k++)
-        if (col_idx[k] < 0 || col_idx[k] >= nf) return fail(h, MLX_ERR_INVALID, "col_idx[%lld]=%d out of [0,%d)", (long long)k, col_idx[k], nf);
+        if (col_idx[k] < 0 || col_idx[k] >= nf) return P.fail(MLX_ERR_INVALID, "col_idx[%lld]=%d out of [0,%d)", (long long)k, col_idx[k], nf);
     // Library-internal relabelling of the local ids: most frequent feature first (stable). The caller's local order
     // only matters at mlx_solve_one, which maps through new2old. Frequent columns first means (a) column segments come
     // out ordered by length, so 64 consecutive segments form a well-filled slice, and (b) the hot head of the dense
@@ -439,7 +458,7 @@ int mlx_add_partition_csr(mlx_handle h, int32_t partition_id, int32_t l, int32_t
     PartHost ph;
     ph.new2old = new2old;
     ph.pid = partition_id; ph.l = l; ph.n_local = n_local; ph.n_feat = nf; ph.dense = false; ph.hasval = (val != nullptr);
-    ph.nnz = nnz; ph.all_present = (n_local == h->n_global);
+    ph.nnz = nnz; ph.all_present = (n_local == n_global);
     // CSC (rows ascending inside a column = the order XTv accumulates in, llf/LogisticRegressionL2.java:140-145)
     std::vector<int32_t> cp(colcnt);
     for (int j = 0; j < nf; j++) cp[j + 1] += cp[j];
@@ -578,35 +597,53 @@ int mlx_add_partition_csr(mlx_handle h, int32_t partition_id, int32_t l, int32_t
         }
     }
 
+
+    P.ph = std::move(ph);
+    P.hasval = (val != nullptr);
+    P.rp = std::move(rp); P.pcol = std::move(pcol); P.pvalv = std::move(pvalv); P.cri = std::move(cri); P.cval = std::move(cval);
+    P.item_ptr = std::move(item_ptr); P.col_item = std::move(col_item); P.ishort = std::move(ishort); P.ilong = std::move(ilong);
+    P.l2g_perm = std::move(l2g_perm);
+    P.rs_ptr = std::move(rs_ptr); P.rs_idx = std::move(rs_idx); P.rs_val = std::move(rs_val);
+    P.cs_ptr = std::move(cs_ptr); P.cs_idx = std::move(cs_idx); P.cs_val = std::move(cs_val);
+    P.cw_blk = std::move(cw_blk); P.cw_slice = std::move(cw_slice);
+    return MLX_OK;
+}
+
+// Uploads a prepared partition and registers it with the handle (sequential: the handle is not thread-safe).
+static int commit_csr(mlx_handle h, CsrPrep &P, int32_t l, int32_t n_local, int64_t nnz, const int8_t *y, const float *weight,
+                      const float *offset)
+{
+    PartHost &ph = P.ph;
+    const bool val = P.hasval;
+    int rc;
     int32_t *d_rp, *d_ci, *d_cri, *d_item, *d_colitem, *d_l2g, *d_ishort, *d_ilong;
     float *d_val = nullptr, *d_cval = nullptr;
-    if ((rc = dev_upload(h, &d_rp, rp.data(), rp.size()))) return rc;
-    if ((rc = dev_upload(h, &d_ci, col_idx_p, (size_t)nnz))) return rc;
-    if ((rc = dev_upload(h, &d_cri, cri.data(), cri.size()))) return rc;
+    if ((rc = dev_upload(h, &d_rp, P.rp.data(), P.rp.size()))) return rc;
+    if ((rc = dev_upload(h, &d_ci, P.pcol.data(), (size_t)nnz))) return rc;
+    if ((rc = dev_upload(h, &d_cri, P.cri.data(), P.cri.size()))) return rc;
     if (val) {
-        if ((rc = dev_upload(h, &d_val, val_p, (size_t)nnz))) return rc;
-        if ((rc = dev_upload(h, &d_cval, cval.data(), cval.size()))) return rc;
+        if ((rc = dev_upload(h, &d_val, P.pvalv.data(), (size_t)nnz))) return rc;
+        if ((rc = dev_upload(h, &d_cval, P.cval.data(), P.cval.size()))) return rc;
     }
-    if ((rc = dev_upload(h, &d_item, item_ptr.data(), item_ptr.size()))) return rc;
-    if ((rc = dev_upload(h, &d_colitem, col_item.data(), col_item.size()))) return rc;
-    if ((rc = dev_upload(h, &d_ishort, ishort.data(), ishort.size()))) return rc;
-    if ((rc = dev_upload(h, &d_ilong, ilong.data(), ilong.size()))) return rc;
-    if ((rc = dev_upload(h, &d_l2g, l2g_perm.data(), (size_t)n_local))) return rc;
+    if ((rc = dev_upload(h, &d_item, P.item_ptr.data(), P.item_ptr.size()))) return rc;
+    if ((rc = dev_upload(h, &d_colitem, P.col_item.data(), P.col_item.size()))) return rc;
+    if ((rc = dev_upload(h, &d_ishort, P.ishort.data(), P.ishort.size()))) return rc;
+    if ((rc = dev_upload(h, &d_ilong, P.ilong.data(), P.ilong.size()))) return rc;
+    if ((rc = dev_upload(h, &d_l2g, P.l2g_perm.data(), (size_t)n_local))) return rc;
     ph.dev.rp = d_rp; ph.dev.ci = d_ci; ph.dev.val = d_val; ph.dev.cri = d_cri; ph.dev.cval = d_cval;
     ph.dev.sell = ph.sell ? 1 : 0; ph.dev.n_rslices = ph.n_rslices; ph.dev.n_cslices = ph.n_cslices;
     if (ph.sell) {
-        int32_t *d_a, *d_b, *d_c, *d_d, *d_e;
+        int32_t *d_a, *d_b, *d_c, *d_d, *d_e, *d_h;
         float *d_f = nullptr, *d_g = nullptr;
-        if ((rc = dev_upload(h, &d_a, rs_ptr.data(), rs_ptr.size()))) return rc;
-        if ((rc = dev_upload(h, &d_b, rs_idx.data(), rs_idx.size()))) return rc;
-        if ((rc = dev_upload(h, &d_c, cs_ptr.data(), cs_ptr.size()))) return rc;
-        if ((rc = dev_upload(h, &d_d, cs_idx.data(), cs_idx.size()))) return rc;
-        if ((rc = dev_upload(h, &d_e, cw_blk.data(), cw_blk.size()))) return rc;
-        int32_t *d_h;
-        if ((rc = dev_upload(h, &d_h, cw_slice.data(), cw_slice.size()))) return rc;
+        if ((rc = dev_upload(h, &d_a, P.rs_ptr.data(), P.rs_ptr.size()))) return rc;
+        if ((rc = dev_upload(h, &d_b, P.rs_idx.data(), P.rs_idx.size()))) return rc;
+        if ((rc = dev_upload(h, &d_c, P.cs_ptr.data(), P.cs_ptr.size()))) return rc;
+        if ((rc = dev_upload(h, &d_d, P.cs_idx.data(), P.cs_idx.size()))) return rc;
+        if ((rc = dev_upload(h, &d_e, P.cw_blk.data(), P.cw_blk.size()))) return rc;
+        if ((rc = dev_upload(h, &d_h, P.cw_slice.data(), P.cw_slice.size()))) return rc;
         if (val) {
-            if ((rc = dev_upload(h, &d_f, rs_val.data(), rs_val.size()))) return rc;
-            if ((rc = dev_upload(h, &d_g, cs_val.data(), cs_val.size()))) return rc;
+            if ((rc = dev_upload(h, &d_f, P.rs_val.data(), P.rs_val.size()))) return rc;
+            if ((rc = dev_upload(h, &d_g, P.cs_val.data(), P.cs_val.size()))) return rc;
         }
         ph.dev.rs_ptr = d_a; ph.dev.rs_idx = d_b; ph.dev.cs_ptr = d_c; ph.dev.cs_idx = d_d; ph.dev.cw_blk = d_e; ph.dev.cw_slice = d_h; ph.dev.n_cunits = ph.n_cunits;
         ph.dev.rs_val = d_f; ph.dev.cs_val = d_g;
@@ -615,6 +652,61 @@ int mlx_add_partition_csr(mlx_handle h, int32_t partition_id, int32_t l, int32_t
     ph.dev.item_ptr = d_item; ph.dev.col_item = d_colitem; ph.dev.l2g = d_l2g; ph.dev.X = nullptr;
     if ((rc = upload_row_meta(h, ph, l, y, weight, offset, false))) return rc;
     return finish_part(h, ph);
+}
+
+int mlx_add_partition_csr(mlx_handle h, int32_t partition_id, int32_t l, int32_t n_local, int64_t nnz,
+                          const int64_t *row_ptr, const int32_t *col_idx, const float *val, const int8_t *y,
+                          const float *weight, const float *offset, const int32_t *local_to_global)
+{
+    if (!h) return MLX_ERR_INVALID;
+    hipSetDevice(h->device);
+    int rc = check_common_rows(h, partition_id, l, local_to_global, n_local);
+    if (rc) return rc;
+    CsrPrep P;
+    if ((rc = prep_csr(P, h->n_global, partition_id, l, n_local, nnz, row_ptr, col_idx, val, y, local_to_global)))
+        return fail(h, rc, "%s", P.error.c_str());
+    return commit_csr(h, P, l, n_local, nnz, y, weight, offset);
+}
+
+// Several partitions at once: the host-side preparation (relabelling, column items, sliced copies) runs on a pool of
+// threads, the uploads follow in argument order. Same result as `count` calls of mlx_add_partition_csr.
+int mlx_add_partitions_csr(mlx_handle h, int32_t count, const int32_t *partition_id, const int32_t *l, const int32_t *n_local,
+                           const int64_t *nnz, const int64_t *const *row_ptr, const int32_t *const *col_idx,
+                           const float *const *val, const int8_t *const *y, const float *const *weight,
+                           const float *const *offset, const int32_t *const *local_to_global)
+{
+    if (!h) return MLX_ERR_INVALID;
+    if (count < 0 || (count > 0 && (!partition_id || !l || !n_local || !nnz || !row_ptr || !col_idx || !y || !local_to_global)))
+        return fail(h, MLX_ERR_INVALID, "bad arguments");
+    hipSetDevice(h->device);
+    unsigned hc = std::thread::hardware_concurrency();
+    const int nthreads = (int)std::max(1u, std::min(hc ? hc : 1u, 16u));
+    for (int b0 = 0; b0 < count; b0 += nthreads) {
+        const int nb = std::min(nthreads, count - b0);
+        std::vector<CsrPrep> preps((size_t)nb);
+        int rc;
+        for (int j = 0; j < nb; j++) {                  // argument checks that need the handle: sequential
+            const int k = b0 + j;
+            if ((rc = check_common_rows(h, partition_id[k], l[k], local_to_global[k], n_local[k]))) return rc;
+            for (int j2 = 0; j2 < j; j2++)
+                if (partition_id[b0 + j2] == partition_id[k]) return fail(h, MLX_ERR_INVALID, "partition %d added twice", partition_id[k]);
+        }
+        std::vector<std::thread> th;
+        for (int j = 0; j < nb; j++)
+            th.emplace_back([&, j] {
+                const int k = b0 + j;
+                prep_csr(preps[(size_t)j], h->n_global, partition_id[k], l[k], n_local[k], nnz[k], row_ptr[k], col_idx[k],
+                         val ? val[k] : nullptr, y[k], local_to_global[k]);
+            });
+        for (auto &t : th) t.join();
+        for (int j = 0; j < nb; j++) {
+            const int k = b0 + j;
+            CsrPrep &P = preps[(size_t)j];
+            if (P.rc) return fail(h, P.rc, "partition %d: %s", partition_id[k], P.error.c_str());
+            if ((rc = commit_csr(h, P, l[k], n_local[k], nnz[k], y[k], weight ? weight[k] : nullptr, offset ? offset[k] : nullptr))) return rc;
+        }
+    }
+    return MLX_OK;
 }
 
 int mlx_add_partition_dense(mlx_handle h, int32_t partition_id, int32_t l, int32_t n_feat, int64_t ld, const float *X,

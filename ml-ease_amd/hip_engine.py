@@ -20,7 +20,7 @@ UNIQUE_ID_BYTES = 128
 # every entry point include/mlease_admm.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "mlx_create", "mlx_destroy", "mlx_last_error", "mlx_set_stream", "mlx_set_profiling", "mlx_set_problem",
-    "mlx_set_regularizer", "mlx_add_partition_csr", "mlx_add_partition_dense", "mlx_finalize", "mlx_set_state",
+    "mlx_set_regularizer", "mlx_add_partition_csr", "mlx_add_partitions_csr", "mlx_add_partition_dense", "mlx_finalize", "mlx_set_state",
     "mlx_admm_iterate", "mlx_admm_solve_local", "mlx_naive_init", "mlx_naive_solve_local", "mlx_naive_finish", "mlx_consensus_buffer", "mlx_admm_consensus_finish", "mlx_get_z",
     "mlx_get_partition_model", "mlx_get_solve_counters", "mlx_set_test_data", "mlx_test_loglik", "mlx_solve_one", "mlx_posterior_variance", "mlx_score_rows", "mlx_comm_get_unique_id", "mlx_comm_init",
     "mlx_version",
@@ -61,6 +61,7 @@ def load_library():
     L.mlx_set_problem.argtypes = [vp, i32, i32, vp, vp, i32, i32, vp]
     L.mlx_set_regularizer.argtypes = [vp, i32]
     L.mlx_add_partition_csr.argtypes = [vp, i32, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp]
+    L.mlx_add_partitions_csr.argtypes = [vp, i32] + [vp] * 11
     L.mlx_add_partition_dense.argtypes = [vp, i32, i32, i32, i64, vp, vp, vp, vp, vp, i32]
     L.mlx_finalize.argtypes = [vp]
     L.mlx_set_state.argtypes = [vp, vp, vp]
@@ -135,6 +136,38 @@ class HipAdmmEngine:
         self._ck(self.L.mlx_add_partition_csr(self.h, int(b.partition_id), int(b.l), int(b.n_local), int(rp[-1]),
                                               _p(rp), _p(ci), _p(val), _p(y), _p(wt), _p(off), _p(l2g)))
         self.nlocal += 1
+
+    def add_partitions(self, blocks: Sequence[PartitionBlock]):
+        """Several CSR partitions in one call (mlx_add_partitions_csr): host preparation on a thread pool."""
+        if not blocks:
+            return
+        keep = []                                   # the arrays must outlive the call
+
+        def arr(a, dt):
+            a = np.ascontiguousarray(a, dt)
+            keep.append(a)
+            return a.ctypes.data
+
+        n = len(blocks)
+        has_val = blocks[0].val is not None
+        if any((b.val is not None) != has_val for b in blocks):
+            raise ValueError("binary.feature and valued partitions cannot be mixed in one call")
+        pid = np.array([b.partition_id for b in blocks], np.int32)
+        ls = np.array([b.l for b in blocks], np.int32)
+        nl = np.array([b.n_local for b in blocks], np.int32)
+        nnz = np.array([len(b.col_idx) for b in blocks], np.int64)
+        PtrArr = C.c_void_p * n
+        rp = PtrArr(*[arr(b.row_ptr, np.int64) for b in blocks])
+        ci = PtrArr(*[arr(b.col_idx, np.int32) for b in blocks])
+        vv = PtrArr(*[arr(b.val, np.float32) for b in blocks]) if has_val else None
+        yy = PtrArr(*[arr(b.y, np.int8) for b in blocks])
+        ww = PtrArr(*[arr(b.weight, np.float32) for b in blocks])
+        oo = PtrArr(*[arr(b.offset, np.float32) for b in blocks])
+        lg = PtrArr(*[arr(b.local_to_global, np.int32) for b in blocks])
+        self._ck(self.L.mlx_add_partitions_csr(self.h, n, _p(pid), _p(ls), _p(nl), _p(nnz), C.cast(rp, C.c_void_p), C.cast(ci, C.c_void_p),
+                                               None if vv is None else C.cast(vv, C.c_void_p), C.cast(yy, C.c_void_p),
+                                               C.cast(ww, C.c_void_p), C.cast(oo, C.c_void_p), C.cast(lg, C.c_void_p)))
+        self.nlocal += n
 
     def add_partition_dense(self, partition_id: int, X: np.ndarray, y: np.ndarray, weight=None, offset=None,
                             local_to_global=None):

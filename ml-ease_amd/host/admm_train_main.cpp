@@ -185,13 +185,22 @@ int run_job(const JobConfig &props)
         ck(h, mlx_set_problem(h, ng, nl, lam.data(), rho.data(), nblocks, props.get_bool("penalize.intercept", false) ? 1 : 0,
                               lambda_map.empty() ? nullptr : lambda_map.data()), "mlx_set_problem");
         ck(h, mlx_set_regularizer(h, reg), "mlx_set_regularizer");
+        std::vector<int32_t> a_pid, a_l, a_nl;
+        std::vector<int64_t> a_nnz;
+        std::vector<const int64_t *> a_rp;
+        std::vector<const int32_t *> a_ci, a_l2g;
+        std::vector<const float *> a_val, a_w, a_o;
+        std::vector<const int8_t *> a_y;
         for (auto &p : ds.parts) {
             if (p.pid % G != g) continue;
             if (p.rows() == 0) throw Fail("Some models failed! partition " + std::to_string(p.pid) + " received no rows");   // utils/LinearModelUtils.java:80-83
-            ck(h, mlx_add_partition_csr(h, p.pid, p.rows(), p.n_local(), (int64_t)p.col.size(), p.row_ptr.data(), p.col.data(),
-                                        ds.binary ? nullptr : p.val.data(), p.y.data(), p.weight.data(), p.offset.data(), p.l2g.data()),
-               "mlx_add_partition_csr");
+            a_pid.push_back(p.pid); a_l.push_back(p.rows()); a_nl.push_back(p.n_local()); a_nnz.push_back((int64_t)p.col.size());
+            a_rp.push_back(p.row_ptr.data()); a_ci.push_back(p.col.data()); a_val.push_back(ds.binary ? nullptr : p.val.data());
+            a_y.push_back(p.y.data()); a_w.push_back(p.weight.data()); a_o.push_back(p.offset.data()); a_l2g.push_back(p.l2g.data());
         }
+        ck(h, mlx_add_partitions_csr(h, (int32_t)a_pid.size(), a_pid.data(), a_l.data(), a_nl.data(), a_nnz.data(), a_rp.data(), a_ci.data(),
+                                     ds.binary ? nullptr : a_val.data(), a_y.data(), a_w.data(), a_o.data(), a_l2g.data()),
+           "mlx_add_partitions_csr");
         ck(h, mlx_finalize(h), "mlx_finalize");
     }
     if (G > 1) {

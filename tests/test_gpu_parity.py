@@ -653,3 +653,20 @@ def test_large_csr_partition_equals_weighted_small_problem():
         assert np.max(np.abs(zb - zs)) <= 1e-7 * np.max(np.abs(zs))
     eb.close()
     es.close()
+
+
+def test_batched_partition_upload_equals_sequential():
+    """mlx_add_partitions_csr (threaded host preparation) == one mlx_add_partition_csr per partition: identical results."""
+    pd = synth_sparse(41, 4000, 3000, 8, 7, weights=True, offsets=True)
+    a = make_engine(pd, [0.5, 5.0], [1.0, 1.0])
+    b = HipAdmmEngine(pd.n_global, [0.5, 5.0], [1.0, 1.0], pd.num_blocks)
+    b.add_partitions(pd.blocks)
+    b.finalize()
+    for _ in range(3):
+        a.iterate(0.01)
+        b.iterate(0.01)
+        assert np.array_equal(a.solve_counters(), b.solve_counters())
+        assert np.array_equal(a.z()[0], b.z()[0])
+    c = HipAdmmEngine(pd.n_global, [1.0], [1.0], pd.num_blocks)
+    with pytest.raises(RuntimeError, match="twice"):
+        c.add_partitions([pd.blocks[0], pd.blocks[1], pd.blocks[0]])

@@ -70,8 +70,7 @@ def main():
     rho = [1.0 if l <= 100 else 10.0 for l in lam]
     eng = HipAdmmEngine(ng, lam, rho, args.partitions, profiling=True)
     t0 = time.time()
-    for b in blocks:
-        eng.add_partition(b)
+    eng.add_partitions(blocks)
     eng.finalize()
     tup = time.time() - t0
     nnz = sum(b.nnz for b in blocks)
