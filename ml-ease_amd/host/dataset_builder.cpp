@@ -275,24 +275,33 @@ void DatasetBuilder::add_to_partition(int pid, int response, const std::vector<s
 {
     if (pid < 0 || pid >= ds_.num_blocks)
         throw std::runtime_error("Map key is wrong! key has to be in the range of [0,numPartitions-1].");   // :585-588
-    PartitionData &p = ds_.parts[(size_t)pid];
     if (response != 1 && response != 0 && response != -1)
         throw std::runtime_error("response = " + std::to_string(response) + " (only 1, 0, -1 are allowed)");   // :419-420
     if (weight < 0) throw std::runtime_error("weight = " + std::to_string(weight) + " (weight cannot < 0)");     // :428-429
-    p.y.push_back(response == 1 ? 1 : -1);                                                                      // :421-423
-    p.weight.push_back(weight);
-    p.offset.push_back(offset);
+    if (pend_rows_.empty()) { pend_rows_.resize((size_t)ds_.num_blocks); pend_feats_.resize((size_t)ds_.num_blocks); }
+    auto &pf = pend_feats_[(size_t)pid];
+    const size_t f0 = pf.size();
+    pf.insert(pf.end(), feats.begin(), feats.end());
+    pend_rows_[(size_t)pid].push_back({response, weight, offset, f0, pf.size()});
+    if (++pending_ >= 65536) flush();
+}
+
+void DatasetBuilder::index_row(PartitionData &p, const PendingRow &r, const std::pair<int32_t, double> *feats,
+                               std::vector<size_t> &ord, std::vector<int32_t> &c2, std::vector<float> &v2)
+{
+    p.y.push_back(r.response == 1 ? 1 : -1);                                                                    // :421-423
+    p.weight.push_back(r.weight);
+    p.offset.push_back(r.offset);
     const size_t start = p.col.size();
-    if (icpt_key_ == -2) icpt_key_ = keys_.find(kInterceptName, strlen(kInterceptName));      // -1 until such a key shows up
     bool sorted = true;
     int32_t prev = -1;
-    for (auto &f : feats) {
+    for (size_t k = r.f0; k < r.f1; k++) {
+        const std::pair<int32_t, double> &f = feats[k];
         if (opt_.binary_feature && f.second != 1.0)
             throw std::runtime_error("Cannot handle non-binary feature value (all feature values have to be 1; or just do not specify the value)");
         int32_t id;
         if (int32_t *hit = p.g2l.find(f.first)) id = *hit;
         else {
-            if (icpt_key_ < 0) icpt_key_ = keys_.find(kInterceptName, strlen(kInterceptName));
             if (f.first == icpt_key_) throw std::runtime_error(std::string("feature name cannot be ") + kInterceptName);   // :470-471
             id = (int32_t)p.local_global.size();
             if (opt_.short_feature_index && id + 1 >= 32767)
@@ -308,16 +317,48 @@ void DatasetBuilder::add_to_partition(int pid, int response, const std::vector<s
     // per-row sort by local id, stable (LibLinearDataset.java:481-482); rows usually arrive sorted already
     const size_t m = p.col.size() - start;
     if (m > 1 && !sorted) {
-        ord_.resize(m);
-        std::iota(ord_.begin(), ord_.end(), 0);
-        std::stable_sort(ord_.begin(), ord_.end(), [&](size_t a, size_t b) { return p.col[start + a] < p.col[start + b]; });
-        c2_.resize(m);
-        if (!opt_.binary_feature) v2_.resize(m);
-        for (size_t i = 0; i < m; i++) { c2_[i] = p.col[start + ord_[i]]; if (!opt_.binary_feature) v2_[i] = p.val[start + ord_[i]]; }
-        std::copy(c2_.begin(), c2_.end(), p.col.begin() + (long)start);
-        if (!opt_.binary_feature) std::copy(v2_.begin(), v2_.end(), p.val.begin() + (long)start);
+        ord.resize(m);
+        std::iota(ord.begin(), ord.end(), 0);
+        std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return p.col[start + a] < p.col[start + b]; });
+        c2.resize(m);
+        if (!opt_.binary_feature) v2.resize(m);
+        for (size_t i = 0; i < m; i++) { c2[i] = p.col[start + ord[i]]; if (!opt_.binary_feature) v2[i] = p.val[start + ord[i]]; }
+        std::copy(c2.begin(), c2.end(), p.col.begin() + (long)start);
+        if (!opt_.binary_feature) std::copy(v2.begin(), v2.end(), p.val.begin() + (long)start);
     }
     p.row_ptr.push_back((int64_t)p.col.size());
+}
+
+void DatasetBuilder::flush()
+{
+    if (pending_ == 0) return;
+    icpt_key_ = keys_.find(kInterceptName, strlen(kInterceptName));               // -1 unless such a key was seen
+    const int np = ds_.num_blocks;
+    const int nthreads = std::min(loader_threads(), np);
+    std::vector<std::string> errors((size_t)np);
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        std::vector<size_t> ord;
+        std::vector<int32_t> c2;
+        std::vector<float> v2;
+        for (;;) {
+            const int k = next.fetch_add(1);
+            if (k >= np) return;
+            try {
+                for (const PendingRow &r : pend_rows_[(size_t)k]) index_row(ds_.parts[(size_t)k], r, pend_feats_[(size_t)k].data(), ord, c2, v2);
+            } catch (const std::exception &e) {
+                errors[(size_t)k] = e.what();
+            }
+            pend_rows_[(size_t)k].clear();
+            pend_feats_[(size_t)k].clear();
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads - 1; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    pending_ = 0;
+    for (auto &e : errors) if (!e.empty()) throw std::runtime_error(e);
 }
 
 void DatasetBuilder::add_raw(InputRow &row)
@@ -373,6 +414,7 @@ void DatasetBuilder::add_prepared(const InputRow &row)
 
 Dataset DatasetBuilder::finish()
 {
+    flush();
     // global dictionary: the interned keys in first-seen order
     ds_.names.clear();
     ds_.gindex.clear();

@@ -185,11 +185,17 @@ class DatasetBuilder {
     std::mt19937_64 rng_;
     KeyInterner keys_;                                  // global ids in first-seen order == Dataset::names at finish()
     int32_t icpt_key_ = -2;                             // interned id of "(INTERCEPT)" once seen
-    std::vector<size_t> ord_;                           // scratch of the per-row sort
-    std::vector<int32_t> c2_;
-    std::vector<float> v2_;
+    // rows are queued per partition and indexed in parallel over partitions (a partition's local first-seen order
+    // depends on its own rows only); flush() runs every FLUSH_ROWS rows and at finish()
+    struct PendingRow { int response; float weight, offset; size_t f0, f1; };
+    std::vector<std::vector<PendingRow>> pend_rows_;
+    std::vector<std::vector<std::pair<int32_t, double>>> pend_feats_;
+    size_t pending_ = 0;
     void intern_strings(InputRow &row);
     void add_to_partition(int pid, int response, const std::vector<std::pair<int32_t, double>> &feats, float weight, float offset);
+    void index_row(PartitionData &p, const PendingRow &r, const std::pair<int32_t, double> *feats, std::vector<size_t> &ord,
+                   std::vector<int32_t> &c2, std::vector<float> &v2);
+    void flush();
 };
 
 struct TestRowsData {                   // jobs/RegressionAdmmTrain.java:766-811 inputs, GLOBAL feature ids
