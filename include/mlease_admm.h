@@ -108,7 +108,9 @@ int mlx_set_regularizer(mlx_handle h, int32_t regularizer);
  *   y[l]       +1 / -1  (response 0 and -1 both map to -1, LibLinearDataset.java:419-423)
  *   weight[l], offset[l] float32 (RegressionPrepareOutput.avsc:28-33); NULL = all 1 / all 0
  *   local_to_global[n_local] with local_to_global[n_local-1] == n_global-1
- * partition_id is the GLOBAL id in [0, num_blocks); a handle may hold any subset. */
+ * partition_id is the GLOBAL id in [0, num_blocks); a handle may hold any subset.
+ * Storage is the library's choice: rows that are at least 30 % filled (n_local <= 2049, strictly increasing column ids,
+ * more than 65536 non-zeros) are kept as a dense tile exactly as if mlx_add_partition_dense had been called. */
 int mlx_add_partition_csr(mlx_handle h, int32_t partition_id, int32_t l, int32_t n_local, int64_t nnz,
                           const int64_t *row_ptr, const int32_t *col_idx, const float *val,
                           const int8_t *y, const float *weight, const float *offset,

@@ -115,7 +115,7 @@ def test_c1_multilambda_vs_golden(c1, gold, csr_path):
         assert abs(st.mindiff - gold["diffsm"][i][1]) <= 1e-5 * gold["diffsm"][i][1]
 
 
-def test_dense_tile_path_equals_csr_path_and_oracle():
+def test_dense_tile_path_equals_csr_path_and_oracle(monkeypatch):
     """Dense fused kernel (one read of X per pass) on a 4-partition dense problem vs the oracle (CSR form)."""
     rng = np.random.default_rng(42)
     nrow, nf, nb = 6000, 300, 4
@@ -131,7 +131,10 @@ def test_dense_tile_path_equals_csr_path_and_oracle():
         sel = np.arange(k, nrow, nb)
         eng.add_partition_dense(k, X[sel], np.where(y01[sel] == 1, 1, -1), wt[sel], off[sel])
     eng.finalize()
+    monkeypatch.setenv("MLX_NO_DENSIFY", "1")          # keep this copy on the CSR kernels (mostly-filled CSR input is densified by default)
     eng_csr = make_engine(pd, [1.0, 50.0], [1.0, 1.0])
+    monkeypatch.delenv("MLX_NO_DENSIFY")
+    eng_auto = make_engine(pd, [1.0, 50.0], [1.0, 1.0])                 # same CSR blocks, stored as dense tiles by the library
     e = np.float32(0.01)
     for it in range(5):
         eps = admm.float_string_roundtrip(e)
@@ -145,6 +148,8 @@ def test_dense_tile_path_equals_csr_path_and_oracle():
             assert_coef_close(eng_csr.z()[1][li], oc.z()[1][li], "csr z it %d" % it)
         assert st.x_passes_dev == st.solves + st.cg_iters + st.newton_iters            # dense: 1 pass per tick
         assert st2.x_passes_dev == 2 * st.x_passes_dev
+        st3 = eng_auto.iterate(eps)
+        assert st3.x_passes_dev == st.x_passes_dev and np.array_equal(eng_auto.z()[0], eng.z()[0])   # densified == uploaded dense
 
 
 @pytest.mark.parametrize("binary", [False, True])
