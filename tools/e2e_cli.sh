@@ -15,7 +15,7 @@ num.blocks=$PARTS
 lambda=1.0
 num.iters=$ITERS
 regularizer=2
-binary.feature=true
+binary.feature=${BINARY:-true}
 EOJ
 $R/ml-ease_amd/host/mlease_admm_train /tmp/oh.job 2>&1 | grep -v "iteration [0-9]*:" | tail -8
 ls -la /tmp/oh_out/final-model/

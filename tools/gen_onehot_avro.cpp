@@ -35,6 +35,12 @@ int main(int argc, char **argv)
     std::vector<std::string> fname(F), lname(L);
     for (int f = 0; f < F; f++) fname[f] = "f" + std::to_string(f);
     for (int l = 0; l < L; l++) lname[l] = std::to_string(l);
+    const bool dense = getenv("GEN_DENSE") != nullptr;       // configs[1] style instead: 1000 dense N(0,1) features named "1".."1000"
+    const int DF = 1000;
+    std::vector<std::string> dname(DF);
+    std::vector<double> dbeta(DF);
+    std::normal_distribution<double> n01(0, 1), nb(0, 0.1);
+    for (int j = 0; j < DF; j++) { dname[j] = std::to_string(j + 1); dbeta[j] = nb(rng); }
     long done = 0;
     for (int fi = 0; fi < files; fi++) {
         char path[512];
@@ -42,7 +48,17 @@ int main(int argc, char **argv)
         AvroFileWriter w(path, schema, getenv("GEN_CODEC") ? getenv("GEN_CODEC") : "null");
         const long n = rows / files + (fi < rows % files ? 1 : 0);
         int lev[20];
-        for (long r = 0; r < n; r++, done++) {
+        for (long r = 0; r < n && dense; r++, done++) {
+            std::vector<float> x(DF);
+            double logit = -1.0;
+            for (int j = 0; j < DF; j++) { x[j] = (float)n01(rng); logit += dbeta[j] * x[j]; }
+            w.put_long(ud(rng) < 1 / (1 + std::exp(-logit)) ? 1 : 0);
+            w.array_start(DF);
+            for (int j = 0; j < DF; j++) { w.put_string(dname[j]); w.put_string(""); w.put_float(x[j]); }
+            w.array_end();
+            w.end_record();
+        }
+        for (long r = 0; r < n && !dense; r++, done++) {
             double logit = -3.0;
             for (int f = 0; f < F; f++) {
                 const double u = ud(rng);
