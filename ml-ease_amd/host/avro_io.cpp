@@ -2,7 +2,10 @@
 #include "avro_io.h"
 
 #include <dirent.h>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -205,11 +208,20 @@ double AvroCursor::read_number(const AvroSchema &r)
 // --------------------------------------------------------------------------------- reader
 AvroFileReader::AvroFileReader(const std::string &path)
 {
-    std::ifstream f(path, std::ios::binary);
-    if (!f) throw std::runtime_error("cannot open " + path);
-    data_.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
-    if (data_.size() < 4 || memcmp(data_.data(), "Obj\x01", 4) != 0) throw std::runtime_error(path + " is not an avro object container file");
-    AvroCursor c(data_.data() + 4, data_.data() + data_.size());
+    // the file is mapped, not copied: blocks are inflated / decoded straight out of the page cache
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("cannot open " + path);
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); throw std::runtime_error("cannot stat " + path); }
+    size_ = (size_t)st.st_size;
+    if (size_ > 0) {
+        void *m = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { close(fd); throw std::runtime_error("cannot map " + path); }
+        base_ = static_cast<const uint8_t *>(m);
+    }
+    close(fd);
+    if (size_ < 4 || memcmp(base_, "Obj\x01", 4) != 0) throw std::runtime_error(path + " is not an avro object container file");
+    AvroCursor c(base_ + 4, base_ + size_);
     codec_ = "null";
     for (;;) {                                      // metadata map<bytes>
         int64_t n = c.read_long();
@@ -224,25 +236,27 @@ AvroFileReader::AvroFileReader(const std::string &path)
         }
     }
     if (codec_ != "null" && codec_ != "deflate") throw std::runtime_error("unsupported avro codec " + codec_);
-    const size_t consumed = (size_t)(c.ptr() - data_.data());
-    if (consumed + 16 > data_.size()) throw std::runtime_error("avro: truncated header");
-    memcpy(sync_, data_.data() + consumed, 16);
+    const size_t consumed = (size_t)(c.ptr() - base_);
+    if (consumed + 16 > size_) throw std::runtime_error("avro: truncated header");
+    memcpy(sync_, base_ + consumed, 16);
     pos_ = consumed + 16;
     schema_ = parse_schema(schema_json_);
 }
+
+AvroFileReader::~AvroFileReader() { if (base_ && size_) munmap(const_cast<uint8_t *>(base_), size_); }
 
 std::vector<AvroFileReader::RawBlock> AvroFileReader::blocks() const
 {
     std::vector<RawBlock> out;
     size_t pos = pos_;
-    while (pos < data_.size()) {
-        AvroCursor hc(data_.data() + pos, data_.data() + data_.size());
+    while (pos < size_) {
+        AvroCursor hc(base_ + pos, base_ + size_);
         const int64_t count = hc.read_long(), size = hc.read_long();
         const uint8_t *q = hc.ptr();
-        if (size < 0 || q + size + 16 > data_.data() + data_.size()) throw std::runtime_error("avro: bad block size");
+        if (size < 0 || q + size + 16 > base_ + size_) throw std::runtime_error("avro: bad block size");
         if (memcmp(q + size, sync_, 16) != 0) throw std::runtime_error("avro: sync marker mismatch");
         out.push_back({count, q, q + size});
-        pos = (size_t)(q + size + 16 - data_.data());
+        pos = (size_t)(q + size + 16 - base_);
     }
     return out;
 }

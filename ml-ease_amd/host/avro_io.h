@@ -59,6 +59,9 @@ class AvroCursor {
 class AvroFileReader {
   public:
     explicit AvroFileReader(const std::string &path);
+    ~AvroFileReader();
+    AvroFileReader(const AvroFileReader &) = delete;
+    AvroFileReader &operator=(const AvroFileReader &) = delete;
     const AvroSchema &schema() const { return *schema_; }
     const std::string &schema_json() const { return schema_json_; }
     // Calls fn(cursor) once per record; fn must consume exactly one record of schema().
@@ -70,7 +73,8 @@ class AvroFileReader {
     bool deflated() const { return codec_ == "deflate"; }
 
   private:
-    std::vector<uint8_t> data_;
+    const uint8_t *base_ = nullptr;      // the mapped file
+    size_t size_ = 0;
     size_t pos_ = 0;
     std::string codec_, schema_json_;
     uint8_t sync_[16];
