@@ -412,12 +412,18 @@ k_colpass_items(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, 
 // sparse X pass on the sliced-ELL copies: one THREAD per row / per column segment.
 // Measured (tools/sparse_probe.hip, profiles/r1_notes.md): the lane-group kernels above are bound by the texture
 // addresser (~1 divergent lane address per clock per CU) and by their semi-coalesced 32-byte index reads; in the
-// sliced layout entry k of 64 consecutive work items is one contiguous 256-byte load, every lane has SU
-// independent index loads + gathers in flight and there is no cross-lane reduction. Each sum runs in the
-// reference's own order (entries by ascending index, intercept last; XTv by ascending row inside a segment) with
-// contraction off, so a row's z_i is bit-identical to LogisticRegressionL2.Xv's (llf/LogisticRegressionL2.java:115-129).
+// sliced layout entry k of 64 consecutive work items is one contiguous 256-byte load, every lane has RSU (rows) / CSU
+// (column items) independent index loads + gathers in flight and there is no cross-lane reduction. Each sum runs
+// sequentially over the item's entries (ascending library column id; ascending row inside an item) with contraction off.
+// RSU = 10: the 20-entry rows of the one-hot configs take two full rounds (8 took three: row pass 418 -> 365 us;
+// 20 in one round 377 us); CSU = 16 was slower than 8 (377 vs 335 us).
 // ------------------------------------------------------------------------------------------------
-#define SU 8
+#ifndef RSU
+#define RSU 10
+#endif
+#ifndef CSU
+#define CSU 8
+#endif
 template <bool HASVAL, int HOT, bool NT>
 __global__ void __launch_bounds__(256)
 k_rowpass_sell(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx)
@@ -468,25 +474,25 @@ k_rowpass_sell(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, c
         const float wtv = cg ? 0.f : pa.wt[rowc];
         const int yv = cg ? 0 : (int)pa.y[rowc];
         double a = 0.0;
-        for (int k = 0; k < L; k += SU) {
-            int idx[SU];
-            float xv[SU];
+        for (int k = 0; k < L; k += RSU) {
+            int idx[RSU];
+            float xv[RSU];
 #pragma unroll
-            for (int u = 0; u < SU; u++) {
+            for (int u = 0; u < RSU; u++) {
                 const int kk = min(k + u, L - 1);
                 // NT: the index stream is read once per tick (single lambda); with several lambdas per partition the
                 // problems of a partition share it through L2 and it must stay cacheable
                 idx[u] = NT ? __builtin_nontemporal_load(rs_idx + base + kk * 64 + lane) : rs_idx[base + kk * 64 + lane];
                 if (HASVAL) xv[u] = NT ? __builtin_nontemporal_load(rs_val + base + kk * 64 + lane) : rs_val[base + kk * 64 + lane];
             }
-            double vv[SU];
+            double vv[RSU];
 #pragma unroll
-            for (int u = 0; u < SU; u++) {
+            for (int u = 0; u < RSU; u++) {
                 if (HOT > 0) vv[u] = idx[u] < HOT ? hot[idx[u]] : v[idx[u]];
                 else vv[u] = v[idx[u]];
             }
 #pragma unroll
-            for (int u = 0; u < SU; u++) {
+            for (int u = 0; u < RSU; u++) {
                 const double term = HASVAL ? vv[u] * (double)xv[u] : vv[u];
                 if (k + u < len) a = a + term;
             }
@@ -554,17 +560,17 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
         const int item = s * 64 + lane;
         const int len = item_ptr[item + 1] - item_ptr[item];
         double a = 0.0;
-        for (int k = 0; k < L; k += SU) {
-            int idx[SU];
-            float xv[SU];
+        for (int k = 0; k < L; k += CSU) {
+            int idx[CSU];
+            float xv[CSU];
 #pragma unroll
-            for (int u = 0; u < SU; u++) {
+            for (int u = 0; u < CSU; u++) {
                 const int kk = min(k + u, L - 1);
                 idx[u] = NT ? __builtin_nontemporal_load(cs_idx + base + kk * 64 + lane) : cs_idx[base + kk * 64 + lane];
                 if (HASVAL) xv[u] = NT ? __builtin_nontemporal_load(cs_val + base + kk * 64 + lane) : cs_val[base + kk * 64 + lane];
             }
 #pragma unroll
-            for (int u = 0; u < SU; u++) {
+            for (int u = 0; u < CSU; u++) {
                 const double c = cf[idx[u]];
                 const double term = HASVAL ? c * (double)xv[u] : c;
                 if (k + u < len) a = a + term;
