@@ -67,6 +67,7 @@ struct mlx_context {
     int maxblk_dense = 0, maxblk_csr = 0, max_nfeat_dense = 0, max_items = 0, max_short = 0, max_long = 0, rowgroup = 64, max_nlocal = 0, max_l = 0;
     int64_t max_parts_len = 0;
     bool csr_hasval = false, any_absent = false, csr_sell = false, csr_small = false;
+    int small_lds_doubles = 0;             // > 0: k_solve_small keeps every problem's work vectors in LDS (doubles needed by the largest)
     int max_cunits = 0, max_rblk_rows = 0;
     int row_hot = 4096;                     // SELL row pass: most frequent columns staged in LDS (0, 2048, 4096, 8192)
     int step_threads = 256;
@@ -226,7 +227,7 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
         // than SMALL_TICKS_PER_LAUNCH ticks
         int64_t ticks = 0;
         for (;;) {
-            mlxk_solve_small(h->stream, h->d_parts, h->d_probs, count, first, h->csr_hasval, SMALL_TICKS_PER_LAUNCH, h->d_done);
+            mlxk_solve_small(h->stream, h->d_parts, h->d_probs, count, first, h->csr_hasval, SMALL_TICKS_PER_LAUNCH, h->d_done, h->small_lds_doubles);
             ticks += SMALL_TICKS_PER_LAUNCH;
             HIPCHECK(h, hipMemcpyAsync(&h->h_done[0], h->d_done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIPCHECK(h, hipStreamSynchronize(h->stream));
@@ -819,6 +820,12 @@ int mlx_finalize(mlx_handle h)
     h->csr_small = getenv("MLX_NO_SMALL") == nullptr;
     for (auto &p : h->parts)
         if (!p.dense && (p.nnz > SMALL_MAX_NNZ || p.l > SMALL_MAX_DIM || p.n_local > SMALL_MAX_DIM)) h->csr_small = false;
+    if (h->csr_small && getenv("MLX_NO_SMALL_LDS") == nullptr) {
+        int64_t need = 0;
+        for (auto &p : h->parts)
+            if (!p.dense) need = std::max<int64_t>(need, 8LL * p.n_local + 3LL * p.l + p.n_items + 2LL * p.nblk);
+        if (need > 0 && need <= 18 * 1024) h->small_lds_doubles = (int)need;      // 144 KiB of the 160 KiB LDS, next to 9 KiB static
+    }
     // (if any CSR partition could not be sliced, all of them run the lane-group kernels; those accept any row chunking)
     bool first_csr = true;
     for (auto &p : h->parts) if (!p.dense) {

@@ -998,7 +998,10 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int 
 // is DONE (or max_ticks, then the host relaunches). Row sums run in the same entry order as the sliced kernels; the
 // loss / coefficient sums are one block reduction instead of per-chunk partials.
 // ------------------------------------------------------------------------------------------------
-template <bool HASVAL>
+// LDSV: every fp64 work vector of the problem (8 n-vectors, wd x2, coef, item sums, partial sums) lives in LDS for the whole
+// solve and is written back at the end -- for problems of a few hundred features the tick loop then waits on LDS instead of
+// ~20 dependent L2 round trips per tick.
+template <bool HASVAL, bool LDSV>
 __global__ void __launch_bounds__(1024)
 k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int nprob, int max_ticks,
               int *__restrict__ done_counter)
@@ -1007,11 +1010,36 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
     constexpr int G = 8, U = 8;             // 8 lanes per row / per column item, 8 loads in flight per lane
     __shared__ double scratch[64];
     __shared__ double stage[1024];
+    extern __shared__ double dyn[];
+    __shared__ ProbDev prl;
     const int q = blockIdx.x;
     if (q >= nprob) return;
-    ProbDev &pr = probs[q];
-    const PartDev &pa = parts[pr.part];
+    ProbDev &prg = probs[q];                 // the descriptor in global memory
+    const PartDev &pa = parts[prg.part];
     const int tid = threadIdx.x, nt = 1024;
+    if (LDSV) {
+        const int n = pa.n_local, l0 = pa.l, ni = pa.n_items, nbk = pa.nblk;
+        if (tid == 0) {
+            prl = prg;
+            double *p = dyn;
+            double **vs[8] = {&prl.w, &prl.w_new, &prl.g, &prl.s, &prl.r, &prl.d, &prl.Hd, &prl.m};
+            for (int v = 0; v < 8; v++) { *vs[v] = p; p += n; }
+            prl.wd[0] = p; p += l0;
+            prl.wd[1] = p; p += l0;
+            prl.coef = p; p += l0;
+            prl.parts = p; p += ni;
+            prl.lossp = p; p += nbk;
+            prl.csump = p; p += nbk;
+        }
+        __syncthreads();
+        for (int j = tid; j < n; j += nt) {
+            prl.w[j] = prg.w[j]; prl.w_new[j] = prg.w_new[j]; prl.g[j] = prg.g[j]; prl.s[j] = prg.s[j];
+            prl.r[j] = prg.r[j]; prl.d[j] = prg.d[j]; prl.Hd[j] = prg.Hd[j]; prl.m[j] = prg.m[j];
+        }
+        for (int i = tid; i < l0; i += nt) { prl.wd[0][i] = prg.wd[0][i]; prl.wd[1][i] = prg.wd[1][i]; }
+        __syncthreads();
+    }
+    ProbDev &pr = LDSV ? prl : prg;          // the working descriptor
     const int gid = tid / G, gl = tid % G, ng = nt / G;
     const int l = pa.l, nitems = pa.n_items;
     const int32_t *__restrict__ rp = pa.rp;
@@ -1052,7 +1080,7 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
     for (int tick = 0; tick < max_ticks; tick++) {
         __syncthreads();
         const int phase = pr.phase;
-        if (phase == PH_DONE) return;
+        if (phase == PH_DONE) break;
         const bool cg = (phase == PH_CG);
         const double *__restrict__ v = cg ? pr.d : pr.w_new;
         const double *__restrict__ wdcur = pr.wd[pr.dsel];
@@ -1093,6 +1121,22 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
         }
         __syncthreads();
         tron_step_body(pa, pr, scratch, stage, done_counter);
+    }
+    if (LDSV) {
+        // write the state back (everything a relaunch, the outputs kernels or the host read)
+        __syncthreads();
+        const int n = pa.n_local, l0 = pa.l;
+        for (int j = tid; j < n; j += nt) {
+            prg.w[j] = prl.w[j]; prg.w_new[j] = prl.w_new[j]; prg.g[j] = prl.g[j]; prg.s[j] = prl.s[j];
+            prg.r[j] = prl.r[j]; prg.d[j] = prl.d[j]; prg.Hd[j] = prl.Hd[j];
+        }
+        for (int i = tid; i < l0; i += nt) { prg.wd[0][i] = prl.wd[0][i]; prg.wd[1][i] = prl.wd[1][i]; }
+        if (tid == 0) {
+            prg.phase = prl.phase; prg.dsel = prl.dsel; prg.iter = prl.iter; prg.cg_iter = prl.cg_iter;
+            prg.newton = prl.newton; prg.accepted = prl.accepted; prg.cg_total = prl.cg_total; prg.ticks = prl.ticks;
+            prg.status = prl.status; prg.f = prl.f; prg.delta = prl.delta; prg.gnorm = prl.gnorm; prg.gnorm1 = prl.gnorm1;
+            prg.rTr = prl.rTr; prg.cgtol = prl.cgtol; prg.prered = prl.prered; prg.gs = prl.gs;
+        }
     }
 }
 
@@ -1531,10 +1575,23 @@ void mlxk_tron_step(hipStream_t st, const PartDev *parts, ProbDev *probs, int np
 }
 
 void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int first, bool hasval,
-                      int max_ticks, int *done_counter)
+                      int max_ticks, int *done_counter, int lds_doubles)
 {
-    if (hasval) hipLaunchKernelGGL((k_solve_small<true>), dim3(nprob), dim3(1024), 0, st, parts, probs + first, nprob, max_ticks, done_counter);
-    else hipLaunchKernelGGL((k_solve_small<false>), dim3(nprob), dim3(1024), 0, st, parts, probs + first, nprob, max_ticks, done_counter);
+    // lds_doubles > 0: the work vectors of every problem fit in LDS (that many doubles for the largest) -> LDS-resident solve
+    if (lds_doubles > 0) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_small<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_small<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            attr_set = true;
+        }
+        const size_t bytes = (size_t)lds_doubles * sizeof(double);
+        if (hasval) hipLaunchKernelGGL((k_solve_small<true, true>), dim3(nprob), dim3(1024), bytes, st, parts, probs + first, nprob, max_ticks, done_counter);
+        else hipLaunchKernelGGL((k_solve_small<false, true>), dim3(nprob), dim3(1024), bytes, st, parts, probs + first, nprob, max_ticks, done_counter);
+        return;
+    }
+    if (hasval) hipLaunchKernelGGL((k_solve_small<true, false>), dim3(nprob), dim3(1024), 0, st, parts, probs + first, nprob, max_ticks, done_counter);
+    else hipLaunchKernelGGL((k_solve_small<false, false>), dim3(nprob), dim3(1024), 0, st, parts, probs + first, nprob, max_ticks, done_counter);
 }
 
 void mlxk_collect_c0(hipStream_t st, const PartDev *parts, const ProbDev *probs, const int *qlist, int nq,

@@ -40,14 +40,17 @@ def c1():
     return load_c1()
 
 
-@pytest.fixture(params=["one_launch", "ticks"])
+@pytest.fixture(params=["one_launch", "one_launch_global", "ticks"])
 def csr_path(request, monkeypatch):
-    """Small CSR partitions are solved by k_solve_small (one launch per solve) unless MLX_NO_SMALL is set (then by the
-    lock-step tick kernels every larger problem uses): the parity tests on small data run on both."""
+    """Small CSR partitions are solved by k_solve_small (one launch per solve, work vectors in LDS when they fit, else in
+    global memory: MLX_NO_SMALL_LDS forces the latter) unless MLX_NO_SMALL is set (then by the lock-step tick kernels every
+    larger problem uses): the parity tests on small data run on all three."""
+    monkeypatch.delenv("MLX_NO_SMALL", raising=False)
+    monkeypatch.delenv("MLX_NO_SMALL_LDS", raising=False)
     if request.param == "ticks":
         monkeypatch.setenv("MLX_NO_SMALL", "1")
-    else:
-        monkeypatch.delenv("MLX_NO_SMALL", raising=False)
+    elif request.param == "one_launch_global":
+        monkeypatch.setenv("MLX_NO_SMALL_LDS", "1")
     return request.param
 
 
