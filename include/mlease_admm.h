@@ -73,7 +73,10 @@ typedef struct mlx_stats {
     double alg_bytes_dev;    /* algorithmic HBM bytes of the X-pass kernels launched       */
     double xpass_ms;         /* device time inside the X-pass kernels (HIP events), 0 if profiling off */
     double total_ms;         /* device time of the whole call (HIP events)                             */
-    int64_t xpass_launches;  /* number of X-pass kernel launches                                       */
+    int64_t xpass_launches;  /* number of X-pass launches (ticks that launched one)                    */
+    double rowpass_ms;       /* CSR path, profiling on: device time of the row-pass launches           */
+    double colpass_ms;       /*   ... of the column-pass launches (xpass_ms = dense + row + column)    */
+    double step_ms;          /*   ... of the TRON/CG step launches                                     */
 } mlx_stats;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */

@@ -38,7 +38,7 @@ struct PartHost {
     bool sell = false;
     std::vector<int32_t> new2old;          // CSR partitions: library local id -> caller's local id (features only)
     int n_rslices = 0, n_cslices = 0, n_rblk = 1, rblk_rows = 0, n_cunits = 0;
-    int nblk = 0, rows_per_blk = 0, n_items = 0, rowgroup = 64, pos = 0, neg = 0;
+    int nblk = 0, rows_per_blk = 0, n_items = 0, n_slots = 0, rowgroup = 64, pos = 0, neg = 0;
     PartDev dev{};
     double *c0 = nullptr;
 };
@@ -71,6 +71,7 @@ struct mlx_context {
     int max_cunits = 0, max_rblk_rows = 0;
     int row_hot = 4096;                     // SELL row pass: most frequent columns staged in LDS (0, 2048, 4096, 8192)
     int step_threads = 256;
+    int step_ch = 2048, step_max_nwg = 1;   // multi-workgroup CSR step: columns per workgroup, chunks of the widest CSR problem
 
     double *d_Z = nullptr;
     float *d_z32 = nullptr, *d_u = nullptr, *d_B = nullptr, *d_UPX = nullptr;
@@ -83,7 +84,8 @@ struct mlx_context {
     unsigned long long *h_diff = nullptr;  // pinned [n_lambda]
     hipEvent_t ev_batch[2] = {nullptr, nullptr};
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
-    std::vector<hipEvent_t> ev_pool;
+    std::vector<hipEvent_t> ev_pool;        // profiling: event pairs, pair i brackets launches of kind ev_kind[i]
+    std::vector<int> ev_kind;               // 0 dense X pass, 1 CSR row pass, 2 CSR column pass, 3 TRON/CG step
     size_t ev_used = 0;
     // scratch vectors of the solve_one problem
     double *sc_vec[8] = {nullptr}, *sc_pinv = nullptr;
@@ -195,8 +197,9 @@ int upload_row_meta(mlx_handle h, PartHost &ph, int32_t l, const int8_t *y, cons
     return MLX_OK;
 }
 
-hipEvent_t next_event(mlx_handle h)
+hipEvent_t next_event(mlx_handle h, int kind = -1)
 {
+    if (kind >= 0) h->ev_kind.push_back(kind);
     if (h->ev_used == h->ev_pool.size()) {
         hipEvent_t e;
         hipEventCreate(&e);
@@ -208,13 +211,30 @@ hipEvent_t next_event(mlx_handle h)
 // One X pass over every unfinished problem of the given lists (+ optional event bracket).
 int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int nqc)
 {
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (h->profiling) { e0 = next_event(h); e1 = next_event(h); hipEventRecord(e0, h->stream); }
-    if (nqd > 0 && mlxk_xpass_dense(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->maxblk_dense, h->max_nfeat_dense, h->n_lambda == 1))
+    auto bracket = [&](int kind, auto &&launch) -> int {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (h->profiling) { e0 = next_event(h, kind); e1 = next_event(h); hipEventRecord(e0, h->stream); }
+        const int rc = launch();
+        if (h->profiling) hipEventRecord(e1, h->stream);
+        return rc;
+    };
+    if (nqd > 0 && bracket(0, [&] { return mlxk_xpass_dense(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->maxblk_dense, h->max_nfeat_dense, h->n_lambda == 1); }))
         return fail(h, MLX_ERR_INVALID, "dense tile wider than 2048 features is not supported; use the CSR form");
-    if (nqc > 0) mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_short, h->max_long, h->rowgroup, h->csr_hasval, h->csr_sell, h->max_cunits, h->max_rblk_rows, h->row_hot, h->n_lambda == 1);
-    if (h->profiling) hipEventRecord(e1, h->stream);
+    if (nqc > 0)
+        for (int which = 1; which <= 2; which++)
+            bracket(which, [&] { return mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_short, h->max_long, h->rowgroup, h->csr_hasval, h->csr_sell, h->max_cunits, h->max_rblk_rows, h->row_hot, h->n_lambda == 1, which); });
     return MLX_OK;
+}
+
+// The TRON/CG step of one tick: one workgroup per dense problem, three column-chunked launches for the CSR problems.
+void launch_step(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int nqc)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->profiling) { e0 = next_event(h, 3); e1 = next_event(h); hipEventRecord(e0, h->stream); }
+    mlxk_tron_step(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->step_threads, h->d_done);
+    for (int which = 0; which < 3; which++)
+        mlxk_step_phase(h->stream, which, h->d_parts, h->d_probs, qcsr, nqc, h->step_ch, h->step_max_nwg, h->d_done);
+    if (h->profiling) hipEventRecord(e1, h->stream);
 }
 
 // Drive ticks until `count` problems starting at `first` are DONE.
@@ -251,7 +271,7 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
     for (;;) {
         for (int i = 0; i < batch; i++) {
             if ((rc = launch_xpass(h, qdense, nqd, qcsr, nqc))) return rc;
-            mlxk_tron_step(h->stream, h->d_parts, h->d_probs, count, first, h->step_threads, h->d_done);
+            launch_step(h, qdense, nqd, qcsr, nqc);
             ticks++;
         }
         HIPCHECK(h, hipMemcpyAsync(&h->h_done[slot], h->d_done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -392,7 +412,7 @@ int mlx_set_regularizer(mlx_handle h, int32_t regularizer)
 // of its inputs (no handle, no device): partitions can be prepared by several threads (mlx_add_partitions_csr).
 struct CsrPrep {
     PartHost ph;
-    std::vector<int32_t> rp, pcol, cri, item_ptr, col_item, ishort, ilong, l2g_perm, rs_ptr, rs_idx, cs_ptr, cs_idx, cw_blk, cw_slice;
+    std::vector<int32_t> rp, pcol, cri, item_ptr, item_dst, col_ptr, ishort, ilong, l2g_perm, rs_ptr, rs_idx, cs_ptr, cs_idx, cw_blk, cw_slice;
     std::vector<float> pvalv, cval, rs_val, cs_val;
     bool hasval = false;
     int rc = MLX_OK;
@@ -479,7 +499,7 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
     const int nb = std::max(1, (l + rbmax - 1) / rbmax);
     const int RB = std::max(64, ((l + nb - 1) / nb + 63) / 64 * 64);
     ph.n_rblk = nb; ph.rblk_rows = RB;
-    std::vector<int32_t> item_ptr, col_item((size_t)nb * (nf + 1)), blk_item0((size_t)nb + 1);
+    std::vector<int32_t> item_ptr, item_col, blk_item0((size_t)nb + 1);
     std::vector<int32_t> cri_b((size_t)nnz);
     std::vector<float> cval_b(val ? (size_t)nnz : 0);
     {
@@ -490,24 +510,34 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
             blk_item0[(size_t)bk] = (int32_t)item_ptr.size();
             const int32_t rend = (int32_t)std::min<int64_t>(l, (int64_t)(bk + 1) * RB);
             for (int j = 0; j < nf; j++) {
-                col_item[(size_t)bk * (nf + 1) + j] = (int32_t)item_ptr.size();
                 int32_t q = pos[(size_t)j];
                 const int32_t e = cp[(size_t)j + 1];
                 int32_t cnt = 0;
                 while (q < e && cri[(size_t)q] < rend) {
-                    if (cnt % seg == 0) item_ptr.push_back(w);
+                    if (cnt % seg == 0) { item_ptr.push_back(w); item_col.push_back(j); }
                     cri_b[(size_t)w] = cri[(size_t)q];
                     if (val) cval_b[(size_t)w] = cval[(size_t)q];
                     w++; q++; cnt++;
                 }
                 pos[(size_t)j] = q;
             }
-            col_item[(size_t)bk * (nf + 1) + nf] = (int32_t)item_ptr.size();
-            while (item_ptr.size() % 64 != 0) item_ptr.push_back(w);          // empty padding items
+            while (item_ptr.size() % 64 != 0) { item_ptr.push_back(w); item_col.push_back(-1); }   // empty padding items
         }
         blk_item0[(size_t)nb] = (int32_t)item_ptr.size();
         ph.n_items = (int)item_ptr.size();
         item_ptr.push_back(w);
+    }
+    // Where the item sums are stored: column-major slots, a column's items in (block, segment) order, so that X'c of
+    // column j is ONE contiguous range col_ptr[j] .. col_ptr[j+1] whatever the number of row blocks.
+    std::vector<int32_t> item_dst((size_t)ph.n_items, -1), col_ptr((size_t)nf + 1, 0);
+    {
+        for (int it = 0; it < ph.n_items; it++)
+            if (item_col[(size_t)it] >= 0) col_ptr[(size_t)item_col[(size_t)it] + 1]++;
+        for (int j = 0; j < nf; j++) col_ptr[(size_t)j + 1] += col_ptr[(size_t)j];
+        std::vector<int32_t> nxt(col_ptr.begin(), col_ptr.end() - 1);
+        for (int it = 0; it < ph.n_items; it++)
+            if (item_col[(size_t)it] >= 0) item_dst[(size_t)it] = nxt[(size_t)item_col[(size_t)it]]++;
+        ph.n_slots = col_ptr[(size_t)nf];
     }
     cri.swap(cri_b);
     cval.swap(cval_b);
@@ -602,7 +632,7 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
     P.ph = std::move(ph);
     P.hasval = (val != nullptr);
     P.rp = std::move(rp); P.pcol = std::move(pcol); P.pvalv = std::move(pvalv); P.cri = std::move(cri); P.cval = std::move(cval);
-    P.item_ptr = std::move(item_ptr); P.col_item = std::move(col_item); P.ishort = std::move(ishort); P.ilong = std::move(ilong);
+    P.item_ptr = std::move(item_ptr); P.item_dst = std::move(item_dst); P.col_ptr = std::move(col_ptr); P.ishort = std::move(ishort); P.ilong = std::move(ilong);
     P.l2g_perm = std::move(l2g_perm);
     P.rs_ptr = std::move(rs_ptr); P.rs_idx = std::move(rs_idx); P.rs_val = std::move(rs_val);
     P.cs_ptr = std::move(cs_ptr); P.cs_idx = std::move(cs_idx); P.cs_val = std::move(cs_val);
@@ -617,7 +647,7 @@ static int commit_csr(mlx_handle h, CsrPrep &P, int32_t l, int32_t n_local, int6
     PartHost &ph = P.ph;
     const bool val = P.hasval;
     int rc;
-    int32_t *d_rp, *d_ci, *d_cri, *d_item, *d_colitem, *d_l2g, *d_ishort, *d_ilong;
+    int32_t *d_rp, *d_ci, *d_cri, *d_item, *d_itemdst, *d_colptr, *d_l2g, *d_ishort, *d_ilong;
     float *d_val = nullptr, *d_cval = nullptr;
     if ((rc = dev_upload(h, &d_rp, P.rp.data(), P.rp.size()))) return rc;
     if ((rc = dev_upload(h, &d_ci, P.pcol.data(), (size_t)nnz))) return rc;
@@ -627,7 +657,8 @@ static int commit_csr(mlx_handle h, CsrPrep &P, int32_t l, int32_t n_local, int6
         if ((rc = dev_upload(h, &d_cval, P.cval.data(), P.cval.size()))) return rc;
     }
     if ((rc = dev_upload(h, &d_item, P.item_ptr.data(), P.item_ptr.size()))) return rc;
-    if ((rc = dev_upload(h, &d_colitem, P.col_item.data(), P.col_item.size()))) return rc;
+    if ((rc = dev_upload(h, &d_itemdst, P.item_dst.data(), P.item_dst.size()))) return rc;
+    if ((rc = dev_upload(h, &d_colptr, P.col_ptr.data(), P.col_ptr.size()))) return rc;
     if ((rc = dev_upload(h, &d_ishort, P.ishort.data(), P.ishort.size()))) return rc;
     if ((rc = dev_upload(h, &d_ilong, P.ilong.data(), P.ilong.size()))) return rc;
     if ((rc = dev_upload(h, &d_l2g, P.l2g_perm.data(), (size_t)n_local))) return rc;
@@ -650,7 +681,7 @@ static int commit_csr(mlx_handle h, CsrPrep &P, int32_t l, int32_t n_local, int6
         ph.dev.rs_val = d_f; ph.dev.cs_val = d_g;
     }
     ph.dev.items_short = d_ishort; ph.dev.items_long = d_ilong; ph.dev.n_short = ph.n_short; ph.dev.n_long = ph.n_long;
-    ph.dev.item_ptr = d_item; ph.dev.col_item = d_colitem; ph.dev.l2g = d_l2g; ph.dev.X = nullptr;
+    ph.dev.item_ptr = d_item; ph.dev.item_dst = d_itemdst; ph.dev.col_ptr = d_colptr; ph.dev.n_slots = ph.n_slots; ph.dev.l2g = d_l2g; ph.dev.X = nullptr;
     if ((rc = upload_row_meta(h, ph, l, y, weight, offset, false))) return rc;
     return finish_part(h, ph);
 }
@@ -851,14 +882,26 @@ int mlx_finalize(mlx_handle h)
     if ((rc = dev_upload(h, &h->d_qdense, qd.data(), qd.size()))) return rc;
     if ((rc = dev_upload(h, &h->d_qcsr, qc.data(), qc.size()))) return rc;
     h->step_threads = (h->max_nlocal > 4096 || (h->nq_dense > 0 && h->max_nlocal >= 512)) ? 1024 : 256;
+    // column chunks of the multi-workgroup CSR step (k_step_a/b/c): 2048 columns (8 per thread) unless that would be more
+    // than 256 chunks per problem
+    {
+        int max_nlocal_csr = 1;
+        for (auto &p : h->parts) if (!p.dense) max_nlocal_csr = std::max(max_nlocal_csr, p.n_local);
+        int ch = getenv("MLX_STEP_CH") ? std::max(256, atoi(getenv("MLX_STEP_CH")) / 256 * 256) : 2048;
+        while ((max_nlocal_csr + ch - 1) / ch > 256) ch *= 2;
+        h->step_ch = ch;
+        h->step_max_nwg = (max_nlocal_csr + ch - 1) / ch;
+    }
 
     // problems (+1 scratch for mlx_solve_one)
     h->h_probs.assign(h->nprob + 1, ProbDev{});
     // All work vectors of all problems are carved out of ONE allocation (256-byte aligned pieces): thousands of problems
     // (configs #4/#5: 1024 partitions x 8 lambdas) must not become 10^5 hipMalloc calls of a few hundred KB each.
     auto carve_size = [](size_t count) { return (count * sizeof(double) + 255) / 256 * 256; };
+    auto step_nwg = [&](int n_local) { return (size_t)((n_local + h->step_ch - 1) / h->step_ch); };
     auto vec_bytes = [&](int n_local, int l, int64_t plen, int nblk, bool dense) {
-        return 8 * carve_size((size_t)n_local) + (dense ? 2 : 3) * carve_size((size_t)l) + carve_size((size_t)plen) + 2 * carve_size((size_t)nblk);
+        return 8 * carve_size((size_t)n_local) + (dense ? 2 : 3) * carve_size((size_t)l) + carve_size((size_t)plen) + 2 * carve_size((size_t)nblk) +
+               (dense ? 0 : carve_size((size_t)n_local) + 3 * carve_size(step_nwg(n_local) * STEP_NP));
     };
     const int scratch_blk = std::max(h->maxblk_dense, h->maxblk_csr);
     size_t slab_bytes = vec_bytes(h->max_nlocal, h->max_l, h->max_parts_len, scratch_blk, false) + carve_size((size_t)h->max_nlocal);
@@ -876,7 +919,11 @@ int mlx_finalize(mlx_handle h)
         for (auto v : vs) *v = carve((size_t)n_local);
         pr.wd[0] = carve((size_t)l);
         pr.wd[1] = carve((size_t)l);
-        if (!dense) pr.coef = carve((size_t)l);
+        if (!dense) {
+            pr.coef = carve((size_t)l);
+            pr.rb[0] = pr.r; pr.rb[1] = carve((size_t)n_local);
+            pr.pA = carve(step_nwg(n_local) * STEP_NP); pr.pB = carve(step_nwg(n_local) * STEP_NP); pr.pC = carve(step_nwg(n_local) * STEP_NP);
+        }
         pr.parts = carve((size_t)plen);
         pr.lossp = carve((size_t)nblk);
         pr.csump = carve((size_t)nblk);
@@ -1007,7 +1054,7 @@ int mlx_admm_solve_local(mlx_handle h, double liblinear_epsilon, float rho_adapt
     }
     HIPCHECK(h, hipMemcpyAsync(h->d_pinv_l, pinv.data(), sizeof(double) * nl, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(h, hipStreamSynchronize(h->stream));     // pinv is a stack vector
-    h->ev_used = 0;
+    h->ev_used = 0; h->ev_kind.clear();
     HIPCHECK(h, hipEventRecord(h->ev_t0, h->stream));
     mlxk_setup(h->stream, h->d_parts, h->d_probs, h->nprob, nl, ng, h->max_nlocal, h->d_z32, h->d_u, h->d_pinv_l,
                liblinear_epsilon, DEFAULT_MAX_ITER);
@@ -1046,13 +1093,16 @@ static int collect_solve_stats(mlx_handle h, int64_t ticks, mlx_stats *stats)
     hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1);
     s.total_ms = ms;
     if (h->profiling) {
-        double acc = 0;
+        double acc[4] = {0, 0, 0, 0};
+        int64_t cnt[4] = {0, 0, 0, 0};
         for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
             float m2 = 0;
-            if (hipEventElapsedTime(&m2, h->ev_pool[i], h->ev_pool[i + 1]) == hipSuccess) acc += m2;
+            const int kind = h->ev_kind[i / 2];
+            if (hipEventElapsedTime(&m2, h->ev_pool[i], h->ev_pool[i + 1]) == hipSuccess) { acc[kind] += m2; cnt[kind]++; }
         }
-        s.xpass_ms = acc;
-        s.xpass_launches = (int64_t)(h->ev_used / 2);
+        s.xpass_ms = acc[0] + acc[1] + acc[2];
+        s.rowpass_ms = acc[1]; s.colpass_ms = acc[2]; s.step_ms = acc[3];
+        s.xpass_launches = std::max(cnt[0], cnt[1]);
     } else {
         s.xpass_launches = ticks;
     }
@@ -1131,7 +1181,7 @@ int mlx_naive_solve_local(mlx_handle h, double liblinear_epsilon, double prior_m
     HIPCHECK(h, hipMemcpyAsync(h->d_pinv_l, pinv.data(), sizeof(double) * nl, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(h, hipMemcpyAsync(h->d_pinv_ovr, ovr.data(), sizeof(double) * ng, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
-    h->ev_used = 0;
+    h->ev_used = 0; h->ev_kind.clear();
     HIPCHECK(h, hipEventRecord(h->ev_t0, h->stream));
     mlxk_setup_naive(h->stream, h->d_parts, h->d_probs, h->nprob, h->max_nlocal, h->d_pinv_l, h->d_pinv_ovr,
                      h->d_naive_pinv, prior_mean, liblinear_epsilon, DEFAULT_MAX_ITER);
@@ -1285,6 +1335,7 @@ int mlx_solve_one(mlx_handle h, int32_t local_index, double *w, const double *pr
     pr.phase = PH_EVAL0; pr.iter = 1; pr.dsel = 0; pr.cg_iter = 0;
     pr.newton = pr.accepted = pr.cg_total = pr.ticks = 0; pr.status = ST_OK;
     pr.f = pr.delta = pr.gnorm = pr.gnorm1 = pr.rTr = pr.cgtol = pr.prered = pr.gs = 0;
+    pr.stage = 0; pr.cdone = 0; pr.rsel = 0; pr.alpha = pr.gsq = pr.snorm = 0;
     HIPCHECK(h, hipMemcpy(h->d_probs + h->nprob, &pr, sizeof(ProbDev), hipMemcpyHostToDevice));
     const bool prof = h->profiling;
     h->profiling = false;

@@ -10,10 +10,15 @@ struct ProbDev;
 int mlxk_xpass_dense(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
                      int max_nfeat, bool stream_once);
 int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
-                   int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cunits, int max_rblk_rows, int hot, bool stream_once);
-// TRON/CG control flow for problems [first, first+nprob)
-void mlxk_tron_step(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int first, int threads,
+                   int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cunits, int max_rblk_rows, int hot, bool stream_once,
+                   int which /* 1 = row pass, 2 = column pass, 3 = both */);
+// TRON/CG control flow for the problems in qlist: one workgroup per problem (dense tiles)
+void mlxk_tron_step(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int threads,
                     int *done_counter);
+// the same for CSR problems, split over column chunks of `ch` columns (max_nwg chunks for the widest problem):
+// three launches per tick, which = 0 (A), 1 (B), 2 (C)
+void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int ch,
+                     int max_nwg, int *done_counter);
 // whole solves of small CSR problems in one launch (one workgroup per problem runs the tick loop)
 void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int first, bool hasval,
                       int max_ticks, int *done_counter, int lds_doubles);

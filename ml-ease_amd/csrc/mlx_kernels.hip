@@ -405,7 +405,7 @@ k_colpass_items(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, 
         }
     }
     a = group_allreduce_sum<G>(a);
-    if (valid && gl == 0) pr.parts[item] = a;
+    if (valid && gl == 0) pr.parts[pa.item_dst[item]] = a;     // real items only are listed
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -552,6 +552,7 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     const float *__restrict__ cs_val = pa.cs_val;
     const int32_t *__restrict__ cs_ptr = pa.cs_ptr;
     const int32_t *__restrict__ item_ptr = pa.item_ptr;
+    const int32_t *__restrict__ item_dst = pa.item_dst;
     double *__restrict__ out = pr.parts;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int s = s0 + wave; s < s1; s += 16) {
@@ -559,6 +560,7 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
         const int L = (cs_ptr[s + 1] - base) >> 6;
         const int item = s * 64 + lane;
         const int len = item_ptr[item + 1] - item_ptr[item];
+        const int dst = item_dst[item];
         double a = 0.0;
         for (int k = 0; k < L; k += CSU) {
             int idx[CSU];
@@ -576,7 +578,7 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
                 if (k + u < len) a = a + term;
             }
         }
-        if (len > 0) out[item] = a;
+        if (len > 0) out[dst] = a;
     }
 }
 
@@ -615,6 +617,7 @@ k_setup(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int npro
         pr.newton = pr.accepted = pr.cg_total = pr.ticks = 0;
         pr.status = ST_OK;
         pr.f = pr.delta = pr.gnorm = pr.gnorm1 = pr.rTr = pr.cgtol = pr.prered = pr.gs = 0.0;
+        pr.stage = 0; pr.cdone = 0; pr.rsel = 0; pr.alpha = pr.gsq = pr.snorm = 0.0;
     }
 }
 
@@ -652,6 +655,7 @@ k_setup_naive(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
         pr.newton = pr.accepted = pr.cg_total = pr.ticks = 0;
         pr.status = ST_OK;
         pr.f = pr.delta = pr.gnorm = pr.gnorm1 = pr.rTr = pr.cgtol = pr.prered = pr.gs = 0.0;
+        pr.stage = 0; pr.cdone = 0; pr.rsel = 0; pr.alpha = pr.gsq = pr.snorm = 0.0;
     }
 }
 
@@ -720,14 +724,11 @@ __device__ __forceinline__ void assemble_out(const PartDev &pa, const ProbDev &p
         }
     } else {
         const double *__restrict__ parts = pr.parts;
-        const int nrb = pa.n_rblk;
+        const int32_t *__restrict__ cptr = pa.col_ptr;
         for (int j = tid; j < nf; j += nt) {
             double a = 0.0;
-            for (int bk = 0; bk < nrb; bk++) {
-                const int32_t *__restrict__ ci = pa.col_item + (int64_t)bk * (nf + 1);
-                const int i0 = ci[j], i1 = ci[j + 1];
-                for (int it = i0; it < i1; it++) a += parts[it];
-            }
+            const int i0 = cptr[j], i1 = cptr[j + 1];
+            for (int it = i0; it < i1; it++) a += parts[it];
             out[j] = a;
         }
         const double cs = block_sum_array(pr.csump, pa.nblk, scratch);
@@ -767,31 +768,9 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
     else assemble_out(pa, pr, Hd, scratch, stage);
     __syncthreads();
     const double *__restrict__ segsum = pr.parts;
-    const int32_t *__restrict__ col_item = pa.col_item;
-    const int nrb = pa.n_rblk;
-    auto xtc = [&](int j) -> double {
-        if (!inl) return Hd[j];
-        if (j >= nf) return csum_icpt;
-        double a = 0.0;
-        if (nrb <= 2) {                 // the common shapes: both blocks' item ranges are fetched before any partial
-            const int i0 = col_item[j], i1 = col_item[j + 1];
-            int k0 = 0, k1 = 0;
-            if (nrb == 2) { k0 = col_item[(nf + 1) + j]; k1 = col_item[(nf + 1) + j + 1]; }
-            for (int it = i0; it < i1; it++) a += segsum[it];
-            for (int it = k0; it < k1; it++) a += segsum[it];
-            return a;
-        }
-        for (int bk = 0; bk < nrb; bk++) {
-            const int32_t *__restrict__ ci = col_item + (int64_t)bk * (nf + 1);
-            const int i0 = ci[j], i1 = ci[j + 1];
-            for (int it = i0; it < i1; it++) a += segsum[it];
-        }
-        return a;
-    };
-
-    // The same for XB strided columns at once (j = jb + u*nt): all item ranges are fetched first, then all first items,
-    // then the (rare) further items -- two dependent latencies per batch instead of per column (step kernel -6 % at
-    // 128 problems x 35 K columns, -7 % at 256 x 70 K).
+    const int32_t *__restrict__ cptr = pa.col_ptr;
+    // X'c for XB strided columns at once (j = jb + u*nt): all slot ranges are fetched first, then all first slots, then the
+    // (rare) further ones -- two dependent latencies per batch instead of per column.
     constexpr int XB = 8;
     auto xtc_batch = [&](int jb, double (&xa)[XB]) {
         if (!inl) {
@@ -799,33 +778,22 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
             for (int u = 0; u < XB; u++) { const int j = jb + u * nt; xa[u] = j < n ? Hd[j] : 0.0; }
             return;
         }
-        if (nrb > 2) {
-#pragma unroll
-            for (int u = 0; u < XB; u++) { const int j = jb + u * nt; xa[u] = j < n ? xtc(j) : 0.0; }
-            return;
-        }
-        int i0[XB], i1[XB], k0[XB], k1[XB];
+        int i0[XB], i1[XB];
 #pragma unroll
         for (int u = 0; u < XB; u++) {
             const int j = jb + u * nt;
             const int jc = min(j, nf - 1);
             const bool col = j < nf && nf > 0;
-            i0[u] = col ? col_item[jc] : 0; i1[u] = col ? col_item[jc + 1] : 0;
-            k0[u] = 0; k1[u] = 0;
-            if (nrb == 2 && col) { k0[u] = col_item[(nf + 1) + jc]; k1[u] = col_item[(nf + 1) + jc + 1]; }
+            i0[u] = col ? cptr[jc] : 0; i1[u] = col ? cptr[jc + 1] : 0;
         }
-        double f0[XB], f1[XB];
+        double f0[XB];
 #pragma unroll
-        for (int u = 0; u < XB; u++) {
-            f0[u] = i1[u] > i0[u] ? segsum[i0[u]] : 0.0;
-            f1[u] = k1[u] > k0[u] ? segsum[k0[u]] : 0.0;
-        }
+        for (int u = 0; u < XB; u++) f0[u] = i1[u] > i0[u] ? segsum[i0[u]] : 0.0;
 #pragma unroll
         for (int u = 0; u < XB; u++) {
             const int j = jb + u * nt;
-            double a = 0.0;                                    // same order as xtc(): block 0's items, then block 1's
+            double a = 0.0;                                    // slot order = (block, segment) order
             if (i1[u] > i0[u]) { a += f0[u]; for (int it = i0[u] + 1; it < i1[u]; it++) a += segsum[it]; }
-            if (k1[u] > k0[u]) { a += f1[u]; for (int it = k0[u] + 1; it < k1[u]; it++) a += segsum[it]; }
             xa[u] = (j == nf) ? csum_icpt : a;
         }
     };
@@ -1038,14 +1006,450 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
 }
 
 __global__ void __launch_bounds__(1024)
-k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int nprob, int *__restrict__ done_counter)
+k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq,
+            int *__restrict__ done_counter)
 {
     __shared__ double scratch[64];
     __shared__ double stage[1024];
-    const int q = blockIdx.x;
-    if (q >= nprob) return;
-    ProbDev &pr = probs[q];
+    if ((int)blockIdx.x >= nq) return;
+    ProbDev &pr = probs[qlist[blockIdx.x]];
     tron_step_body(parts[pr.part], pr, scratch, stage, done_counter);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Multi-workgroup TRON/CG step of the CSR tick path (bw/Tron.java:30-179, same statements as tron_step_body).
+// A tick's step is three launches -- A, B, C -- because a CG step has two global reductions in sequence
+// (alpha = rTr / d.Hd, then beta = r'.r' / rTr) and every coordinate update needs the scalar before it:
+//     A  Hd = d*pinv + X'c            partial d.Hd                    | EVAL: gradient candidate, sum t^2 pinv, |grad|^2
+//     B  s += alpha d ; r' = r - alpha Hd   partial |s|^2, |r'|^2 (+ the boundary sums s.d, s.s, d.d, speculatively)
+//                                                                     | EVAL: accept/reject, w/g copies, trcg prologue
+//     C  d = beta d + r'  (or the trust-region boundary step)  ;  at the end of trcg: w_new = w + s, g.s, s.r
+// Each problem is cut into column chunks of `ch` columns, one 256-thread workgroup per chunk, so 128 problems of 35 K
+// columns are ~4 500 workgroups instead of 128. Reductions: every workgroup writes its partial sums, and the LAST one to
+// arrive (device-scope fence + counter, no spinning) adds them in chunk order and commits the problem's scalars for the
+// next launch -- fixed order, hence bit-reproducible; nobody reads a scalar in the launch that writes it (ProbDev::stage
+// keeps a problem whose phase changed in B out of the same tick's C).
+// Norms are sqrt(sum v^2) of sums gathered inside the update loops (euclideanNorm's scaled form up to the last bits).
+// ------------------------------------------------------------------------------------------------
+#define STEP_T 256
+#define STEP_XB 4      // columns per thread and round (independent loads in flight)
+
+// Partial sums of this workgroup (thread 0 holds them) -> px[wg]; returns true in every thread of the last workgroup of
+// the problem to arrive, with the chunk-ordered totals in tot[] (LDS).
+template <int NP>
+__device__ __forceinline__ bool step_arrive(ProbDev &pr, double *__restrict__ px, int wg, int nwg, const double (&mine)[NP],
+                                            double *tot /* LDS [STEP_NP] */, double *stage /* LDS [STEP_T] */, int *flag /* LDS */)
+{
+    static_assert(NP <= STEP_NP, "partials per workgroup");
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < NP; k++) __hip_atomic_store(px + wg * STEP_NP + k, mine[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        const int old = atomicAdd(&pr.cdone, 1);
+        *flag = (old == nwg - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!*flag) return false;
+    __threadfence();
+    // chunk-ordered sums: the loads run in parallel (one partial per thread), the additions sequentially per column
+    constexpr int WPR = STEP_T / STEP_NP;          // workgroups' partials per round
+    double a = 0.0;
+    for (int w0 = 0; w0 < nwg; w0 += WPR) {
+        const int w = w0 + tid / STEP_NP, k = tid % STEP_NP;
+        __syncthreads();
+        stage[tid] = (w < nwg && k < NP) ? __hip_atomic_load(px + w * STEP_NP + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        __syncthreads();
+        if (tid < NP) {
+            const int cnt = min(WPR, nwg - w0);
+            for (int i = 0; i < cnt; i++) a += stage[i * STEP_NP + tid];
+        }
+    }
+    if (tid < NP) tot[tid] = a;
+    if (tid == 0) pr.cdone = 0;                    // everybody has arrived: ready for the next launch
+    __syncthreads();
+    return true;
+}
+
+// sqrt of a sum of squares gathered in an update loop; a sum that overflowed (or is NaN) is reported as NaN so that the
+// caller stops the solve with ST_NAN instead of comparing against inf
+__device__ __forceinline__ double norm_of_sumsq(double ss) { return (ss < 1e300) ? sqrt(ss) : (0.0 / 0.0); }
+
+struct StepGeom { int n, nf, j0, j1, wg, nwg; };
+
+__device__ __forceinline__ bool step_geom(const PartDev &pa, int ch, StepGeom &g)
+{
+    g.n = pa.n_local; g.nf = pa.n_feat;
+    g.wg = blockIdx.x;
+    g.j0 = g.wg * ch;
+    if (g.j0 >= g.n) return false;
+    g.j1 = min(g.n, g.j0 + ch);
+    g.nwg = (g.n + ch - 1) / ch;
+    return true;
+}
+
+// ---- phase A ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(STEP_T)
+k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int ch)
+{
+#pragma clang fp contract(off)
+    __shared__ double scratch[64];
+    __shared__ double stage[STEP_T];
+    __shared__ double tot[STEP_NP];
+    __shared__ int flag;
+    ProbDev &pr = probs[qlist[blockIdx.y]];
+    const int phase = pr.phase;
+    if (phase == PH_DONE || pr.stage != 0) return;
+    const PartDev &pa = parts[pr.part];
+    StepGeom G;
+    if (!step_geom(pa, ch, G)) return;
+    const int tid = threadIdx.x, n = G.n, nf = G.nf;
+    const bool cg = (phase == PH_CG);
+    // the intercept's column sum (the chunk that holds column nf) and the loss (chunk 0) come from the row pass's partials
+    double csum_icpt = 0.0, loss = 0.0;
+    if (G.j1 == n) csum_icpt = block_sum_array(pr.csump, pa.nblk, scratch);
+    if (G.wg == 0 && !cg) loss = block_sum_array(pr.lossp, pa.nblk, scratch);
+    const double *__restrict__ segsum = pr.parts;
+    const int32_t *__restrict__ cptr = pa.col_ptr;
+    const double *__restrict__ v = cg ? pr.d : pr.w_new;
+    const double *__restrict__ m = pr.m;
+    const double *__restrict__ c0 = pa.c0;
+    const double *__restrict__ pvec = pr.pinv_vec;
+    const double pscal = pr.pinv;
+    double *__restrict__ Hd = pr.Hd;
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int jb = G.j0 + tid; jb < G.j1; jb += STEP_XB * STEP_T) {
+        int i0[STEP_XB], i1[STEP_XB];
+        double vv[STEP_XB], mm[STEP_XB], pj[STEP_XB], cc[STEP_XB];
+#pragma unroll
+        for (int u = 0; u < STEP_XB; u++) {
+            const int j = jb + u * STEP_T;
+            const int jc = min(j, G.j1 - 1);
+            const bool col = j < nf;
+            const int jf = min(jc, max(nf - 1, 0));
+            i0[u] = (col && nf > 0) ? cptr[jf] : 0; i1[u] = (col && nf > 0) ? cptr[jf + 1] : 0;
+            vv[u] = v[jc];
+            pj[u] = pvec ? pvec[jc] : pscal;
+            mm[u] = cg ? 0.0 : m[jc];
+            cc[u] = (phase == PH_EVAL0) ? c0[jc] : 0.0;
+        }
+        double f0[STEP_XB];
+#pragma unroll
+        for (int u = 0; u < STEP_XB; u++) f0[u] = i1[u] > i0[u] ? segsum[i0[u]] : 0.0;
+#pragma unroll
+        for (int u = 0; u < STEP_XB; u++) {
+            const int j = jb + u * STEP_T;
+            if (j >= G.j1) continue;
+            double xa = 0.0;                                   // slot order = (row block, segment) order
+            if (i1[u] > i0[u]) { xa += f0[u]; for (int it = i0[u] + 1; it < i1[u]; it++) xa += segsum[it]; }
+            if (j == nf) xa = csum_icpt;
+            if (cg) {
+                const double hd = vv[u] * pj[u] + xa;          // Hs[i] = (s[i]*priorVar_inv[i] + Hs[i]) * 1
+                Hd[j] = hd;
+                acc[0] += vv[u] * hd;
+            } else {
+                const double t = vv[u] - mm[u];
+                acc[0] += t * t * pj[u];                       // fun :187-188
+                const double hd = t * pj[u] + xa;              // grad :224 (multiplier 1)
+                Hd[j] = hd;
+                acc[1] += hd * hd;
+                if (phase == PH_EVAL0) {
+                    const double g0 = (0.0 - mm[u]) * pj[u] + cc[u];      // grad(0)
+                    acc[2] += g0 * g0;
+                }
+            }
+        }
+    }
+    block_allreduce_sum<3>(acc, scratch);
+    const double mine[4] = {acc[0], acc[1], acc[2], loss};
+    // (chunk 0 carries the loss in slot 3; the other chunks add 0 to it)
+    if (!step_arrive<4>(pr, pr.pA, G.wg, G.nwg, mine, tot, stage, &flag)) return;
+    if (tid == 0) {
+        if (cg) pr.alpha = pr.rTr / tot[0];
+#pragma unroll
+        for (int k = 0; k < 4; k++) pr.tot[k] = tot[k];
+        pr.stage = 1;
+    }
+}
+
+// Everything Tron.tron decides after fun(w_new) is known (bw/Tron.java:75-122) and its prologue (:47-62), from the
+// problem's scalars and phase A's totals. Pure function: every workgroup of phase B evaluates it identically.
+struct EvalDecision {
+    double f, delta, gnorm, gnorm1, gsq;
+    int iter;
+    bool copy_w, copy_g, accept, start, nullstep, finished, nan;
+};
+
+__device__ __forceinline__ EvalDecision eval_decide(const ProbDev &pr, int phase)
+{
+#pragma clang fp contract(off)
+    EvalDecision D;
+    const double tpp = pr.tot[0], hsq = pr.tot[1], g0sq = pr.tot[2], loss = pr.tot[3];
+    double fnew = 2.0 * loss;
+    fnew = fnew + tpp;
+    fnew = fnew / 2.0;
+    D.copy_w = D.copy_g = D.accept = D.start = D.nullstep = D.finished = D.nan = false;
+    D.gnorm1 = pr.gnorm1; D.iter = pr.iter; D.gsq = pr.gsq;
+    if (phase == PH_EVAL0) {
+        // Tron prologue (:47-62): gnorm1 = ||grad(0)||, f, g, delta at the warm start
+        D.gnorm1 = norm_of_sumsq(g0sq);
+        D.gnorm = norm_of_sumsq(hsq);
+        D.gsq = hsq;
+        D.f = fnew; D.delta = D.gnorm;
+        D.copy_g = true;
+        if (D.gnorm <= pr.eps * D.gnorm1) D.finished = true;            // search = 0
+        else D.start = true;
+    } else {
+        const double eta0 = 1e-4, eta1 = 0.25, eta2 = 0.75;
+        const double sigma1 = 0.25, sigma2 = 0.5, sigma3 = 4;
+        double f = pr.f, delta = pr.delta, gnorm = pr.gnorm;
+        const double gs = pr.gs, prered = pr.prered;
+        const double actred = f - fnew;
+        const double snorm = pr.snorm;
+        if (pr.iter == 1) delta = fmin(delta, snorm);
+        double alpha;
+        if (fnew - f - gs <= 0) alpha = sigma3;
+        else alpha = fmax(sigma1, -0.5 * (gs / (fnew - f - gs)));
+        if (actred < eta0 * prered) delta = fmin(fmax(alpha, sigma1) * snorm, sigma2 * delta);
+        else if (actred < eta1 * prered) delta = fmax(sigma1 * delta, fmin(alpha * snorm, sigma2 * delta));
+        else if (actred < eta2 * prered) delta = fmax(sigma1 * delta, fmin(alpha * snorm, sigma3 * delta));
+        else delta = fmax(delta, fmin(alpha * snorm, sigma3 * delta));
+        bool brk = false;
+        D.accept = actred > eta0 * prered;
+        if (D.accept) {
+            D.iter = pr.iter + 1;
+            D.copy_w = D.copy_g = true;
+            f = fnew;
+            gnorm = norm_of_sumsq(hsq);
+            D.gsq = hsq;
+            if (gnorm <= pr.eps * pr.gnorm1) brk = true;
+        }
+        if (!brk) {
+            if (f < -1.0e+32) brk = true;
+            else if (fabs(actred) <= 0 && prered <= 0) brk = true;
+            else if (fabs(actred) <= 1.0e-12 * fabs(f) && fabs(prered) <= 1.0e-12 * fabs(f)) brk = true;
+        }
+        D.f = f; D.delta = delta; D.gnorm = gnorm;
+        if (brk || D.iter > pr.max_iter) D.finished = true;             // while (iter <= max_iter && search)
+        else D.start = true;
+    }
+    if (!(fnew == fnew) || !(D.gnorm == D.gnorm) || !(D.gnorm1 == D.gnorm1)) { D.nan = true; D.finished = true; D.start = false; }
+    // trcg exits at once when ||r|| <= 0.1 ||g|| with r = -g (:144), i.e. only for g = 0
+    if (D.start && D.gnorm <= 0.1 * D.gnorm) D.nullstep = true;
+    return D;
+}
+
+// ---- phase B ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(STEP_T)
+k_step_b(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int ch,
+         int *__restrict__ done_counter)
+{
+#pragma clang fp contract(off)
+    __shared__ double scratch[96];
+    __shared__ double stage[STEP_T];
+    __shared__ double tot[STEP_NP];
+    __shared__ int flag;
+    ProbDev &pr = probs[qlist[blockIdx.y]];
+    const int phase = pr.phase;
+    if (phase == PH_DONE || pr.stage != 1) return;
+    const PartDev &pa = parts[pr.part];
+    StepGeom G;
+    if (!step_geom(pa, ch, G)) return;
+    const int tid = threadIdx.x;
+    double *__restrict__ s = pr.s, *__restrict__ d = pr.d;
+    const double *__restrict__ Hd = pr.Hd;
+    if (phase == PH_CG) {
+        // daxpy(alpha, d, s); r' = r - alpha Hd into the other residual buffer; the sums of both continuations
+        const double alpha = pr.alpha, nalpha = -alpha;
+        const double *__restrict__ rc = pr.rb[pr.rsel];
+        double *__restrict__ rn = pr.rb[pr.rsel ^ 1];
+        double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int jb = G.j0 + tid; jb < G.j1; jb += STEP_XB * STEP_T) {
+            double dv[STEP_XB], sv[STEP_XB], rv[STEP_XB], hv[STEP_XB];
+#pragma unroll
+            for (int u = 0; u < STEP_XB; u++) {
+                const int jc = min(jb + u * STEP_T, G.j1 - 1);
+                dv[u] = d[jc]; sv[u] = s[jc]; rv[u] = rc[jc]; hv[u] = Hd[jc];
+            }
+#pragma unroll
+            for (int u = 0; u < STEP_XB; u++) {
+                const int j = jb + u * STEP_T;
+                if (j >= G.j1) continue;
+                const double s1 = sv[u] + alpha * dv[u];               // daxpy(alpha, d, s)
+                s[j] = s1;
+                acc[0] += s1 * s1;
+                const double sb = s1 + nalpha * dv[u];                 // the boundary case steps back first (:153)
+                acc[1] += sb * dv[u];
+                acc[2] += sb * sb;
+                acc[3] += dv[u] * dv[u];
+                const double r1 = rv[u] + nalpha * hv[u];              // daxpy(-alpha, Hd, r)
+                rn[j] = r1;
+                acc[4] += r1 * r1;
+            }
+        }
+        block_allreduce_sum<5>(acc, scratch);
+        if (!step_arrive<5>(pr, pr.pB, G.wg, G.nwg, acc, tot, stage, &flag)) return;
+        if (tid == 0) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) pr.tot[k] = tot[k];
+            pr.stage = 2;
+        }
+        return;
+    }
+    // ---- PH_EVAL0 / PH_EVAL
+    const EvalDecision D = eval_decide(pr, phase);
+    double *__restrict__ w = pr.w, *__restrict__ w_new = pr.w_new, *__restrict__ g = pr.g;
+    double *__restrict__ r0 = pr.rb[0];
+    if (D.copy_w || D.copy_g || D.start) {
+        for (int jb = G.j0 + tid; jb < G.j1; jb += STEP_XB * STEP_T) {
+            double hv[STEP_XB], gv[STEP_XB], wn[STEP_XB], wv[STEP_XB];
+#pragma unroll
+            for (int u = 0; u < STEP_XB; u++) {
+                const int jc = min(jb + u * STEP_T, G.j1 - 1);
+                hv[u] = Hd[jc];
+                gv[u] = D.copy_g ? 0.0 : g[jc];
+                wn[u] = (D.copy_w || D.nullstep) ? w_new[jc] : 0.0;
+                wv[u] = (D.nullstep && !D.copy_w) ? w[jc] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < STEP_XB; u++) {
+                const int j = jb + u * STEP_T;
+                if (j >= G.j1) continue;
+                if (D.copy_w) w[j] = wn[u];
+                if (D.copy_g) g[j] = hv[u];
+                if (D.start) {
+                    // trcg prologue (:133-141): s = 0, r = -g, d = r
+                    const double gj = D.copy_g ? hv[u] : gv[u];
+                    const double rj = -gj;
+                    s[j] = 0.0; r0[j] = rj; d[j] = rj;
+                    // the CG loop exits at once with s = 0: the (null) step is evaluated like any other
+                    if (D.nullstep) w_new[j] = (D.copy_w ? wn[u] : wv[u]) + 1.0 * 0.0;
+                }
+            }
+        }
+    }
+    const double none[1] = {0.0};
+    if (!step_arrive<1>(pr, pr.pB, G.wg, G.nwg, none, tot, stage, &flag)) return;
+    if (tid == 0) {
+        pr.f = D.f; pr.delta = D.delta; pr.gnorm = D.gnorm; pr.gnorm1 = D.gnorm1; pr.gsq = D.gsq; pr.iter = D.iter;
+        pr.ticks += 1;
+        if (phase == PH_EVAL0 || D.accept) pr.dsel ^= 1;
+        if (D.accept) pr.accepted += 1;
+        if (D.nan) pr.status = ST_NAN;
+        if (D.start) {
+            pr.rTr = D.gsq;                    // r = -g: r.r = g.g
+            pr.cgtol = 0.1 * D.gnorm;
+            pr.cg_iter = 0;
+            pr.rsel = 0;
+            if (D.nullstep) { pr.gs = 0.0; pr.prered = -0.5 * (0.0 - 0.0); pr.snorm = 0.0; pr.newton += 1; pr.phase = PH_EVAL; }
+            else pr.phase = PH_CG;
+        }
+        if (D.finished) {
+            pr.phase = PH_DONE;
+            atomicAdd(done_counter, 1);
+        }
+        pr.stage = 0;
+    }
+}
+
+// ---- phase C (CG ticks only) ----------------------------------------------------------------------
+__global__ void __launch_bounds__(STEP_T)
+k_step_c(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int ch)
+{
+#pragma clang fp contract(off)
+    __shared__ double scratch[64];
+    __shared__ double stage[STEP_T];
+    __shared__ double tot[STEP_NP];
+    __shared__ int flag;
+    ProbDev &pr = probs[qlist[blockIdx.y]];
+    if (pr.phase != PH_CG || pr.stage != 2) return;
+    const PartDev &pa = parts[pr.part];
+    StepGeom G;
+    if (!step_geom(pa, ch, G)) return;
+    const int tid = threadIdx.x;
+    const double ss = pr.tot[0], std_ = pr.tot[1], sts = pr.tot[2], dtd = pr.tot[3], rnew = pr.tot[4];
+    const double alpha = pr.alpha, nalpha = -alpha, rTr0 = pr.rTr, delta0 = pr.delta;
+    const double snorm = norm_of_sumsq(ss);
+    const bool boundary = snorm > delta0;
+    const bool nan = !(snorm == snorm);
+    double alpha2 = 0.0, beta = 0.0;
+    bool end_cg;
+    if (boundary) {
+        // cg reaches trust region boundary (:150-168)
+        const double dsq = delta0 * delta0;
+        const double rad = sqrt(std_ * std_ + dtd * (dsq - sts));
+        if (std_ >= 0) alpha2 = (dsq - sts) / (std_ + rad);
+        else alpha2 = (rad - std_) / dtd;
+        end_cg = true;
+    } else {
+        beta = rnew / rTr0;
+        end_cg = norm_of_sumsq(rnew) <= pr.cgtol;                      // loop-top test of the next trip (:144)
+    }
+    if (nan) end_cg = true;
+    const double nalpha2 = -alpha2;
+    double *__restrict__ s = pr.s, *__restrict__ d = pr.d;
+    const double *__restrict__ Hd = pr.Hd;
+    const double *__restrict__ rc = pr.rb[pr.rsel];
+    double *__restrict__ rn = pr.rb[pr.rsel ^ 1];
+    const double *__restrict__ w = pr.w, *__restrict__ g = pr.g;
+    double *__restrict__ w_new = pr.w_new;
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int jb = G.j0 + tid; jb < G.j1; jb += STEP_XB * STEP_T) {
+        double dv[STEP_XB], r1[STEP_XB], sv[STEP_XB], hv[STEP_XB], rv[STEP_XB], wv[STEP_XB], gv[STEP_XB];
+#pragma unroll
+        for (int u = 0; u < STEP_XB; u++) {
+            const int jc = min(jb + u * STEP_T, G.j1 - 1);
+            dv[u] = d[jc];
+            r1[u] = boundary ? 0.0 : rn[jc];
+            sv[u] = (boundary || end_cg) ? s[jc] : 0.0;
+            hv[u] = boundary ? Hd[jc] : 0.0;
+            rv[u] = boundary ? rc[jc] : 0.0;
+            wv[u] = end_cg ? w[jc] : 0.0;
+            gv[u] = end_cg ? g[jc] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < STEP_XB; u++) {
+            const int j = jb + u * STEP_T;
+            if (j >= G.j1) continue;
+            double sf = sv[u], rf = r1[u];
+            if (boundary) {
+                const double sb = sv[u] + nalpha * dv[u];              // daxpy(-alpha, d, s)
+                sf = sb + alpha2 * dv[u];                              // daxpy(alpha', d, s)
+                s[j] = sf;
+                rf = rv[u] + nalpha2 * hv[u];                          // daxpy(-alpha', Hd, r)
+                rn[j] = rf;
+            } else {
+                double dj = dv[u];
+                if (beta != 1.0) dj = dj * beta;                       // scale(beta, d)
+                d[j] = dj + 1.0 * r1[u];                               // daxpy(one, r, d)
+            }
+            if (end_cg) {
+                // back in tron(): w_new = w + s, gs, prered (:69-73)
+                w_new[j] = wv[u] + 1.0 * sf;
+                acc[0] += gv[u] * sf;
+                acc[1] += sf * rf;
+                acc[2] += sf * sf;
+            }
+        }
+    }
+    block_allreduce_sum<3>(acc, scratch);
+    if (!step_arrive<3>(pr, pr.pC, G.wg, G.nwg, acc, tot, stage, &flag)) return;
+    if (tid == 0) {
+        if (!boundary) pr.rTr = rnew;
+        pr.rsel ^= 1;
+        pr.cg_iter += 1;
+        pr.ticks += 1;
+        if (nan) pr.status = ST_NAN;       // the EVAL tick that follows sees NaN in f or g and stops the solve
+        if (end_cg) {
+            pr.gs = tot[0];
+            pr.prered = -0.5 * (tot[0] - tot[1]);
+            pr.snorm = norm_of_sumsq(tot[2]);
+            pr.newton += 1;
+            pr.cg_total += pr.cg_iter;
+            pr.phase = PH_EVAL;
+        }
+        pr.stage = 0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1174,7 +1578,7 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
             const int itc = min(it, nitems - 1);
             const int k0 = item_ptr[itc], k1 = valid ? item_ptr[itc + 1] : k0;
             const double a = group_dot(cri, cval, coef, k0, k1);
-            if (valid && gl == 0 && k1 > k0) segsum[it] = a;
+            if (valid && gl == 0 && k1 > k0) segsum[pa.item_dst[itc]] = a;
         }
         __syncthreads();
         tron_step_body(pa, pr, scratch, stage, done_counter);
@@ -1576,8 +1980,9 @@ static void launch_rowpass(hipStream_t st, const PartDev *parts, ProbDev *probs,
 }
 
 int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
-                   int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cunits, int max_rblk_rows, int hot, bool stream_once)
+                   int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cunits, int max_rblk_rows, int hot, bool stream_once, int which)
 {
+    const bool do_row = which & 1, do_col = which & 2;
     if (nq <= 0) return 0;
     if (sell) {
         const size_t lds = (size_t)max_rblk_rows * sizeof(double);
@@ -1592,13 +1997,13 @@ int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const i
 #define LAUNCH_COLLDS(HV, NTF) hipLaunchKernelGGL((k_colpass_lds<HV, NTF>), dim3(XGRID(nq, max_cunits)), dim3(1024), lds, st, parts, probs, qlist, nq, max_cunits)
 #define LAUNCH_SELL(HV, NTF)                                         \
         do {                                                         \
-            switch (hot) {                                           \
+            if (do_row) switch (hot) {                               \
             case 2048: LAUNCH_ROWSELL(HV, 2048, NTF); break;         \
             case 4096: LAUNCH_ROWSELL(HV, 4096, NTF); break;         \
             case 8192: LAUNCH_ROWSELL(HV, 8192, NTF); break;         \
             default: LAUNCH_ROWSELL(HV, 0, NTF); break;              \
             }                                                        \
-            if (max_cunits > 0) LAUNCH_COLLDS(HV, NTF);              \
+            if (do_col && max_cunits > 0) LAUNCH_COLLDS(HV, NTF);    \
         } while (0)
         if (hasval) { if (stream_once) LAUNCH_SELL(true, true); else LAUNCH_SELL(true, false); }
         else { if (stream_once) LAUNCH_SELL(false, true); else LAUNCH_SELL(false, false); }
@@ -1607,28 +2012,38 @@ int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const i
 #undef LAUNCH_ROWSELL
         return 0;
     }
-    switch (rowgroup) {
+    if (do_row) switch (rowgroup) {
     case 8: launch_rowpass<8>(st, parts, probs, qlist, nq, maxblk, hasval); break;
     case 16: launch_rowpass<16>(st, parts, probs, qlist, nq, maxblk, hasval); break;
     case 32: launch_rowpass<32>(st, parts, probs, qlist, nq, maxblk, hasval); break;
     default: launch_rowpass<64>(st, parts, probs, qlist, nq, maxblk, hasval); break;
     }
     const int gs = (max_short + 31) / 32, gl = (max_long + 3) / 4;
-    if (gl > 0) {
+    if (do_col && gl > 0) {
         if (hasval) hipLaunchKernelGGL((k_colpass_items<64, true>), dim3(XGRID(nq, gl)), dim3(256), 0, st, parts, probs, qlist, nq, gl);
         else hipLaunchKernelGGL((k_colpass_items<64, false>), dim3(XGRID(nq, gl)), dim3(256), 0, st, parts, probs, qlist, nq, gl);
     }
-    if (gs > 0) {
+    if (do_col && gs > 0) {
         if (hasval) hipLaunchKernelGGL((k_colpass_items<8, true>), dim3(XGRID(nq, gs)), dim3(256), 0, st, parts, probs, qlist, nq, gs);
         else hipLaunchKernelGGL((k_colpass_items<8, false>), dim3(XGRID(nq, gs)), dim3(256), 0, st, parts, probs, qlist, nq, gs);
     }
     return 0;
 }
 
-void mlxk_tron_step(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int first, int threads,
+void mlxk_tron_step(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int threads,
                     int *done_counter)
 {
-    hipLaunchKernelGGL(k_tron_step, dim3(nprob), dim3(threads), 0, st, parts, probs + first, nprob, done_counter);
+    if (nq > 0) hipLaunchKernelGGL(k_tron_step, dim3(nq), dim3(threads), 0, st, parts, probs, qlist, nq, done_counter);
+}
+
+void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int ch,
+                     int max_nwg, int *done_counter)
+{
+    if (nq <= 0) return;
+    const dim3 grid((unsigned)max_nwg, (unsigned)nq);
+    if (which == 0) hipLaunchKernelGGL(k_step_a, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
+    else if (which == 1) hipLaunchKernelGGL(k_step_b, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch, done_counter);
+    else hipLaunchKernelGGL(k_step_c, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
 }
 
 void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int first, bool hasval,

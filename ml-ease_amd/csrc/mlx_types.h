@@ -8,6 +8,7 @@
 
 enum { PH_DONE = 0, PH_EVAL0 = 1, PH_CG = 2, PH_EVAL = 3 };
 enum { ST_OK = 0, ST_NAN = 1, ST_TICKCAP = 2 };
+enum { STEP_NP = 8 };       // doubles per workgroup and phase in ProbDev::pA/pB/pC
 
 struct PartDev {
     int32_t l;             // rows
@@ -29,8 +30,13 @@ struct PartDev {
     const int32_t *cri;        // [nnz] row ids in item order (block-major, column-major inside a block)
     const float *cval;         // [nnz] values in the same order, or nullptr
     const int32_t *item_ptr;   // [n_items+1] entry offsets of the items
-    const int32_t *col_item;   // [n_rblk][n_feat+1] first item of (block, column); [b][n_feat] = end of block b's real items
+    // Item sums are STORED column-major: item t writes its sum to slot item_dst[t] (-1 = empty/padding item), and the slots
+    // of column j are col_ptr[j] .. col_ptr[j+1]-1 in (block, segment) order -- one range per column whatever n_rblk is, and
+    // consecutive columns read consecutive slots.
+    const int32_t *item_dst;   // [n_items]
+    const int32_t *col_ptr;    // [n_feat+1]
     int32_t n_items;           // incl. padding items
+    int32_t n_slots;           // real items = col_ptr[n_feat]
     int32_t n_rblk, rblk_rows;
     const int32_t *items_short;  // real item ids with <= 64 entries (8-lane groups; fallback kernels)
     const int32_t *items_long;   // real item ids with 65..SEG entries (one wave each)
@@ -70,6 +76,18 @@ struct ProbDev {
     double pinv;           // scalar prior precision 1/(1/rho) (used when pinv_vec == nullptr)
     const double *pinv_vec;    // per-coordinate 1/priorVar (mlx_solve_one) or nullptr
     double *w, *w_new, *g, *s, *r, *d, *Hd, *m;   // n_local each
+    // multi-workgroup step (k_step_a/b/c, CSR tick path): the residual is double buffered (rb[rsel] = r of the current CG
+    // step, rb[rsel^1] receives r - alpha*Hd, so the trust-region boundary case can still see the old r), per-workgroup
+    // partial sums of the three phases, and the scalars the fused phases carry from one tick to the next.
+    double *rb[2];
+    int32_t rsel;
+    int32_t cdone;         // phase-C arrival counter (the last workgroup to arrive commits the scalars)
+    double *pA, *pB, *pC;  // [n_step_wg][STEP_NP] each
+    int32_t stage;         // which phase kernel acts next in this tick: 0 = A (after the X pass), 1 = B, 2 = C
+    double alpha;          // CG step length of this tick (phase A's last workgroup commits it)
+    double tot[STEP_NP];   // fixed-order totals of the previous phase's partial sums
+    double gsq;            // sum g_j^2 at the last accepted point (= rTr of the next trcg call)
+    double snorm;          // ||s|| at the end of the last trcg call
     double *wd[2];         // [l] wt_i * D_i at the accepted / trial point
     double *coef;          // [l] row coefficients of the current pass (CSR path only)
     double *parts;         // dense: [nblk][n_local] partial X'c ; CSR: itemsum [n_items]

@@ -32,7 +32,8 @@ class MlxStats(C.Structure):
                 ("newton_iters", C.c_int64), ("accepted", C.c_int64), ("cg_iters", C.c_int64),
                 ("x_passes_ref", C.c_int64), ("x_passes_dev", C.c_int64), ("ticks", C.c_int64),
                 ("alg_bytes_dev", C.c_double), ("xpass_ms", C.c_double), ("total_ms", C.c_double),
-                ("xpass_launches", C.c_int64)]
+                ("xpass_launches", C.c_int64), ("rowpass_ms", C.c_double), ("colpass_ms", C.c_double),
+                ("step_ms", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -78,7 +78,7 @@ def main():
 
     e = np.float32(0.01)
     mindiff = 99999999.0
-    acc = dict(solves=0, cg=0, newton=0, pref=0, pdev=0, ticks=0, alg=0.0, xms=0.0, tms=0.0)
+    acc = dict(solves=0, cg=0, newton=0, pref=0, pdev=0, ticks=0, alg=0.0, xms=0.0, tms=0.0, rms=0.0, cms=0.0, sms=0.0)
     recs = []
     for it in range(1, args.warmup + args.steps + 1):
         if it > 1 and mindiff < 0.001:
@@ -92,6 +92,7 @@ def main():
             acc["solves"] += st.solves; acc["cg"] += st.cg_iters; acc["newton"] += st.newton_iters
             acc["pref"] += st.x_passes_ref; acc["pdev"] += st.x_passes_dev; acc["ticks"] += st.ticks
             acc["alg"] += st.alg_bytes_dev; acc["xms"] += st.xpass_ms; acc["tms"] += st.total_ms
+            acc["rms"] += st.rowpass_ms; acc["cms"] += st.colpass_ms; acc["sms"] += st.step_ms
         if it == 1 and args.check:
             import oracle_lib as ol
             oc = ol.OracleAdmm(blocks[:args.check], ng, lam, rho, num_blocks=args.partitions)
@@ -113,7 +114,10 @@ def main():
            "x_passes_ref_per_s": round(acc["pref"] / dt, 1), "x_passes_dev_per_s": round(acc["pdev"] / dt, 1),
            "ticks_per_step": acc["ticks"] / args.steps, "cg_per_solve": acc["cg"] / max(1, acc["solves"]),
            "xpass_GBps_alg": round(acc["alg"] / max(1e-9, acc["xms"] * 1e-3) / 1e9, 1), "xpass_share": round(acc["xms"] / (dt * 1e3), 3),
-           "device_ms_share": round(acc["tms"] / (dt * 1e3), 3), "iters": recs}
+           "device_ms_share": round(acc["tms"] / (dt * 1e3), 3),
+           "us_per_tick": {"row": round(1e3 * acc["rms"] / max(1, acc["ticks"]), 1), "col": round(1e3 * acc["cms"] / max(1, acc["ticks"]), 1),
+                           "step": round(1e3 * acc["sms"] / max(1, acc["ticks"]), 1)},
+           "iters": recs}
     print(json.dumps(out))
 
 
