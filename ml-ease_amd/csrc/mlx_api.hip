@@ -226,13 +226,13 @@ int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
     return MLX_OK;
 }
 
-// The TRON/CG step of one tick: one workgroup per dense problem, three column-chunked launches for the CSR problems.
+// The TRON/CG step of one tick: one workgroup per dense problem; three column-chunked launches + a commit for the CSR problems.
 void launch_step(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int nqc)
 {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) { e0 = next_event(h, 3); e1 = next_event(h); hipEventRecord(e0, h->stream); }
     mlxk_tron_step(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->step_threads, h->d_done);
-    for (int which = 0; which < 3; which++)
+    for (int which = 0; which < 4; which++)
         mlxk_step_phase(h->stream, which, h->d_parts, h->d_probs, qcsr, nqc, h->step_ch, h->step_max_nwg, h->d_done);
     if (h->profiling) hipEventRecord(e1, h->stream);
 }
@@ -1335,7 +1335,7 @@ int mlx_solve_one(mlx_handle h, int32_t local_index, double *w, const double *pr
     pr.phase = PH_EVAL0; pr.iter = 1; pr.dsel = 0; pr.cg_iter = 0;
     pr.newton = pr.accepted = pr.cg_total = pr.ticks = 0; pr.status = ST_OK;
     pr.f = pr.delta = pr.gnorm = pr.gnorm1 = pr.rTr = pr.cgtol = pr.prered = pr.gs = 0;
-    pr.stage = 0; pr.cdone = 0; pr.rsel = 0; pr.alpha = pr.gsq = pr.snorm = 0;
+    pr.rsel = 0; pr.gsq = pr.snorm = 0;
     HIPCHECK(h, hipMemcpy(h->d_probs + h->nprob, &pr, sizeof(ProbDev), hipMemcpyHostToDevice));
     const bool prof = h->profiling;
     h->profiling = false;

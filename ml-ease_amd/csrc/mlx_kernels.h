@@ -16,7 +16,7 @@ int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const i
 void mlxk_tron_step(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int threads,
                     int *done_counter);
 // the same for CSR problems, split over column chunks of `ch` columns (max_nwg chunks for the widest problem):
-// three launches per tick, which = 0 (A), 1 (B), 2 (C)
+// four launches per tick, which = 0 (A), 1 (B), 2 (C), 3 (commit)
 void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int ch,
                      int max_nwg, int *done_counter);
 // whole solves of small CSR problems in one launch (one workgroup per problem runs the tick loop)

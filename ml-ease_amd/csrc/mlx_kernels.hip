@@ -617,7 +617,7 @@ k_setup(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int npro
         pr.newton = pr.accepted = pr.cg_total = pr.ticks = 0;
         pr.status = ST_OK;
         pr.f = pr.delta = pr.gnorm = pr.gnorm1 = pr.rTr = pr.cgtol = pr.prered = pr.gs = 0.0;
-        pr.stage = 0; pr.cdone = 0; pr.rsel = 0; pr.alpha = pr.gsq = pr.snorm = 0.0;
+        pr.rsel = 0; pr.gsq = pr.snorm = 0.0;
     }
 }
 
@@ -655,7 +655,7 @@ k_setup_naive(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
         pr.newton = pr.accepted = pr.cg_total = pr.ticks = 0;
         pr.status = ST_OK;
         pr.f = pr.delta = pr.gnorm = pr.gnorm1 = pr.rTr = pr.cgtol = pr.prered = pr.gs = 0.0;
-        pr.stage = 0; pr.cdone = 0; pr.rsel = 0; pr.alpha = pr.gsq = pr.snorm = 0.0;
+        pr.rsel = 0; pr.gsq = pr.snorm = 0.0;
     }
 }
 
@@ -1018,47 +1018,39 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, cons
 
 // ------------------------------------------------------------------------------------------------
 // Multi-workgroup TRON/CG step of the CSR tick path (bw/Tron.java:30-179, same statements as tron_step_body).
-// A tick's step is three launches -- A, B, C -- because a CG step has two global reductions in sequence
+// A tick's step is four launches -- A, B, C, commit -- because a CG step has two global reductions in sequence
 // (alpha = rTr / d.Hd, then beta = r'.r' / rTr) and every coordinate update needs the scalar before it:
 //     A  Hd = d*pinv + X'c            partial d.Hd                    | EVAL: gradient candidate, sum t^2 pinv, |grad|^2
 //     B  s += alpha d ; r' = r - alpha Hd   partial |s|^2, |r'|^2 (+ the boundary sums s.d, s.s, d.d, speculatively)
 //                                                                     | EVAL: accept/reject, w/g copies, trcg prologue
-//     C  d = beta d + r'  (or the trust-region boundary step)  ;  at the end of trcg: w_new = w + s, g.s, s.r
+//     C  d = beta d + r'  (or the trust-region boundary step)  ;  at the end of trcg: w_new = w + s, partial g.s, s.r
+//     commit  one workgroup per problem writes the problem's scalars (phase, f, delta, rTr, counters ...)
 // Each problem is cut into column chunks of `ch` columns, one 256-thread workgroup per chunk, so 128 problems of 35 K
-// columns are ~4 500 workgroups instead of 128. Reductions: every workgroup writes its partial sums, and the LAST one to
-// arrive (device-scope fence + counter, no spinning) adds them in chunk order and commits the problem's scalars for the
-// next launch -- fixed order, hence bit-reproducible; nobody reads a scalar in the launch that writes it (ProbDev::stage
-// keeps a problem whose phase changed in B out of the same tick's C).
+// columns are ~2 300 workgroups instead of 128. Reductions cross the KERNEL BOUNDARY only: every workgroup writes its
+// partial sums, and every workgroup of the next launch adds all of them in chunk order itself (a few hundred L2 hits) and
+// derives the same scalars from them -- fixed order, hence bit-reproducible, and no device-scope fence inside a kernel
+// (on this multi-XCD part a fence writes back / invalidates a whole L2: a last-arrival reduction with one fence per
+// workgroup ran the three phases at 1.3 TB/s). No scalar of ProbDev is written before the commit launch, so A, B and C
+// all see the tick's initial phase.
 // Norms are sqrt(sum v^2) of sums gathered inside the update loops (euclideanNorm's scaled form up to the last bits).
 // ------------------------------------------------------------------------------------------------
 #define STEP_T 256
 #define STEP_XB 4      // columns per thread and round (independent loads in flight)
 
-// Partial sums of this workgroup (thread 0 holds them) -> px[wg]; returns true in every thread of the last workgroup of
-// the problem to arrive, with the chunk-ordered totals in tot[] (LDS).
+// chunk-ordered totals of the previous launch's partial sums px[nwg][STEP_NP] -> tot[NP] (LDS); the loads run in
+// parallel (one partial per thread), the additions sequentially per column
 template <int NP>
-__device__ __forceinline__ bool step_arrive(ProbDev &pr, double *__restrict__ px, int wg, int nwg, const double (&mine)[NP],
-                                            double *tot /* LDS [STEP_NP] */, double *stage /* LDS [STEP_T] */, int *flag /* LDS */)
+__device__ __forceinline__ void step_gather(const double *__restrict__ px, int nwg, double *tot /* LDS [NP] */,
+                                            double *stage /* LDS [STEP_T] */)
 {
     static_assert(NP <= STEP_NP, "partials per workgroup");
     const int tid = threadIdx.x;
-    if (tid == 0) {
-#pragma unroll
-        for (int k = 0; k < NP; k++) __hip_atomic_store(px + wg * STEP_NP + k, mine[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        const int old = atomicAdd(&pr.cdone, 1);
-        *flag = (old == nwg - 1) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!*flag) return false;
-    __threadfence();
-    // chunk-ordered sums: the loads run in parallel (one partial per thread), the additions sequentially per column
     constexpr int WPR = STEP_T / STEP_NP;          // workgroups' partials per round
     double a = 0.0;
     for (int w0 = 0; w0 < nwg; w0 += WPR) {
         const int w = w0 + tid / STEP_NP, k = tid % STEP_NP;
         __syncthreads();
-        stage[tid] = (w < nwg && k < NP) ? __hip_atomic_load(px + w * STEP_NP + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        stage[tid] = (w < nwg && k < NP) ? px[w * STEP_NP + k] : 0.0;
         __syncthreads();
         if (tid < NP) {
             const int cnt = min(WPR, nwg - w0);
@@ -1066,9 +1058,7 @@ __device__ __forceinline__ bool step_arrive(ProbDev &pr, double *__restrict__ px
         }
     }
     if (tid < NP) tot[tid] = a;
-    if (tid == 0) pr.cdone = 0;                    // everybody has arrived: ready for the next launch
     __syncthreads();
-    return true;
 }
 
 // sqrt of a sum of squares gathered in an update loop; a sum that overflowed (or is NaN) is reported as NaN so that the
@@ -1082,9 +1072,9 @@ __device__ __forceinline__ bool step_geom(const PartDev &pa, int ch, StepGeom &g
     g.n = pa.n_local; g.nf = pa.n_feat;
     g.wg = blockIdx.x;
     g.j0 = g.wg * ch;
+    g.nwg = (g.n + ch - 1) / ch;
     if (g.j0 >= g.n) return false;
     g.j1 = min(g.n, g.j0 + ch);
-    g.nwg = (g.n + ch - 1) / ch;
     return true;
 }
 
@@ -1094,12 +1084,9 @@ k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
 {
 #pragma clang fp contract(off)
     __shared__ double scratch[64];
-    __shared__ double stage[STEP_T];
-    __shared__ double tot[STEP_NP];
-    __shared__ int flag;
     ProbDev &pr = probs[qlist[blockIdx.y]];
     const int phase = pr.phase;
-    if (phase == PH_DONE || pr.stage != 0) return;
+    if (phase == PH_DONE) return;
     const PartDev &pa = parts[pr.part];
     StepGeom G;
     if (!step_geom(pa, ch, G)) return;
@@ -1161,30 +1148,26 @@ k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
         }
     }
     block_allreduce_sum<3>(acc, scratch);
-    const double mine[4] = {acc[0], acc[1], acc[2], loss};
-    // (chunk 0 carries the loss in slot 3; the other chunks add 0 to it)
-    if (!step_arrive<4>(pr, pr.pA, G.wg, G.nwg, mine, tot, stage, &flag)) return;
     if (tid == 0) {
-        if (cg) pr.alpha = pr.rTr / tot[0];
-#pragma unroll
-        for (int k = 0; k < 4; k++) pr.tot[k] = tot[k];
-        pr.stage = 1;
+        double *__restrict__ px = pr.pA + G.wg * STEP_NP;
+        px[0] = acc[0]; px[1] = acc[1]; px[2] = acc[2];
+        px[3] = loss;                                          // chunk 0 carries the loss, the others add 0
     }
 }
 
 // Everything Tron.tron decides after fun(w_new) is known (bw/Tron.java:75-122) and its prologue (:47-62), from the
-// problem's scalars and phase A's totals. Pure function: every workgroup of phase B evaluates it identically.
+// problem's scalars and phase A's totals. Pure function: every workgroup of phase B and the commit evaluate it identically.
 struct EvalDecision {
     double f, delta, gnorm, gnorm1, gsq;
     int iter;
     bool copy_w, copy_g, accept, start, nullstep, finished, nan;
 };
 
-__device__ __forceinline__ EvalDecision eval_decide(const ProbDev &pr, int phase)
+__device__ __forceinline__ EvalDecision eval_decide(const ProbDev &pr, int phase, const double *totA)
 {
 #pragma clang fp contract(off)
     EvalDecision D;
-    const double tpp = pr.tot[0], hsq = pr.tot[1], g0sq = pr.tot[2], loss = pr.tot[3];
+    const double tpp = totA[0], hsq = totA[1], g0sq = totA[2], loss = totA[3];
     double fnew = 2.0 * loss;
     fnew = fnew + tpp;
     fnew = fnew / 2.0;
@@ -1239,28 +1222,61 @@ __device__ __forceinline__ EvalDecision eval_decide(const ProbDev &pr, int phase
     return D;
 }
 
+// What one trcg trip decides once |s + alpha d| and |r - alpha Hd| are known (bw/Tron.java:150-175), from the problem's
+// scalars and the totals of phases A and B. Pure function: phase C and the commit evaluate it identically.
+struct CgDecision {
+    double alpha, alpha2, beta, rnew;
+    bool boundary, end_cg, nan;
+};
+
+__device__ __forceinline__ CgDecision cg_decide(const ProbDev &pr, const double *totA, const double *totB)
+{
+#pragma clang fp contract(off)
+    CgDecision D;
+    D.alpha = pr.rTr / totA[0];
+    const double ss = totB[0], std_ = totB[1], sts = totB[2], dtd = totB[3];
+    D.rnew = totB[4];
+    const double delta0 = pr.delta;
+    const double snorm = norm_of_sumsq(ss);
+    D.boundary = snorm > delta0;
+    D.nan = !(snorm == snorm);
+    D.alpha2 = 0.0; D.beta = 0.0;
+    if (D.boundary) {
+        // cg reaches trust region boundary (:150-168)
+        const double dsq = delta0 * delta0;
+        const double rad = sqrt(std_ * std_ + dtd * (dsq - sts));
+        if (std_ >= 0) D.alpha2 = (dsq - sts) / (std_ + rad);
+        else D.alpha2 = (rad - std_) / dtd;
+        D.end_cg = true;
+    } else {
+        D.beta = D.rnew / pr.rTr;
+        D.end_cg = norm_of_sumsq(D.rnew) <= pr.cgtol;                  // loop-top test of the next trip (:144)
+    }
+    if (D.nan) D.end_cg = true;
+    return D;
+}
+
 // ---- phase B ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(STEP_T)
-k_step_b(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int ch,
-         int *__restrict__ done_counter)
+k_step_b(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int ch)
 {
 #pragma clang fp contract(off)
     __shared__ double scratch[96];
     __shared__ double stage[STEP_T];
-    __shared__ double tot[STEP_NP];
-    __shared__ int flag;
+    __shared__ double totA[4];
     ProbDev &pr = probs[qlist[blockIdx.y]];
     const int phase = pr.phase;
-    if (phase == PH_DONE || pr.stage != 1) return;
+    if (phase == PH_DONE) return;
     const PartDev &pa = parts[pr.part];
     StepGeom G;
     if (!step_geom(pa, ch, G)) return;
     const int tid = threadIdx.x;
+    step_gather<4>(pr.pA, G.nwg, totA, stage);
     double *__restrict__ s = pr.s, *__restrict__ d = pr.d;
     const double *__restrict__ Hd = pr.Hd;
     if (phase == PH_CG) {
         // daxpy(alpha, d, s); r' = r - alpha Hd into the other residual buffer; the sums of both continuations
-        const double alpha = pr.alpha, nalpha = -alpha;
+        const double alpha = pr.rTr / totA[0], nalpha = -alpha;
         const double *__restrict__ rc = pr.rb[pr.rsel];
         double *__restrict__ rn = pr.rb[pr.rsel ^ 1];
         double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
@@ -1288,67 +1304,43 @@ k_step_b(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
             }
         }
         block_allreduce_sum<5>(acc, scratch);
-        if (!step_arrive<5>(pr, pr.pB, G.wg, G.nwg, acc, tot, stage, &flag)) return;
         if (tid == 0) {
+            double *__restrict__ px = pr.pB + G.wg * STEP_NP;
 #pragma unroll
-            for (int k = 0; k < 5; k++) pr.tot[k] = tot[k];
-            pr.stage = 2;
+            for (int k = 0; k < 5; k++) px[k] = acc[k];
         }
         return;
     }
     // ---- PH_EVAL0 / PH_EVAL
-    const EvalDecision D = eval_decide(pr, phase);
+    const EvalDecision D = eval_decide(pr, phase, totA);
     double *__restrict__ w = pr.w, *__restrict__ w_new = pr.w_new, *__restrict__ g = pr.g;
     double *__restrict__ r0 = pr.rb[0];
-    if (D.copy_w || D.copy_g || D.start) {
-        for (int jb = G.j0 + tid; jb < G.j1; jb += STEP_XB * STEP_T) {
-            double hv[STEP_XB], gv[STEP_XB], wn[STEP_XB], wv[STEP_XB];
+    if (!(D.copy_w || D.copy_g || D.start)) return;
+    for (int jb = G.j0 + tid; jb < G.j1; jb += STEP_XB * STEP_T) {
+        double hv[STEP_XB], gv[STEP_XB], wn[STEP_XB], wv[STEP_XB];
 #pragma unroll
-            for (int u = 0; u < STEP_XB; u++) {
-                const int jc = min(jb + u * STEP_T, G.j1 - 1);
-                hv[u] = Hd[jc];
-                gv[u] = D.copy_g ? 0.0 : g[jc];
-                wn[u] = (D.copy_w || D.nullstep) ? w_new[jc] : 0.0;
-                wv[u] = (D.nullstep && !D.copy_w) ? w[jc] : 0.0;
-            }
+        for (int u = 0; u < STEP_XB; u++) {
+            const int jc = min(jb + u * STEP_T, G.j1 - 1);
+            hv[u] = Hd[jc];
+            gv[u] = D.copy_g ? 0.0 : g[jc];
+            wn[u] = (D.copy_w || D.nullstep) ? w_new[jc] : 0.0;
+            wv[u] = (D.nullstep && !D.copy_w) ? w[jc] : 0.0;
+        }
 #pragma unroll
-            for (int u = 0; u < STEP_XB; u++) {
-                const int j = jb + u * STEP_T;
-                if (j >= G.j1) continue;
-                if (D.copy_w) w[j] = wn[u];
-                if (D.copy_g) g[j] = hv[u];
-                if (D.start) {
-                    // trcg prologue (:133-141): s = 0, r = -g, d = r
-                    const double gj = D.copy_g ? hv[u] : gv[u];
-                    const double rj = -gj;
-                    s[j] = 0.0; r0[j] = rj; d[j] = rj;
-                    // the CG loop exits at once with s = 0: the (null) step is evaluated like any other
-                    if (D.nullstep) w_new[j] = (D.copy_w ? wn[u] : wv[u]) + 1.0 * 0.0;
-                }
+        for (int u = 0; u < STEP_XB; u++) {
+            const int j = jb + u * STEP_T;
+            if (j >= G.j1) continue;
+            if (D.copy_w) w[j] = wn[u];
+            if (D.copy_g) g[j] = hv[u];
+            if (D.start) {
+                // trcg prologue (:133-141): s = 0, r = -g, d = r
+                const double gj = D.copy_g ? hv[u] : gv[u];
+                const double rj = -gj;
+                s[j] = 0.0; r0[j] = rj; d[j] = rj;
+                // the CG loop exits at once with s = 0: the (null) step is evaluated like any other
+                if (D.nullstep) w_new[j] = (D.copy_w ? wn[u] : wv[u]) + 1.0 * 0.0;
             }
         }
-    }
-    const double none[1] = {0.0};
-    if (!step_arrive<1>(pr, pr.pB, G.wg, G.nwg, none, tot, stage, &flag)) return;
-    if (tid == 0) {
-        pr.f = D.f; pr.delta = D.delta; pr.gnorm = D.gnorm; pr.gnorm1 = D.gnorm1; pr.gsq = D.gsq; pr.iter = D.iter;
-        pr.ticks += 1;
-        if (phase == PH_EVAL0 || D.accept) pr.dsel ^= 1;
-        if (D.accept) pr.accepted += 1;
-        if (D.nan) pr.status = ST_NAN;
-        if (D.start) {
-            pr.rTr = D.gsq;                    // r = -g: r.r = g.g
-            pr.cgtol = 0.1 * D.gnorm;
-            pr.cg_iter = 0;
-            pr.rsel = 0;
-            if (D.nullstep) { pr.gs = 0.0; pr.prered = -0.5 * (0.0 - 0.0); pr.snorm = 0.0; pr.newton += 1; pr.phase = PH_EVAL; }
-            else pr.phase = PH_CG;
-        }
-        if (D.finished) {
-            pr.phase = PH_DONE;
-            atomicAdd(done_counter, 1);
-        }
-        pr.stage = 0;
     }
 }
 
@@ -1359,34 +1351,18 @@ k_step_c(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
 #pragma clang fp contract(off)
     __shared__ double scratch[64];
     __shared__ double stage[STEP_T];
-    __shared__ double tot[STEP_NP];
-    __shared__ int flag;
+    __shared__ double totA[4], totB[5];
     ProbDev &pr = probs[qlist[blockIdx.y]];
-    if (pr.phase != PH_CG || pr.stage != 2) return;
+    if (pr.phase != PH_CG) return;
     const PartDev &pa = parts[pr.part];
     StepGeom G;
     if (!step_geom(pa, ch, G)) return;
     const int tid = threadIdx.x;
-    const double ss = pr.tot[0], std_ = pr.tot[1], sts = pr.tot[2], dtd = pr.tot[3], rnew = pr.tot[4];
-    const double alpha = pr.alpha, nalpha = -alpha, rTr0 = pr.rTr, delta0 = pr.delta;
-    const double snorm = norm_of_sumsq(ss);
-    const bool boundary = snorm > delta0;
-    const bool nan = !(snorm == snorm);
-    double alpha2 = 0.0, beta = 0.0;
-    bool end_cg;
-    if (boundary) {
-        // cg reaches trust region boundary (:150-168)
-        const double dsq = delta0 * delta0;
-        const double rad = sqrt(std_ * std_ + dtd * (dsq - sts));
-        if (std_ >= 0) alpha2 = (dsq - sts) / (std_ + rad);
-        else alpha2 = (rad - std_) / dtd;
-        end_cg = true;
-    } else {
-        beta = rnew / rTr0;
-        end_cg = norm_of_sumsq(rnew) <= pr.cgtol;                      // loop-top test of the next trip (:144)
-    }
-    if (nan) end_cg = true;
-    const double nalpha2 = -alpha2;
+    step_gather<4>(pr.pA, G.nwg, totA, stage);
+    step_gather<5>(pr.pB, G.nwg, totB, stage);
+    const CgDecision D = cg_decide(pr, totA, totB);
+    const bool boundary = D.boundary, end_cg = D.end_cg;
+    const double nalpha = -D.alpha, alpha2 = D.alpha2, nalpha2 = -D.alpha2, beta = D.beta;
     double *__restrict__ s = pr.s, *__restrict__ d = pr.d;
     const double *__restrict__ Hd = pr.Hd;
     const double *__restrict__ rc = pr.rb[pr.rsel];
@@ -1432,23 +1408,66 @@ k_step_c(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
             }
         }
     }
+    if (!end_cg) return;
     block_allreduce_sum<3>(acc, scratch);
-    if (!step_arrive<3>(pr, pr.pC, G.wg, G.nwg, acc, tot, stage, &flag)) return;
     if (tid == 0) {
-        if (!boundary) pr.rTr = rnew;
+        double *__restrict__ px = pr.pC + G.wg * STEP_NP;
+        px[0] = acc[0]; px[1] = acc[1]; px[2] = acc[2];
+    }
+}
+
+// ---- commit: one workgroup per problem writes the scalars of the tick ---------------------------------------------
+__global__ void __launch_bounds__(STEP_T)
+k_step_commit(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int ch,
+              int *__restrict__ done_counter)
+{
+#pragma clang fp contract(off)
+    __shared__ double stage[STEP_T];
+    __shared__ double totA[4], totB[5], totC[3];
+    ProbDev &pr = probs[qlist[blockIdx.x]];
+    const int phase = pr.phase;
+    if (phase == PH_DONE) return;
+    const PartDev &pa = parts[pr.part];
+    const int nwg = (pa.n_local + ch - 1) / ch;
+    step_gather<4>(pr.pA, nwg, totA, stage);
+    if (phase == PH_CG) {
+        step_gather<5>(pr.pB, nwg, totB, stage);
+        const CgDecision D = cg_decide(pr, totA, totB);
+        if (D.end_cg) step_gather<3>(pr.pC, nwg, totC, stage);        // (uniform: every thread holds the same D)
+        if (threadIdx.x != 0) return;
+        if (!D.boundary) pr.rTr = D.rnew;
         pr.rsel ^= 1;
         pr.cg_iter += 1;
         pr.ticks += 1;
-        if (nan) pr.status = ST_NAN;       // the EVAL tick that follows sees NaN in f or g and stops the solve
-        if (end_cg) {
-            pr.gs = tot[0];
-            pr.prered = -0.5 * (tot[0] - tot[1]);
-            pr.snorm = norm_of_sumsq(tot[2]);
+        if (D.nan) pr.status = ST_NAN;       // the EVAL tick that follows still runs; the host reports the status
+        if (D.end_cg) {
+            pr.gs = totC[0];
+            pr.prered = -0.5 * (totC[0] - totC[1]);
+            pr.snorm = norm_of_sumsq(totC[2]);
             pr.newton += 1;
             pr.cg_total += pr.cg_iter;
             pr.phase = PH_EVAL;
         }
-        pr.stage = 0;
+        return;
+    }
+    const EvalDecision D = eval_decide(pr, phase, totA);
+    if (threadIdx.x != 0) return;
+    pr.f = D.f; pr.delta = D.delta; pr.gnorm = D.gnorm; pr.gnorm1 = D.gnorm1; pr.gsq = D.gsq; pr.iter = D.iter;
+    pr.ticks += 1;
+    if (phase == PH_EVAL0 || D.accept) pr.dsel ^= 1;
+    if (D.accept) pr.accepted += 1;
+    if (D.nan) pr.status = ST_NAN;
+    if (D.start) {
+        pr.rTr = D.gsq;                    // r = -g: r.r = g.g
+        pr.cgtol = 0.1 * D.gnorm;
+        pr.cg_iter = 0;
+        pr.rsel = 0;
+        if (D.nullstep) { pr.gs = 0.0; pr.prered = -0.5 * (0.0 - 0.0); pr.snorm = 0.0; pr.newton += 1; pr.phase = PH_EVAL; }
+        else pr.phase = PH_CG;
+    }
+    if (D.finished) {
+        pr.phase = PH_DONE;
+        atomicAdd(done_counter, 1);
     }
 }
 
@@ -2042,8 +2061,9 @@ void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *p
     if (nq <= 0) return;
     const dim3 grid((unsigned)max_nwg, (unsigned)nq);
     if (which == 0) hipLaunchKernelGGL(k_step_a, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
-    else if (which == 1) hipLaunchKernelGGL(k_step_b, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch, done_counter);
-    else hipLaunchKernelGGL(k_step_c, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
+    else if (which == 1) hipLaunchKernelGGL(k_step_b, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
+    else if (which == 2) hipLaunchKernelGGL(k_step_c, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
+    else hipLaunchKernelGGL(k_step_commit, dim3((unsigned)nq), dim3(STEP_T), 0, st, parts, probs, qlist, ch, done_counter);
 }
 
 void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int first, bool hasval,

@@ -81,11 +81,7 @@ struct ProbDev {
     // partial sums of the three phases, and the scalars the fused phases carry from one tick to the next.
     double *rb[2];
     int32_t rsel;
-    int32_t cdone;         // phase-C arrival counter (the last workgroup to arrive commits the scalars)
     double *pA, *pB, *pC;  // [n_step_wg][STEP_NP] each
-    int32_t stage;         // which phase kernel acts next in this tick: 0 = A (after the X pass), 1 = B, 2 = C
-    double alpha;          // CG step length of this tick (phase A's last workgroup commits it)
-    double tot[STEP_NP];   // fixed-order totals of the previous phase's partial sums
     double gsq;            // sum g_j^2 at the last accepted point (= rTr of the next trcg call)
     double snorm;          // ||s|| at the end of the last trcg call
     double *wd[2];         // [l] wt_i * D_i at the accepted / trial point
