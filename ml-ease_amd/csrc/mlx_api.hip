@@ -22,7 +22,8 @@
 namespace {
 
 constexpr int CSC_SEG = 256;          // max entries of one column work item
-constexpr int RBLK_MAX_ROWS = 20224;  // rows of one row block: 20224 fp64 coefficients = 158 KiB of the 160 KiB LDS
+constexpr int RBLK_MAX_ROWS = 20160;  // rows of one row block: 20160 fp64 coefficients (+ a zero slot) = 157.5 KiB of the 160 KiB LDS
+constexpr int ROW_SLICE_MAX_COLS = 19456;   // columns of one column slice of the row pass: 152 KiB of LDS (+ zero slot + scratch)
 constexpr int CUNIT_ENTRIES = 262144; // padded entries per work unit of the LDS column pass
 constexpr int DEFAULT_MAX_ITER = 10000;   // llf/LibLinear.java:97
 constexpr int64_t TICK_CAP = 2000000;
@@ -37,7 +38,7 @@ struct PartHost {
     int n_short = 0, n_long = 0;
     bool sell = false;
     std::vector<int32_t> new2old;          // CSR partitions: library local id -> caller's local id (features only)
-    int n_rslices = 0, n_cslices = 0, n_rblk = 1, rblk_rows = 0, n_cunits = 0;
+    int n_cs = 1, slw = 64, n_rgroups = 0, n_cslices = 0, n_rblk = 1, rblk_rows = 0, n_cunits = 0;
     int nblk = 0, rows_per_blk = 0, n_items = 0, n_slots = 0, rowgroup = 64, pos = 0, neg = 0;
     PartDev dev{};
     double *c0 = nullptr;
@@ -69,7 +70,7 @@ struct mlx_context {
     bool csr_hasval = false, any_absent = false, csr_sell = false, csr_small = false;
     int small_lds_doubles = 0;             // > 0: k_solve_small keeps every problem's work vectors in LDS (doubles needed by the largest)
     int max_cunits = 0, max_rblk_rows = 0;
-    int row_hot = 4096;                     // SELL row pass: most frequent columns staged in LDS (0, 2048, 4096, 8192)
+    int max_row_lds = 0;                    // sliced row pass: columns of the widest column slice (LDS doubles, + zero slot)
     int step_threads = 256;
     int step_ch = 2048, step_max_nwg = 1;   // multi-workgroup CSR step: columns per workgroup, chunks of the widest CSR problem
 
@@ -222,7 +223,7 @@ int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
         return fail(h, MLX_ERR_INVALID, "dense tile wider than 2048 features is not supported; use the CSR form");
     if (nqc > 0)
         for (int which = 1; which <= 2; which++)
-            bracket(which, [&] { return mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_short, h->max_long, h->rowgroup, h->csr_hasval, h->csr_sell, h->max_cunits, h->max_rblk_rows, h->row_hot, h->n_lambda == 1, which); });
+            bracket(which, [&] { return mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_short, h->max_long, h->rowgroup, h->csr_hasval, h->csr_sell, h->max_cunits, h->max_rblk_rows, h->max_row_lds, h->n_lambda == 1, which); });
     return MLX_OK;
 }
 
@@ -412,7 +413,8 @@ int mlx_set_regularizer(mlx_handle h, int32_t regularizer)
 // of its inputs (no handle, no device): partitions can be prepared by several threads (mlx_add_partitions_csr).
 struct CsrPrep {
     PartHost ph;
-    std::vector<int32_t> rp, pcol, cri, item_ptr, item_dst, col_ptr, ishort, ilong, l2g_perm, rs_ptr, rs_idx, cs_ptr, cs_idx, cw_blk, cw_slice;
+    std::vector<int32_t> rp, pcol, cri, item_ptr, item_dst, col_ptr, ishort, ilong, l2g_perm, rs_ptr, cs_ptr, cw_blk, cw_slice;
+    std::vector<uint16_t> rs_idx, cs_idx;
     std::vector<float> pvalv, cval, rs_val, cs_val;
     bool hasval = false;
     int rc = MLX_OK;
@@ -559,35 +561,60 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
     ph.rows_per_blk = rpb;
     ph.nblk = (l + rpb - 1) / rpb;
 
-    // Sliced-ELL copies for the thread-per-item passes (k_rowpass_sell / k_colpass_sell): built when padding the rows of a
-    // 64-row slice to the slice's longest row costs <= 1.5x the non-zeros (uniform-ish rows: one-hot data pads nothing).
-    std::vector<int32_t> rs_ptr, rs_idx, cs_ptr, cs_idx, cw_blk, cw_slice;
+    // Sliced-ELL copies for the thread-per-item passes (k_rowpass_lds / k_colpass_lds). Both passes gather from LDS only:
+    //  * row side: the columns are cut into n_cs column slices of slw columns (one slice of the gathered vector = <= 152 KiB
+    //    of LDS), the rows into groups of 64; block (slice s, group g) holds the entries of those 64 rows whose column
+    //    lies in slice s, padded to the group's longest such run: entry k of the 64 rows is 64 contiguous uint16
+    //    slice-local ids (padding = slw, a slot that holds 0.0). Blocks are stored slice-major, so a workgroup that owns a
+    //    range of row groups reads one contiguous piece per slice, whatever that range is (it is chosen at finalize).
+    //  * column side: see below (row ids relative to the row block, uint16, padding = rblk_rows).
+    // Built when the padded row side costs <= 2x the non-zeros (one-hot rows: ~1.5x, the cold slices hold 0-3 entries a row).
+    std::vector<int32_t> rs_ptr, cs_ptr, cw_blk, cw_slice;
+    std::vector<uint16_t> rs_idx, cs_idx;
     const int32_t cunit_entries = getenv("MLX_CUNIT") ? atoi(getenv("MLX_CUNIT")) : CUNIT_ENTRIES;
     std::vector<float> rs_val, cs_val;
     {
-        const int nrs = (l + 63) / 64;
-        rs_ptr.assign((size_t)nrs + 1, 0);
-        int64_t padded = 0;                                 // in 64 bits: the slice offsets themselves are int32
-        for (int s = 0; s < nrs; s++) {
-            int mx = 0;
-            for (int r = s * 64; r < std::min(l, s * 64 + 64); r++) mx = std::max(mx, rp[r + 1] - rp[r]);
-            padded += (int64_t)mx * 64;
-            rs_ptr[(size_t)s + 1] = (int32_t)std::min<int64_t>(padded, std::numeric_limits<int32_t>::max());
+        const int ngr = (l + 63) / 64;
+        const int slmax = getenv("MLX_SLW") ? std::max(64, atoi(getenv("MLX_SLW")) / 64 * 64) : ROW_SLICE_MAX_COLS;
+        const int ncs_r = std::max(1, (nf + slmax - 1) / slmax);
+        const int slw = std::max(64, ((nf + ncs_r - 1) / ncs_r + 63) / 64 * 64);
+        ph.n_cs = ncs_r; ph.slw = slw; ph.n_rgroups = ngr;
+        // entries of row r in slice s: [cut[r][s], cut[r][s+1]) of the row's (ascending) entries
+        std::vector<int32_t> cut((size_t)l * (ncs_r + 1));
+        for (int r = 0; r < l; r++) {
+            int32_t k = rp[r];
+            for (int sl = 0; sl < ncs_r; sl++) {
+                cut[(size_t)r * (ncs_r + 1) + sl] = k;
+                const int32_t hi = (sl + 1) * slw;
+                while (k < rp[r + 1] && col_idx_p[k] < hi) k++;
+            }
+            cut[(size_t)r * (ncs_r + 1) + ncs_r] = k;
         }
-        ph.sell = nnz > 0 && (double)padded <= 1.5 * (double)nnz + 4096.0 && padded < (int64_t)std::numeric_limits<int32_t>::max() &&
+        rs_ptr.assign((size_t)ncs_r * ngr + 1, 0);
+        int64_t padded = 0;                                 // in 64 bits: the block offsets themselves are int32
+        for (int sl = 0; sl < ncs_r; sl++)
+            for (int g = 0; g < ngr; g++) {
+                int mx = 0;
+                for (int r = g * 64; r < std::min(l, g * 64 + 64); r++)
+                    mx = std::max(mx, cut[(size_t)r * (ncs_r + 1) + sl + 1] - cut[(size_t)r * (ncs_r + 1) + sl]);
+                padded += (int64_t)mx * 64;
+                rs_ptr[(size_t)sl * ngr + g + 1] = (int32_t)std::min<int64_t>(padded, std::numeric_limits<int32_t>::max());
+            }
+        ph.sell = nnz > 0 && (double)padded <= 2.0 * (double)nnz + 4096.0 && padded < (int64_t)std::numeric_limits<int32_t>::max() &&
                   (int64_t)nnz + 64LL * ph.n_items < (int64_t)std::numeric_limits<int32_t>::max() / 2 && getenv("MLX_NO_SELL") == nullptr;
         if (ph.sell) {
-            ph.n_rslices = nrs;
-            rs_idx.assign((size_t)padded, 0);
+            rs_idx.assign((size_t)padded, (uint16_t)slw);
             if (val) rs_val.assign((size_t)padded, 0.f);
-            for (int r = 0; r < l; r++) {
-                const int32_t base = rs_ptr[(size_t)(r >> 6)], lane = r & 63;
-                for (int32_t k = rp[r]; k < rp[r + 1]; k++) {
-                    const size_t dst = (size_t)base + (size_t)(k - rp[r]) * 64 + (size_t)lane;
-                    rs_idx[dst] = col_idx_p[k];
-                    if (val) rs_val[dst] = val_p[k];
+            for (int sl = 0; sl < ncs_r; sl++)
+                for (int r = 0; r < l; r++) {
+                    const int32_t base = rs_ptr[(size_t)sl * ngr + (r >> 6)], lane = r & 63;
+                    const int32_t k0 = cut[(size_t)r * (ncs_r + 1) + sl], k1 = cut[(size_t)r * (ncs_r + 1) + sl + 1];
+                    for (int32_t k = k0; k < k1; k++) {
+                        const size_t dst = (size_t)base + (size_t)(k - k0) * 64 + (size_t)lane;
+                        rs_idx[dst] = (uint16_t)(col_idx_p[k] - sl * slw);
+                        if (val) rs_val[dst] = val_p[k];
+                    }
                 }
-            }
             // item slices: slice s = items 64s..64s+63 (blocks are padded to 64 items, so a slice lies in one block);
             // columns are already sorted by frequency, so the 64 items of a slice have similar lengths. Row ids are
             // stored relative to the block: they index the block's coefficients in LDS.
@@ -599,14 +626,14 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
                 for (int t = s2 * 64; t < s2 * 64 + 64; t++) mx = std::max(mx, item_ptr[(size_t)t + 1] - item_ptr[(size_t)t]);
                 cs_ptr[(size_t)s2 + 1] = cs_ptr[(size_t)s2] + mx * 64;
             }
-            cs_idx.assign((size_t)cs_ptr[(size_t)ncs], 0);
+            cs_idx.assign((size_t)cs_ptr[(size_t)ncs], (uint16_t)RB);       // padding gathers the zero slot behind the block
             if (val) cs_val.assign((size_t)cs_ptr[(size_t)ncs], 0.f);
             for (int bk = 0; bk < nb; bk++) {
                 for (int it = blk_item0[(size_t)bk]; it < blk_item0[(size_t)bk + 1]; it++) {
                     const int32_t base = cs_ptr[(size_t)(it >> 6)], lane = it & 63;
                     for (int32_t k = item_ptr[(size_t)it]; k < item_ptr[(size_t)it + 1]; k++) {
                         const size_t dst = (size_t)base + (size_t)(k - item_ptr[(size_t)it]) * 64 + (size_t)lane;
-                        cs_idx[dst] = cri[(size_t)k] - bk * RB;
+                        cs_idx[dst] = (uint16_t)(cri[(size_t)k] - bk * RB);
                         if (val) cs_val[dst] = cval[(size_t)k];
                     }
                 }
@@ -623,8 +650,7 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
             }
             cw_slice.push_back(ncs);
             ph.n_cunits = (int)cw_blk.size();
-            ph.rows_per_blk = l >= 4096 ? 512 : 256;
-            ph.nblk = (l + ph.rows_per_blk - 1) / ph.rows_per_blk;
+            // (the row chunk of a row-pass workgroup, hence nblk, is chosen at mlx_finalize from the handle's whole work)
         }
     }
 
@@ -663,9 +689,10 @@ static int commit_csr(mlx_handle h, CsrPrep &P, int32_t l, int32_t n_local, int6
     if ((rc = dev_upload(h, &d_ilong, P.ilong.data(), P.ilong.size()))) return rc;
     if ((rc = dev_upload(h, &d_l2g, P.l2g_perm.data(), (size_t)n_local))) return rc;
     ph.dev.rp = d_rp; ph.dev.ci = d_ci; ph.dev.val = d_val; ph.dev.cri = d_cri; ph.dev.cval = d_cval;
-    ph.dev.sell = ph.sell ? 1 : 0; ph.dev.n_rslices = ph.n_rslices; ph.dev.n_cslices = ph.n_cslices;
+    ph.dev.sell = ph.sell ? 1 : 0; ph.dev.n_cs = ph.n_cs; ph.dev.slw = ph.slw; ph.dev.n_rgroups = ph.n_rgroups; ph.dev.n_cslices = ph.n_cslices;
     if (ph.sell) {
-        int32_t *d_a, *d_b, *d_c, *d_d, *d_e, *d_h;
+        int32_t *d_a, *d_c, *d_e, *d_h;
+        uint16_t *d_b, *d_d;
         float *d_f = nullptr, *d_g = nullptr;
         if ((rc = dev_upload(h, &d_a, P.rs_ptr.data(), P.rs_ptr.size()))) return rc;
         if ((rc = dev_upload(h, &d_b, P.rs_idx.data(), P.rs_idx.size()))) return rc;
@@ -823,6 +850,24 @@ int mlx_finalize(mlx_handle h)
     int rc;
     const int np = (int)h->parts.size(), nl = h->n_lambda, ng = h->n_global;
     h->nprob = np * nl;
+    // Sliced CSR partitions: the row chunk of one row-pass workgroup (a range of 64-row groups; the sliced layout does not
+    // depend on it). Every workgroup stages the whole gathered vector once, slice by slice, so chunks are as long as the
+    // handle's total work allows: about three workgroups per CU over all problems, 16..128 groups (1 024..8 192 rows).
+    h->csr_sell = true;
+    for (auto &p : h->parts) if (!p.dense) h->csr_sell = h->csr_sell && p.sell;
+    if (h->csr_sell) {
+        int64_t total_groups = 0;
+        for (auto &p : h->parts) if (!p.dense) total_groups += (int64_t)nl * p.n_rgroups;
+        int ngc = (int)std::min<int64_t>(128, std::max<int64_t>(16, (total_groups / 768 + 15) / 16 * 16));
+        if (const char *e = getenv("MLX_ROW_NG")) ngc = std::max(16, std::min(128, atoi(e) / 16 * 16));
+        for (auto &p : h->parts) if (!p.dense) {
+            p.dev.rgroups_per_chunk = ngc;
+            p.rows_per_blk = ngc * 64;
+            p.nblk = (p.n_rgroups + ngc - 1) / ngc;
+            p.dev.rows_per_blk = p.rows_per_blk; p.dev.nblk = p.nblk;
+            h->max_row_lds = std::max(h->max_row_lds, p.slw);
+        }
+    }
     std::vector<PartDev> pd(np);
     for (int k = 0; k < np; k++) pd[k] = h->parts[k].dev;
     if ((rc = dev_upload(h, &h->d_parts, pd.data(), pd.size()))) return rc;
@@ -845,9 +890,7 @@ int mlx_finalize(mlx_handle h)
         for (int li = 0; li < nl; li++) (p.dense ? qd : qc).push_back(k * nl + li);
     }
     // a single row-group width / value mode for all CSR partitions of the handle
-    h->csr_sell = true;
-    for (auto &p : h->parts) if (!p.dense) { h->csr_sell = h->csr_sell && p.sell; h->max_cunits = std::max(h->max_cunits, p.n_cunits); h->max_rblk_rows = std::max(h->max_rblk_rows, p.rblk_rows); }
-    if (const char *e = getenv("MLX_ROW_HOT")) h->row_hot = atoi(e);
+    for (auto &p : h->parts) if (!p.dense) { h->max_cunits = std::max(h->max_cunits, p.n_cunits); h->max_rblk_rows = std::max(h->max_rblk_rows, p.rblk_rows); }
     h->csr_small = getenv("MLX_NO_SMALL") == nullptr;
     for (auto &p : h->parts)
         if (!p.dense && (p.nnz > SMALL_MAX_NNZ || p.l > SMALL_MAX_DIM || p.n_local > SMALL_MAX_DIM)) h->csr_small = false;

@@ -409,26 +409,57 @@ k_colpass_items(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// sparse X pass on the sliced-ELL copies: one THREAD per row / per column segment.
-// Measured (tools/sparse_probe.hip, profiles/r1_notes.md): the lane-group kernels above are bound by the texture
-// addresser (~1 divergent lane address per clock per CU) and by their semi-coalesced 32-byte index reads; in the
-// sliced layout entry k of 64 consecutive work items is one contiguous 256-byte load, every lane has RSU (rows) / CSU
-// (column items) independent index loads + gathers in flight and there is no cross-lane reduction. Each sum runs
-// sequentially over the item's entries (ascending library column id; ascending row inside an item) with contraction off.
-// RSU = 10: the 20-entry rows of the one-hot configs take two full rounds (8 took three: row pass 418 -> 365 us;
-// 20 in one round 377 us); CSU = 16 was slower than 8 (377 vs 335 us).
+// sparse X pass on the sliced-ELL copies: one THREAD per row / per column item, EVERY gather served by LDS.
+// Measured (tools/sparse_probe.hip, profiles/r1_notes.md): lane-group kernels are bound by the texture addresser (~1
+// divergent lane address per clock per CU) and by their semi-coalesced index reads; thread-per-row kernels that gather
+// from global memory by the L2 random-request rate (a 64-byte line moves for every 8 bytes used: the 25 % "cold" gathers
+// of the one-hot data cost as much as the 75 % served by a 4096-entry LDS copy). Here the gathered vector itself is cut
+// into slices that fit in LDS and staged slice by slice (coalesced 16-byte loads), the index streams are uint16 (slice- /
+// block-local ids: half the bytes of the dominant stream), entry k of 64 consecutive work items is one contiguous
+// 128-byte load, every lane has LSU independent index loads + LDS reads in flight and there is no cross-lane reduction.
+// Padding entries point at an LDS slot that holds 0.0 (x + 0.0 == x): no length masks, no per-item length loads.
+// Each sum runs sequentially over the item's entries (ascending library column id; ascending row inside an item) with
+// contraction off -- the same order as before the slicing, so results are unchanged bit for bit.
 // ------------------------------------------------------------------------------------------------
-#ifndef RSU
-#define RSU 10
+#ifndef LSU
+#define LSU 8
 #endif
-#ifndef CSU
-#define CSU 8
-#endif
-template <bool HASVAL, int HOT, bool NT>
-__global__ void __launch_bounds__(256)
-k_rowpass_sell(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx)
+template <bool HASVAL, bool NT>
+__device__ __forceinline__ double sell_lds_sum(double a, const uint16_t *__restrict__ idx, const float *__restrict__ val, int base,
+                                               int L, int lane, const double *__restrict__ lds, int zslot)
 {
 #pragma clang fp contract(off)
+    for (int k = 0; k < L; k += LSU) {
+        int id[LSU];
+        float xv[LSU];
+#pragma unroll
+        for (int u = 0; u < LSU; u++) {
+            const int kk = min(k + u, L - 1);               // unconditional clamped loads (a predicated load is waited for alone)
+            const int off = base + kk * 64 + lane;
+            const int t = NT ? (int)__builtin_nontemporal_load(idx + off) : (int)idx[off];
+            id[u] = (k + u < L) ? t : zslot;
+            if (HASVAL) xv[u] = NT ? __builtin_nontemporal_load(val + off) : val[off];
+        }
+#pragma unroll
+        for (int u = 0; u < LSU; u++) {
+            const double c = lds[id[u]];
+            a = a + (HASVAL ? c * (double)xv[u] : c);
+        }
+    }
+    return a;
+}
+
+// Row pass. One 1024-thread workgroup = (problem, chunk of <= 128 row groups of 64 rows): for every column slice it stages
+// that slice of the gathered vector (d or w_new) in LDS and every wave walks its row groups' blocks of that slice; a
+// thread keeps the running sums of its (up to ROW_MAXG) rows in registers across the slices, then applies the row map.
+// Workgroups are mapped XCD-aware: all chunks of problem p run on XCD p % 8, so the vector they all stage stays in that L2.
+#define ROW_MAXG 8
+template <bool HASVAL, bool NT>
+__global__ void __launch_bounds__(1024)
+k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx)
+{
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) double vs[];      // [slw + 1]: the staged slice, then the zero slot
     __shared__ double scratch[48];
     int pi_, bx_;
     if (!xcd_map(nq, gx, pi_, bx_)) return;
@@ -437,74 +468,63 @@ k_rowpass_sell(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, c
     const int phase = pr.phase;
     if (phase == PH_DONE) return;
     const PartDev &pa = parts[pr.part];
-    const int b = bx_;
-    if (b >= pa.nblk) return;
+    const int c = bx_;
+    if (c >= pa.nblk) return;
     const bool cg = (phase == PH_CG);
     const double *__restrict__ v = cg ? pr.d : pr.w_new;
     const double *__restrict__ wdcur = pr.wd[pr.dsel];
     double *__restrict__ wdnew = pr.wd[pr.dsel ^ 1];
     double *__restrict__ coef = pr.coef;
-    const int32_t *__restrict__ rp = pa.rp;
-    const int32_t *__restrict__ rs_ptr = pa.rs_ptr;
-    const int32_t *__restrict__ rs_idx = pa.rs_idx;
+    const int nf = pa.n_feat, slw = pa.slw, ncs = pa.n_cs, ngr = pa.n_rgroups, l = pa.l;
+    const int g0 = c * pa.rgroups_per_chunk;
+    const int gcount = min(pa.rgroups_per_chunk, ngr - g0);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint16_t *__restrict__ rs_idx = pa.rs_idx;
     const float *__restrict__ rs_val = pa.rs_val;
-    const double vb = v[pa.n_feat];
-    const int l = pa.l;
-    const int r0 = b * pa.rows_per_blk;
-    const int r1 = min(l, r0 + pa.rows_per_blk);
-    // the HOT most frequent columns (library ids are frequency-sorted) are gathered from LDS instead of through
-    // the texture addresser / L2
-    __shared__ double hot[HOT > 0 ? HOT : 1];
-    if (HOT > 0) {
-        const int nh = min(HOT, pa.n_local);
-        for (int j = threadIdx.x; j < nh; j += 256) hot[j] = v[j];
+    double acc[ROW_MAXG];
+#pragma unroll
+    for (int i = 0; i < ROW_MAXG; i++) acc[i] = 0.0;
+    for (int sl = 0; sl < ncs; sl++) {
+        const int c0 = sl * slw;
+        const int cnt = min(slw, nf - c0);
+        __syncthreads();                                     // the previous slice's readers are done
+        {
+            const double2 *__restrict__ src = reinterpret_cast<const double2 *>(v + c0);    // c0 is a multiple of 64
+            const int np2 = cnt >> 1;
+            for (int i = tid; i < np2; i += 1024) {
+                const double2 v2 = src[i];
+                vs[2 * i] = v2.x;
+                vs[2 * i + 1] = v2.y;
+            }
+            if ((cnt & 1) && tid == 0) vs[cnt - 1] = v[c0 + cnt - 1];
+            if (tid == 0) vs[slw] = 0.0;
+        }
         __syncthreads();
-    }
-    double red[2] = {0.0, 0.0};          // loss, sum of coef
-    for (int rowb = r0; rowb < r1; rowb += 256) {
-        const int row = rowb + threadIdx.x;
-        const bool valid = row < r1;
-        const int rowc = min(row, l - 1);
-        const int slice = rowc >> 6, lane = rowc & 63;
-        const int base = rs_ptr[slice];
-        const int L = (rs_ptr[slice + 1] - base) >> 6;
-        const int len = valid ? rp[rowc + 1] - rp[rowc] : 0;
-        const double wdv0 = cg ? wdcur[rowc] : 0.0;
-        const float offv = cg ? 0.f : pa.off[rowc];
-        const float wtv = cg ? 0.f : pa.wt[rowc];
-        const int yv = cg ? 0 : (int)pa.y[rowc];
-        double a = 0.0;
-        for (int k = 0; k < L; k += RSU) {
-            int idx[RSU];
-            float xv[RSU];
+        const int32_t *__restrict__ ptr = pa.rs_ptr + (int64_t)sl * ngr + g0;
 #pragma unroll
-            for (int u = 0; u < RSU; u++) {
-                const int kk = min(k + u, L - 1);
-                // NT: the index stream is read once per tick (single lambda); with several lambdas per partition the
-                // problems of a partition share it through L2 and it must stay cacheable
-                idx[u] = NT ? __builtin_nontemporal_load(rs_idx + base + kk * 64 + lane) : rs_idx[base + kk * 64 + lane];
-                if (HASVAL) xv[u] = NT ? __builtin_nontemporal_load(rs_val + base + kk * 64 + lane) : rs_val[base + kk * 64 + lane];
-            }
-            double vv[RSU];
-#pragma unroll
-            for (int u = 0; u < RSU; u++) {
-                if (HOT > 0) vv[u] = idx[u] < HOT ? hot[idx[u]] : v[idx[u]];
-                else vv[u] = v[idx[u]];
-            }
-#pragma unroll
-            for (int u = 0; u < RSU; u++) {
-                const double term = HASVAL ? vv[u] * (double)xv[u] : vv[u];
-                if (k + u < len) a = a + term;
+        for (int i = 0; i < ROW_MAXG; i++) {
+            const int gi = wave + 16 * i;
+            if (gi < gcount) {
+                const int base = ptr[gi];
+                const int L = (ptr[gi + 1] - base) >> 6;
+                acc[i] = sell_lds_sum<HASVAL, NT>(acc[i], rs_idx, rs_val, base, L, lane, vs, slw);
             }
         }
-        if (valid) {
-            const double t = a + vb;
+    }
+    const double vb = v[nf];
+    double red[2] = {0.0, 0.0};          // loss, sum of coef
+#pragma unroll
+    for (int i = 0; i < ROW_MAXG; i++) {
+        const int gi = wave + 16 * i;
+        const int row = (g0 + gi) * 64 + lane;
+        if (gi < gcount && row < l) {
+            const double t = acc[i] + vb;
             double cf;
             if (cg) {
-                cf = wdv0 * t;
+                cf = wdcur[row] * t;
             } else {
                 double loss, wdv;
-                row_eval(t + (double)offv, yv, (double)wtv, loss, wdv, cf);
+                row_eval(t + (double)pa.off[row], (int)pa.y[row], (double)pa.wt[row], loss, wdv, cf);
                 wdnew[row] = wdv;
                 red[0] += loss;
             }
@@ -513,19 +533,19 @@ k_rowpass_sell(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, c
         }
     }
     block_allreduce_sum<2>(red, scratch);
-    if (threadIdx.x == 0) { pr.lossp[b] = red[0]; pr.csump[b] = red[1]; }
+    if (tid == 0) { pr.lossp[c] = red[0]; pr.csump[c] = red[1]; }
 }
 
 // Column pass with the row coefficients in LDS. One workgroup = (problem, work unit): the unit's row block of `coef`
-// (<= 19 456 doubles) is staged once, then every wave walks item slices of that block: one THREAD per item, entry k of
-// the 64 items one coalesced 256-B index load, the gather served by LDS instead of the L2 request path (which is what
+// (<= 20 160 doubles) is staged once, then every wave walks item slices of that block: one THREAD per item, entry k of
+// the 64 items one coalesced 128-B index load, the gather served by LDS instead of the L2 request path (which is what
 // bounds the global-gather form: ~250 G random 8-byte requests/s chip-wide). Sums run in row order, contraction off.
 template <bool HASVAL, bool NT>
 __global__ void __launch_bounds__(1024)
 k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx)
 {
 #pragma clang fp contract(off)
-    extern __shared__ double cf[];
+    extern __shared__ __attribute__((aligned(16))) double cf[];      // [rblk_rows + 1]: the block's coefficients, then the zero slot
     int pi_, bx_;
     if (!xcd_map(nq, gx, pi_, bx_)) return;
     const int q = qlist[pi_];
@@ -546,39 +566,21 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
             cf[2 * i + 1] = v2.y;
         }
         if ((nr & 1) && threadIdx.x == 0) cf[nr - 1] = src[nr - 1];
+        if (threadIdx.x == 0) cf[pa.rblk_rows] = 0.0;
     }
     __syncthreads();
-    const int32_t *__restrict__ cs_idx = pa.cs_idx;
+    const uint16_t *__restrict__ cs_idx = pa.cs_idx;
     const float *__restrict__ cs_val = pa.cs_val;
     const int32_t *__restrict__ cs_ptr = pa.cs_ptr;
-    const int32_t *__restrict__ item_ptr = pa.item_ptr;
     const int32_t *__restrict__ item_dst = pa.item_dst;
     double *__restrict__ out = pr.parts;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int s = s0 + wave; s < s1; s += 16) {
         const int base = cs_ptr[s];
         const int L = (cs_ptr[s + 1] - base) >> 6;
-        const int item = s * 64 + lane;
-        const int len = item_ptr[item + 1] - item_ptr[item];
-        const int dst = item_dst[item];
-        double a = 0.0;
-        for (int k = 0; k < L; k += CSU) {
-            int idx[CSU];
-            float xv[CSU];
-#pragma unroll
-            for (int u = 0; u < CSU; u++) {
-                const int kk = min(k + u, L - 1);
-                idx[u] = NT ? __builtin_nontemporal_load(cs_idx + base + kk * 64 + lane) : cs_idx[base + kk * 64 + lane];
-                if (HASVAL) xv[u] = NT ? __builtin_nontemporal_load(cs_val + base + kk * 64 + lane) : cs_val[base + kk * 64 + lane];
-            }
-#pragma unroll
-            for (int u = 0; u < CSU; u++) {
-                const double c = cf[idx[u]];
-                const double term = HASVAL ? c * (double)xv[u] : c;
-                if (k + u < len) a = a + term;
-            }
-        }
-        if (len > 0) out[dst] = a;
+        const int dst = item_dst[s * 64 + lane];
+        const double a = sell_lds_sum<HASVAL, NT>(0.0, cs_idx, cs_val, base, L, lane, cf, pa.rblk_rows);
+        if (dst >= 0) out[dst] = a;
     }
 }
 
@@ -1999,36 +2001,30 @@ static void launch_rowpass(hipStream_t st, const PartDev *parts, ProbDev *probs,
 }
 
 int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
-                   int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cunits, int max_rblk_rows, int hot, bool stream_once, int which)
+                   int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cunits, int max_rblk_rows, int row_slw, bool stream_once, int which)
 {
     const bool do_row = which & 1, do_col = which & 2;
     if (nq <= 0) return 0;
     if (sell) {
-        const size_t lds = (size_t)max_rblk_rows * sizeof(double);
+        const size_t lds_col = ((size_t)max_rblk_rows + 1) * sizeof(double), lds_row = ((size_t)row_slw + 1) * sizeof(double);
         static bool attr_set = false;
         if (!attr_set) {
-#define SETLDS(HV, NTF) hipFuncSetAttribute(reinterpret_cast<const void *>(&k_colpass_lds<HV, NTF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+#define SETLDS(HV, NTF)                                                                                                                        \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_colpass_lds<HV, NTF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowpass_lds<HV, NTF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)
             SETLDS(true, true); SETLDS(true, false); SETLDS(false, true); SETLDS(false, false);
 #undef SETLDS
             attr_set = true;
         }
-#define LAUNCH_ROWSELL(HV, H, NTF) hipLaunchKernelGGL((k_rowpass_sell<HV, H, NTF>), dim3(XGRID(nq, maxblk)), dim3(256), 0, st, parts, probs, qlist, nq, maxblk)
-#define LAUNCH_COLLDS(HV, NTF) hipLaunchKernelGGL((k_colpass_lds<HV, NTF>), dim3(XGRID(nq, max_cunits)), dim3(1024), lds, st, parts, probs, qlist, nq, max_cunits)
-#define LAUNCH_SELL(HV, NTF)                                         \
-        do {                                                         \
-            if (do_row) switch (hot) {                               \
-            case 2048: LAUNCH_ROWSELL(HV, 2048, NTF); break;         \
-            case 4096: LAUNCH_ROWSELL(HV, 4096, NTF); break;         \
-            case 8192: LAUNCH_ROWSELL(HV, 8192, NTF); break;         \
-            default: LAUNCH_ROWSELL(HV, 0, NTF); break;              \
-            }                                                        \
-            if (do_col && max_cunits > 0) LAUNCH_COLLDS(HV, NTF);    \
+#define LAUNCH_SELL(HV, NTF)                                                                                                                   \
+        do {                                                                                                                                   \
+            if (do_row) hipLaunchKernelGGL((k_rowpass_lds<HV, NTF>), dim3(XGRID(nq, maxblk)), dim3(1024), lds_row, st, parts, probs, qlist, nq, maxblk); \
+            if (do_col && max_cunits > 0)                                                                                                      \
+                hipLaunchKernelGGL((k_colpass_lds<HV, NTF>), dim3(XGRID(nq, max_cunits)), dim3(1024), lds_col, st, parts, probs, qlist, nq, max_cunits); \
         } while (0)
         if (hasval) { if (stream_once) LAUNCH_SELL(true, true); else LAUNCH_SELL(true, false); }
         else { if (stream_once) LAUNCH_SELL(false, true); else LAUNCH_SELL(false, false); }
 #undef LAUNCH_SELL
-#undef LAUNCH_COLLDS
-#undef LAUNCH_ROWSELL
         return 0;
     }
     if (do_row) switch (rowgroup) {

@@ -41,15 +41,20 @@ struct PartDev {
     const int32_t *items_short;  // real item ids with <= 64 entries (8-lane groups; fallback kernels)
     const int32_t *items_long;   // real item ids with 65..SEG entries (one wave each)
     int32_t n_short, n_long;
-    // Sliced-ELL copies (slices of 64 work items, entry k of the 64 items contiguous): coalesced index streams for
-    // thread-per-row / thread-per-item passes. sell != 0 when built (row padding <= 1.5x nnz).
+    // Sliced-ELL copies for the LDS passes; sell != 0 when built (row-side padding <= 2x nnz).
+    // Row side: n_cs column slices of slw columns x n_rgroups groups of 64 rows; block (s, g) at rs_ptr[s*n_rgroups + g]
+    // holds, entry-major ([k][lane]), the slice-local uint16 column ids of the 64 rows' entries in slice s, padded with slw
+    // (the LDS slot behind the staged slice, which holds 0.0).
     int32_t sell;
-    int32_t n_rslices, n_cslices;
-    const int32_t *rs_ptr;     // [n_rslices+1] entry offset of each row slice (rows 64s .. 64s+63)
-    const int32_t *rs_idx;     // [rs_ptr[n_rslices]] local column ids, slot (slice, k, lane) at rs_ptr[s] + k*64 + lane
+    int32_t n_cs, slw, n_rgroups, n_cslices;
+    int32_t rgroups_per_chunk; // row groups one row-pass workgroup owns (set at finalize); nblk = chunks
+    const int32_t *rs_ptr;     // [n_cs*n_rgroups + 1] entry offsets
+    const uint16_t *rs_idx;
     const float *rs_val;       // values in the same layout or nullptr (binary.feature)
-    const int32_t *cs_ptr;     // [n_cslices+1] same for the items: slice s = items 64s .. 64s+63 (one block each)
-    const int32_t *cs_idx;     // row ids RELATIVE to the item's row block (index into the LDS-staged coefficients)
+    // Column side: slice s = items 64s .. 64s+63 (one row block each), entry-major; row ids RELATIVE to the item's row
+    // block as uint16 (index into the LDS-staged coefficients), padded with rblk_rows (zero slot).
+    const int32_t *cs_ptr;     // [n_cslices+1]
+    const uint16_t *cs_idx;
     const float *cs_val;
     int32_t n_cunits;          // work units of the LDS column pass: unit u = slices [cw_slice[u], cw_slice[u+1]) of block cw_blk[u]
     const int32_t *cw_blk;     // [n_cunits]

@@ -24,8 +24,8 @@ class TronStats(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_ORACLE_DIR, "admm_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_ORACLE_DIR, f) for f in ("admm_oracle.c", "synth.c")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _ORACLE_DIR, "-s", "liboracle.so"])
     return _LIB_PATH
 
@@ -70,6 +70,7 @@ def lib():
         L.orc_test_loglik_sum.restype = f64
         L.orc_test_loglik_sum.argtypes = [i32, vp, i32, vp, vp, vp, vp, vp, vp]
         L.orc_score_rows.argtypes = [i32, vp, i32, vp, vp, vp, vp, vp]
+        L.orc_synth_dense.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, i32, i32, f64, vp, vp, vp]
         L.orc_admm_run.restype = i32
         L.orc_admm_run.argtypes = [vp, i32, f64, i32, i32, vp, vp]
         _lib = L
@@ -248,3 +249,12 @@ def score_rows(model32, row_ptr, gidx, val, offset=None) -> np.ndarray:
     out = np.empty(len(rp) - 1, np.float32)
     lib().orc_score_rows(len(z), _p(z), len(rp) - 1, _p(rp), _p(gi), _p(v), _p(o), _p(out))
     return out
+
+
+def synth_dense(row0: int, rows: int, nfeat: int, beta: np.ndarray, seed: int, stream: int = 0, bias: float = -1.0, stride: int = 1):
+    """C twin of tools/synth_data.dense_rows_np (oracle/synth.c): (X float32 [rows, nfeat], y int8)."""
+    X = np.empty((rows, nfeat), np.float32)
+    y = np.empty(rows, np.int8)
+    b = np.ascontiguousarray(beta, np.float64)
+    lib().orc_synth_dense(int(seed), int(stream), int(row0), int(stride), int(rows), int(nfeat), float(bias), _p(b), _p(X), _p(y))
+    return X, y

@@ -60,9 +60,10 @@ def dense_beta(nfeat: int, seed: int = SEED) -> np.ndarray:
     return 0.1 * (ih12_np(np.arange(nfeat), seed, 1).astype(np.float64) / 65536.0)
 
 
-def dense_rows_np(row0: int, rows: int, nfeat: int, seed: int = SEED, stream: int = 0, bias: float = -1.0):
-    """Rows row0 .. row0+rows-1 of the dense matrix: (X float32 [rows, nfeat], y int8 +1/-1)."""
-    r = np.arange(row0, row0 + rows, dtype=np.uint64)
+def dense_rows_np(row0: int, rows: int, nfeat: int, seed: int = SEED, stream: int = 0, bias: float = -1.0, stride: int = 1):
+    """Rows row0, row0+stride, ... (`rows` of them) of the dense matrix: (X float32 [rows, nfeat], y int8 +1/-1).
+    Partition k of P = (row0=k, stride=P): SURVEY 8d's `row % P` assignment."""
+    r = (row0 + stride * np.arange(rows)).astype(np.uint64)
     counter = r[:, None] * np.uint64(nfeat) + np.arange(nfeat, dtype=np.uint64)[None, :]
     X = (ih12_np(counter, seed, stream).astype(np.float32)) / np.float32(65536.0)
     logit = X.astype(np.float64) @ dense_beta(nfeat, seed) + bias
@@ -88,9 +89,10 @@ def _hash_t(torch, counter, key: int):
     return x ^ _lsr_t(torch, x, 31)
 
 
-def dense_rows_torch(torch, device, row0: int, rows: int, nfeat: int, seed: int = SEED, stream: int = 0, bias: float = -1.0):
+def dense_rows_torch(torch, device, row0: int, rows: int, nfeat: int, seed: int = SEED, stream: int = 0, bias: float = -1.0,
+                     stride: int = 1):
     """Same values as dense_rows_np, generated on `device`: (X float32 [rows, nfeat], y int8)."""
-    r = torch.arange(row0, row0 + rows, dtype=torch.int64, device=device)
+    r = row0 + stride * torch.arange(rows, dtype=torch.int64, device=device)
     counter = r[:, None] * nfeat + torch.arange(nfeat, dtype=torch.int64, device=device)[None, :]
     s = torch.zeros(counter.shape, dtype=torch.int64, device=device)
     for k in range(3):
