@@ -564,8 +564,8 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
     // Sliced-ELL copies for the thread-per-item passes (k_rowpass_lds / k_colpass_lds). Both passes gather from LDS only:
     //  * row side: the columns are cut into n_cs column slices of slw columns (one slice of the gathered vector = <= 152 KiB
     //    of LDS), the rows into groups of 64; block (slice s, group g) holds the entries of those 64 rows whose column
-    //    lies in slice s, padded to the group's longest such run: entry k of the 64 rows is 64 contiguous uint16
-    //    slice-local ids (padding = slw, a slot that holds 0.0). Blocks are stored slice-major, so a workgroup that owns a
+    //    lies in slice s, padded to the group's longest such run (in packs of 4): entries 4p..4p+3 of a row are four
+    //    contiguous uint16 slice-local ids, pack p of the 64 rows 512 contiguous bytes (padding = slw, a slot that holds 0.0). Blocks are stored slice-major, so a workgroup that owns a
     //    range of row groups reads one contiguous piece per slice, whatever that range is (it is chosen at finalize).
     //  * column side: see below (row ids relative to the row block, uint16, padding = rblk_rows).
     // Built when the padded row side costs <= 2x the non-zeros (one-hot rows: ~1.5x, the cold slices hold 0-3 entries a row).
@@ -597,7 +597,7 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
                 int mx = 0;
                 for (int r = g * 64; r < std::min(l, g * 64 + 64); r++)
                     mx = std::max(mx, cut[(size_t)r * (ncs_r + 1) + sl + 1] - cut[(size_t)r * (ncs_r + 1) + sl]);
-                padded += (int64_t)mx * 64;
+                padded += (int64_t)((mx + 3) / 4) * 256;    // entries in packs of 4 per lane: one 8-byte load = 4 ids
                 rs_ptr[(size_t)sl * ngr + g + 1] = (int32_t)std::min<int64_t>(padded, std::numeric_limits<int32_t>::max());
             }
         ph.sell = nnz > 0 && (double)padded <= 2.0 * (double)nnz + 4096.0 && padded < (int64_t)std::numeric_limits<int32_t>::max() &&
@@ -610,7 +610,7 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
                     const int32_t base = rs_ptr[(size_t)sl * ngr + (r >> 6)], lane = r & 63;
                     const int32_t k0 = cut[(size_t)r * (ncs_r + 1) + sl], k1 = cut[(size_t)r * (ncs_r + 1) + sl + 1];
                     for (int32_t k = k0; k < k1; k++) {
-                        const size_t dst = (size_t)base + (size_t)(k - k0) * 64 + (size_t)lane;
+                        const size_t dst = (size_t)base + (size_t)((k - k0) >> 2) * 256 + (size_t)lane * 4 + (size_t)((k - k0) & 3);
                         rs_idx[dst] = (uint16_t)(col_idx_p[k] - sl * slw);
                         if (val) rs_val[dst] = val_p[k];
                     }
@@ -624,7 +624,7 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
             for (int s2 = 0; s2 < ncs; s2++) {
                 int32_t mx = 0;
                 for (int t = s2 * 64; t < s2 * 64 + 64; t++) mx = std::max(mx, item_ptr[(size_t)t + 1] - item_ptr[(size_t)t]);
-                cs_ptr[(size_t)s2 + 1] = cs_ptr[(size_t)s2] + mx * 64;
+                cs_ptr[(size_t)s2 + 1] = cs_ptr[(size_t)s2] + (mx + 3) / 4 * 256;
             }
             cs_idx.assign((size_t)cs_ptr[(size_t)ncs], (uint16_t)RB);       // padding gathers the zero slot behind the block
             if (val) cs_val.assign((size_t)cs_ptr[(size_t)ncs], 0.f);
@@ -632,7 +632,8 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
                 for (int it = blk_item0[(size_t)bk]; it < blk_item0[(size_t)bk + 1]; it++) {
                     const int32_t base = cs_ptr[(size_t)(it >> 6)], lane = it & 63;
                     for (int32_t k = item_ptr[(size_t)it]; k < item_ptr[(size_t)it + 1]; k++) {
-                        const size_t dst = (size_t)base + (size_t)(k - item_ptr[(size_t)it]) * 64 + (size_t)lane;
+                        const int32_t e = k - item_ptr[(size_t)it];
+                        const size_t dst = (size_t)base + (size_t)(e >> 2) * 256 + (size_t)lane * 4 + (size_t)(e & 3);
                         cs_idx[dst] = (uint16_t)(cri[(size_t)k] - bk * RB);
                         if (val) cs_val[dst] = cval[(size_t)k];
                     }

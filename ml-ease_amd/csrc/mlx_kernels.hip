@@ -415,38 +415,75 @@ k_colpass_items(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, 
 // from global memory by the L2 random-request rate (a 64-byte line moves for every 8 bytes used: the 25 % "cold" gathers
 // of the one-hot data cost as much as the 75 % served by a 4096-entry LDS copy). Here the gathered vector itself is cut
 // into slices that fit in LDS and staged slice by slice (coalesced 16-byte loads), the index streams are uint16 (slice- /
-// block-local ids: half the bytes of the dominant stream), entry k of 64 consecutive work items is one contiguous
-// 128-byte load, every lane has LSU independent index loads + LDS reads in flight and there is no cross-lane reduction.
+// block-local ids: half the bytes of the dominant stream) in packs of four per work item, pack p of 64 consecutive work
+// items one contiguous 512-byte load, every lane has LSU such loads + 4 LSU LDS reads in flight and there is no
+// cross-lane reduction.
 // Padding entries point at an LDS slot that holds 0.0 (x + 0.0 == x): no length masks, no per-item length loads.
 // Each sum runs sequentially over the item's entries (ascending library column id; ascending row inside an item) with
 // contraction off -- the same order as before the slicing, so results are unchanged bit for bit.
 // ------------------------------------------------------------------------------------------------
 #ifndef LSU
-#define LSU 8
+#define LSU 6          // 8-byte index loads (4 ids each) in flight per lane: the 20-entry rows of the one-hot configs take one round
 #endif
+// Sum of one work item (a row's entries in one column slice / a column item): packs of 4 uint16 ids, pack p of the 64
+// lanes' items contiguous (base is a multiple of 256 ids); L4 = packs per item.
 template <bool HASVAL, bool NT>
 __device__ __forceinline__ double sell_lds_sum(double a, const uint16_t *__restrict__ idx, const float *__restrict__ val, int base,
-                                               int L, int lane, const double *__restrict__ lds, int zslot)
+                                               int L4, int lane, const double *__restrict__ lds, int zslot)
 {
 #pragma clang fp contract(off)
-    for (int k = 0; k < L; k += LSU) {
-        int id[LSU];
-        float xv[LSU];
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const u2v *__restrict__ ip = reinterpret_cast<const u2v *>(idx + base) + lane;
+    const f4v *__restrict__ vp = reinterpret_cast<const f4v *>(val + base) + lane;
+    const unsigned zz = (unsigned)zslot | ((unsigned)zslot << 16);
+    constexpr int U = HASVAL ? 4 : LSU;                     // valued entries carry a float4 per pack: fewer packs in flight
+    for (int k = 0; k < L4; k += U) {
+        u2v q[U];
+        f4v xv[U];
 #pragma unroll
-        for (int u = 0; u < LSU; u++) {
-            const int kk = min(k + u, L - 1);               // unconditional clamped loads (a predicated load is waited for alone)
-            const int off = base + kk * 64 + lane;
-            const int t = NT ? (int)__builtin_nontemporal_load(idx + off) : (int)idx[off];
-            id[u] = (k + u < L) ? t : zslot;
-            if (HASVAL) xv[u] = NT ? __builtin_nontemporal_load(val + off) : val[off];
+        for (int u = 0; u < U; u++) {
+            const int kk = min(k + u, L4 - 1);              // unconditional clamped loads (a predicated load is waited for alone)
+            q[u] = NT ? __builtin_nontemporal_load(ip + kk * 64) : ip[kk * 64];
+            if (HASVAL) xv[u] = NT ? __builtin_nontemporal_load(vp + kk * 64) : vp[kk * 64];
         }
 #pragma unroll
-        for (int u = 0; u < LSU; u++) {
-            const double c = lds[id[u]];
-            a = a + (HASVAL ? c * (double)xv[u] : c);
+        for (int u = 0; u < U; u++) {
+            const bool in = (k + u < L4);
+            const unsigned q0 = in ? q[u].x : zz, q1 = in ? q[u].y : zz;
+            const double c0 = lds[q0 & 0xFFFFu], c1 = lds[q0 >> 16], c2 = lds[q1 & 0xFFFFu], c3 = lds[q1 >> 16];
+            a = a + (HASVAL ? c0 * (double)xv[u].x : c0);
+            a = a + (HASVAL ? c1 * (double)xv[u].y : c1);
+            a = a + (HASVAL ? c2 * (double)xv[u].z : c2);
+            a = a + (HASVAL ? c3 * (double)xv[u].w : c3);
         }
     }
     return a;
+}
+
+// Staging of up to STAGE_MAX2 * 1024 double2 from global memory into LDS through registers, so that the loads of one
+// slice can be in flight while the previous slice is still being read (issue stage_fetch, work, barrier, stage_store).
+#define STAGE_MAX2 10
+struct StageRegs { double2 r[STAGE_MAX2]; };
+__device__ __forceinline__ void stage_fetch(StageRegs &R, const double *__restrict__ src, int cnt, int tid)
+{
+    const double2 *__restrict__ s2 = reinterpret_cast<const double2 *>(src);
+    const int np2 = cnt >> 1;
+#pragma unroll
+    for (int u = 0; u < STAGE_MAX2; u++) {
+        const int i = tid + u * 1024;
+        R.r[u] = s2[min(i, max(np2 - 1, 0))];
+    }
+}
+__device__ __forceinline__ void stage_store(const StageRegs &R, double *__restrict__ lds, const double *__restrict__ src, int cnt, int tid)
+{
+    const int np2 = cnt >> 1;
+#pragma unroll
+    for (int u = 0; u < STAGE_MAX2; u++) {
+        const int i = tid + u * 1024;
+        if (i < np2) { lds[2 * i] = R.r[u].x; lds[2 * i + 1] = R.r[u].y; }
+    }
+    if ((cnt & 1) && tid == 0) lds[cnt - 1] = src[cnt - 1];
 }
 
 // Row pass. One 1024-thread workgroup = (problem, chunk of <= 128 row groups of 64 rows): for every column slice it stages
@@ -484,30 +521,24 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     double acc[ROW_MAXG];
 #pragma unroll
     for (int i = 0; i < ROW_MAXG; i++) acc[i] = 0.0;
+    StageRegs SR;
+    if (nf > 0) stage_fetch(SR, v, min(slw, nf), tid);
     for (int sl = 0; sl < ncs; sl++) {
         const int c0 = sl * slw;
         const int cnt = min(slw, nf - c0);
         __syncthreads();                                     // the previous slice's readers are done
-        {
-            const double2 *__restrict__ src = reinterpret_cast<const double2 *>(v + c0);    // c0 is a multiple of 64
-            const int np2 = cnt >> 1;
-            for (int i = tid; i < np2; i += 1024) {
-                const double2 v2 = src[i];
-                vs[2 * i] = v2.x;
-                vs[2 * i + 1] = v2.y;
-            }
-            if ((cnt & 1) && tid == 0) vs[cnt - 1] = v[c0 + cnt - 1];
-            if (tid == 0) vs[slw] = 0.0;
-        }
+        stage_store(SR, vs, v + c0, cnt, tid);               // c0 is a multiple of 64: aligned pairs
+        if (tid == 0) vs[slw] = 0.0;
         __syncthreads();
+        if (sl + 1 < ncs) stage_fetch(SR, v + c0 + slw, min(slw, nf - c0 - slw), tid);     // in flight while this slice is read
         const int32_t *__restrict__ ptr = pa.rs_ptr + (int64_t)sl * ngr + g0;
 #pragma unroll
         for (int i = 0; i < ROW_MAXG; i++) {
             const int gi = wave + 16 * i;
             if (gi < gcount) {
                 const int base = ptr[gi];
-                const int L = (ptr[gi + 1] - base) >> 6;
-                acc[i] = sell_lds_sum<HASVAL, NT>(acc[i], rs_idx, rs_val, base, L, lane, vs, slw);
+                const int L4 = (ptr[gi + 1] - base) >> 8;
+                acc[i] = sell_lds_sum<HASVAL, NT>(acc[i], rs_idx, rs_val, base, L4, lane, vs, slw);
             }
         }
     }
@@ -558,14 +589,10 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     const int r0 = blk * pa.rblk_rows;
     const int nr = min(pa.rblk_rows, pa.l - r0);
     {
+        StageRegs SR;
         const double *__restrict__ src = pr.coef + r0;      // r0 is a multiple of 64: 16-byte aligned pairs
-        const int np2 = nr >> 1;
-        for (int i = threadIdx.x; i < np2; i += 1024) {
-            const double2 v2 = reinterpret_cast<const double2 *>(src)[i];
-            cf[2 * i] = v2.x;
-            cf[2 * i + 1] = v2.y;
-        }
-        if ((nr & 1) && threadIdx.x == 0) cf[nr - 1] = src[nr - 1];
+        stage_fetch(SR, src, nr, threadIdx.x);               // <= 20 160 doubles: all loads of the block in flight at once
+        stage_store(SR, cf, src, nr, threadIdx.x);
         if (threadIdx.x == 0) cf[pa.rblk_rows] = 0.0;
     }
     __syncthreads();
@@ -577,9 +604,9 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int s = s0 + wave; s < s1; s += 16) {
         const int base = cs_ptr[s];
-        const int L = (cs_ptr[s + 1] - base) >> 6;
+        const int L4 = (cs_ptr[s + 1] - base) >> 8;
         const int dst = item_dst[s * 64 + lane];
-        const double a = sell_lds_sum<HASVAL, NT>(0.0, cs_idx, cs_val, base, L, lane, cf, pa.rblk_rows);
+        const double a = sell_lds_sum<HASVAL, NT>(0.0, cs_idx, cs_val, base, L4, lane, cf, pa.rblk_rows);
         if (dst >= 0) out[dst] = a;
     }
 }

@@ -92,6 +92,7 @@ class OracleDataset:
                       np.ascontiguousarray(offset, np.float32)]
         k = self._keep
         self.h = lib().orc_dataset_create(self.l, self.n, _p(k[0]), _p(k[1]), _p(k[2]), _p(k[3]), _p(k[4]), _p(k[5]))
+        self._keep = None            # orc_dataset_create copies everything into its own row-sparse layout
 
     @classmethod
     def from_block(cls, b) -> "OracleDataset":
