@@ -444,14 +444,22 @@ __device__ __forceinline__ double sell_lds_sum(double a, const uint16_t *__restr
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int kk = min(k + u, L4 - 1);              // unconditional clamped loads (a predicated load is waited for alone)
+#if defined(MLX_ABLATE) && (MLX_ABLATE & 2)      /* timing experiments only (tools/ablate.sh): no index loads */
+            q[u].x = (unsigned)((lane * 37 + kk * 101) & 0x3FFF) * 0x10001u; q[u].y = q[u].x + 0x00010001u;
+#else
             q[u] = NT ? __builtin_nontemporal_load(ip + kk * 64) : ip[kk * 64];
+#endif
             if (HASVAL) xv[u] = NT ? __builtin_nontemporal_load(vp + kk * 64) : vp[kk * 64];
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const bool in = (k + u < L4);
             const unsigned q0 = in ? q[u].x : zz, q1 = in ? q[u].y : zz;
+#if defined(MLX_ABLATE) && (MLX_ABLATE & 1)      /* timing experiments only: no LDS gathers */
+            const double c0 = (double)(q0 & 0xFFFFu), c1 = (double)(q0 >> 16), c2 = (double)(q1 & 0xFFFFu), c3 = (double)(q1 >> 16);
+#else
             const double c0 = lds[q0 & 0xFFFFu], c1 = lds[q0 >> 16], c2 = lds[q1 & 0xFFFFu], c3 = lds[q1 >> 16];
+#endif
             a = a + (HASVAL ? c0 * (double)xv[u].x : c0);
             a = a + (HASVAL ? c1 * (double)xv[u].y : c1);
             a = a + (HASVAL ? c2 * (double)xv[u].z : c2);

@@ -14,7 +14,7 @@ import numpy as np
 from .dataset import ModelFittingError, PartitionBlock
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmlease_hip.so")
+LIB_PATH = os.environ.get("MLX_LIB_PATH") or os.path.join(_HERE, "csrc", "libmlease_hip.so")   # MLX_LIB_PATH: A/B builds (tools/ablate.sh)
 UNIQUE_ID_BYTES = 128
 
 # every entry point include/mlease_admm.h declares (checked by tests/test_abi.py)
