@@ -51,6 +51,7 @@ struct mlx_context {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool profiling = false;
+    bool faithful = false;                 // MLX_FAITHFUL=1: order-faithful verification mode, CSR partitions only
     std::string err;
 
     int n_global = 0, n_lambda = 0, num_blocks = 0, penalize_intercept = 0, regularizer = 2;
@@ -243,12 +244,12 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
 {
     HIPCHECK(h, hipMemsetAsync(h->d_done, 0, sizeof(int), h->stream));
     h->h_done[0] = h->h_done[1] = 0;
-    if (h->csr_small && nqd == 0 && nqc == count && !h->profiling) {
+    if (h->csr_small && nqd == 0 && nqc == count && (!h->profiling || h->faithful)) {
         // small CSR problems: the whole solve in one launch (k_solve_small), relaunched only if a problem needs more
         // than SMALL_TICKS_PER_LAUNCH ticks
         int64_t ticks = 0;
         for (;;) {
-            mlxk_solve_small(h->stream, h->d_parts, h->d_probs, count, first, h->csr_hasval, SMALL_TICKS_PER_LAUNCH, h->d_done, h->small_lds_doubles);
+            mlxk_solve_small(h->stream, h->d_parts, h->d_probs, count, first, h->csr_hasval, SMALL_TICKS_PER_LAUNCH, h->d_done, h->small_lds_doubles, h->faithful);
             ticks += SMALL_TICKS_PER_LAUNCH;
             HIPCHECK(h, hipMemcpyAsync(&h->h_done[0], h->d_done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIPCHECK(h, hipStreamSynchronize(h->stream));
@@ -336,6 +337,7 @@ int mlx_create(int device_id, mlx_handle *out)
         return fail(nullptr, MLX_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", device_id, prop.gcnArchName);
     mlx_context *h = new mlx_context();
     h->device = device_id;
+    h->faithful = getenv("MLX_FAITHFUL") != nullptr && atoi(getenv("MLX_FAITHFUL")) != 0;
     if (hipSetDevice(device_id) != hipSuccess) { delete h; return fail(nullptr, MLX_ERR_HIP, "hipSetDevice failed"); }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(nullptr, MLX_ERR_HIP, "hipStreamCreate failed"); }
     h->own_stream = true;
@@ -434,7 +436,7 @@ struct CsrPrep {
 
 static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t l, int32_t n_local, int64_t nnz,
                     const int64_t *row_ptr, const int32_t *col_idx, const float *val, const int8_t *y,
-                    const int32_t *local_to_global)
+                    const int32_t *local_to_global, bool faithful)
 {
     if (!row_ptr || (nnz > 0 && !col_idx) || !y) return P.fail(MLX_ERR_INVALID, "NULL row data");
     if (row_ptr[0] != 0 || row_ptr[l] != nnz) return P.fail(MLX_ERR_INVALID, "row_ptr[0] must be 0 and row_ptr[l] == nnz");
@@ -456,7 +458,8 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
         std::vector<int32_t> cnt((size_t)nf, 0);
         for (int64_t k = 0; k < nnz; k++) cnt[(size_t)col_idx[k]]++;
         for (int j = 0; j < nf; j++) new2old[(size_t)j] = j;
-        std::stable_sort(new2old.begin(), new2old.end(), [&](int32_t a, int32_t b) { return cnt[(size_t)a] > cnt[(size_t)b]; });
+        // (verification mode: the caller's first-seen order is kept, so a row's entries are summed in the reference's order)
+        if (!faithful) std::stable_sort(new2old.begin(), new2old.end(), [&](int32_t a, int32_t b) { return cnt[(size_t)a] > cnt[(size_t)b]; });
         for (int j = 0; j < nf; j++) newid[(size_t)new2old[(size_t)j]] = j;
     }
     std::vector<int32_t> pcol((size_t)nnz), l2g_perm((size_t)n_local);
@@ -496,8 +499,9 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
     // Row blocks (the LDS column pass stages one block of the row coefficients) and work items: the entries of column j
     // inside block b, rows ascending, cut into segments of <= CSC_SEG entries; items numbered block-major, each block
     // padded to a multiple of 64 items. cri/cval are re-ordered into item order so item_ptr is monotone.
-    const int seg = getenv("MLX_SEG") ? atoi(getenv("MLX_SEG")) : CSC_SEG;
-    const int rbmax = getenv("MLX_RBMAX") ? atoi(getenv("MLX_RBMAX")) : RBLK_MAX_ROWS;
+    // (verification mode: one row block, unsplit columns -- a column's sum then runs over its rows in ascending order, XTv's order)
+    const int seg = faithful ? std::numeric_limits<int32_t>::max() : (getenv("MLX_SEG") ? atoi(getenv("MLX_SEG")) : CSC_SEG);
+    const int rbmax = faithful ? std::numeric_limits<int32_t>::max() - 64 : (getenv("MLX_RBMAX") ? atoi(getenv("MLX_RBMAX")) : RBLK_MAX_ROWS);
     const int nb = std::max(1, (l + rbmax - 1) / rbmax);
     const int RB = std::max(64, ((l + nb - 1) / nb + 63) / 64 * 64);
     ph.n_rblk = nb; ph.rblk_rows = RB;
@@ -601,7 +605,8 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
                 rs_ptr[(size_t)sl * ngr + g + 1] = (int32_t)std::min<int64_t>(padded, std::numeric_limits<int32_t>::max());
             }
         ph.sell = nnz > 0 && (double)padded <= 2.0 * (double)nnz + 4096.0 && padded < (int64_t)std::numeric_limits<int32_t>::max() &&
-                  (int64_t)nnz + 64LL * ph.n_items < (int64_t)std::numeric_limits<int32_t>::max() / 2 && getenv("MLX_NO_SELL") == nullptr;
+                  (int64_t)nnz + 64LL * ph.n_items < (int64_t)std::numeric_limits<int32_t>::max() / 2 && getenv("MLX_NO_SELL") == nullptr &&
+                  !faithful;
         if (ph.sell) {
             rs_idx.assign((size_t)padded, (uint16_t)slw);
             if (val) rs_val.assign((size_t)padded, 0.f);
@@ -753,9 +758,9 @@ int mlx_add_partition_csr(mlx_handle h, int32_t partition_id, int32_t l, int32_t
     hipSetDevice(h->device);
     int rc = check_common_rows(h, partition_id, l, local_to_global, n_local);
     if (rc) return rc;
-    if (csr_is_dense_enough(l, n_local, nnz, row_ptr, col_idx)) return add_csr_as_dense_tile(h, partition_id, l, n_local, row_ptr, col_idx, val, y, weight, offset, local_to_global);
+    if (!h->faithful && csr_is_dense_enough(l, n_local, nnz, row_ptr, col_idx)) return add_csr_as_dense_tile(h, partition_id, l, n_local, row_ptr, col_idx, val, y, weight, offset, local_to_global);
     CsrPrep P;
-    if ((rc = prep_csr(P, h->n_global, partition_id, l, n_local, nnz, row_ptr, col_idx, val, y, local_to_global)))
+    if ((rc = prep_csr(P, h->n_global, partition_id, l, n_local, nnz, row_ptr, col_idx, val, y, local_to_global, h->faithful)))
         return fail(h, rc, "%s", P.error.c_str());
     return commit_csr(h, P, l, n_local, nnz, y, weight, offset);
 }
@@ -788,9 +793,9 @@ int mlx_add_partitions_csr(mlx_handle h, int32_t count, const int32_t *partition
         for (int j = 0; j < nb; j++)
             th.emplace_back([&, j] {
                 const int k = b0 + j;
-                if (csr_is_dense_enough(l[k], n_local[k], nnz[k], row_ptr[k], col_idx[k])) { as_tile[(size_t)j] = 1; return; }
+                if (!h->faithful && csr_is_dense_enough(l[k], n_local[k], nnz[k], row_ptr[k], col_idx[k])) { as_tile[(size_t)j] = 1; return; }
                 prep_csr(preps[(size_t)j], h->n_global, partition_id[k], l[k], n_local[k], nnz[k], row_ptr[k], col_idx[k],
-                         val ? val[k] : nullptr, y[k], local_to_global[k]);
+                         val ? val[k] : nullptr, y[k], local_to_global[k], h->faithful);
             });
         for (auto &t : th) t.join();
         for (int j = 0; j < nb; j++) {
@@ -818,6 +823,7 @@ int mlx_add_partition_dense(mlx_handle h, int32_t partition_id, int32_t l, int32
     int rc = check_common_rows(h, partition_id, l, local_to_global, n_local);
     if (rc) return rc;
     if (!X || !y || n_feat < 1 || ld < n_feat) return fail(h, MLX_ERR_INVALID, "bad dense tile arguments");
+    if (h->faithful) return fail(h, MLX_ERR_INVALID, "MLX_FAITHFUL (verification mode) supports CSR partitions only");
     if (n_feat > 2048) return fail(h, MLX_ERR_INVALID, "dense tile wider than 2048 features is not supported; use the CSR form");
     PartHost ph;
     ph.pid = partition_id; ph.l = l; ph.n_local = n_local; ph.n_feat = n_feat; ph.dense = true; ph.hasval = true;
@@ -895,7 +901,8 @@ int mlx_finalize(mlx_handle h)
     h->csr_small = getenv("MLX_NO_SMALL") == nullptr;
     for (auto &p : h->parts)
         if (!p.dense && (p.nnz > SMALL_MAX_NNZ || p.l > SMALL_MAX_DIM || p.n_local > SMALL_MAX_DIM)) h->csr_small = false;
-    if (h->csr_small && getenv("MLX_NO_SMALL_LDS") == nullptr) {
+    if (h->faithful) h->csr_small = true;                   // the verification kernel is the one-launch solve, whatever the size
+    if (h->csr_small && getenv("MLX_NO_SMALL_LDS") == nullptr && !h->faithful) {
         int64_t need = 0;
         for (auto &p : h->parts)
             if (!p.dense) need = std::max<int64_t>(need, 8LL * p.n_local + 3LL * p.l + p.n_items + 2LL * p.nblk);
@@ -945,7 +952,8 @@ int mlx_finalize(mlx_handle h)
     auto step_nwg = [&](int n_local) { return (size_t)((n_local + h->step_ch - 1) / h->step_ch); };
     auto vec_bytes = [&](int n_local, int l, int64_t plen, int nblk, bool dense) {
         return 8 * carve_size((size_t)n_local) + (dense ? 2 : 3) * carve_size((size_t)l) + carve_size((size_t)plen) + 2 * carve_size((size_t)nblk) +
-               (dense ? 0 : carve_size((size_t)n_local) + 3 * carve_size(step_nwg(n_local) * STEP_NP));
+               (dense ? 0 : carve_size((size_t)n_local) + 3 * carve_size(step_nwg(n_local) * STEP_NP)) +
+               (h->faithful ? carve_size((size_t)l) + carve_size((size_t)n_local) : 0);
     };
     const int scratch_blk = std::max(h->maxblk_dense, h->maxblk_csr);
     size_t slab_bytes = vec_bytes(h->max_nlocal, h->max_l, h->max_parts_len, scratch_blk, false) + carve_size((size_t)h->max_nlocal);
@@ -968,6 +976,7 @@ int mlx_finalize(mlx_handle h)
             pr.rb[0] = pr.r; pr.rb[1] = carve((size_t)n_local);
             pr.pA = carve(step_nwg(n_local) * STEP_NP); pr.pB = carve(step_nwg(n_local) * STEP_NP); pr.pC = carve(step_nwg(n_local) * STEP_NP);
         }
+        if (h->faithful) { pr.rowtmp = carve((size_t)l); pr.c0f = carve((size_t)n_local); }
         pr.parts = carve((size_t)plen);
         pr.lossp = carve((size_t)nblk);
         pr.csump = carve((size_t)nblk);

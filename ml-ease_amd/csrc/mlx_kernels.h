@@ -21,7 +21,7 @@ void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *p
                      int max_nwg, int *done_counter);
 // whole solves of small CSR problems in one launch (one workgroup per problem runs the tick loop)
 void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int first, bool hasval,
-                      int max_ticks, int *done_counter, int lds_doubles);
+                      int max_ticks, int *done_counter, int lds_doubles, bool faithful);
 void mlxk_collect_c0(hipStream_t st, const PartDev *parts, const ProbDev *probs, const int *qlist, int nq,
                      double *const *c0_ptrs);
 void mlxk_setup(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int n_lambda, int n_global,

@@ -17,6 +17,7 @@
 
 #include "mlx_kernels.h"
 #include "mlx_types.h"
+#include "portable_math.h"
 
 #define WAVE 64
 
@@ -103,12 +104,15 @@ __device__ __forceinline__ double norm_from_sumsq(double ss, const double *__res
 // row-wise scalar maps
 // ------------------------------------------------------------------------------------------------
 // fun + grad at one row (llf/LogisticRegressionL2.java:172-178, :211-215): z = x.w + offset
+// PM: the portable exp/log1p of portable_math.h (verification mode only; the oracle's -DORC_PORTABLE_MATH twin uses the same)
+template <bool PM = false>
 __device__ __forceinline__ void row_eval(double z, int y, double wt, double &loss, double &wd, double &coef)
 {
+#pragma clang fp contract(off)
     const double yz = (double)y * z;
-    if (yz >= 0) loss = wt * log1p(exp(-yz));
-    else loss = wt * (-yz + log1p(exp(yz)));
-    const double p = 1.0 / (1.0 + exp(-yz));
+    if (yz >= 0) loss = wt * (PM ? pm_log1p(pm_exp(-yz)) : log1p(exp(-yz)));
+    else loss = wt * (-yz + (PM ? pm_log1p(pm_exp(yz)) : log1p(exp(yz))));
+    const double p = 1.0 / (1.0 + (PM ? pm_exp(-yz) : exp(-yz)));
     wd = wt * (p * (1.0 - p));          // weight[i] * D[i]  (:243 multiplies in this order)
     coef = wt * (p - 1.0) * (double)y;  // :215
 }
@@ -423,50 +427,98 @@ k_colpass_items(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, 
 // contraction off -- the same order as before the slicing, so results are unchanged bit for bit.
 // ------------------------------------------------------------------------------------------------
 #ifndef LSU
-#define LSU 6          // 8-byte index loads (4 ids each) in flight per lane: the 20-entry rows of the one-hot configs take one round
+#define LSU 6          // 8-byte index loads (4 ids each) in flight per lane in the deep loop
 #endif
-// Sum of one work item (a row's entries in one column slice / a column item): packs of 4 uint16 ids, pack p of the 64
-// lanes' items contiguous (base is a multiple of 256 ids); L4 = packs per item.
-template <bool HASVAL, bool NT>
-__device__ __forceinline__ double sell_lds_sum(double a, const uint16_t *__restrict__ idx, const float *__restrict__ val, int base,
-                                               int L4, int lane, const double *__restrict__ lds, int zslot)
+typedef unsigned int u2v_t __attribute__((ext_vector_type(2)));
+typedef float f4v_t __attribute__((ext_vector_type(4)));
+
+// the four gathers + adds of one pack (ids q, values xv), in entry order
+template <bool HASVAL>
+__device__ __forceinline__ double pack_sum(double a, u2v_t q, f4v_t xv, const double *__restrict__ lds)
 {
 #pragma clang fp contract(off)
-    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    const u2v *__restrict__ ip = reinterpret_cast<const u2v *>(idx + base) + lane;
-    const f4v *__restrict__ vp = reinterpret_cast<const f4v *>(val + base) + lane;
+#if defined(MLX_ABLATE) && (MLX_ABLATE & 1)      /* timing experiments only (tools/ablate_build.sh): no LDS gathers */
+    const double c0 = (double)(q.x & 0xFFFFu), c1 = (double)(q.x >> 16), c2 = (double)(q.y & 0xFFFFu), c3 = (double)(q.y >> 16);
+#else
+    const double c0 = lds[q.x & 0xFFFFu], c1 = lds[q.x >> 16], c2 = lds[q.y & 0xFFFFu], c3 = lds[q.y >> 16];
+#endif
+    a = a + (HASVAL ? c0 * (double)xv.x : c0);
+    a = a + (HASVAL ? c1 * (double)xv.y : c1);
+    a = a + (HASVAL ? c2 * (double)xv.z : c2);
+    a = a + (HASVAL ? c3 * (double)xv.w : c3);
+    return a;
+}
+
+template <bool NT>
+__device__ __forceinline__ u2v_t pack_load(const uint16_t *__restrict__ idx, int base, int kk, int lane)
+{
+#if defined(MLX_ABLATE) && (MLX_ABLATE & 2)      /* timing experiments only: no index loads */
+    u2v_t q; q.x = (unsigned)((lane * 37 + kk * 101 + base) & 0x3FFF) * 0x10001u; q.y = q.x + 0x00010001u; return q;
+#else
+    const u2v_t *__restrict__ ip = reinterpret_cast<const u2v_t *>(idx + base) + kk * 64 + lane;
+    return NT ? __builtin_nontemporal_load(ip) : *ip;
+#endif
+}
+template <bool NT>
+__device__ __forceinline__ f4v_t pack_load_val(const float *__restrict__ val, int base, int kk, int lane)
+{
+    const f4v_t *__restrict__ vp = reinterpret_cast<const f4v_t *>(val + base) + kk * 64 + lane;
+    return NT ? __builtin_nontemporal_load(vp) : *vp;
+}
+
+// Packs kb .. L4-1 of ONE work item (a row's entries in one column slice / a column item), LSU packs in flight: the deep
+// loop for long items. base is a multiple of 256 ids; pack p of the 64 lanes' items is contiguous.
+template <bool HASVAL, bool NT>
+__device__ __forceinline__ double sell_lds_sum(double a, const uint16_t *__restrict__ idx, const float *__restrict__ val, int base,
+                                               int kb, int L4, int lane, const double *__restrict__ lds, int zslot)
+{
+#pragma clang fp contract(off)
     const unsigned zz = (unsigned)zslot | ((unsigned)zslot << 16);
     constexpr int U = HASVAL ? 4 : LSU;                     // valued entries carry a float4 per pack: fewer packs in flight
-    for (int k = 0; k < L4; k += U) {
-        u2v q[U];
-        f4v xv[U];
+    for (int k = kb; k < L4; k += U) {
+        u2v_t q[U];
+        f4v_t xv[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int kk = min(k + u, L4 - 1);              // unconditional clamped loads (a predicated load is waited for alone)
-#if defined(MLX_ABLATE) && (MLX_ABLATE & 2)      /* timing experiments only (tools/ablate.sh): no index loads */
-            q[u].x = (unsigned)((lane * 37 + kk * 101) & 0x3FFF) * 0x10001u; q[u].y = q[u].x + 0x00010001u;
-#else
-            q[u] = NT ? __builtin_nontemporal_load(ip + kk * 64) : ip[kk * 64];
-#endif
-            if (HASVAL) xv[u] = NT ? __builtin_nontemporal_load(vp + kk * 64) : vp[kk * 64];
+            q[u] = pack_load<NT>(idx, base, kk, lane);
+            if (HASVAL) xv[u] = pack_load_val<NT>(val, base, kk, lane);
+            if (k + u >= L4) { q[u].x = zz; q[u].y = zz; }
         }
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const bool in = (k + u < L4);
-            const unsigned q0 = in ? q[u].x : zz, q1 = in ? q[u].y : zz;
-#if defined(MLX_ABLATE) && (MLX_ABLATE & 1)      /* timing experiments only: no LDS gathers */
-            const double c0 = (double)(q0 & 0xFFFFu), c1 = (double)(q0 >> 16), c2 = (double)(q1 & 0xFFFFu), c3 = (double)(q1 >> 16);
-#else
-            const double c0 = lds[q0 & 0xFFFFu], c1 = lds[q0 >> 16], c2 = lds[q1 & 0xFFFFu], c3 = lds[q1 >> 16];
-#endif
-            a = a + (HASVAL ? c0 * (double)xv[u].x : c0);
-            a = a + (HASVAL ? c1 * (double)xv[u].y : c1);
-            a = a + (HASVAL ? c2 * (double)xv[u].z : c2);
-            a = a + (HASVAL ? c3 * (double)xv[u].w : c3);
-        }
+        for (int u = 0; u < U; u++) a = pack_sum<HASVAL>(a, q[u], xv[u], lds);
     }
     return a;
+}
+
+// The first KP packs of NI work items at once (NI*KP loads in flight, ONE memory latency for all of them): what makes
+// the short items -- the 0-3 entries a row has in a cold column slice, the rare features' column items -- cheap, where a
+// loop over items pays a full dependent-load latency per item. bases / L4s are wave-uniform.
+template <bool HASVAL, bool NT, int NI, int KP>
+__device__ __forceinline__ void sell_lds_first(double (&a)[NI], const uint16_t *__restrict__ idx, const float *__restrict__ val,
+                                               const int (&base)[NI], const int (&L4)[NI], int k0, int lane,
+                                               const double *__restrict__ lds, int zslot)
+{
+#pragma clang fp contract(off)
+    const unsigned zz = (unsigned)zslot | ((unsigned)zslot << 16);
+    u2v_t q[NI][KP];
+    f4v_t xv[NI][KP];
+#pragma unroll
+    for (int i = 0; i < NI; i++)
+#pragma unroll
+        for (int u = 0; u < KP; u++) {
+            const int kk = max(min(k0 + u, L4[i] - 1), 0);
+            q[i][u] = pack_load<NT>(idx, base[i], kk, lane);
+            if (HASVAL) xv[i][u] = pack_load_val<NT>(val, base[i], kk, lane);
+            if (k0 + u >= L4[i]) { q[i][u].x = zz; q[i][u].y = zz; }
+        }
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+#pragma unroll
+        for (int u = 0; u < KP; u++) a[i] = pack_sum<HASVAL>(a[i], q[i][u], xv[i][u], lds);
+        // keep the LDS reads of later items behind this item's adds: hoisting all NI*KP*4 of them costs 8 VGPRs per pack
+        if ((i & 1) == 1) asm volatile("" ::: "memory");
+    }
 }
 
 // Staging of up to STAGE_MAX2 * 1024 double2 from global memory into LDS through registers, so that the loads of one
@@ -524,29 +576,48 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     const int g0 = c * pa.rgroups_per_chunk;
     const int gcount = min(pa.rgroups_per_chunk, ngr - g0);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wg0 = wave * ROW_MAXG;                          // this wave's first row group within the chunk
     const uint16_t *__restrict__ rs_idx = pa.rs_idx;
     const float *__restrict__ rs_val = pa.rs_val;
     double acc[ROW_MAXG];
 #pragma unroll
     for (int i = 0; i < ROW_MAXG; i++) acc[i] = 0.0;
+    // binary features: the next slice is fetched into registers while this one is read; valued entries need those
+    // registers for their float4 per pack and fetch at the slice boundary instead
+    constexpr bool PREFETCH = !HASVAL;
     StageRegs SR;
-    if (nf > 0) stage_fetch(SR, v, min(slw, nf), tid);
+    if (PREFETCH && nf > 0) stage_fetch(SR, v, min(slw, nf), tid);
     for (int sl = 0; sl < ncs; sl++) {
         const int c0 = sl * slw;
         const int cnt = min(slw, nf - c0);
         __syncthreads();                                     // the previous slice's readers are done
+        if (!PREFETCH) stage_fetch(SR, v + c0, cnt, tid);
         stage_store(SR, vs, v + c0, cnt, tid);               // c0 is a multiple of 64: aligned pairs
         if (tid == 0) vs[slw] = 0.0;
         __syncthreads();
-        if (sl + 1 < ncs) stage_fetch(SR, v + c0 + slw, min(slw, nf - c0 - slw), tid);     // in flight while this slice is read
+        if (PREFETCH && sl + 1 < ncs) stage_fetch(SR, v + c0 + slw, min(slw, nf - c0 - slw), tid);     // in flight while this slice is read
+        // block offsets of this wave's ROW_MAXG consecutive groups: one load, then lane broadcasts (wave-uniform scalars)
         const int32_t *__restrict__ ptr = pa.rs_ptr + (int64_t)sl * ngr + g0;
+        const int pv = ptr[min(wg0 + min(lane, ROW_MAXG), gcount)];
+        int base[ROW_MAXG], L4[ROW_MAXG];
+        int kmax = 0;
 #pragma unroll
         for (int i = 0; i < ROW_MAXG; i++) {
-            const int gi = wave + 16 * i;
-            if (gi < gcount) {
-                const int base = ptr[gi];
-                const int L4 = (ptr[gi + 1] - base) >> 8;
-                acc[i] = sell_lds_sum<HASVAL, NT>(acc[i], rs_idx, rs_val, base, L4, lane, vs, slw);
+            base[i] = __builtin_amdgcn_readlane(pv, i);
+            const int nx = __builtin_amdgcn_readlane(pv, i + 1);
+            L4[i] = (wg0 + i < gcount) ? (nx - base[i]) >> 8 : 0;
+            kmax = max(kmax, L4[i]);
+        }
+        // one pack of every group per round: ROW_MAXG loads in flight (valued: in two halves, a float4 rides with each pack)
+        for (int k = 0; k < kmax; k++) {
+            if (HASVAL) {
+                constexpr int H = ROW_MAXG / 2;
+                sell_lds_first<HASVAL, NT, H, 1>(*reinterpret_cast<double (*)[H]>(&acc[0]), rs_idx, rs_val, *reinterpret_cast<const int (*)[H]>(&base[0]),
+                                                 *reinterpret_cast<const int (*)[H]>(&L4[0]), k, lane, vs, slw);
+                sell_lds_first<HASVAL, NT, H, 1>(*reinterpret_cast<double (*)[H]>(&acc[H]), rs_idx, rs_val, *reinterpret_cast<const int (*)[H]>(&base[H]),
+                                                 *reinterpret_cast<const int (*)[H]>(&L4[H]), k, lane, vs, slw);
+            } else {
+                sell_lds_first<HASVAL, NT, ROW_MAXG, 1>(acc, rs_idx, rs_val, base, L4, k, lane, vs, slw);
             }
         }
     }
@@ -554,7 +625,7 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     double red[2] = {0.0, 0.0};          // loss, sum of coef
 #pragma unroll
     for (int i = 0; i < ROW_MAXG; i++) {
-        const int gi = wave + 16 * i;
+        const int gi = wg0 + i;
         const int row = (g0 + gi) * 64 + lane;
         if (gi < gcount && row < l) {
             const double t = acc[i] + vb;
@@ -610,12 +681,29 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     const int32_t *__restrict__ item_dst = pa.item_dst;
     double *__restrict__ out = pr.parts;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int s = s0 + wave; s < s1; s += 16) {
-        const int base = cs_ptr[s];
-        const int L4 = (cs_ptr[s + 1] - base) >> 8;
-        const int dst = item_dst[s * 64 + lane];
-        const double a = sell_lds_sum<HASVAL, NT>(0.0, cs_idx, cs_val, base, L4, lane, cf, pa.rblk_rows);
-        if (dst >= 0) out[dst] = a;
+    // COL_B item slices per wave and round: their offsets, then their destinations and first packs, are fetched together
+    // (three dependent latencies per round instead of per slice); items longer than the first packs continue in the deep loop
+    constexpr int COL_B = 8, KP = HASVAL ? 1 : 2;
+    const int zs = pa.rblk_rows;
+    for (int sb = s0 + wave; sb < s1; sb += 16 * COL_B) {
+        int base[COL_B], L4[COL_B], dst[COL_B];
+        double a[COL_B];
+#pragma unroll
+        for (int u = 0; u < COL_B; u++) {
+            const int sl = sb + 16 * u;
+            const int sc = min(sl, s1 - 1);
+            base[u] = __builtin_amdgcn_readfirstlane(cs_ptr[sc]);
+            const int nx = __builtin_amdgcn_readfirstlane(cs_ptr[sc + 1]);
+            L4[u] = (sl < s1) ? (nx - base[u]) >> 8 : 0;
+            dst[u] = (sl < s1) ? item_dst[sc * 64 + lane] : -1;
+            a[u] = 0.0;
+        }
+        sell_lds_first<HASVAL, NT, COL_B, KP>(a, cs_idx, cs_val, base, L4, 0, lane, cf, zs);
+#pragma unroll
+        for (int u = 0; u < COL_B; u++) {
+            if (L4[u] > KP) a[u] = sell_lds_sum<HASVAL, NT>(a[u], cs_idx, cs_val, base[u], KP, L4[u], lane, cf, zs);
+            if (dst[u] >= 0) out[dst[u]] = a[u];
+        }
     }
 }
 
@@ -784,6 +872,71 @@ k_collect_c0(const PartDev *__restrict__ parts, const ProbDev *__restrict__ prob
     assemble_out(parts[pr.part], pr, c0_ptrs[blockIdx.x], scratch, stage);
 }
 
+// ---- order-faithful verification mode (MLX_FAITHFUL=1): every n- or l-long reduction is done by
+// ONE thread in the reference's sequential order, with the reference's formulas (bw/Tron.java:204-252). Slow by design.
+// The operands are staged through LDS 1024 at a time by all threads (coalesced loads, products formed in parallel -- an
+// elementwise operation, identical to the reference's), and thread 0 folds each chunk in index order.
+__device__ __forceinline__ double seq_bcast(double v, double *scratch)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) scratch[0] = v;
+    __syncthreads();
+    const double out = scratch[0];
+    __syncthreads();
+    return out;
+}
+template <typename F>
+__device__ __forceinline__ double seq_fold_sum(double init, int n, double *scratch, double *stage, F term)
+{
+#pragma clang fp contract(off)
+    double a = init;
+    for (int base = 0; base < n; base += 1024) {
+        const int j = base + (int)threadIdx.x;
+        __syncthreads();
+        if (j < n && threadIdx.x < 1024) stage[threadIdx.x] = term(j);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int cnt = min(1024, n - base);
+            for (int i = 0; i < cnt; i++) a += stage[i];
+        }
+    }
+    return seq_bcast(a, scratch);
+}
+__device__ __forceinline__ double seq_dot(const double *x, const double *y, int n, double *scratch, double *stage)   // Tron.dot :204-213
+{
+    return seq_fold_sum(0.0, n, scratch, stage, [=](int j) { return x[j] * y[j]; });
+}
+__device__ __forceinline__ double seq_sum(const double *x, int n, double *scratch, double *stage)
+{
+    return seq_fold_sum(0.0, n, scratch, stage, [=](int j) { return x[j]; });
+}
+__device__ __forceinline__ double seq_norm(const double *v, int n, double *scratch, double *stage)                   // Tron.euclideanNorm :220-252
+{
+#pragma clang fp contract(off)
+    if (n < 1) return 0.0;
+    if (n == 1) return seq_bcast(fabs(v[0]), scratch);
+    double scale = 0, sum = 1;
+    for (int base = 0; base < n; base += 1024) {
+        const int j = base + (int)threadIdx.x;
+        __syncthreads();
+        if (j < n && threadIdx.x < 1024) stage[threadIdx.x] = v[j];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int cnt = min(1024, n - base);
+            for (int i = 0; i < cnt; i++) {
+                const double vi = stage[i];
+                if (vi != 0) {
+                    const double a = fabs(vi);
+                    if (scale < a) { const double t = scale / a; sum = 1 + sum * (t * t); scale = a; }
+                    else { const double t = a / scale; sum += t * t; }
+                }
+            }
+        }
+    }
+    return seq_bcast(scale * sqrt(sum), scratch);
+}
+
+template <bool SEQ>
 __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, double *scratch, double *stage,
                                                int *__restrict__ done_counter)
 {
@@ -801,7 +954,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
     const bool inl = !pa.dense;
     const int nf = pa.n_feat;
     double csum_icpt = 0.0;
-    if (inl) csum_icpt = block_sum_array(pr.csump, pa.nblk, scratch);
+    if (inl) csum_icpt = SEQ ? seq_sum(pr.coef, pa.l, scratch, stage) : block_sum_array(pr.csump, pa.nblk, scratch);   // SEQ: XTv's row order
     else assemble_out(pa, pr, Hd, scratch, stage);
     __syncthreads();
     const double *__restrict__ segsum = pr.parts;
@@ -856,6 +1009,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
             }
         }
         block_allreduce_sum<1>(a1, scratch);
+        if (SEQ) a1[0] = seq_dot(d, Hd, n, scratch, stage);
         double alpha = rTr0 / a1[0];
         double ss1[1] = {0.0};
         _Pragma("unroll 8") for (int j = tid; j < n; j += nt) {
@@ -864,7 +1018,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
             ss1[0] += sj * sj;
         }
         block_allreduce_sum<1>(ss1, scratch);
-        const double snorm = norm_from_sumsq(ss1[0], s, n, scratch);
+        const double snorm = SEQ ? seq_norm(s, n, scratch, stage) : norm_from_sumsq(ss1[0], s, n, scratch);
         bool end_cg = false;
         if (snorm > delta0) {
             // cg reaches trust region boundary (:150-168)
@@ -878,6 +1032,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
                 a3[2] += d[j] * d[j];
             }
             block_allreduce_sum<3>(a3, scratch);
+            if (SEQ) { a3[0] = seq_dot(s, d, n, scratch, stage); a3[1] = seq_dot(s, s, n, scratch, stage); a3[2] = seq_dot(d, d, n, scratch, stage); }
             const double std_ = a3[0], sts = a3[1], dtd = a3[2];
             const double dsq = delta0 * delta0;
             const double rad = sqrt(std_ * std_ + dtd * (dsq - sts));
@@ -898,6 +1053,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
                 a2[0] += rj * rj;
             }
             block_allreduce_sum<1>(a2, scratch);
+            if (SEQ) a2[0] = seq_dot(r, r, n, scratch, stage);
             const double rnew = a2[0];
             const double beta = rnew / rTr0;
             _Pragma("unroll 8") for (int j = tid; j < n; j += nt) {
@@ -905,7 +1061,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
                 if (beta != 1.0) dj = dj * beta;                   // scale(beta, d)
                 d[j] = dj + 1.0 * r[j];                            // daxpy(one, r, d)
             }
-            const double rnorm = norm_from_sumsq(rnew, r, n, scratch);
+            const double rnorm = SEQ ? seq_norm(r, n, scratch, stage) : norm_from_sumsq(rnew, r, n, scratch);
             if (tid == 0) pr.rTr = rnew;
             if (rnorm <= cgtol0) end_cg = true;                  // loop-top test of the next trip (:144)
         }
@@ -920,6 +1076,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
                 a2[1] += s[j] * r[j];
             }
             block_allreduce_sum<2>(a2, scratch);
+            if (SEQ) { a2[0] = seq_dot(g, s, n, scratch, stage); a2[1] = seq_dot(s, r, n, scratch, stage); }
             if (tid == 0) {
                 pr.gs = a2[0];
                 pr.prered = -0.5 * (a2[0] - a2[1]);
@@ -948,21 +1105,28 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
         }
     }
     block_allreduce_sum<1>(a1, scratch);
-    const double loss = block_sum_array(pr.lossp, pa.nblk, scratch);
+    const double loss = SEQ ? seq_sum(pr.rowtmp, pa.l, scratch, stage) : block_sum_array(pr.lossp, pa.nblk, scratch);
     double fnew = 2.0 * loss;
-    fnew = fnew + a1[0];
+    if (SEQ) {
+        // fun :184-189 adds the prior terms to the running f one by one
+        const ProbDev *prp = &pr;
+        fnew = seq_fold_sum(fnew, n, scratch, stage, [=](int j) { const double temp = w_new[j] - m[j]; return temp * temp * pinv_at(*prp, j); });
+    } else {
+        fnew = fnew + a1[0];
+    }
     fnew = fnew / 2.0;
     __syncthreads();
+    const double *__restrict__ c0 = SEQ ? pr.c0f : pa.c0;
 
     if (phase == PH_EVAL0) {
         // Tron prologue (:47-62): gnorm1 = ||grad(0)||, f, g, delta at the warm start
         _Pragma("unroll 8") for (int j = tid; j < n; j += nt) {
             g[j] = Hd[j];
-            s[j] = (0.0 - m[j]) * pinv_at(pr, j) + pa.c0[j];        // grad(0) staged in s[]
+            s[j] = (0.0 - m[j]) * pinv_at(pr, j) + c0[j];           // grad(0) staged in s[]
         }
         __syncthreads();
-        const double gnorm1 = block_norm(s, n, scratch);
-        const double gnorm = block_norm(g, n, scratch);
+        const double gnorm1 = SEQ ? seq_norm(s, n, scratch, stage) : block_norm(s, n, scratch);
+        const double gnorm = SEQ ? seq_norm(g, n, scratch, stage) : block_norm(g, n, scratch);
         if (tid == 0) {
             pr.f = fnew; pr.gnorm1 = gnorm1; pr.gnorm = gnorm; pr.delta = gnorm;
             pr.dsel ^= 1; pr.ticks += 1;
@@ -977,7 +1141,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
         double f = pr.f, delta = delta0, gnorm = gnorm_cur;
         const double gs = pr.gs, prered = pr.prered;
         const double actred = f - fnew;
-        const double snorm = block_norm(s, n, scratch);
+        const double snorm = SEQ ? seq_norm(s, n, scratch, stage) : block_norm(s, n, scratch);
         if (pr.iter == 1) delta = fmin(delta, snorm);
         double alpha;
         if (fnew - f - gs <= 0) alpha = sigma3;
@@ -994,7 +1158,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
             _Pragma("unroll 8") for (int j = tid; j < n; j += nt) { w[j] = w_new[j]; g[j] = Hd[j]; }
             f = fnew;
             __syncthreads();
-            gnorm = block_norm(g, n, scratch);
+            gnorm = SEQ ? seq_norm(g, n, scratch, stage) : block_norm(g, n, scratch);
             if (gnorm <= eps0 * gnorm1_0) brk = true;
         }
         if (!brk) {
@@ -1022,6 +1186,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
             a2[0] += rj * rj;
         }
         block_allreduce_sum<1>(a2, scratch);
+        if (SEQ) a2[0] = seq_dot(r, r, n, scratch, stage);
         const double gn = gnorm_cur;      // ||r|| = ||-g|| = ||g||
         if (tid == 0) {
             pr.rTr = a2[0];
@@ -1050,7 +1215,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, cons
     __shared__ double stage[1024];
     if ((int)blockIdx.x >= nq) return;
     ProbDev &pr = probs[qlist[blockIdx.x]];
-    tron_step_body(parts[pr.part], pr, scratch, stage, done_counter);
+    tron_step_body<false>(parts[pr.part], pr, scratch, stage, done_counter);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1518,13 +1683,16 @@ k_step_commit(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
 // LDSV: every fp64 work vector of the problem (8 n-vectors, wd x2, coef, item sums, partial sums) lives in LDS for the whole
 // solve and is written back at the end -- for problems of a few hundred features the tick loop then waits on LDS instead of
 // ~20 dependent L2 round trips per tick.
-template <bool HASVAL, bool LDSV>
+// SEQ: the order-faithful verification mode (MLX_FAITHFUL=1): ONE lane per row / per (unsplit) column so that every row and
+// column sum runs in the reference's order, one thread for every n- or l-long reduction (tron_step_body<true>), grad(0)
+// from its own pass at w = 0 like bw/Tron.java:50-53, and the portable exp/log1p the oracle's verification twin uses too.
+template <bool HASVAL, bool LDSV, bool SEQ>
 __global__ void __launch_bounds__(1024)
 k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int nprob, int max_ticks,
               int *__restrict__ done_counter)
 {
 #pragma clang fp contract(off)
-    constexpr int G = 8, U = 8;             // 8 lanes per row / per column item, 8 loads in flight per lane
+    constexpr int G = SEQ ? 1 : 8, U = 8;   // lanes per row / per column item, loads in flight per lane
     __shared__ double scratch[64];
     __shared__ double stage[1024];
     extern __shared__ double dyn[];
@@ -1594,12 +1762,18 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
         for (int m = G / 2; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
         return a;
     };
-    for (int tick = 0; tick < max_ticks; tick++) {
+    // SEQ: tick -1 is the reference's fun(0) + grad(0) (bw/Tron.java:50-53): an EVAL pass at w = 0 (d is free before the
+    // first trcg) whose X'c is kept in c0f
+    const bool c0_tick = SEQ && pr.phase == PH_EVAL0;
+    if (c0_tick) {
+        for (int j = tid; j < pa.n_local; j += nt) pr.d[j] = 0.0;
+    }
+    for (int tick = c0_tick ? -1 : 0; tick < max_ticks; tick++) {
         __syncthreads();
         const int phase = pr.phase;
         if (phase == PH_DONE) break;
-        const bool cg = (phase == PH_CG);
-        const double *__restrict__ v = cg ? pr.d : pr.w_new;
+        const bool cg = (phase == PH_CG) && tick >= 0;
+        const double *__restrict__ v = tick < 0 ? pr.d : (cg ? pr.d : pr.w_new);
         const double *__restrict__ wdcur = pr.wd[pr.dsel];
         double *__restrict__ wdnew = pr.wd[pr.dsel ^ 1];
         const double vb = v[pa.n_feat];
@@ -1617,9 +1791,10 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
                     cf = wdcur[row] * t;
                 } else {
                     double loss, wdv;
-                    row_eval(t + (double)pa.off[row], (int)pa.y[row], (double)pa.wt[row], loss, wdv, cf);
+                    row_eval<SEQ>(t + (double)pa.off[row], (int)pa.y[row], (double)pa.wt[row], loss, wdv, cf);
                     wdnew[row] = wdv;
                     red[0] += loss;
+                    if (SEQ) pr.rowtmp[row] = loss;
                 }
                 coef[row] = cf;
                 red[1] += cf;
@@ -1637,7 +1812,14 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
             if (valid && gl == 0 && k1 > k0) segsum[pa.item_dst[itc]] = a;
         }
         __syncthreads();
-        tron_step_body(pa, pr, scratch, stage, done_counter);
+        if (SEQ && tick < 0) {
+            // c0f = X' t(0): unsplit columns, so a column's slot IS its sum; the intercept's is the row-ordered sum of coef
+            const double ci = seq_sum(coef, l, scratch, stage);
+            for (int j = tid; j < pa.n_local; j += nt)
+                pr.c0f[j] = (j == pa.n_feat) ? ci : (pa.col_ptr[j + 1] > pa.col_ptr[j] ? segsum[pa.col_ptr[j]] : 0.0);
+            continue;
+        }
+        tron_step_body<SEQ>(pa, pr, scratch, stage, done_counter);
     }
     if (LDSV) {
         // write the state back (everything a relaunch, the outputs kernels or the host read)
@@ -2098,23 +2280,28 @@ void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *p
 }
 
 void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int first, bool hasval,
-                      int max_ticks, int *done_counter, int lds_doubles)
+                      int max_ticks, int *done_counter, int lds_doubles, bool faithful)
 {
+    if (faithful) {
+        if (hasval) hipLaunchKernelGGL((k_solve_small<true, false, true>), dim3(nprob), dim3(1024), 0, st, parts, probs + first, nprob, max_ticks, done_counter);
+        else hipLaunchKernelGGL((k_solve_small<false, false, true>), dim3(nprob), dim3(1024), 0, st, parts, probs + first, nprob, max_ticks, done_counter);
+        return;
+    }
     // lds_doubles > 0: the work vectors of every problem fit in LDS (that many doubles for the largest) -> LDS-resident solve
     if (lds_doubles > 0) {
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_small<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_small<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_small<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_small<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
             attr_set = true;
         }
         const size_t bytes = (size_t)lds_doubles * sizeof(double);
-        if (hasval) hipLaunchKernelGGL((k_solve_small<true, true>), dim3(nprob), dim3(1024), bytes, st, parts, probs + first, nprob, max_ticks, done_counter);
-        else hipLaunchKernelGGL((k_solve_small<false, true>), dim3(nprob), dim3(1024), bytes, st, parts, probs + first, nprob, max_ticks, done_counter);
+        if (hasval) hipLaunchKernelGGL((k_solve_small<true, true, false>), dim3(nprob), dim3(1024), bytes, st, parts, probs + first, nprob, max_ticks, done_counter);
+        else hipLaunchKernelGGL((k_solve_small<false, true, false>), dim3(nprob), dim3(1024), bytes, st, parts, probs + first, nprob, max_ticks, done_counter);
         return;
     }
-    if (hasval) hipLaunchKernelGGL((k_solve_small<true, false>), dim3(nprob), dim3(1024), 0, st, parts, probs + first, nprob, max_ticks, done_counter);
-    else hipLaunchKernelGGL((k_solve_small<false, false>), dim3(nprob), dim3(1024), 0, st, parts, probs + first, nprob, max_ticks, done_counter);
+    if (hasval) hipLaunchKernelGGL((k_solve_small<true, false, false>), dim3(nprob), dim3(1024), 0, st, parts, probs + first, nprob, max_ticks, done_counter);
+    else hipLaunchKernelGGL((k_solve_small<false, false, false>), dim3(nprob), dim3(1024), 0, st, parts, probs + first, nprob, max_ticks, done_counter);
 }
 
 void mlxk_collect_c0(hipStream_t st, const PartDev *parts, const ProbDev *probs, const int *qlist, int nq,

@@ -84,6 +84,7 @@ struct ProbDev {
     // multi-workgroup step (k_step_a/b/c, CSR tick path): the residual is double buffered (rb[rsel] = r of the current CG
     // step, rb[rsel^1] receives r - alpha*Hd, so the trust-region boundary case can still see the old r), per-workgroup
     // partial sums of the three phases, and the scalars the fused phases carry from one tick to the next.
+    double *rowtmp, *c0f;  // verification mode only (MLX_FAITHFUL): per-row losses [l], grad(0)'s data part [n_local]
     double *rb[2];
     int32_t rsel;
     double *pA, *pB, *pC;  // [n_step_wg][STEP_NP] each

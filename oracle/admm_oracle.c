@@ -36,6 +36,14 @@
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+
+#ifdef ORC_PORTABLE_MATH
+/* Verification twin (liboracle_pm.so): exp / log1p from the +,-,*,/ implementations that the HIP library's order-faithful
+ * mode (MLX_FAITHFUL=1) evaluates as well, so that the two can be compared bit for bit (tests/test_gpu_parity.py). */
+#include "portable_math.h"
+#define exp pm_exp
+#define log1p pm_log1p
+#endif
 #endif
 
 typedef struct { int index; double value; } orc_node;   /* bw/FeatureNode.java */

@@ -15,6 +15,7 @@ import numpy as np
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _ORACLE_DIR = os.path.join(_ROOT, "oracle")
 _LIB_PATH = os.path.join(_ORACLE_DIR, "liboracle.so")
+_LIB_PM_PATH = os.path.join(_ORACLE_DIR, "liboracle_pm.so")     # verification twin: portable exp/log1p (oracle/Makefile)
 
 
 class TronStats(C.Structure):
@@ -26,19 +27,20 @@ class TronStats(C.Structure):
 def build(force: bool = False) -> str:
     srcs = [os.path.join(_ORACLE_DIR, f) for f in ("admm_oracle.c", "synth.c")]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
-        subprocess.check_call(["make", "-C", _ORACLE_DIR, "-s", "liboracle.so"])
+        subprocess.check_call(["make", "-C", _ORACLE_DIR, "-s", "liboracle.so", "liboracle_pm.so"])
     return _LIB_PATH
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            build()
-        L = C.CDLL(_LIB_PATH)
+def lib(pm: bool = False):
+    """pm=True: the verification twin whose exp/log1p are ml-ease_amd/csrc/portable_math.h (same restatement otherwise)."""
+    if pm not in _libs:
+        path = _LIB_PM_PATH if pm else _LIB_PATH
+        if not os.path.exists(path):
+            build(force=True)
+        L = C.CDLL(path)
         vp, i32, f64, f32 = C.c_void_p, C.c_int, C.c_double, C.c_float
         L.orc_dataset_create.restype = vp
         L.orc_dataset_create.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp]
@@ -73,8 +75,8 @@ def lib():
         L.orc_synth_dense.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, i32, i32, f64, vp, vp, vp]
         L.orc_admm_run.restype = i32
         L.orc_admm_run.argtypes = [vp, i32, f64, i32, i32, vp, vp]
-        _lib = L
-    return _lib
+        _libs[pm] = L
+    return _libs[pm]
 
 
 def _p(a: Optional[np.ndarray]):
@@ -84,19 +86,20 @@ def _p(a: Optional[np.ndarray]):
 class OracleDataset:
     """One partition in the reference's row-sparse layout (built from the C-ABI CSR block)."""
 
-    def __init__(self, l, n_local, row_ptr, col_idx, val, y, weight, offset):
+    def __init__(self, l, n_local, row_ptr, col_idx, val, y, weight, offset, pm: bool = False):
         self.l, self.n = int(l), int(n_local)
+        self.L = lib(pm)
         self._keep = [np.ascontiguousarray(row_ptr, np.int64), np.ascontiguousarray(col_idx, np.int32),
                       None if val is None else np.ascontiguousarray(val, np.float32),
                       np.ascontiguousarray(y, np.int8), np.ascontiguousarray(weight, np.float32),
                       np.ascontiguousarray(offset, np.float32)]
         k = self._keep
-        self.h = lib().orc_dataset_create(self.l, self.n, _p(k[0]), _p(k[1]), _p(k[2]), _p(k[3]), _p(k[4]), _p(k[5]))
+        self.h = self.L.orc_dataset_create(self.l, self.n, _p(k[0]), _p(k[1]), _p(k[2]), _p(k[3]), _p(k[4]), _p(k[5]))
         self._keep = None            # orc_dataset_create copies everything into its own row-sparse layout
 
     @classmethod
-    def from_block(cls, b) -> "OracleDataset":
-        return cls(b.l, b.n_local, b.row_ptr, b.col_idx, b.val, b.y, b.weight, b.offset)
+    def from_block(cls, b, pm: bool = False) -> "OracleDataset":
+        return cls(b.l, b.n_local, b.row_ptr, b.col_idx, b.val, b.y, b.weight, b.offset, pm=pm)
 
     def eval(self, w, prior_mean, prior_var, s=None):
         w = np.ascontiguousarray(w, np.float64)
@@ -106,7 +109,7 @@ class OracleDataset:
         g = np.empty(self.n)
         Hs = np.empty(self.n) if s is not None else None
         s_ = None if s is None else np.ascontiguousarray(s, np.float64)
-        lib().orc_eval(self.h, _p(w), _p(pm), _p(pv), _p(s_), C.byref(f), _p(g), _p(Hs))
+        self.L.orc_eval(self.h, _p(w), _p(pm), _p(pv), _p(s_), C.byref(f), _p(g), _p(Hs))
         return f.value, g, Hs
 
     def train(self, init, prior_mean, prior_var, epsilon, max_iter=10000):
@@ -114,7 +117,7 @@ class OracleDataset:
         pm = np.ascontiguousarray(prior_mean, np.float64)
         pv = np.ascontiguousarray(prior_var, np.float64)
         st = TronStats()
-        lib().orc_train(self.h, _p(w), _p(pm), _p(pv), float(epsilon), int(max_iter), C.byref(st))
+        self.L.orc_train(self.h, _p(w), _p(pm), _p(pv), float(epsilon), int(max_iter), C.byref(st))
         return w, st
 
     def posterior_variance(self, w, prior_var, full):
@@ -124,14 +127,14 @@ class OracleDataset:
         out = np.empty(self.n)
         M = np.empty((self.n, self.n)) if full else None
         H = np.empty((self.n, self.n)) if full else None
-        rc = lib().orc_posterior_variance(self.h, _p(w), _p(pv), int(bool(full)), _p(out), _p(M), _p(H))
+        rc = self.L.orc_posterior_variance(self.h, _p(w), _p(pv), int(bool(full)), _p(out), _p(M), _p(H))
         if rc != 0:
             raise ArithmeticError("CholeskyDecomposition failed (%d)" % rc)
         return out, M, H
 
     def __del__(self):
         try:
-            lib().orc_dataset_destroy(self.h)
+            self.L.orc_dataset_destroy(self.h)
         except Exception:
             pass
 
@@ -141,83 +144,84 @@ class OracleAdmm:
 
     def __init__(self, blocks: Sequence, n_global: int, lambdas: Sequence[float], rhos: Sequence[float],
                  num_blocks: Optional[int] = None, penalize_intercept: bool = False, regularizer: int = 2,
-                 lambda_map: Optional[np.ndarray] = None):
+                 lambda_map: Optional[np.ndarray] = None, pm: bool = False):
+        self.L = lib(pm)
         order = np.argsort(np.asarray(lambdas, dtype=np.float32), kind="stable")
         self.lambdas = np.ascontiguousarray(np.asarray(lambdas, dtype=np.float32)[order])
         self.rhos = np.ascontiguousarray(np.asarray(rhos, dtype=np.float32)[order])
         self.nlocal = len(blocks)
         self.N = int(num_blocks if num_blocks is not None else len(blocks))
         self.ng, self.nl = int(n_global), len(lambdas)
-        self.h = lib().orc_admm_create(self.N, self.nlocal, self.ng, self.nl, _p(self.lambdas), _p(self.rhos),
+        self.h = self.L.orc_admm_create(self.N, self.nlocal, self.ng, self.nl, _p(self.lambdas), _p(self.rhos),
                                        int(penalize_intercept))
         if regularizer != 2 or lambda_map is not None:
             lm = None if lambda_map is None else np.ascontiguousarray(lambda_map, np.float32)
-            lib().orc_admm_set_options(self.h, int(regularizer), _p(lm))
+            self.L.orc_admm_set_options(self.h, int(regularizer), _p(lm))
         self.ds: List[OracleDataset] = []
         for k, b in enumerate(blocks):
-            d = OracleDataset.from_block(b)
+            d = OracleDataset.from_block(b, pm=pm)
             self.ds.append(d)
             l2g = np.ascontiguousarray(b.local_to_global, np.int32)
-            lib().orc_admm_set_partition(self.h, k, d.h, _p(l2g))
+            self.L.orc_admm_set_partition(self.h, k, d.h, _p(l2g))
 
     def solve_local(self, epsilon, rho_adapt_rate=1.0, nthreads=1):
-        lib().orc_admm_solve_local(self.h, float(epsilon), float(rho_adapt_rate), int(nthreads))
+        self.L.orc_admm_solve_local(self.h, float(epsilon), float(rho_adapt_rate), int(nthreads))
 
     def naive_solve_local(self, epsilon, prior_mean=0.0, nthreads=1):
-        lib().orc_admm_naive_solve_local(self.h, float(epsilon), float(prior_mean), int(nthreads))
+        self.L.orc_admm_naive_solve_local(self.h, float(epsilon), float(prior_mean), int(nthreads))
 
     def naive_finish(self):
-        lib().orc_admm_naive_finish(self.h)
+        self.L.orc_admm_naive_finish(self.h)
 
     def partial_means(self):
         n = self.nl * self.ng
-        xb = np.ctypeslib.as_array(lib().orc_admm_xbar(self.h), shape=(n,))
-        ub = np.ctypeslib.as_array(lib().orc_admm_ubar(self.h), shape=(n,))
+        xb = np.ctypeslib.as_array(self.L.orc_admm_xbar(self.h), shape=(n,))
+        ub = np.ctypeslib.as_array(self.L.orc_admm_ubar(self.h), shape=(n,))
         return xb, ub        # views into the oracle's buffers (writable: all-reduce in place)
 
     def finish(self):
         mx, mn = C.c_double(), C.c_double()
-        lib().orc_admm_finish(self.h, C.byref(mx), C.byref(mn))
+        self.L.orc_admm_finish(self.h, C.byref(mx), C.byref(mn))
         return mx.value, mn.value
 
     def iterate(self, epsilon, rho_adapt_rate=1.0, nthreads=1):
         mx, mn = C.c_double(), C.c_double()
-        lib().orc_admm_iterate(self.h, float(epsilon), float(rho_adapt_rate), int(nthreads), C.byref(mx), C.byref(mn))
+        self.L.orc_admm_iterate(self.h, float(epsilon), float(rho_adapt_rate), int(nthreads), C.byref(mx), C.byref(mn))
         return mx.value, mn.value
 
     def run(self, niter, epsilon_stop=1e-4, aggressive=False, nthreads=1):
         diffs = np.zeros(2 * niter)
         eps = np.zeros(niter)
-        done = lib().orc_admm_run(self.h, int(niter), float(epsilon_stop), int(aggressive), int(nthreads),
+        done = self.L.orc_admm_run(self.h, int(niter), float(epsilon_stop), int(aggressive), int(nthreads),
                                   _p(diffs), _p(eps))
         return done, diffs.reshape(-1, 2)[:done], eps[:done]
 
     def z(self):
         Z = np.empty((self.nl, self.ng))
         z32 = np.empty((self.nl, self.ng), np.float32)
-        lib().orc_admm_get_z(self.h, _p(Z), _p(z32))
+        self.L.orc_admm_get_z(self.h, _p(Z), _p(z32))
         return Z, z32
 
     def set_state(self, Z=None, u=None):
         Z_ = None if Z is None else np.ascontiguousarray(Z, np.float64)
         u_ = None if u is None else np.ascontiguousarray(u, np.float32)
-        lib().orc_admm_set_state(self.h, _p(Z_), _p(u_))
+        self.L.orc_admm_set_state(self.h, _p(Z_), _p(u_))
 
     def partition_model(self, k, li):
         b = np.empty(self.ng, np.float32)
         upx = np.empty(self.ng, np.float32)
         un = np.empty(self.ng, np.float32)
-        lib().orc_admm_get_partition_model(self.h, int(k), int(li), _p(b), _p(upx), _p(un))
+        self.L.orc_admm_get_partition_model(self.h, int(k), int(li), _p(b), _p(upx), _p(un))
         return b, upx, un
 
     def stats(self):
         arr = (TronStats * (self.nlocal * self.nl))()
-        lib().orc_admm_get_stats(self.h, arr)
+        self.L.orc_admm_get_stats(self.h, arr)
         return list(arr)
 
     def __del__(self):
         try:
-            lib().orc_admm_destroy(self.h)
+            self.L.orc_admm_destroy(self.h)
         except Exception:
             pass
 

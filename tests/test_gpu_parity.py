@@ -1,8 +1,8 @@
 """-m gpu : parity of the HIP path (through the C-ABI) against the CPU oracle and the committed fixtures.
 
 Tolerance (BASELINE.json north_star): coefficients within 1e-5 relative. Outputs are float32, so the
-check is |gpu - oracle| <= 1e-5 * max(|oracle|, COEF_FLOOR) per coefficient with COEF_FLOOR = 1e-2 * the
-vector's max magnitude (a coefficient 100x smaller than the largest is compared on an absolute 1e-7
+check is |gpu - oracle| <= 1e-5 * max(|oracle|, COEF_FLOOR) per coefficient with COEF_FLOOR = 1e-4 * the
+vector's max magnitude (a coefficient 10 000x smaller than the largest is compared on an absolute 1e-9
 scale), plus a count of bit-identical float32 values. Trajectories (TRON / CG counters) must be EQUAL.
 """
 import numpy as np
@@ -21,7 +21,7 @@ RTOL = 1e-5
 def assert_coef_close(got, want, what=""):
     got = np.asarray(got, np.float64)
     want = np.asarray(want, np.float64)
-    floor = 1e-2 * max(np.max(np.abs(want)), 1e-30)
+    floor = 1e-4 * max(np.max(np.abs(want)), 1e-30)
     err = np.abs(got - want) / np.maximum(np.abs(want), floor)
     assert np.max(err) <= RTOL, "%s: max rel err %.3e at %d" % (what, np.max(err), int(np.argmax(err)))
     return float(np.mean(got.astype(np.float32) == want.astype(np.float32)))
@@ -678,3 +678,95 @@ def test_batched_partition_upload_equals_sequential():
     c = HipAdmmEngine(pd.n_global, [1.0], [1.0], pd.num_blocks)
     with pytest.raises(RuntimeError, match="twice"):
         c.add_partitions([pd.blocks[0], pd.blocks[1], pd.blocks[0]])
+
+
+# ---- one-hot data (configs[2..4] shape): what differs from the oracle, and by how much -------------------------------------
+def _counters(oc):
+    return np.array([(s.newton_iters, s.accepted, s.cg_iters, s.x_passes) for s in oc.stats()])
+
+
+@pytest.mark.parametrize("kind", ["onehot", "valued"])
+def test_order_faithful_mode_is_bit_identical_to_the_oracle(kind, monkeypatch):
+    """MLX_FAITHFUL=1: library column ids = the partition's first-seen order, one thread per row / per UNSPLIT
+    column summing in the reference's order, every n- or l-long dot / norm / loss sum folded sequentially by one thread with
+    the reference's formulas, grad(0) from its own pass. The oracle twin (liboracle_pm.so) evaluates the same portable
+    exp/log1p. Then nothing is left that could differ: 10 ADMM iterations at epsilon 0.01 on one-hot partitions of 40 000
+    rows x ~70 000 local features must be counter-equal and bit-identical in EVERY output -- which shows that the
+    summation order (and the last bit of exp/log1p) is the only difference between the product path and the oracle."""
+    from fixtures import onehot_blocks
+    monkeypatch.setenv("MLX_FAITHFUL", "1")
+    if kind == "onehot":
+        pd = onehot_blocks(160000, 4)
+        iters = 10
+    else:
+        pd = synth_sparse(11, 6000, 300, 12, 3, weights=True, offsets=True)
+        iters = 6
+    lam, rho = [0.5, 4.0] if kind == "valued" else [1.0], [1.0, 2.0] if kind == "valued" else [1.0]
+    eng = make_engine(pd, lam, rho)
+    oc = ol.OracleAdmm(pd.blocks, pd.n_global, lam, rho, pm=True)
+    for it in range(iters):
+        st = eng.iterate(0.01)
+        mo = oc.iterate(0.01, 1.0, nthreads=8)
+        assert np.array_equal(eng.solve_counters(), _counters(oc)), "iteration %d: TRON/CG counters differ" % (it + 1)
+        for k in range(len(pd.blocks)):
+            for li in range(len(lam)):
+                for a, b, name in zip(eng.partition_model(k, li), oc.partition_model(k, li), ("beta", "uplusx", "u_next")):
+                    assert np.array_equal(a, b), "iteration %d partition %d lambda %d: %s not bit-identical" % (it + 1, k, li, name)
+        assert np.array_equal(eng.z()[0], oc.z()[0]), "iteration %d: driver z (double) not bit-identical" % (it + 1)
+        assert st.maxdiff == mo[0]
+    eng.close()
+
+
+def test_order_faithful_mode_on_the_sample_data(c1, gold, monkeypatch):
+    """The same mode on BASELINE configs[0]: bit-identical to the oracle twin, and -- C1 being well conditioned -- within 1e-5
+    of the PLAIN oracle's golden even though the elementary functions differ in the last bit (trajectories equal)."""
+    monkeypatch.setenv("MLX_FAITHFUL", "1")
+    eng = make_engine(c1, [1.0], [1.0])
+    oc = ol.OracleAdmm(c1.blocks, c1.n_global, [1.0], [1.0], pm=True)
+    for it in range(3):
+        eng.iterate(0.01)
+        oc.iterate(0.01, 1.0, nthreads=2)
+        assert np.array_equal(eng.solve_counters(), _counters(oc))
+        assert np.array_equal(eng.solve_counters(), gold["counters"][it])
+        assert np.array_equal(eng.z()[0], oc.z()[0])
+        assert_coef_close(eng.z()[0][0], gold["Z"][it][0], "C1 faithful vs plain-oracle golden, iteration %d" % (it + 1))
+    eng.close()
+
+
+def test_onehot_admm_run_stays_within_the_reference_order_spread():
+    """ADMM level, product path (was tools/check_onehot_full.py): 12 iterations with the driver's epsilon schedule from z = 0
+    on 8 one-hot partitions of 40 000 rows. At every iteration the HIP path's consensus z is no further from the oracle's
+    than 1.5x the distance of the SAME oracle run on row-permuted partitions (an order Hadoop does not define,
+    llf/LibLinearDataset.java:467-478), and the held-out test log-likelihoods agree to 1e-4."""
+    from fixtures import onehot_blocks, permute_rows
+    pd = onehot_blocks(360000, 9)
+    train, test = pd.blocks[:8], pd.blocks[8]
+    perm = [permute_rows(b, 7 + i) for i, b in enumerate(train)]
+    lam, rho = [1.0], [1.0]
+    oc = ol.OracleAdmm(train, pd.n_global, lam, rho)
+    op = ol.OracleAdmm(perm, pd.n_global, lam, rho)
+    eng = HipAdmmEngine(pd.n_global, lam, rho, 8)
+    eng.add_partitions(train)
+    eng.finalize()
+    gi = test.local_to_global[test.col_idx].astype(np.int32)
+    trow = (test.row_ptr, gi, None, np.where(test.y == 1, 1, 0).astype(np.int8))
+    eng.set_test_data(*trow)
+    e = np.float32(0.01)
+    mind = 99999999.0
+    worst = 0.0
+    for it in range(1, 13):
+        if it > 1 and mind < 0.001:
+            e = np.float32(e / np.float32(10))
+        ee = admm.float_string_roundtrip(e)
+        mo = oc.iterate(ee, 1.0, nthreads=8)
+        op.iterate(ee, 1.0, nthreads=8)
+        eng.iterate(ee)
+        mind = mo[1]
+        zo, zp, zg = oc.z()[0][0], op.z()[0][0], eng.z()[0][0]
+        dp, dg = np.max(np.abs(zp - zo)), np.max(np.abs(zg - zo))
+        worst = max(worst, dg / max(dp, 1e-300))
+        assert dg <= 1.5 * dp + 1e-12, "iteration %d: |z_gpu - z_oracle| = %.3e > 1.5 x |z_perm - z_oracle| = %.3e" % (it, dg, dp)
+        llo = ol.test_loglik_sum(zo, *trow, None, None) / test.l
+        llg = float(eng.test_loglik_sums()[0]) / test.l
+        assert abs(llo - llg) <= 1e-4, "iteration %d: test loglik %.8f vs %.8f" % (it, llg, llo)
+    eng.close()
