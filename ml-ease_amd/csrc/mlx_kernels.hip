@@ -576,7 +576,8 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     const int g0 = c * pa.rgroups_per_chunk;
     const int gcount = min(pa.rgroups_per_chunk, ngr - g0);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wg0 = wave * ROW_MAXG;                          // this wave's first row group within the chunk
+    const int gpw = (gcount + 15) >> 4;                       // consecutive row groups per wave (<= ROW_MAXG)
+    const int wg0 = wave * gpw;                               // this wave's first row group within the chunk
     const uint16_t *__restrict__ rs_idx = pa.rs_idx;
     const float *__restrict__ rs_val = pa.rs_val;
     double acc[ROW_MAXG];
@@ -584,7 +585,13 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     for (int i = 0; i < ROW_MAXG; i++) acc[i] = 0.0;
     // binary features: the next slice is fetched into registers while this one is read; valued entries need those
     // registers for their float4 per pack and fetch at the slice boundary instead
-    constexpr bool PREFETCH = !HASVAL;
+#ifndef ROW_PREFETCH
+#define ROW_PREFETCH 1
+#endif
+#ifndef ROW_KP
+#define ROW_KP 1
+#endif
+    constexpr bool PREFETCH = !HASVAL && ROW_PREFETCH;
     StageRegs SR;
     if (PREFETCH && nf > 0) stage_fetch(SR, v, min(slw, nf), tid);
     for (int sl = 0; sl < ncs; sl++) {
@@ -605,11 +612,11 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
         for (int i = 0; i < ROW_MAXG; i++) {
             base[i] = __builtin_amdgcn_readlane(pv, i);
             const int nx = __builtin_amdgcn_readlane(pv, i + 1);
-            L4[i] = (wg0 + i < gcount) ? (nx - base[i]) >> 8 : 0;
+            L4[i] = (i < gpw && wg0 + i < gcount) ? (nx - base[i]) >> 8 : 0;
             kmax = max(kmax, L4[i]);
         }
         // one pack of every group per round: ROW_MAXG loads in flight (valued: in two halves, a float4 rides with each pack)
-        for (int k = 0; k < kmax; k++) {
+        for (int k = 0; k < kmax; k += (HASVAL ? 1 : ROW_KP)) {
             if (HASVAL) {
                 constexpr int H = ROW_MAXG / 2;
                 sell_lds_first<HASVAL, NT, H, 1>(*reinterpret_cast<double (*)[H]>(&acc[0]), rs_idx, rs_val, *reinterpret_cast<const int (*)[H]>(&base[0]),
@@ -617,7 +624,7 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
                 sell_lds_first<HASVAL, NT, H, 1>(*reinterpret_cast<double (*)[H]>(&acc[H]), rs_idx, rs_val, *reinterpret_cast<const int (*)[H]>(&base[H]),
                                                  *reinterpret_cast<const int (*)[H]>(&L4[H]), k, lane, vs, slw);
             } else {
-                sell_lds_first<HASVAL, NT, ROW_MAXG, 1>(acc, rs_idx, rs_val, base, L4, k, lane, vs, slw);
+                sell_lds_first<HASVAL, NT, ROW_MAXG, ROW_KP>(acc, rs_idx, rs_val, base, L4, k, lane, vs, slw);
             }
         }
     }
@@ -627,7 +634,7 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     for (int i = 0; i < ROW_MAXG; i++) {
         const int gi = wg0 + i;
         const int row = (g0 + gi) * 64 + lane;
-        if (gi < gcount && row < l) {
+        if (i < gpw && gi < gcount && row < l) {
             const double t = acc[i] + vb;
             double cf;
             if (cg) {
