@@ -23,7 +23,8 @@ namespace {
 
 constexpr int CSC_SEG = 256;          // max entries of one column work item
 constexpr int RBLK_MAX_ROWS = 20160;  // rows of one row block: 20160 fp64 coefficients (+ a zero slot) = 157.5 KiB of the 160 KiB LDS
-constexpr int ROW_SLICE_MAX_COLS = 19456;   // columns of one column slice of the row pass: 152 KiB of LDS (+ zero slot + scratch)
+constexpr int ROW_SLICE_MAX_COLS = 19456;   // columns of the hot slice of the row pass: 152 KiB of LDS (+ zero slot + scratch)
+constexpr int ROW_COLD_COLS = 65535;        // columns of one cold slice (uint16 ids 0..65534, 0xFFFF = padding)
 constexpr int CUNIT_ENTRIES = 262144; // padded entries per work unit of the LDS column pass
 constexpr int DEFAULT_MAX_ITER = 10000;   // llf/LibLinear.java:97
 constexpr int64_t TICK_CAP = 2000000;
@@ -71,13 +72,14 @@ struct mlx_context {
     bool csr_hasval = false, any_absent = false, csr_sell = false, csr_small = false;
     int small_lds_doubles = 0;             // > 0: k_solve_small keeps every problem's work vectors in LDS (doubles needed by the largest)
     int max_cunits = 0, max_rblk_rows = 0;
-    int max_row_lds = 0;                    // sliced row pass: columns of the widest column slice (LDS doubles, + zero slot)
+    int max_row_lds = 0;                    // sliced row pass: columns of the widest hot slice (LDS doubles, + zero slot)
+    int row_ngc = 16;                       // row groups per row-pass workgroup (16, 32, 64 or 128)
     int step_threads = 256;
     int step_ch = 2048, step_max_nwg = 1;   // multi-workgroup CSR step: columns per workgroup, chunks of the widest CSR problem
 
     double *d_Z = nullptr;
     float *d_z32 = nullptr, *d_u = nullptr, *d_B = nullptr, *d_UPX = nullptr;
-    double *d_cons = nullptr;              // [xbar | ubar], 2 * n_lambda * n_global
+    double *d_cons = nullptr;              // [xbar | ubar], 2 * n_lambda * n_global, + 1 status slot summed with them (exchange())
     bool cons_external = false;
     double *d_weight_l = nullptr, *d_pinv_l = nullptr, *d_cmap = nullptr;
     unsigned long long *d_diffbits = nullptr;
@@ -101,6 +103,7 @@ struct mlx_context {
 
     ncclComm_t comm = nullptr;
     int comm_nranks = 1;
+    bool comm_always = false;              // MLX_COMM_ALWAYS=1: run the collective also at nranks == 1 (tests)
 
     mlx_stats last{};
 };
@@ -224,7 +227,7 @@ int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
         return fail(h, MLX_ERR_INVALID, "dense tile wider than 2048 features is not supported; use the CSR form");
     if (nqc > 0)
         for (int which = 1; which <= 2; which++)
-            bracket(which, [&] { return mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_short, h->max_long, h->rowgroup, h->csr_hasval, h->csr_sell, h->max_cunits, h->max_rblk_rows, h->max_row_lds, h->n_lambda == 1, which); });
+            bracket(which, [&] { return mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_short, h->max_long, h->rowgroup, h->csr_hasval, h->csr_sell, h->max_cunits, h->max_rblk_rows, h->max_row_lds, h->row_ngc, h->n_lambda == 1, which); });
     return MLX_OK;
 }
 
@@ -407,6 +410,7 @@ int mlx_set_regularizer(mlx_handle h, int32_t regularizer)
 {
     if (!h) return MLX_ERR_INVALID;
     if (regularizer != 1 && regularizer != 2) return fail(h, MLX_ERR_INVALID, "Only L1 and L2 regularization supported!");
+    if (h->finalized) return fail(h, MLX_ERR_INVALID, "mlx_set_regularizer must be called before mlx_finalize (the z-update weights are derived there)");
     h->regularizer = regularizer;
     return MLX_OK;
 }
@@ -565,14 +569,17 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
     ph.rows_per_blk = rpb;
     ph.nblk = (l + rpb - 1) / rpb;
 
-    // Sliced-ELL copies for the thread-per-item passes (k_rowpass_lds / k_colpass_lds). Both passes gather from LDS only:
-    //  * row side: the columns are cut into n_cs column slices of slw columns (one slice of the gathered vector = <= 152 KiB
-    //    of LDS), the rows into groups of 64; block (slice s, group g) holds the entries of those 64 rows whose column
-    //    lies in slice s, padded to the group's longest such run (in packs of 4): entries 4p..4p+3 of a row are four
-    //    contiguous uint16 slice-local ids, pack p of the 64 rows 512 contiguous bytes (padding = slw, a slot that holds 0.0). Blocks are stored slice-major, so a workgroup that owns a
-    //    range of row groups reads one contiguous piece per slice, whatever that range is (it is chosen at finalize).
+    // Sliced-ELL copies for the thread-per-item passes (k_rowpass_lds / k_colpass_lds).
+    //  * row side: library column ids are frequency-sorted, so the first slw columns (<= 19 456 = 152 KiB of fp64) are the
+    //    HOT slice, gathered from an LDS copy of the vector (88 % of the entries of the one-hot configs); the remaining
+    //    columns form COLD slices of 65 535 columns each, gathered from global memory (L2). Rows come in groups of 64; block
+    //    (slice s, group g) holds the entries of those 64 rows whose column lies in slice s, padded to the group's longest
+    //    such run in packs of 4: entries 4p..4p+3 of a row are four contiguous uint16 slice-local ids, pack p of the 64
+    //    rows 512 contiguous bytes. Padding id: slw in the hot slice (an LDS slot that holds 0.0), 0xFFFF in a cold one.
+    //    Blocks are stored slice-major, so a workgroup that owns a range of row groups reads one contiguous piece per
+    //    slice, whatever that range is (it is chosen at finalize).
     //  * column side: see below (row ids relative to the row block, uint16, padding = rblk_rows).
-    // Built when the padded row side costs <= 2x the non-zeros (one-hot rows: ~1.5x, the cold slices hold 0-3 entries a row).
+    // Built when the padded row side costs <= 2x the non-zeros.
     std::vector<int32_t> rs_ptr, cs_ptr, cw_blk, cw_slice;
     std::vector<uint16_t> rs_idx, cs_idx;
     const int32_t cunit_entries = getenv("MLX_CUNIT") ? atoi(getenv("MLX_CUNIT")) : CUNIT_ENTRIES;
@@ -580,16 +587,18 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
     {
         const int ngr = (l + 63) / 64;
         const int slmax = getenv("MLX_SLW") ? std::max(64, atoi(getenv("MLX_SLW")) / 64 * 64) : ROW_SLICE_MAX_COLS;
-        const int ncs_r = std::max(1, (nf + slmax - 1) / slmax);
-        const int slw = std::max(64, ((nf + ncs_r - 1) / ncs_r + 63) / 64 * 64);
+        const int slw = std::max(64, (std::min(nf, slmax) + 63) / 64 * 64);
+        const int ncold = nf > slw ? (nf - slw + ROW_COLD_COLS - 1) / ROW_COLD_COLS : 0;
+        const int ncs_r = 1 + ncold;
         ph.n_cs = ncs_r; ph.slw = slw; ph.n_rgroups = ngr;
+        auto slice_lo = [&](int sl) { return sl == 0 ? 0 : slw + (sl - 1) * ROW_COLD_COLS; };
         // entries of row r in slice s: [cut[r][s], cut[r][s+1]) of the row's (ascending) entries
         std::vector<int32_t> cut((size_t)l * (ncs_r + 1));
         for (int r = 0; r < l; r++) {
             int32_t k = rp[r];
             for (int sl = 0; sl < ncs_r; sl++) {
                 cut[(size_t)r * (ncs_r + 1) + sl] = k;
-                const int32_t hi = (sl + 1) * slw;
+                const int64_t hi = (int64_t)slice_lo(sl + 1);
                 while (k < rp[r + 1] && col_idx_p[k] < hi) k++;
             }
             cut[(size_t)r * (ncs_r + 1) + ncs_r] = k;
@@ -608,15 +617,16 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
                   (int64_t)nnz + 64LL * ph.n_items < (int64_t)std::numeric_limits<int32_t>::max() / 2 && getenv("MLX_NO_SELL") == nullptr &&
                   !faithful;
         if (ph.sell) {
-            rs_idx.assign((size_t)padded, (uint16_t)slw);
+            rs_idx.assign((size_t)padded, (uint16_t)0xFFFF);
             if (val) rs_val.assign((size_t)padded, 0.f);
+            std::fill(rs_idx.begin(), rs_idx.begin() + rs_ptr[(size_t)ngr], (uint16_t)slw);      // the hot slice pads with the zero slot
             for (int sl = 0; sl < ncs_r; sl++)
                 for (int r = 0; r < l; r++) {
                     const int32_t base = rs_ptr[(size_t)sl * ngr + (r >> 6)], lane = r & 63;
                     const int32_t k0 = cut[(size_t)r * (ncs_r + 1) + sl], k1 = cut[(size_t)r * (ncs_r + 1) + sl + 1];
                     for (int32_t k = k0; k < k1; k++) {
                         const size_t dst = (size_t)base + (size_t)((k - k0) >> 2) * 256 + (size_t)lane * 4 + (size_t)((k - k0) & 3);
-                        rs_idx[dst] = (uint16_t)(col_idx_p[k] - sl * slw);
+                        rs_idx[dst] = (uint16_t)(col_idx_p[k] - slice_lo(sl));
                         if (val) rs_val[dst] = val_p[k];
                     }
                 }
@@ -865,8 +875,10 @@ int mlx_finalize(mlx_handle h)
     if (h->csr_sell) {
         int64_t total_groups = 0;
         for (auto &p : h->parts) if (!p.dense) total_groups += (int64_t)nl * p.n_rgroups;
-        int ngc = (int)std::min<int64_t>(128, std::max<int64_t>(16, (total_groups / 768 + 15) / 16 * 16));
-        if (const char *e = getenv("MLX_ROW_NG")) ngc = std::max(16, std::min(128, atoi(e) / 16 * 16));
+        int ngc = 16;                                    // 16 * {1, 2, 4, 8}: the row pass is compiled for these group counts per wave
+        while (ngc < 128 && total_groups / ngc > 768) ngc *= 2;
+        if (const char *e = getenv("MLX_ROW_NG")) { ngc = 16; while (ngc < 128 && ngc < atoi(e)) ngc *= 2; }
+        h->row_ngc = ngc;
         for (auto &p : h->parts) if (!p.dense) {
             p.dev.rgroups_per_chunk = ngc;
             p.rows_per_blk = ngc * 64;
@@ -1040,7 +1052,7 @@ int mlx_finalize(mlx_handle h)
     if ((rc = dev_alloc(h, &h->d_u, pl))) return rc;
     if ((rc = dev_alloc(h, &h->d_B, pl))) return rc;
     if ((rc = dev_alloc(h, &h->d_UPX, pl))) return rc;
-    if ((rc = dev_alloc(h, &h->d_cons, 2 * zl))) return rc;
+    if ((rc = dev_alloc(h, &h->d_cons, 2 * zl + 1))) return rc;
     if ((rc = dev_alloc(h, &h->d_diffbits, (size_t)nl))) return rc;
     if ((rc = dev_alloc(h, &h->d_pinv_l, (size_t)nl))) return rc;
     HIPCHECK(h, hipMemset(h->d_Z, 0, sizeof(double) * zl));
@@ -1196,18 +1208,40 @@ int mlx_admm_consensus_finish(mlx_handle h, mlx_stats *stats)
     return MLX_OK;
 }
 
-int mlx_admm_iterate(mlx_handle h, double liblinear_epsilon, float rho_adapt_rate, mlx_stats *stats)
+// The exchange step of one iteration: ncclAllReduce(SUM) of [xbar | ubar] over the handle's communicator. The local
+// solve's status rides along in one extra slot, so that a rank whose solve failed still JOINS the collective (the others
+// would block in it forever otherwise) and every rank learns that the iteration failed: the reference aborts the whole
+// job when any reducer throws (jobs/RegressionAdmmTrain.java:713-716 -> job failure at :357).
+static int exchange(mlx_handle h, int local_rc, const char *what)
 {
-    int rc = mlx_admm_solve_local(h, liblinear_epsilon, rho_adapt_rate, nullptr);
-    if (rc) return rc;
-    if (h->comm && h->comm_nranks > 1) {
+    if (h->comm && (h->comm_nranks > 1 || h->comm_always)) {
         const size_t cnt = 2 * (size_t)h->n_lambda * h->n_global;
-        ncclResult_t r = ncclAllReduce(h->d_cons, h->d_cons, cnt, ncclDouble, ncclSum, h->comm, h->stream);
-        if (r != ncclSuccess) return fail(h, MLX_ERR_COMM, "ncclAllReduce failed: %s", ncclGetErrorString(r));
-    } else if ((int)h->parts.size() != h->num_blocks) {
+        const double flag = local_rc ? 1.0 : 0.0;
+        double total = 0.0;
+        if (hipMemcpyAsync(h->d_cons + cnt, &flag, sizeof flag, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess)
+            return local_rc ? local_rc : fail(h, MLX_ERR_HIP, "%s: status upload failed", what);
+        ncclResult_t r = ncclAllReduce(h->d_cons, h->d_cons, cnt + 1, ncclDouble, ncclSum, h->comm, h->stream);
+        if (r != ncclSuccess) return local_rc ? local_rc : fail(h, MLX_ERR_COMM, "ncclAllReduce failed: %s", ncclGetErrorString(r));
+        if (hipMemcpyAsync(&total, h->d_cons + cnt, sizeof total, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess)
+            return local_rc ? local_rc : fail(h, MLX_ERR_HIP, "%s: status download failed", what);
+        if (local_rc) return local_rc;                       // this rank's own error text is already set
+        if (total != 0.0) return fail(h, MLX_ERR_MODEL_FITTING, "Model fitting error! %s failed on another rank (%d of %d)", what, (int)total, h->comm_nranks);
+        return MLX_OK;
+    }
+    if (local_rc) return local_rc;
+    if ((int)h->parts.size() != h->num_blocks)
         return fail(h, MLX_ERR_MISSING_MODELS, "Some models failed! this handle holds %zu of %d partitions and no communicator is set",
                     h->parts.size(), h->num_blocks);
-    }
+    return MLX_OK;
+}
+
+int mlx_admm_iterate(mlx_handle h, double liblinear_epsilon, float rho_adapt_rate, mlx_stats *stats)
+{
+    if (!h || !h->finalized) return fail(h, MLX_ERR_INVALID, "mlx_finalize first");
+    int rc = exchange(h, mlx_admm_solve_local(h, liblinear_epsilon, rho_adapt_rate, nullptr), "the ADMM iteration");
+    if (rc) return rc;
     return mlx_admm_consensus_finish(h, stats);
 }
 
@@ -1265,16 +1299,9 @@ int mlx_naive_finish(mlx_handle h)
 
 int mlx_naive_init(mlx_handle h, double liblinear_epsilon, double prior_mean, mlx_stats *stats)
 {
-    int rc = mlx_naive_solve_local(h, liblinear_epsilon, prior_mean, stats);
+    if (!h || !h->finalized) return fail(h, MLX_ERR_INVALID, "mlx_finalize first");
+    int rc = exchange(h, mlx_naive_solve_local(h, liblinear_epsilon, prior_mean, stats), "the mean-model warm start");
     if (rc) return rc;
-    if (h->comm && h->comm_nranks > 1) {
-        const size_t cnt = 2 * (size_t)h->n_lambda * h->n_global;
-        ncclResult_t r = ncclAllReduce(h->d_cons, h->d_cons, cnt, ncclDouble, ncclSum, h->comm, h->stream);
-        if (r != ncclSuccess) return fail(h, MLX_ERR_COMM, "ncclAllReduce failed: %s", ncclGetErrorString(r));
-    } else if ((int)h->parts.size() != h->num_blocks) {
-        return fail(h, MLX_ERR_MISSING_MODELS, "Some models failed! this handle holds %zu of %d partitions and no communicator is set",
-                    h->parts.size(), h->num_blocks);
-    }
     return mlx_naive_finish(h);
 }
 
@@ -1613,6 +1640,7 @@ int mlx_comm_init(mlx_handle h, const char unique_id[MLX_UNIQUE_ID_BYTES], int32
     ncclResult_t r = ncclCommInitRank(&h->comm, nranks, id, rank);
     if (r != ncclSuccess) return fail(h, MLX_ERR_COMM, "ncclCommInitRank failed: %s", ncclGetErrorString(r));
     h->comm_nranks = nranks;
+    h->comm_always = getenv("MLX_COMM_ALWAYS") != nullptr && atoi(getenv("MLX_COMM_ALWAYS")) != 0;
     return MLX_OK;
 }
 

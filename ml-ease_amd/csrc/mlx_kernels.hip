@@ -21,6 +21,24 @@
 
 #define WAVE 64
 
+// Timing experiments only (tools/ablate_build.sh -DMLX_PHASE_TIMING): thread 0 of every workgroup of the sparse passes adds
+// the 100 MHz wall-clock ticks it spent in each phase to g_phase[]; read back with mlx_debug_phase_times().
+#ifdef MLX_PHASE_TIMING
+__device__ unsigned long long g_phase[16];
+#define PT_INIT unsigned long long pt_last = wall_clock64()
+#define PT_MARK(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_phase[k], t_ - pt_last); pt_last = t_; } } while (0)
+extern "C" int mlx_debug_phase_times(double *out16)
+{
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof h) != hipSuccess) return -1;
+    for (int i = 0; i < 16; i++) out16[i] = (double)h[i] * 0.01;      // microseconds
+    return 0;
+}
+#else
+#define PT_INIT
+#define PT_MARK(k)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // wave / block reductions (deterministic trees; fp64)
 // ------------------------------------------------------------------------------------------------
@@ -546,18 +564,61 @@ __device__ __forceinline__ void stage_store(const StageRegs &R, double *__restri
     if ((cnt & 1) && tid == 0) lds[cnt - 1] = src[cnt - 1];
 }
 
-// Row pass. One 1024-thread workgroup = (problem, chunk of <= 128 row groups of 64 rows): for every column slice it stages
-// that slice of the gathered vector (d or w_new) in LDS and every wave walks its row groups' blocks of that slice; a
-// thread keeps the running sums of its (up to ROW_MAXG) rows in registers across the slices, then applies the row map.
-// Workgroups are mapped XCD-aware: all chunks of problem p run on XCD p % 8, so the vector they all stage stays in that L2.
-#define ROW_MAXG 8
-template <bool HASVAL, bool NT>
+// The first pack of NI work items whose ids index GLOBAL memory (the cold column slices of the row pass): NI id loads in
+// flight, then 4 NI gathers in flight -- two memory latencies for all of them. Padding id 0xFFFF adds 0.0.
+template <bool HASVAL, bool NT, int NI>
+__device__ __forceinline__ void sell_gather_round(double *a, const uint16_t *__restrict__ idx, const float *__restrict__ val,
+                                                  const int *base, const int *L4, int k, int lane,
+                                                  const double *__restrict__ src)
+{
+#pragma clang fp contract(off)
+    u2v_t q[NI];
+    f4v_t xv[NI];
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+        const int kk = max(min(k, L4[i] - 1), 0);
+        q[i] = pack_load<NT>(idx, base[i], kk, lane);
+        if (HASVAL) xv[i] = pack_load_val<NT>(val, base[i], kk, lane);
+        if (k >= L4[i]) { q[i].x = 0xFFFFFFFFu; q[i].y = 0xFFFFFFFFu; }
+    }
+    double c[NI][4];
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+        const unsigned id[4] = {q[i].x & 0xFFFFu, q[i].x >> 16, q[i].y & 0xFFFFu, q[i].y >> 16};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const double g = src[id[e] == 0xFFFFu ? 0u : id[e]];        // unconditional load, clamped address
+            c[i][e] = id[e] == 0xFFFFu ? 0.0 : g;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+        a[i] = a[i] + (HASVAL ? c[i][0] * (double)xv[i].x : c[i][0]);
+        a[i] = a[i] + (HASVAL ? c[i][1] * (double)xv[i].y : c[i][1]);
+        a[i] = a[i] + (HASVAL ? c[i][2] * (double)xv[i].z : c[i][2]);
+        a[i] = a[i] + (HASVAL ? c[i][3] * (double)xv[i].w : c[i][3]);
+    }
+}
+
+// Row pass. One 1024-thread workgroup = (problem, chunk of 16 GPW row groups of 64 rows); a wave owns GPW consecutive
+// groups, a thread one row of each and keeps their running sums in registers. The HOT slice of the gathered vector (d or
+// w_new; the slw most frequent columns) is staged in LDS once, then per slice -- hot first, then the cold ones in
+// ascending column order, so a row's entries are added in ascending column id as before -- the block offsets of the
+// wave's groups come from ONE load and the packs of all its groups are fetched together: a handful of dependent memory
+// latencies per workgroup, where a loop over groups paid three per group and slice (in-kernel phase timing,
+// profiles/r2_notes.md). Workgroups are mapped XCD-aware: all chunks of problem p run on XCD p % 8, so the vector they all
+// stage and gather stays in that L2.
+#ifndef ROW_KP
+#define ROW_KP 1       // packs per group and round of the hot slice
+#endif
+template <bool HASVAL, bool NT, int GPW>
 __global__ void __launch_bounds__(1024)
 k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx)
 {
 #pragma clang fp contract(off)
-    extern __shared__ __attribute__((aligned(16))) double vs[];      // [slw + 1]: the staged slice, then the zero slot
+    extern __shared__ __attribute__((aligned(16))) double vs[];      // [slw + 1]: the staged hot slice, then the zero slot
     __shared__ double scratch[48];
+    PT_INIT;
     int pi_, bx_;
     if (!xcd_map(nq, gx, pi_, bx_)) return;
     const int q = qlist[pi_];
@@ -573,84 +634,97 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     double *__restrict__ wdnew = pr.wd[pr.dsel ^ 1];
     double *__restrict__ coef = pr.coef;
     const int nf = pa.n_feat, slw = pa.slw, ncs = pa.n_cs, ngr = pa.n_rgroups, l = pa.l;
-    const int g0 = c * pa.rgroups_per_chunk;
-    const int gcount = min(pa.rgroups_per_chunk, ngr - g0);
+    const int g0 = c * (16 * GPW);
+    const int gcount = min(16 * GPW, ngr - g0);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int gpw = (gcount + 15) >> 4;                       // consecutive row groups per wave (<= ROW_MAXG)
-    const int wg0 = wave * gpw;                               // this wave's first row group within the chunk
+    const int wg0 = wave * GPW;                               // this wave's first row group within the chunk
     const uint16_t *__restrict__ rs_idx = pa.rs_idx;
     const float *__restrict__ rs_val = pa.rs_val;
-    double acc[ROW_MAXG];
+    double acc[GPW];
 #pragma unroll
-    for (int i = 0; i < ROW_MAXG; i++) acc[i] = 0.0;
-    // binary features: the next slice is fetched into registers while this one is read; valued entries need those
-    // registers for their float4 per pack and fetch at the slice boundary instead
-#ifndef ROW_PREFETCH
-#define ROW_PREFETCH 1
-#endif
-#ifndef ROW_KP
-#define ROW_KP 1
-#endif
-    constexpr bool PREFETCH = !HASVAL && ROW_PREFETCH;
-    StageRegs SR;
-    if (PREFETCH && nf > 0) stage_fetch(SR, v, min(slw, nf), tid);
-    for (int sl = 0; sl < ncs; sl++) {
-        const int c0 = sl * slw;
-        const int cnt = min(slw, nf - c0);
-        __syncthreads();                                     // the previous slice's readers are done
-        if (!PREFETCH) stage_fetch(SR, v + c0, cnt, tid);
-        stage_store(SR, vs, v + c0, cnt, tid);               // c0 is a multiple of 64: aligned pairs
+    for (int i = 0; i < GPW; i++) acc[i] = 0.0;
+    {
+        StageRegs SR;
+        const int cnt = min(slw, nf);
+        stage_fetch(SR, v, cnt, tid);                        // all loads of the slice in flight at once
+        stage_store(SR, vs, v, cnt, tid);
         if (tid == 0) vs[slw] = 0.0;
-        __syncthreads();
-        if (PREFETCH && sl + 1 < ncs) stage_fetch(SR, v + c0 + slw, min(slw, nf - c0 - slw), tid);     // in flight while this slice is read
-        // block offsets of this wave's ROW_MAXG consecutive groups: one load, then lane broadcasts (wave-uniform scalars)
+    }
+    PT_MARK(0);
+    __syncthreads();
+    PT_MARK(1);
+    for (int sl = 0; sl < ncs; sl++) {
+        // block offsets of this wave's GPW consecutive groups: one load, then lane broadcasts (wave-uniform scalars)
         const int32_t *__restrict__ ptr = pa.rs_ptr + (int64_t)sl * ngr + g0;
-        const int pv = ptr[min(wg0 + min(lane, ROW_MAXG), gcount)];
-        int base[ROW_MAXG], L4[ROW_MAXG];
+        const int pv = ptr[min(wg0 + min(lane, GPW), gcount)];
+        int base[GPW], L4[GPW];
         int kmax = 0;
 #pragma unroll
-        for (int i = 0; i < ROW_MAXG; i++) {
+        for (int i = 0; i < GPW; i++) {
             base[i] = __builtin_amdgcn_readlane(pv, i);
             const int nx = __builtin_amdgcn_readlane(pv, i + 1);
-            L4[i] = (i < gpw && wg0 + i < gcount) ? (nx - base[i]) >> 8 : 0;
+            L4[i] = (wg0 + i < gcount) ? (nx - base[i]) >> 8 : 0;
             kmax = max(kmax, L4[i]);
         }
-        // one pack of every group per round: ROW_MAXG loads in flight (valued: in two halves, a float4 rides with each pack)
-        for (int k = 0; k < kmax; k += (HASVAL ? 1 : ROW_KP)) {
-            if (HASVAL) {
-                constexpr int H = ROW_MAXG / 2;
-                sell_lds_first<HASVAL, NT, H, 1>(*reinterpret_cast<double (*)[H]>(&acc[0]), rs_idx, rs_val, *reinterpret_cast<const int (*)[H]>(&base[0]),
-                                                 *reinterpret_cast<const int (*)[H]>(&L4[0]), k, lane, vs, slw);
-                sell_lds_first<HASVAL, NT, H, 1>(*reinterpret_cast<double (*)[H]>(&acc[H]), rs_idx, rs_val, *reinterpret_cast<const int (*)[H]>(&base[H]),
-                                                 *reinterpret_cast<const int (*)[H]>(&L4[H]), k, lane, vs, slw);
-            } else {
-                sell_lds_first<HASVAL, NT, ROW_MAXG, ROW_KP>(acc, rs_idx, rs_val, base, L4, k, lane, vs, slw);
+        PT_MARK(2);
+        if (sl == 0) {
+            constexpr int KP = HASVAL ? 1 : ROW_KP;
+            for (int k = 0; k < kmax; k += KP)
+                sell_lds_first<HASVAL, NT, GPW, KP>(acc, rs_idx, rs_val, base, L4, k, lane, vs, slw);
+            PT_MARK(3);
+        } else {
+            const double *__restrict__ src = v + slw + (int64_t)(sl - 1) * 65535;
+            // (GPW gathers x 4 in flight; 8 groups, or 4 valued ones, go in two halves: their 32 results do not fit beside the rest)
+            constexpr int NIH = (GPW > 4 || (HASVAL && GPW > 2)) ? GPW / 2 : GPW;
+            for (int k = 0; k < kmax; k++) {
+                sell_gather_round<HASVAL, NT, NIH>(acc, rs_idx, rs_val, base, L4, k, lane, src);
+                if (NIH < GPW) sell_gather_round<HASVAL, NT, NIH>(acc + NIH, rs_idx, rs_val, base + NIH, L4 + NIH, k, lane, src);
             }
+            PT_MARK(4);
         }
     }
+    // row maps: the loads of (up to) four of the wave's rows are issued before the first is used (clamped, unconditional)
     const double vb = v[nf];
     double red[2] = {0.0, 0.0};          // loss, sum of coef
+    constexpr int EH = GPW < 4 ? GPW : 4;
 #pragma unroll
-    for (int i = 0; i < ROW_MAXG; i++) {
-        const int gi = wg0 + i;
-        const int row = (g0 + gi) * 64 + lane;
-        if (i < gpw && gi < gcount && row < l) {
-            const double t = acc[i] + vb;
-            double cf;
-            if (cg) {
-                cf = wdcur[row] * t;
-            } else {
-                double loss, wdv;
-                row_eval(t + (double)pa.off[row], (int)pa.y[row], (double)pa.wt[row], loss, wdv, cf);
-                wdnew[row] = wdv;
-                red[0] += loss;
+    for (int i0 = 0; i0 < GPW; i0 += EH) {
+        int rowi[EH];
+        bool ok[EH];
+        double wdv0[EH];
+        float offv[EH], wtv[EH];
+        int yv[EH];
+#pragma unroll
+        for (int i = 0; i < EH; i++) {
+            const int row = (g0 + wg0 + i0 + i) * 64 + lane;
+            ok[i] = (wg0 + i0 + i < gcount) && row < l;
+            rowi[i] = min(row, l - 1);
+            wdv0[i] = cg ? wdcur[rowi[i]] : 0.0;
+            offv[i] = cg ? 0.f : pa.off[rowi[i]];
+            wtv[i] = cg ? 0.f : pa.wt[rowi[i]];
+            yv[i] = cg ? 0 : (int)pa.y[rowi[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < EH; i++) {
+            if (ok[i]) {
+                const double t = acc[i0 + i] + vb;
+                double cf;
+                if (cg) {
+                    cf = wdv0[i] * t;
+                } else {
+                    double loss, wdv;
+                    row_eval(t + (double)offv[i], yv[i], (double)wtv[i], loss, wdv, cf);
+                    wdnew[rowi[i]] = wdv;
+                    red[0] += loss;
+                }
+                coef[rowi[i]] = cf;
+                red[1] += cf;
             }
-            coef[row] = cf;
-            red[1] += cf;
         }
     }
     block_allreduce_sum<2>(red, scratch);
     if (tid == 0) { pr.lossp[c] = red[0]; pr.csump[c] = red[1]; }
+    PT_MARK(5);
 }
 
 // Column pass with the row coefficients in LDS. One workgroup = (problem, work unit): the unit's row block of `coef`
@@ -663,6 +737,7 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
 {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) double cf[];      // [rblk_rows + 1]: the block's coefficients, then the zero slot
+    PT_INIT;
     int pi_, bx_;
     if (!xcd_map(nq, gx, pi_, bx_)) return;
     const int q = qlist[pi_];
@@ -682,6 +757,7 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
         if (threadIdx.x == 0) cf[pa.rblk_rows] = 0.0;
     }
     __syncthreads();
+    PT_MARK(8);
     const uint16_t *__restrict__ cs_idx = pa.cs_idx;
     const float *__restrict__ cs_val = pa.cs_val;
     const int32_t *__restrict__ cs_ptr = pa.cs_ptr;
@@ -705,12 +781,15 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
             dst[u] = (sl < s1) ? item_dst[sc * 64 + lane] : -1;
             a[u] = 0.0;
         }
+        PT_MARK(9);
         sell_lds_first<HASVAL, NT, COL_B, KP>(a, cs_idx, cs_val, base, L4, 0, lane, cf, zs);
+        PT_MARK(10);
 #pragma unroll
         for (int u = 0; u < COL_B; u++) {
             if (L4[u] > KP) a[u] = sell_lds_sum<HASVAL, NT>(a[u], cs_idx, cs_val, base[u], KP, L4[u], lane, cf, zs);
             if (dst[u] >= 0) out[dst[u]] = a[u];
         }
+        PT_MARK(11);
     }
 }
 
@@ -2225,7 +2304,7 @@ static void launch_rowpass(hipStream_t st, const PartDev *parts, ProbDev *probs,
 }
 
 int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
-                   int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cunits, int max_rblk_rows, int row_slw, bool stream_once, int which)
+                   int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cunits, int max_rblk_rows, int row_slw, int row_ngc, bool stream_once, int which)
 {
     const bool do_row = which & 1, do_col = which & 2;
     if (nq <= 0) return 0;
@@ -2235,20 +2314,30 @@ int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const i
         if (!attr_set) {
 #define SETLDS(HV, NTF)                                                                                                                        \
             hipFuncSetAttribute(reinterpret_cast<const void *>(&k_colpass_lds<HV, NTF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); \
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowpass_lds<HV, NTF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowpass_lds<HV, NTF, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowpass_lds<HV, NTF, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowpass_lds<HV, NTF, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowpass_lds<HV, NTF, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)
             SETLDS(true, true); SETLDS(true, false); SETLDS(false, true); SETLDS(false, false);
 #undef SETLDS
             attr_set = true;
         }
+#define LAUNCH_ROW(HV, NTF, GP) hipLaunchKernelGGL((k_rowpass_lds<HV, NTF, GP>), dim3(XGRID(nq, maxblk)), dim3(1024), lds_row, st, parts, probs, qlist, nq, maxblk)
 #define LAUNCH_SELL(HV, NTF)                                                                                                                   \
         do {                                                                                                                                   \
-            if (do_row) hipLaunchKernelGGL((k_rowpass_lds<HV, NTF>), dim3(XGRID(nq, maxblk)), dim3(1024), lds_row, st, parts, probs, qlist, nq, maxblk); \
+            if (do_row) switch (row_ngc) {                                                                                                     \
+                case 16: LAUNCH_ROW(HV, NTF, 1); break;                                                                                        \
+                case 32: LAUNCH_ROW(HV, NTF, 2); break;                                                                                        \
+                case 64: LAUNCH_ROW(HV, NTF, 4); break;                                                                                        \
+                default: LAUNCH_ROW(HV, NTF, 8); break;                                                                                        \
+            }                                                                                                                                  \
             if (do_col && max_cunits > 0)                                                                                                      \
                 hipLaunchKernelGGL((k_colpass_lds<HV, NTF>), dim3(XGRID(nq, max_cunits)), dim3(1024), lds_col, st, parts, probs, qlist, nq, max_cunits); \
         } while (0)
         if (hasval) { if (stream_once) LAUNCH_SELL(true, true); else LAUNCH_SELL(true, false); }
         else { if (stream_once) LAUNCH_SELL(false, true); else LAUNCH_SELL(false, false); }
 #undef LAUNCH_SELL
+#undef LAUNCH_ROW
         return 0;
     }
     if (do_row) switch (rowgroup) {

@@ -11,6 +11,7 @@
 #include <sys/stat.h>
 
 #include <chrono>
+#include <filesystem>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -230,6 +231,12 @@ int run_job(const JobConfig &props)
     }
     auto t_uploaded = clk::now();
 
+    // a previous run's per-iteration outputs must not survive into this one (the reference starts from a fresh output.base.path)
+    {
+        std::error_code ec;
+        std::filesystem::remove_all(out + "/best-model", ec);
+        std::filesystem::remove_all(out + "/sample-test-loglik", ec);
+    }
     // ---- the loop (:278-497)
     double mindiff = 99999999;
     float liblinear_eps = 0.01f;                                                            // :279
@@ -250,6 +257,9 @@ int run_job(const JobConfig &props)
             fprintf(stderr, "[mlease] Sample test loglik for lambda=%s is: %.10g\n", key.c_str(), ll);
             if (ll > (double)best_loglik && it > 0) {
                 ck(hs[0], mlx_get_z(hs[0], nullptr, zf.data()), "mlx_get_z");
+                // fs.delete(outBasePath + "/best-model", true) before every write (:838-840): exactly ONE model file exists
+                std::error_code ec;
+                std::filesystem::remove_all(out + "/best-model", ec);
                 AvroFileWriter bw(out + "/best-model/best-iteration-" + std::to_string(it) + ".avro", kLinearModelSchemaJson);
                 write_model_record(bw, key, zf.data() + (size_t)li * ng, ds);
                 bw.close();

@@ -220,6 +220,10 @@ AvroFileReader::AvroFileReader(const std::string &path)
         base_ = static_cast<const uint8_t *>(m);
     }
     close(fd);
+    struct Unmap {                          // the constructor can still throw: release the mapping then (the destructor does not run)
+        AvroFileReader *r; bool armed = true;
+        ~Unmap() { if (armed && r->base_ && r->size_) { munmap(const_cast<uint8_t *>(r->base_), r->size_); r->base_ = nullptr; r->size_ = 0; } }
+    } guard{this};
     if (size_ < 4 || memcmp(base_, "Obj\x01", 4) != 0) throw std::runtime_error(path + " is not an avro object container file");
     AvroCursor c(base_ + 4, base_ + size_);
     codec_ = "null";
@@ -241,6 +245,7 @@ AvroFileReader::AvroFileReader(const std::string &path)
     memcpy(sync_, base_ + consumed, 16);
     pos_ = consumed + 16;
     schema_ = parse_schema(schema_json_);
+    guard.armed = false;
 }
 
 AvroFileReader::~AvroFileReader() { if (base_ && size_) munmap(const_cast<uint8_t *>(base_), size_); }
@@ -335,7 +340,12 @@ AvroFileWriter::AvroFileWriter(const std::string &path, const std::string &schem
     put_varint(file_, 0);
     file_.insert(file_.end(), kSync, kSync + 16);
 }
-AvroFileWriter::~AvroFileWriter() { if (!closed_) { try { close(); } catch (...) {} } }
+AvroFileWriter::~AvroFileWriter()
+{
+    // callers close() explicitly and see its exceptions; a writer dropped on an error path must not throw from here
+    if (!closed_) { try { close(); } catch (...) {} }
+    if (out_) fclose(out_);
+}
 void AvroFileWriter::put_long(int64_t v) { put_varint(block_, v); }
 void AvroFileWriter::put_float(float v) { uint8_t b[4]; memcpy(b, &v, 4); block_.insert(block_.end(), b, b + 4); }
 void AvroFileWriter::put_double(double v) { uint8_t b[8]; memcpy(b, &v, 8); block_.insert(block_.end(), b, b + 8); }
@@ -365,21 +375,41 @@ void AvroFileWriter::flush_block()
     file_.insert(file_.end(), kSync, kSync + 16);
     block_.clear();
     block_count_ = 0;
+    if (file_.size() > (8u << 20)) write_out();
 }
 static void mkdirs_for(const std::string &path)
 {
     for (size_t i = 1; i < path.size(); i++)
         if (path[i] == '/') mkdir(path.substr(0, i).c_str(), 0777);
 }
+// Finished blocks are streamed to the file (at most ~8 MiB stay in memory) and every write is checked: a full disk or
+// an IO error raises instead of leaving a truncated container behind an exit code 0.
+void AvroFileWriter::write_out()
+{
+    if (file_.empty()) return;
+    if (!out_) {
+        mkdirs_for(path_);
+        out_ = fopen(path_.c_str(), "wb");
+        if (!out_) throw std::runtime_error("cannot write " + path_);
+    }
+    if (fwrite(file_.data(), 1, file_.size(), out_) != file_.size()) throw std::runtime_error("write failed: " + path_);
+    file_.clear();
+}
 void AvroFileWriter::close()
 {
     if (closed_) return;
     flush_block();
-    mkdirs_for(path_);
-    std::ofstream f(path_, std::ios::binary);
-    if (!f) throw std::runtime_error("cannot write " + path_);
-    f.write((const char *)file_.data(), (std::streamsize)file_.size());
+    write_out();
+    if (!out_) {                         // nothing buffered can only mean an empty header -- still create the file
+        mkdirs_for(path_);
+        out_ = fopen(path_.c_str(), "wb");
+        if (!out_) throw std::runtime_error("cannot write " + path_);
+    }
     closed_ = true;
+    FILE *f = out_;
+    out_ = nullptr;
+    if (fflush(f) != 0 || ferror(f)) { fclose(f); throw std::runtime_error("write failed: " + path_); }
+    if (fclose(f) != 0) throw std::runtime_error("close failed: " + path_);
 }
 
 }  // namespace mlh

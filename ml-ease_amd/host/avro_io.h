@@ -11,6 +11,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <cstdio>
 #include <string>
 #include <vector>
 
@@ -104,7 +105,9 @@ class AvroFileWriter {
     std::vector<uint8_t> block_, file_;
     int64_t block_count_ = 0;
     bool closed_ = false;
+    FILE *out_ = nullptr;
     void flush_block();
+    void write_out();
 };
 
 extern const char *kLinearModelSchemaJson;        // avro/LinearModelAvro.avsc:16-31

@@ -202,6 +202,10 @@ int run_job(const JobConfig &props)
         score_and_write(*m, out + "/lambda-" + lam);
     }
     if (is_dir(model_base + "/best-model") && !list_avro_files(model_base + "/best-model").empty()) {
+        // the training job keeps exactly one best-iteration-<i>.avro (it deletes the directory before each write,
+        // jobs/RegressionAdmmTrain.java:838-840); several files mean a foreign or stale directory: refuse rather than score a wrong model
+        const std::vector<std::string> files = list_avro_files(model_base + "/best-model");
+        if (files.size() > 1) throw Fail("more than one model file under " + model_base + "/best-model (" + std::to_string(files.size()) + "): expected a single best-iteration-<i>.avro");
         const std::vector<Model> best = read_model_file(model_base + "/best-model");
         if (!best.empty()) score_and_write(best.front(), out + "/best-model");
     }

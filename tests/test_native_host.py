@@ -218,6 +218,17 @@ def test_cli_end_to_end_matches_golden(tmp_path, c1):
     ll = avro_io.read_records(str(tmp_path / "out" / "sample-test-loglik" / "iteration-20.avro"))
     assert ll[0]["lambda"] == "1.0" and ll[0]["iter"] == 20 and -1.0 < ll[0]["testLoglik"] < 0.0
     assert os.path.isdir(tmp_path / "out" / "best-model") and os.path.exists(tmp_path / "out" / "lambda-rho" / "part-r-00000.avro")
+    # updateLogLikBestModel deletes the directory before every write (jobs/RegressionAdmmTrain.java:838-840): ONE file, the
+    # iteration with the best test loglik; and a second run into the same output directory leaves no stale files behind
+    best = sorted(os.listdir(tmp_path / "out" / "best-model"))
+    lls = [avro_io.read_records(str(tmp_path / "out" / "sample-test-loglik" / ("iteration-%d.avro" % i)))[0]["testLoglik"] for i in range(1, 21)]
+    assert best == ["best-iteration-%d.avro" % (int(np.argmax(np.asarray(lls, np.float32))) + 1)], (best, lls)
+    (tmp_path / "out" / "best-model" / "best-iteration-99.avro").write_bytes(b"stale")
+    (tmp_path / "out" / "sample-test-loglik" / "iteration-77.avro").write_bytes(b"stale")
+    r2 = subprocess.run(r.args, capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert sorted(os.listdir(tmp_path / "out" / "best-model")) == best
+    assert not os.path.exists(tmp_path / "out" / "sample-test-loglik" / "iteration-77.avro")
 
 
 @pytest.mark.gpu

@@ -118,6 +118,13 @@ def main():
            "us_per_tick": {"row": round(1e3 * acc["rms"] / max(1, acc["ticks"]), 1), "col": round(1e3 * acc["cms"] / max(1, acc["ticks"]), 1),
                            "step": round(1e3 * acc["sms"] / max(1, acc["ticks"]), 1)},
            "iters": recs}
+    try:                                         # timing-experiment builds only (tools/ablate_build.sh -DMLX_PHASE_TIMING)
+        import ctypes
+        pt = (ctypes.c_double * 16)()
+        if eng.L.mlx_debug_phase_times(pt) == 0:
+            out["phase_us_sum_over_workgroups"] = [round(v, 1) for v in pt]
+    except AttributeError:
+        pass
     print(json.dumps(out))
 
 
