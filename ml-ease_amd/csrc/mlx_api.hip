@@ -887,6 +887,21 @@ int mlx_finalize(mlx_handle h)
             h->max_row_lds = std::max(h->max_row_lds, p.slw);
         }
     }
+    // Dense tiles: 512-row chunks are the optimum when the handle's problems make >= ~1000 of them (profiles/r1_notes.md);
+    // with FEW problems (the 64-partition job strong-scaled over 8 GPUs leaves 8 per GPU = 248 chunks for 256 CUs, one
+    // wave per SIMD where the pass needs two) the chunks shrink until about 1000 workgroups exist, down to 64 rows.
+    if (getenv("MLX_DENSE_RPB") == nullptr) {
+        int64_t dense_rows = 0;
+        for (auto &p : h->parts) if (p.dense) dense_rows += (int64_t)nl * p.l;
+        if (dense_rows > 0 && dense_rows / 512 < 1024) {
+            int rpb = (int)std::max<int64_t>(64, std::min<int64_t>(512, (dense_rows / 1024 + 15) / 16 * 16));
+            for (auto &p : h->parts) if (p.dense && p.l >= 4096) {
+                p.rows_per_blk = rpb;
+                p.nblk = (p.l + rpb - 1) / rpb;
+                p.dev.rows_per_blk = p.rows_per_blk; p.dev.nblk = p.nblk;
+            }
+        }
+    }
     std::vector<PartDev> pd(np);
     for (int k = 0; k < np; k++) pd[k] = h->parts[k].dev;
     if ((rc = dev_upload(h, &h->d_parts, pd.data(), pd.size()))) return rc;
