@@ -35,6 +35,8 @@ constexpr int SMALL_MAX_DIM = 16384;
 struct PartHost {
     int pid = 0, l = 0, n_local = 0, n_feat = 0;
     bool dense = false, hasval = false, all_present = false;
+    int multi_R = 0;                       // lambda sweep: row blocks sized for R = 2, 4 or 8 lambdas side by side in LDS (0 = not)
+    bool row_multi_ok = false;             // the shared row pass can hold this partition's packs in registers
     int64_t nnz = 0, ld = 0;
     int n_short = 0, n_long = 0;
     bool sell = false;
@@ -74,6 +76,9 @@ struct mlx_context {
     int max_cunits = 0, max_rblk_rows = 0;
     int max_row_lds = 0;                    // sliced row pass: columns of the widest hot slice (LDS doubles, + zero slot)
     int row_ngc = 16;                       // row groups per row-pass workgroup (16, 32, 64 or 128)
+    int multi_R = 0;                        // > 0: lambda sweep on the shared-X passes (k_rowpass_multi / k_colpass_multi)
+    bool row_multi = false;                 // ... including the row pass (binary partitions whose packs fit in registers)
+    int *d_plist = nullptr; int np_csr = 0; // first problem of every CSR partition
     int step_threads = 256;
     int step_ch = 2048, step_max_nwg = 1;   // multi-workgroup CSR step: columns per workgroup, chunks of the widest CSR problem
 
@@ -225,9 +230,18 @@ int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
     };
     if (nqd > 0 && bracket(0, [&] { return mlxk_xpass_dense(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->maxblk_dense, h->max_nfeat_dense, h->n_lambda == 1); }))
         return fail(h, MLX_ERR_INVALID, "dense tile wider than 2048 features is not supported; use the CSR form");
+    // lambda sweeps: the whole-handle list runs on the shared-X passes (one workgroup per partition piece carries all lambdas)
+    const bool multi = h->multi_R > 0 && qcsr == h->d_qcsr && nqc == h->nq_csr;
     if (nqc > 0)
         for (int which = 1; which <= 2; which++)
-            bracket(which, [&] { return mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_short, h->max_long, h->rowgroup, h->csr_hasval, h->csr_sell, h->max_cunits, h->max_rblk_rows, h->max_row_lds, h->row_ngc, h->n_lambda == 1, which); });
+            bracket(which, [&] {
+                if (multi && (which == 2 || h->row_multi)) {
+                    mlxk_xpass_multi(h->stream, h->d_parts, h->d_probs, h->d_plist, h->np_csr, h->n_lambda, h->multi_R, h->maxblk_csr, h->csr_hasval,
+                                     h->max_cunits, h->max_rblk_rows, h->max_row_lds, h->row_ngc, h->row_multi, which);
+                    return 0;
+                }
+                return mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_short, h->max_long, h->rowgroup, h->csr_hasval, h->csr_sell, h->max_cunits, h->max_rblk_rows, h->max_row_lds, h->row_ngc, h->n_lambda == 1, which);
+            });
     return MLX_OK;
 }
 
@@ -440,7 +454,7 @@ struct CsrPrep {
 
 static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t l, int32_t n_local, int64_t nnz,
                     const int64_t *row_ptr, const int32_t *col_idx, const float *val, const int8_t *y,
-                    const int32_t *local_to_global, bool faithful)
+                    const int32_t *local_to_global, bool faithful, int n_lambda)
 {
     if (!row_ptr || (nnz > 0 && !col_idx) || !y) return P.fail(MLX_ERR_INVALID, "NULL row data");
     if (row_ptr[0] != 0 || row_ptr[l] != nnz) return P.fail(MLX_ERR_INVALID, "row_ptr[0] must be 0 and row_ptr[l] == nnz");
@@ -505,7 +519,12 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
     // padded to a multiple of 64 items. cri/cval are re-ordered into item order so item_ptr is monotone.
     // (verification mode: one row block, unsplit columns -- a column's sum then runs over its rows in ascending order, XTv's order)
     const int seg = faithful ? std::numeric_limits<int32_t>::max() : (getenv("MLX_SEG") ? atoi(getenv("MLX_SEG")) : CSC_SEG);
-    const int rbmax = faithful ? std::numeric_limits<int32_t>::max() - 64 : (getenv("MLX_RBMAX") ? atoi(getenv("MLX_RBMAX")) : RBLK_MAX_ROWS);
+    int rbmax = faithful ? std::numeric_limits<int32_t>::max() - 64 : (getenv("MLX_RBMAX") ? atoi(getenv("MLX_RBMAX")) : RBLK_MAX_ROWS);
+    // lambda sweeps of 2..8 lambdas: the shared column pass keeps the block's coefficients of R = 2 / 4 / 8 lambdas in LDS at once
+    if (!faithful && n_lambda >= 2 && n_lambda <= 8 && getenv("MLX_NO_MULTI") == nullptr) {
+        ph.multi_R = n_lambda <= 2 ? 2 : (n_lambda <= 4 ? 4 : 8);
+        rbmax = std::min(rbmax, (RBLK_MAX_ROWS + 1) / ph.multi_R / 64 * 64 - 64);
+    }
     const int nb = std::max(1, (l + rbmax - 1) / rbmax);
     const int RB = std::max(64, ((l + nb - 1) / nb + 63) / 64 * 64);
     ph.n_rblk = nb; ph.rblk_rows = RB;
@@ -616,6 +635,15 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
         ph.sell = nnz > 0 && (double)padded <= 2.0 * (double)nnz + 4096.0 && padded < (int64_t)std::numeric_limits<int32_t>::max() &&
                   (int64_t)nnz + 64LL * ph.n_items < (int64_t)std::numeric_limits<int32_t>::max() / 2 && getenv("MLX_NO_SELL") == nullptr &&
                   !faithful;
+        if (ph.sell && ph.multi_R && ncs_r <= 2) {
+            // the shared row pass keeps a row group's packs in registers: <= 6 hot and <= 3 cold packs per group
+            int mxh = 0, mxc = 0;
+            for (int g = 0; g < ngr; g++) {
+                mxh = std::max(mxh, (rs_ptr[(size_t)g + 1] - rs_ptr[(size_t)g]) >> 8);
+                if (ncs_r == 2) mxc = std::max(mxc, (rs_ptr[(size_t)ngr + g + 1] - rs_ptr[(size_t)ngr + g]) >> 8);
+            }
+            ph.row_multi_ok = mxh <= 6 && mxc <= 3;
+        }
         if (ph.sell) {
             rs_idx.assign((size_t)padded, (uint16_t)0xFFFF);
             if (val) rs_val.assign((size_t)padded, 0.f);
@@ -770,7 +798,7 @@ int mlx_add_partition_csr(mlx_handle h, int32_t partition_id, int32_t l, int32_t
     if (rc) return rc;
     if (!h->faithful && csr_is_dense_enough(l, n_local, nnz, row_ptr, col_idx)) return add_csr_as_dense_tile(h, partition_id, l, n_local, row_ptr, col_idx, val, y, weight, offset, local_to_global);
     CsrPrep P;
-    if ((rc = prep_csr(P, h->n_global, partition_id, l, n_local, nnz, row_ptr, col_idx, val, y, local_to_global, h->faithful)))
+    if ((rc = prep_csr(P, h->n_global, partition_id, l, n_local, nnz, row_ptr, col_idx, val, y, local_to_global, h->faithful, h->n_lambda)))
         return fail(h, rc, "%s", P.error.c_str());
     return commit_csr(h, P, l, n_local, nnz, y, weight, offset);
 }
@@ -805,7 +833,7 @@ int mlx_add_partitions_csr(mlx_handle h, int32_t count, const int32_t *partition
                 const int k = b0 + j;
                 if (!h->faithful && csr_is_dense_enough(l[k], n_local[k], nnz[k], row_ptr[k], col_idx[k])) { as_tile[(size_t)j] = 1; return; }
                 prep_csr(preps[(size_t)j], h->n_global, partition_id[k], l[k], n_local[k], nnz[k], row_ptr[k], col_idx[k],
-                         val ? val[k] : nullptr, y[k], local_to_global[k], h->faithful);
+                         val ? val[k] : nullptr, y[k], local_to_global[k], h->faithful, h->n_lambda);
             });
         for (auto &t : th) t.join();
         for (int j = 0; j < nb; j++) {
@@ -872,12 +900,20 @@ int mlx_finalize(mlx_handle h)
     // handle's total work allows: about three workgroups per CU over all problems, 16..128 groups (1 024..8 192 rows).
     h->csr_sell = true;
     for (auto &p : h->parts) if (!p.dense) h->csr_sell = h->csr_sell && p.sell;
+    if (h->csr_sell && nl >= 2) {
+        int R = -1;
+        bool rm = true, hv = false;
+        for (auto &p : h->parts) if (!p.dense) { R = (R == -1 || R == p.multi_R) ? p.multi_R : 0; rm = rm && p.row_multi_ok; hv = hv || p.hasval; }
+        h->multi_R = R > 0 ? R : 0;
+        h->row_multi = h->multi_R > 0 && rm && !hv;
+    }
     if (h->csr_sell) {
         int64_t total_groups = 0;
         for (auto &p : h->parts) if (!p.dense) total_groups += (int64_t)nl * p.n_rgroups;
         int ngc = 16;                                    // 16 * {1, 2, 4, 8}: the row pass is compiled for these group counts per wave
         while (ngc < 128 && total_groups / ngc > 768) ngc *= 2;
         if (const char *e = getenv("MLX_ROW_NG")) { ngc = 16; while (ngc < 128 && ngc < atoi(e)) ngc *= 2; }
+        if (h->row_multi) ngc = 16;                      // the shared row pass: one row group per wave
         h->row_ngc = ngc;
         for (auto &p : h->parts) if (!p.dense) {
             p.dev.rgroups_per_chunk = ngc;
@@ -955,6 +991,12 @@ int mlx_finalize(mlx_handle h)
         // holes (when ncp is not a multiple of 8) are dropped: placement is a speed matter only
         qc.clear();
         for (int q : ordered) if (q >= 0) qc.push_back(q);
+    }
+    if (h->multi_R) {
+        std::vector<int> pl;
+        for (int k = 0; k < np; k++) if (!h->parts[k].dense) pl.push_back(k * nl);
+        h->np_csr = (int)pl.size();
+        if ((rc = dev_upload(h, &h->d_plist, pl.data(), pl.size()))) return rc;
     }
     h->nq_dense = (int)qd.size(); h->nq_csr = (int)qc.size();
     if ((rc = dev_upload(h, &h->d_qdense, qd.data(), qd.size()))) return rc;

@@ -12,6 +12,10 @@ int mlxk_xpass_dense(hipStream_t st, const PartDev *parts, ProbDev *probs, const
 int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
                    int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cunits, int max_rblk_rows, int row_slw, int row_ngc, bool stream_once,
                    int which /* 1 = row pass, 2 = column pass, 3 = both */);
+// Shared-X passes of a lambda sweep (n_lambda <= 8): one workgroup per (partition, piece) carries all lambdas; plist = first
+// problem of every CSR partition. row_multi false = only the column pass has a shared form for these partitions.
+void mlxk_xpass_multi(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *plist, int np, int nl, int R, int maxblk,
+                      bool hasval, int max_cunits, int max_rblk_rows, int row_slw, int row_ngc, bool row_multi, int which);
 // TRON/CG control flow for the problems in qlist: one workgroup per problem (dense tiles)
 void mlxk_tron_step(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int threads,
                     int *done_counter);

@@ -794,6 +794,257 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// Shared-X passes for lambda sweeps (BASELINE configs[4]: the reference replicates every row once per lambda through the
+// shuffle, jobs/RegressionAdmmTrain.java:553-568). One workgroup = (PARTITION, piece of it) and carries ALL of the
+// partition's lambda problems, so the index / value streams -- the dominant traffic -- are read ONCE per tick:
+//   * row pass: the packs of the wave's rows are loaded into registers once, then for every unfinished lambda the hot
+//     slice of ITS vector is staged in LDS and the same packs drive the gathers (hot from LDS, cold from L2);
+//   * column pass: the row blocks are R times shorter (R = the lambda count rounded up to 2, 4 or 8) so that the block's
+//     coefficients of ALL lambdas sit in LDS side by side; every pack is loaded once and feeds R running sums.
+// Each lambda keeps its own phase (CG / EVAL / DONE), vectors and outputs: per problem the arithmetic and its order are
+// exactly those of the single-lambda kernels, finished lambdas are skipped.
+// ------------------------------------------------------------------------------------------------
+#define RM_MAXH 6      // hot packs per row group held in registers (24 entries per row)
+#define RM_MAXC 3      // cold packs per row group (12 entries per row); partitions beyond either run the per-problem row pass
+template <bool HASVAL, bool NT, int GPW>
+__global__ void __launch_bounds__(1024)
+k_rowpass_multi(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ plist, int np, int gx, int nl)
+{
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) double vs[];      // [slw + 1]: the staged hot slice of one lambda, then the zero slot
+    __shared__ double scratch[48];
+    int pi_, bx_;
+    if (!xcd_map(np, gx, pi_, bx_)) return;
+    const int q0 = plist[pi_];
+    const PartDev &pa = parts[probs[q0].part];
+    const int c = bx_;
+    if (c >= pa.nblk) return;
+    const int nf = pa.n_feat, slw = pa.slw, ngr = pa.n_rgroups, l = pa.l;
+    const int g0 = c * (16 * GPW);
+    const int gcount = min(16 * GPW, ngr - g0);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wg0 = wave * GPW;
+    const uint16_t *__restrict__ rs_idx = pa.rs_idx;
+    const float *__restrict__ rs_val = pa.rs_val;
+    const bool has_cold = pa.n_cs > 1;
+    // ---- the wave's packs, once: hot block offsets from slice 0, cold ones from slice 1 (n_cs <= 2 is a launch condition)
+    int nh[GPW], nc[GPW];
+    u2v_t qh[GPW][RM_MAXH], qc[GPW][RM_MAXC];
+    f4v_t xh[GPW][RM_MAXH], xc[GPW][RM_MAXC];
+    {
+        const int32_t *__restrict__ ptr = pa.rs_ptr + g0;
+        const int pv = ptr[min(wg0 + min(lane, GPW), gcount)];
+        const int pw = has_cold ? ptr[ngr + min(wg0 + min(lane, GPW), gcount)] : 0;
+        const unsigned zz = (unsigned)slw | ((unsigned)slw << 16);
+#pragma unroll
+        for (int i = 0; i < GPW; i++) {
+            const bool on = wg0 + i < gcount;
+            const int bh = __builtin_amdgcn_readlane(pv, i), bc = __builtin_amdgcn_readlane(pw, i);
+            nh[i] = on ? (__builtin_amdgcn_readlane(pv, i + 1) - bh) >> 8 : 0;
+            nc[i] = (on && has_cold) ? (__builtin_amdgcn_readlane(pw, i + 1) - bc) >> 8 : 0;
+#pragma unroll
+            for (int p = 0; p < RM_MAXH; p++) {
+                const int kk = max(min(p, nh[i] - 1), 0);
+                qh[i][p] = pack_load<NT>(rs_idx, bh, kk, lane);
+                if (HASVAL) xh[i][p] = pack_load_val<NT>(rs_val, bh, kk, lane);
+                if (p >= nh[i]) { qh[i][p].x = zz; qh[i][p].y = zz; }
+            }
+#pragma unroll
+            for (int p = 0; p < RM_MAXC; p++) {
+                const int kk = max(min(p, nc[i] - 1), 0);
+                qc[i][p] = pack_load<NT>(rs_idx, bc, kk, lane);
+                if (HASVAL) xc[i][p] = pack_load_val<NT>(rs_val, bc, kk, lane);
+                if (p >= nc[i]) { qc[i][p].x = 0xFFFFFFFFu; qc[i][p].y = 0xFFFFFFFFu; }
+            }
+        }
+    }
+    for (int li = 0; li < nl; li++) {
+        ProbDev &pr = probs[q0 + li];
+        const int phase = pr.phase;
+        if (phase == PH_DONE) continue;                       // (uniform over the workgroup)
+        const bool cg = (phase == PH_CG);
+        const double *__restrict__ v = cg ? pr.d : pr.w_new;
+        const double *__restrict__ wdcur = pr.wd[pr.dsel];
+        double *__restrict__ wdnew = pr.wd[pr.dsel ^ 1];
+        double *__restrict__ coef = pr.coef;
+        __syncthreads();                                      // the previous lambda's readers are done
+        {
+            StageRegs SR;
+            const int cnt = min(slw, nf);
+            stage_fetch(SR, v, cnt, tid);
+            stage_store(SR, vs, v, cnt, tid);
+            if (tid == 0) vs[slw] = 0.0;
+        }
+        __syncthreads();
+        double acc[GPW];
+        const double *__restrict__ src = v + slw;             // cold ids are relative to the end of the hot slice
+        // The packs are loop invariant, and so would be the 4 LDS / global offsets derived from each: hoisted out of the lambda
+        // loop they cost 4 more registers per pack and spill. Opaque copies keep only the packs alive across iterations.
+#pragma unroll
+        for (int i = 0; i < GPW; i++) {
+#pragma unroll
+            for (int p = 0; p < RM_MAXH; p++) asm volatile("" : "+v"(qh[i][p].x), "+v"(qh[i][p].y));
+#pragma unroll
+            for (int p = 0; p < RM_MAXC; p++) asm volatile("" : "+v"(qc[i][p].x), "+v"(qc[i][p].y));
+        }
+#pragma unroll
+        for (int i = 0; i < GPW; i++) {
+            double a = 0.0;
+#pragma unroll
+            for (int p = 0; p < RM_MAXH; p++)
+                if (p < nh[i]) a = pack_sum<HASVAL>(a, qh[i][p], xh[i][p], vs);
+            // cold gathers of the group: all loads first (clamped, unconditional), then the adds in entry order
+            double cv[RM_MAXC][4];
+#pragma unroll
+            for (int p = 0; p < RM_MAXC; p++) {
+                const unsigned id[4] = {qc[i][p].x & 0xFFFFu, qc[i][p].x >> 16, qc[i][p].y & 0xFFFFu, qc[i][p].y >> 16};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const double g = has_cold ? src[id[e] == 0xFFFFu ? 0u : id[e]] : 0.0;
+                    cv[p][e] = id[e] == 0xFFFFu ? 0.0 : g;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < RM_MAXC; p++)
+                if (p < nc[i]) {
+                    a = a + (HASVAL ? cv[p][0] * (double)xc[i][p].x : cv[p][0]);
+                    a = a + (HASVAL ? cv[p][1] * (double)xc[i][p].y : cv[p][1]);
+                    a = a + (HASVAL ? cv[p][2] * (double)xc[i][p].z : cv[p][2]);
+                    a = a + (HASVAL ? cv[p][3] * (double)xc[i][p].w : cv[p][3]);
+                }
+            acc[i] = a;
+            asm volatile("" ::: "memory");                    // one group's gathers at a time (their results would not fit twice)
+        }
+        const double vb = v[nf];
+        double red[2] = {0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < GPW; i++) {
+            const int row = (g0 + wg0 + i) * 64 + lane;
+            const bool ok = (wg0 + i < gcount) && row < l;
+            const int rc = min(row, l - 1);
+            const double wdv0 = cg ? wdcur[rc] : 0.0;
+            const float offv = cg ? 0.f : pa.off[rc];
+            const float wtv = cg ? 0.f : pa.wt[rc];
+            const int yv = cg ? 0 : (int)pa.y[rc];
+            if (ok) {
+                const double t = acc[i] + vb;
+                double cf;
+                if (cg) {
+                    cf = wdv0 * t;
+                } else {
+                    double loss, wdv;
+                    row_eval(t + (double)offv, yv, (double)wtv, loss, wdv, cf);
+                    wdnew[rc] = wdv;
+                    red[0] += loss;
+                }
+                coef[rc] = cf;
+                red[1] += cf;
+            }
+        }
+        block_allreduce_sum<2>(red, scratch);
+        if (tid == 0) { pr.lossp[c] = red[0]; pr.csump[c] = red[1]; }
+    }
+}
+
+// Column pass for R lambdas at once: LDS holds the block's coefficients of lambda li at cf[li * (rblk_rows + 1) ...], each
+// region followed by its zero slot. COL_MB item slices per wave and round; a pack is loaded once and adds into R sums.
+template <bool HASVAL, bool NT, int R>
+__global__ void __launch_bounds__(1024)
+k_colpass_multi(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ plist, int np, int gx, int nl)
+{
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) double cf[];
+    int pi_, bx_;
+    if (!xcd_map(np, gx, pi_, bx_)) return;
+    const int q0 = plist[pi_];
+    const PartDev &pa = parts[probs[q0].part];
+    if (bx_ >= pa.n_cunits) return;
+    const int blk = pa.cw_blk[bx_];
+    const int s0 = pa.cw_slice[bx_], s1 = pa.cw_slice[bx_ + 1];
+    const int rbr = pa.rblk_rows, reg = rbr + 1;
+    const int r0 = blk * rbr;
+    const int nr = min(rbr, pa.l - r0);
+    bool act[R];
+    double *outp[R];
+    bool any = false;
+#pragma unroll
+    for (int li = 0; li < R; li++) {
+        act[li] = li < nl && probs[q0 + min(li, nl - 1)].phase != PH_DONE;
+        outp[li] = probs[q0 + min(li, nl - 1)].parts;
+        any = any || act[li];
+    }
+    if (!any) return;
+#pragma unroll
+    for (int li = 0; li < R; li++) {
+        if (act[li]) {
+            StageRegs SR;
+            const double *__restrict__ src = probs[q0 + li].coef + r0;      // r0 is a multiple of 64: 16-byte aligned pairs
+            stage_fetch(SR, src, nr, threadIdx.x);
+            stage_store(SR, cf + li * reg, src, nr, threadIdx.x);
+        }
+        if (threadIdx.x == 0) cf[li * reg + rbr] = 0.0;
+    }
+    __syncthreads();
+    const uint16_t *__restrict__ cs_idx = pa.cs_idx;
+    const float *__restrict__ cs_val = pa.cs_val;
+    const int32_t *__restrict__ cs_ptr = pa.cs_ptr;
+    const int32_t *__restrict__ item_dst = pa.item_dst;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int COL_MB = R >= 8 ? 2 : (R >= 4 ? 4 : 8);
+    const unsigned zz = (unsigned)rbr | ((unsigned)rbr << 16);
+    for (int sb = s0 + wave; sb < s1; sb += 16 * COL_MB) {
+        int base[COL_MB], L4[COL_MB], dst[COL_MB];
+        u2v_t q0v[COL_MB];
+        f4v_t x0v[COL_MB];
+#pragma unroll
+        for (int u = 0; u < COL_MB; u++) {
+            const int sl = sb + 16 * u;
+            const int sc = min(sl, s1 - 1);
+            base[u] = __builtin_amdgcn_readfirstlane(cs_ptr[sc]);
+            const int nx = __builtin_amdgcn_readfirstlane(cs_ptr[sc + 1]);
+            L4[u] = (sl < s1) ? (nx - base[u]) >> 8 : 0;
+            dst[u] = (sl < s1) ? item_dst[sc * 64 + lane] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < COL_MB; u++) {
+            q0v[u] = pack_load<NT>(cs_idx, base[u], 0, lane);
+            if (HASVAL) x0v[u] = pack_load_val<NT>(cs_val, base[u], 0, lane);
+            if (L4[u] < 1) { q0v[u].x = zz; q0v[u].y = zz; }
+        }
+#pragma unroll
+        for (int u = 0; u < COL_MB; u++) {
+            double a[R];
+#pragma unroll
+            for (int li = 0; li < R; li++) a[li] = act[li] ? pack_sum<HASVAL>(0.0, q0v[u], x0v[u], cf + li * reg) : 0.0;
+            // long items: LSUM packs in flight, every pack feeds the R sums
+            constexpr int LSUM = HASVAL ? 2 : 4;
+            for (int k = 1; k < L4[u]; k += LSUM) {
+                u2v_t q[LSUM];
+                f4v_t xv[LSUM];
+#pragma unroll
+                for (int t = 0; t < LSUM; t++) {
+                    const int kk = min(k + t, L4[u] - 1);
+                    q[t] = pack_load<NT>(cs_idx, base[u], kk, lane);
+                    if (HASVAL) xv[t] = pack_load_val<NT>(cs_val, base[u], kk, lane);
+                    if (k + t >= L4[u]) { q[t].x = zz; q[t].y = zz; }
+                }
+#pragma unroll
+                for (int li = 0; li < R; li++)
+                    if (act[li]) {
+#pragma unroll
+                        for (int t = 0; t < LSUM; t++) a[li] = pack_sum<HASVAL>(a[li], q[t], xv[t], cf + li * reg);
+                    }
+            }
+            if (dst[u] >= 0) {
+#pragma unroll
+                for (int li = 0; li < R; li++)
+                    if (act[li]) outp[li][dst[u]] = a[li];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // per-iteration problem setup: warm start z~, prior mean z~ - u_k on the partition's local index set
 // (jobs/RegressionAdmmTrain.java:692-698 ; llf/LibLinear.java:236-245 initSetup)
 // ------------------------------------------------------------------------------------------------
@@ -921,7 +1172,8 @@ __device__ __forceinline__ void assemble_out(const PartDev &pa, const ProbDev &p
             const int j = base + c;
             double a = 0.0;
             if (j < n) {
-#pragma unroll 4
+                // 16 slice loads in flight: few-problem shapes cut the rows into up to ~250 chunks (mlx_finalize)
+#pragma unroll 16
                 for (int p = g; p < P; p += NG) a += parts[(int64_t)p * n + j];
             }
             stage[g * CW + c] = a;
@@ -2356,6 +2608,35 @@ int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const i
         else hipLaunchKernelGGL((k_colpass_items<8, false>), dim3(XGRID(nq, gs)), dim3(256), 0, st, parts, probs, qlist, nq, gs);
     }
     return 0;
+}
+
+// Shared-X passes of a lambda sweep: plist = first problem of every CSR partition (its n_lambda problems are consecutive)
+void mlxk_xpass_multi(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *plist, int np, int nl, int R, int maxblk,
+                      bool hasval, int max_cunits, int max_rblk_rows, int row_slw, int row_ngc, bool row_multi, int which)
+{
+    if (np <= 0) return;
+    const size_t lds_col = (size_t)R * ((size_t)max_rblk_rows + 1) * sizeof(double), lds_row = ((size_t)row_slw + 1) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+#define SETM(HV)                                                                                                                              \
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_colpass_multi<HV, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); \
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_colpass_multi<HV, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); \
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_colpass_multi<HV, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)
+        SETM(true); SETM(false);
+#undef SETM
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowpass_multi<false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        attr_set = true;
+    }
+    // (the shared row pass exists for binary.feature partitions, one row group per wave: its packs stay in registers across
+    // the lambda loop, and a float4 of values per pack or a second group does not fit beside them)
+    if ((which & 1) && row_multi && !hasval && row_ngc == 16)
+        hipLaunchKernelGGL((k_rowpass_multi<false, false, 1>), dim3(XGRID(np, maxblk)), dim3(1024), lds_row, st, parts, probs, plist, np, maxblk, nl);
+    if ((which & 2) && max_cunits > 0) {
+#define LCOL(HV, RR) hipLaunchKernelGGL((k_colpass_multi<HV, false, RR>), dim3(XGRID(np, max_cunits)), dim3(1024), lds_col, st, parts, probs, plist, np, max_cunits, nl)
+        if (hasval) { if (R == 2) LCOL(true, 2); else if (R == 4) LCOL(true, 4); else LCOL(true, 8); }
+        else { if (R == 2) LCOL(false, 2); else if (R == 4) LCOL(false, 4); else LCOL(false, 8); }
+#undef LCOL
+    }
 }
 
 void mlxk_tron_step(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int threads,

@@ -717,6 +717,34 @@ def _counters(oc):
     return np.array([(s.newton_iters, s.accepted, s.cg_iters, s.x_passes) for s in oc.stats()])
 
 
+@pytest.mark.parametrize("binary,nlam", [(True, 8), (True, 3), (False, 5), (False, 2)])
+def test_lambda_sweep_shared_x_passes(binary, nlam, monkeypatch):
+    """BASELINE configs[4] in the small: a lambda sweep on the tick kernels runs the shared-X passes (k_rowpass_multi for
+    binary partitions, k_colpass_multi with R = 2 / 4 / 8 lambdas side by side in LDS; the reference replicates every row per
+    lambda instead, jobs/RegressionAdmmTrain.java:553-568). Per problem the result must be the per-problem kernels' result:
+    TRON/CG counters equal to the oracle's, coefficients within 1e-5, lambdas finishing at different ticks included."""
+    monkeypatch.setenv("MLX_NO_SMALL", "1")
+    pd = synth_sparse(23, 9000, 400, 14, 3, binary=binary, weights=not binary, offsets=not binary)
+    lam = [0.05, 0.3, 1.0, 3.0, 10.0, 30.0, 100.0, 300.0][:nlam]
+    rho = [1.0 if v <= 100 else 10.0 for v in lam]
+    eng = make_engine(pd, lam, rho)
+    oc = ol.OracleAdmm(pd.blocks, pd.n_global, lam, rho)
+    for it in range(4):
+        eng.iterate(0.01)
+        oc.iterate(0.01, 1.0, nthreads=4)
+        assert np.array_equal(eng.solve_counters(), _counters(oc)), "iteration %d" % (it + 1)
+        for li in range(nlam):
+            assert_coef_close(eng.z()[1][li], oc.z()[1][li], "lambda %g iteration %d" % (lam[li], it + 1), floor=1e-2)
+    eng.close()
+    # the same sweep on the per-problem passes: same trajectories
+    monkeypatch.setenv("MLX_NO_MULTI", "1")
+    eng2 = make_engine(pd, lam, rho)
+    for it in range(4):
+        eng2.iterate(0.01)
+    assert np.array_equal(eng2.solve_counters(), _counters(oc))
+    eng2.close()
+
+
 @pytest.mark.parametrize("kind", ["onehot", "valued"])
 def test_order_faithful_mode_is_bit_identical_to_the_oracle(kind, monkeypatch):
     """MLX_FAITHFUL=1: library column ids = the partition's first-seen order, one thread per row / per UNSPLIT
