@@ -41,6 +41,7 @@ struct PartHost {
     int n_short = 0, n_long = 0;
     bool sell = false;
     std::vector<int32_t> new2old;          // CSR partitions: library local id -> caller's local id (features only)
+    std::vector<int32_t> col_ptr_h;        // CSR partitions: host copy of col_ptr (slots of each column)
     int n_cs = 1, slw = 64, n_rgroups = 0, n_cslices = 0, n_rblk = 1, rblk_rows = 0, n_cunits = 0;
     int nblk = 0, rows_per_blk = 0, n_items = 0, n_slots = 0, rowgroup = 64, pos = 0, neg = 0;
     PartDev dev{};
@@ -521,7 +522,9 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
     const int seg = faithful ? std::numeric_limits<int32_t>::max() : (getenv("MLX_SEG") ? atoi(getenv("MLX_SEG")) : CSC_SEG);
     int rbmax = faithful ? std::numeric_limits<int32_t>::max() - 64 : (getenv("MLX_RBMAX") ? atoi(getenv("MLX_RBMAX")) : RBLK_MAX_ROWS);
     // lambda sweeps of 2..8 lambdas: the shared column pass keeps the block's coefficients of R = 2 / 4 / 8 lambdas in LDS at once
-    if (!faithful && n_lambda >= 2 && n_lambda <= 8 && getenv("MLX_NO_MULTI") == nullptr) {
+    // (opt-in, MLX_MULTI=1: measured SLOWER than the per-problem passes sharing the streams through L2 -- the passes are not
+    // bound by the index stream, and R times shorter row blocks multiply the column items; profiles/r2_notes.md)
+    if (!faithful && n_lambda >= 2 && n_lambda <= 8 && getenv("MLX_MULTI") != nullptr && atoi(getenv("MLX_MULTI")) != 0) {
         ph.multi_R = n_lambda <= 2 ? 2 : (n_lambda <= 4 ? 4 : 8);
         rbmax = std::min(rbmax, (RBLK_MAX_ROWS + 1) / ph.multi_R / 64 * 64 - 64);
     }
@@ -702,6 +705,7 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
     P.ph = std::move(ph);
     P.hasval = (val != nullptr);
     P.rp = std::move(rp); P.pcol = std::move(pcol); P.pvalv = std::move(pvalv); P.cri = std::move(cri); P.cval = std::move(cval);
+    ph.col_ptr_h = col_ptr;
     P.item_ptr = std::move(item_ptr); P.item_dst = std::move(item_dst); P.col_ptr = std::move(col_ptr); P.ishort = std::move(ishort); P.ilong = std::move(ilong);
     P.l2g_perm = std::move(l2g_perm);
     P.rs_ptr = std::move(rs_ptr); P.rs_idx = std::move(rs_idx); P.rs_val = std::move(rs_val);
@@ -862,7 +866,29 @@ int mlx_add_partition_dense(mlx_handle h, int32_t partition_id, int32_t l, int32
     if (rc) return rc;
     if (!X || !y || n_feat < 1 || ld < n_feat) return fail(h, MLX_ERR_INVALID, "bad dense tile arguments");
     if (h->faithful) return fail(h, MLX_ERR_INVALID, "MLX_FAITHFUL (verification mode) supports CSR partitions only");
-    if (n_feat > 2048) return fail(h, MLX_ERR_INVALID, "dense tile wider than 2048 features is not supported; use the CSR form");
+    if (n_feat > 2048) {
+        // The fused dense pass keeps a row's slice in registers (<= 2048 columns); wider tiles run the sparse passes on their
+        // non-zero entries (same sums: the zeros they skip add +0.0), every column still present (n_local = n_feat + 1).
+        std::vector<float> Xh((size_t)l * n_feat), wv, ov;
+        std::vector<int8_t> yh((size_t)l);
+        const hipMemcpyKind kind = x_on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost;
+        HIPCHECK(h, hipMemcpy2D(Xh.data(), sizeof(float) * n_feat, X, sizeof(float) * ld, sizeof(float) * n_feat, l, kind));
+        HIPCHECK(h, hipMemcpy(yh.data(), y, (size_t)l, kind));
+        if (weight) { wv.resize((size_t)l); HIPCHECK(h, hipMemcpy(wv.data(), weight, sizeof(float) * l, kind)); }
+        if (offset) { ov.resize((size_t)l); HIPCHECK(h, hipMemcpy(ov.data(), offset, sizeof(float) * l, kind)); }
+        std::vector<int64_t> rp((size_t)l + 1, 0);
+        std::vector<int32_t> ci;
+        std::vector<float> vv;
+        for (int i = 0; i < l; i++) {
+            for (int j = 0; j < n_feat; j++) {
+                const float x = Xh[(size_t)i * n_feat + j];
+                if (x != 0.0f) { ci.push_back(j); vv.push_back(x); }
+            }
+            rp[(size_t)i + 1] = (int64_t)ci.size();
+        }
+        return mlx_add_partition_csr(h, partition_id, l, n_local, (int64_t)ci.size(), rp.data(), ci.data(), vv.data(), yh.data(),
+                                     weight ? wv.data() : nullptr, offset ? ov.data() : nullptr, local_to_global);
+    }
     PartHost ph;
     ph.pid = partition_id; ph.l = l; ph.n_local = n_local; ph.n_feat = n_feat; ph.dense = true; ph.hasval = true;
     ph.nnz = (int64_t)l * n_feat; ph.all_present = (n_local == h->n_global);
@@ -929,8 +955,9 @@ int mlx_finalize(mlx_handle h)
     if (getenv("MLX_DENSE_RPB") == nullptr) {
         int64_t dense_rows = 0;
         for (auto &p : h->parts) if (p.dense) dense_rows += (int64_t)nl * p.l;
-        if (dense_rows > 0 && dense_rows / 512 < 1024) {
-            int rpb = (int)std::max<int64_t>(64, std::min<int64_t>(512, (dense_rows / 1024 + 15) / 16 * 16));
+        const int64_t want = getenv("MLX_DENSE_WGS") ? std::max(64, atoi(getenv("MLX_DENSE_WGS"))) : 1024;
+        if (dense_rows > 0 && dense_rows / 512 < want) {
+            int rpb = (int)std::max<int64_t>(64, std::min<int64_t>(512, (dense_rows / want + 15) / 16 * 16));
             for (auto &p : h->parts) if (p.dense && p.l >= 4096) {
                 p.rows_per_blk = rpb;
                 p.nblk = (p.l + rpb - 1) / rpb;
@@ -976,7 +1003,8 @@ int mlx_finalize(mlx_handle h)
     for (auto &p : h->parts) if (!p.dense) {
         if (first_csr) { h->rowgroup = p.rowgroup; first_csr = false; }
         else h->rowgroup = std::max(h->rowgroup, p.rowgroup);
-        if (p.hasval != h->csr_hasval) return fail(h, MLX_ERR_INVALID, "binary.feature and valued CSR partitions cannot be mixed in one handle");
+        // (binary.feature and valued partitions may share a handle: the valued kernels then run for all of them and read 1.0
+        // where a partition has no value array -- x * 1.0 == x, the sums are those of the binary kernels bit for bit)
     }
     // Order of the CSR work list = XCD placement (xcd_map in mlx_kernels.hip puts list position i on XCD i % 8):
     // the n_lambda problems of one partition share its index streams, so they go to the SAME XCD, back to back:
@@ -1589,9 +1617,9 @@ int mlx_posterior_variance(mlx_handle h, int32_t local_index, const double *w, c
     hipSetDevice(h->device);
     const PartHost &p = h->parts[local_index];
     const int n = p.n_local, nf = p.n_feat, l = p.l;
-    if (!p.dense && (n > 8192 || (int64_t)l * ((nf + 3) / 4 * 4) > ((int64_t)1 << 30)))
-        return fail(h, MLX_ERR_INVALID, "posterior variance of a CSR partition needs a temporary dense tile: n_local <= 8192 and l*n_local <= 2^30");
-    if (full && n > 8192) return fail(h, MLX_ERR_INVALID, "full posterior covariance is limited to n_local <= 8192 (the reference allocates double[n][n])");
+    if (full && !p.dense && (n > 8192 || (int64_t)l * ((nf + 3) / 4 * 4) > ((int64_t)1 << 30)))
+        return fail(h, MLX_ERR_INVALID, "full posterior covariance of a CSR partition needs a temporary dense tile: n_local <= 8192 and l*n_local <= 2^30");
+    if (full && n > 8192) return fail(h, MLX_ERR_INVALID, "full posterior covariance is limited to n_local <= 8192 (the reference allocates double[n][n] on the JVM heap)");
     auto old_of = [&](int j) { return (!p.dense && j < n - 1) ? p.new2old[(size_t)j] : j; };
     int rc;
     // D_ii at w: one EVAL pass of the scratch problem leaves weight_i p_i (1 - p_i) in wd[dsel ^ 1]
@@ -1607,6 +1635,30 @@ int mlx_posterior_variance(mlx_handle h, int32_t local_index, const double *w, c
     h->profiling = prof;
     if (rc) return rc;
     const double *d_wd = pr.wd[1];
+
+    if (!p.dense && !full) {
+        // hessianDiagonal straight from the column items (no dense tile, any n_local): slots on the device, a column's slots and
+        // the intercept's sum of wd on the host
+        double *d_slots = nullptr;
+        const size_t ns = (size_t)std::max(p.n_slots, 1);
+        if (hipMalloc((void **)&d_slots, ns * sizeof(double)) != hipSuccess) return fail(h, MLX_ERR_HIP, "hipMalloc failed");
+        mlxk_hess_diag_items(h->stream, p.n_items, p.dev.item_ptr, p.dev.item_dst, p.dev.cri, p.dev.cval, d_wd, d_slots);
+        std::vector<double> slots(ns), wdh((size_t)l);
+        bool ok = hipMemcpyAsync(slots.data(), d_slots, ns * sizeof(double), hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
+                  hipMemcpyAsync(wdh.data(), d_wd, (size_t)l * sizeof(double), hipMemcpyDeviceToHost, h->stream) == hipSuccess &&
+                  hipStreamSynchronize(h->stream) == hipSuccess && hipGetLastError() == hipSuccess;
+        hipFree(d_slots);
+        if (!ok) return fail(h, MLX_ERR_HIP, "posterior variance kernels failed");
+        for (int j = 0; j < nf; j++) {
+            double a = 0.0;
+            for (int32_t it = p.col_ptr_h[(size_t)j]; it < p.col_ptr_h[(size_t)j + 1]; it++) a += slots[(size_t)it];
+            post_var[old_of(j)] = 1.0 / (pinv[(size_t)j] + a);
+        }
+        double sw = 0.0;
+        for (int i = 0; i < l; i++) sw += wdh[(size_t)i];
+        post_var[old_of(nf)] = 1.0 / (pinv[(size_t)nf] + sw);
+        return MLX_OK;
+    }
 
     // the partition as a dense tile
     const float *X = p.dev.X;

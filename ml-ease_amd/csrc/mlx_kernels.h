@@ -51,6 +51,8 @@ void mlxk_round_z(hipStream_t st, int64_t n, const double *Z, float *z32);
 void mlxk_densify(hipStream_t st, int l, const int32_t *rp, const int32_t *ci, const float *val, float *X, int64_t ld);
 void mlxk_hess_colsums(hipStream_t st, const float *X, int64_t ld, int l, const double *wd, double *part, int nchunk,
                        int rows_per_chunk, double *out /* [2*ld + 1]: s1, s2, sum wd */);
+void mlxk_hess_diag_items(hipStream_t st, int n_items, const int32_t *item_ptr, const int32_t *item_dst, const int32_t *cri,
+                          const float *cval, const double *wd, double *slots /* [n_slots] */);
 void mlxk_gram_f64(hipStream_t st, const float *X, int64_t ld, int l, const double *wd, const int *blocks_xy, int nblocks,
                    int ksplit, int rows_per_split, double *P, int npad);
 void mlxk_gram_finish(hipStream_t st, const double *P, int ksplit, int npad, int nf, const double *colsums, int64_t ld,

@@ -345,7 +345,7 @@ k_rowpass_csr(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
             for (int u = 0; u < RU; u++) {
                 const int kc = min(kb + gl + u * G, k1 - 1);
                 idx[u] = ci[kc];
-                if (HASVAL) xv[u] = val[kc];
+                if (HASVAL) xv[u] = val ? val[kc] : 1.0f;          // (a binary partition in a valued handle: x * 1.0 == x)
             }
             double vv[RU];
 #pragma unroll
@@ -414,7 +414,7 @@ k_colpass_items(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, 
         for (int u = 0; u < CU; u++) {
             const int kc = min(kb + gl + u * G, k1 - 1);
             idx[u] = cri[kc];
-            if (HASVAL) xv[u] = cval[kc];
+            if (HASVAL) xv[u] = cval ? cval[kc] : 1.0f;
         }
         double cc[CU];
 #pragma unroll
@@ -480,6 +480,7 @@ __device__ __forceinline__ u2v_t pack_load(const uint16_t *__restrict__ idx, int
 template <bool NT>
 __device__ __forceinline__ f4v_t pack_load_val(const float *__restrict__ val, int base, int kk, int lane)
 {
+    if (val == nullptr) return (f4v_t){1.0f, 1.0f, 1.0f, 1.0f};     // a binary partition in a valued handle: x * 1.0 == x
     const f4v_t *__restrict__ vp = reinterpret_cast<const f4v_t *>(val + base) + kk * 64 + lane;
     return NT ? __builtin_nontemporal_load(vp) : *vp;
 }
@@ -768,17 +769,21 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     // (three dependent latencies per round instead of per slice); items longer than the first packs continue in the deep loop
     constexpr int COL_B = 8, KP = HASVAL ? 1 : 2;
     const int zs = pa.rblk_rows;
-    for (int sb = s0 + wave; sb < s1; sb += 16 * COL_B) {
+    // batches of COL_B CONSECUTIVE slices, dealt to the 16 waves round-robin (slices are sorted by length: every wave gets
+    // long and short ones): a batch's offsets are one load (lane u reads cs_ptr[s + u]) and lane broadcasts, then the
+    // destinations and first packs of all COL_B are fetched together
+    for (int sb = s0 + wave * COL_B; sb < s1; sb += 16 * COL_B) {
         int base[COL_B], L4[COL_B], dst[COL_B];
         double a[COL_B];
+        const int pv = cs_ptr[min(sb + min(lane, COL_B), s1)];
 #pragma unroll
         for (int u = 0; u < COL_B; u++) {
-            const int sl = sb + 16 * u;
-            const int sc = min(sl, s1 - 1);
-            base[u] = __builtin_amdgcn_readfirstlane(cs_ptr[sc]);
-            const int nx = __builtin_amdgcn_readfirstlane(cs_ptr[sc + 1]);
+            const int sl = sb + u;
+            base[u] = __builtin_amdgcn_readlane(pv, u);
+            const int nx = __builtin_amdgcn_readlane(pv, u + 1);
             L4[u] = (sl < s1) ? (nx - base[u]) >> 8 : 0;
-            dst[u] = (sl < s1) ? item_dst[sc * 64 + lane] : -1;
+            const int dl = item_dst[min(sl, s1 - 1) * 64 + lane];            // unconditional, clamped
+            dst[u] = (sl < s1) ? dl : -1;
             a[u] = 0.0;
         }
         PT_MARK(9);
@@ -1172,8 +1177,8 @@ __device__ __forceinline__ void assemble_out(const PartDev &pa, const ProbDev &p
             const int j = base + c;
             double a = 0.0;
             if (j < n) {
-                // 16 slice loads in flight: few-problem shapes cut the rows into up to ~250 chunks (mlx_finalize)
-#pragma unroll 16
+                // 8 slice loads in flight: few-problem shapes cut the rows into up to ~250 chunks (mlx_finalize)
+#pragma unroll 8
                 for (int p = g; p < P; p += NG) a += parts[(int64_t)p * n + j];
             }
             stage[g * CW + c] = a;
@@ -1575,7 +1580,9 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, cons
 // Norms are sqrt(sum v^2) of sums gathered inside the update loops (euclideanNorm's scaled form up to the last bits).
 // ------------------------------------------------------------------------------------------------
 #define STEP_T 256
+#ifndef STEP_XB
 #define STEP_XB 4      // columns per thread and round (independent loads in flight)
+#endif
 
 // chunk-ordered totals of the previous launch's partial sums px[nwg][STEP_NP] -> tot[NP] (LDS); the loads run in
 // parallel (one partial per thread), the additions sequentially per column
@@ -2085,7 +2092,7 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
             for (int u = 0; u < U; u++) {
                 const int kk = min(kb + u * G, k1 - 1);
                 idx[u] = idxs[kk];
-                if (HASVAL) xv[u] = vals[kk];
+                if (HASVAL) xv[u] = vals ? vals[kk] : 1.0f;
             }
             double vv[U];
 #pragma unroll
@@ -2293,6 +2300,27 @@ k_hess_colsums_reduce(const double *__restrict__ part, int nchunk, int64_t ld, c
         block_allreduce_sum<1>(v, scratch);
         if (threadIdx.x == 0) out[2 * ld] = v[0];
     }
+}
+
+// hessianDiagonal of a CSR partition without densifying it (any n_local): one thread per column item adds wd_i x_ic^2 over
+// the item's entries in row order and writes the item's slot; the host adds a column's slots (llf/LogisticRegressionL2.java:304-327)
+template <bool HASVAL>
+__global__ void __launch_bounds__(256)
+k_hess_diag_items(int n_items, const int32_t *__restrict__ item_ptr, const int32_t *__restrict__ item_dst,
+                  const int32_t *__restrict__ cri, const float *__restrict__ cval, const double *__restrict__ wd,
+                  double *__restrict__ slots)
+{
+#pragma clang fp contract(off)
+    const int it = blockIdx.x * 256 + threadIdx.x;
+    if (it >= n_items) return;
+    const int dst = item_dst[it];
+    if (dst < 0) return;
+    double a = 0.0;
+    for (int k = item_ptr[it]; k < item_ptr[it + 1]; k++) {
+        const double x = HASVAL ? (double)cval[k] : 1.0;
+        a += wd[cri[k]] * x * x;
+    }
+    slots[dst] = a;
 }
 
 // X' D X, lower-triangle 128 x 128 blocks, rows split in `ksplit` ranges: P[ks][npad][npad] partial Gram matrices.
@@ -2775,6 +2803,15 @@ void mlxk_hess_colsums(hipStream_t st, const float *X, int64_t ld, int l, const 
     const int gx = (int)((ld + 255) / 256);
     hipLaunchKernelGGL(k_hess_colsums, dim3(gx, nchunk), dim3(256), 0, st, X, ld, l, rows_per_chunk, wd, part);
     hipLaunchKernelGGL(k_hess_colsums_reduce, dim3(gx), dim3(256), 0, st, part, nchunk, ld, wd, l, out);
+}
+
+void mlxk_hess_diag_items(hipStream_t st, int n_items, const int32_t *item_ptr, const int32_t *item_dst, const int32_t *cri,
+                          const float *cval, const double *wd, double *slots)
+{
+    const int gx = (n_items + 255) / 256;
+    if (gx <= 0) return;
+    if (cval) hipLaunchKernelGGL((k_hess_diag_items<true>), dim3(gx), dim3(256), 0, st, n_items, item_ptr, item_dst, cri, cval, wd, slots);
+    else hipLaunchKernelGGL((k_hess_diag_items<false>), dim3(gx), dim3(256), 0, st, n_items, item_ptr, item_dst, cri, cval, wd, slots);
 }
 
 void mlxk_gram_f64(hipStream_t st, const float *X, int64_t ld, int l, const double *wd, const int *blocks_xy, int nblocks,

@@ -150,9 +150,7 @@ class HipAdmmEngine:
             return a.ctypes.data
 
         n = len(blocks)
-        has_val = blocks[0].val is not None
-        if any((b.val is not None) != has_val for b in blocks):
-            raise ValueError("binary.feature and valued partitions cannot be mixed in one call")
+        has_val = any(b.val is not None for b in blocks)       # mixed calls are fine: per-entry NULL = binary.feature
         pid = np.array([b.partition_id for b in blocks], np.int32)
         ls = np.array([b.l for b in blocks], np.int32)
         nl = np.array([b.n_local for b in blocks], np.int32)
@@ -160,7 +158,7 @@ class HipAdmmEngine:
         PtrArr = C.c_void_p * n
         rp = PtrArr(*[arr(b.row_ptr, np.int64) for b in blocks])
         ci = PtrArr(*[arr(b.col_idx, np.int32) for b in blocks])
-        vv = PtrArr(*[arr(b.val, np.float32) for b in blocks]) if has_val else None
+        vv = PtrArr(*[(arr(b.val, np.float32) if b.val is not None else None) for b in blocks]) if has_val else None
         yy = PtrArr(*[arr(b.y, np.int8) for b in blocks])
         ww = PtrArr(*[arr(b.weight, np.float32) for b in blocks])
         oo = PtrArr(*[arr(b.offset, np.float32) for b in blocks])

@@ -712,6 +712,63 @@ def test_batched_partition_upload_equals_sequential():
         c.add_partitions([pd.blocks[0], pd.blocks[1], pd.blocks[0]])
 
 
+def test_binary_and_valued_partitions_share_a_handle(csr_path):
+    """binary.feature partitions (no value array) next to valued ones in ONE handle: the valued kernels serve both (a missing
+    value array reads as 1.0, and x * 1.0 == x), results equal to the oracle's per-partition binary / valued datasets."""
+    import copy
+    pd = synth_sparse(31, 5000, 250, 10, 3, weights=True, offsets=True)
+    blocks = [copy.copy(b) for b in pd.blocks]
+    blocks[1].val = None                                     # partition 1 becomes a binary.feature partition
+    eng = HipAdmmEngine(pd.n_global, [1.0, 5.0], [1.0, 1.0], 3)
+    eng.add_partition(blocks[0])
+    eng.add_partitions(blocks[1:])                           # a mixed batch call
+    eng.finalize()
+    oc = ol.OracleAdmm(blocks, pd.n_global, [1.0, 5.0], [1.0, 1.0])
+    for it in range(4):
+        eng.iterate(0.01)
+        oc.iterate(0.01, 1.0, nthreads=3)
+        assert np.array_equal(eng.solve_counters(), _counters(oc))
+        for li in range(2):
+            assert_coef_close(eng.z()[1][li], oc.z()[1][li], "mixed handle it %d lambda %d" % (it + 1, li), floor=1e-2)
+    eng.close()
+
+
+def test_limits_lifted_wide_dense_tile_and_wide_posterior_diagonal():
+    """(a) A dense tile wider than the fused pass's 2048 columns is accepted and runs the sparse passes on its non-zeros:
+    same trajectory as the oracle. (b) hessianDiagonal (posterior variance, full = False) of a CSR partition with more than
+    8192 local features needs no dense tile any more."""
+    rng = np.random.default_rng(3)
+    nrow, nf = 1200, 2500
+    X = (rng.normal(0, 1, (nrow, nf)) * (rng.random((nrow, nf)) < 0.6)).astype(np.float32)
+    y01 = (rng.random(nrow) < 0.35).astype(np.int8)
+    pd = dataset.dense_partitions(X, y01, 2)                 # CSR blocks that carry every entry, zeros included (the oracle's input)
+    eng = HipAdmmEngine(pd.n_global, [1.0], [1.0], 2)
+    for k, b in enumerate(pd.blocks):
+        eng.add_partition_dense(k, b.val.reshape(b.l, nf), b.y)
+    eng.finalize()
+    blocks = pd.blocks
+    oc = ol.OracleAdmm(blocks, nf + 1, [1.0], [1.0])
+    for it in range(3):
+        eng.iterate(0.01)
+        oc.iterate(0.01, 1.0, nthreads=2)
+        assert np.array_equal(eng.solve_counters(), _counters(oc))
+        assert_coef_close(eng.z()[1][0], oc.z()[1][0], "wide dense tile it %d" % (it + 1), floor=1e-2)
+    eng.close()
+    # (b)
+    from fixtures import onehot_blocks
+    po = onehot_blocks(4000, 1, levels=2000)
+    b = po.blocks[0]
+    assert b.n_local > 8192
+    e2 = make_engine(po, [1.0], [1.0])
+    od = ol.OracleDataset.from_block(b)
+    pv = rng.uniform(0.3, 3.0, b.n_local)
+    w = rng.normal(0, 0.2, b.n_local)
+    dv, _, _ = od.posterior_variance(w, pv, False)
+    gv, _, _ = e2.posterior_variance(0, w, pv, False)
+    assert np.max(np.abs(gv - dv) / dv) < 1e-12
+    e2.close()
+
+
 # ---- one-hot data (configs[2..4] shape): what differs from the oracle, and by how much -------------------------------------
 def _counters(oc):
     return np.array([(s.newton_iters, s.accepted, s.cg_iters, s.x_passes) for s in oc.stats()])
@@ -724,6 +781,7 @@ def test_lambda_sweep_shared_x_passes(binary, nlam, monkeypatch):
     lambda instead, jobs/RegressionAdmmTrain.java:553-568). Per problem the result must be the per-problem kernels' result:
     TRON/CG counters equal to the oracle's, coefficients within 1e-5, lambdas finishing at different ticks included."""
     monkeypatch.setenv("MLX_NO_SMALL", "1")
+    monkeypatch.setenv("MLX_MULTI", "1")                    # opt-in: measured slower than the per-problem passes (DESIGN 4)
     pd = synth_sparse(23, 9000, 400, 14, 3, binary=binary, weights=not binary, offsets=not binary)
     lam = [0.05, 0.3, 1.0, 3.0, 10.0, 30.0, 100.0, 300.0][:nlam]
     rho = [1.0 if v <= 100 else 10.0 for v in lam]
@@ -736,8 +794,8 @@ def test_lambda_sweep_shared_x_passes(binary, nlam, monkeypatch):
         for li in range(nlam):
             assert_coef_close(eng.z()[1][li], oc.z()[1][li], "lambda %g iteration %d" % (lam[li], it + 1), floor=1e-2)
     eng.close()
-    # the same sweep on the per-problem passes: same trajectories
-    monkeypatch.setenv("MLX_NO_MULTI", "1")
+    # the same sweep on the (default) per-problem passes: same trajectories
+    monkeypatch.delenv("MLX_MULTI")
     eng2 = make_engine(pd, lam, rho)
     for it in range(4):
         eng2.iterate(0.01)
