@@ -702,10 +702,10 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
     }
 
 
+    ph.col_ptr_h = col_ptr;
     P.ph = std::move(ph);
     P.hasval = (val != nullptr);
     P.rp = std::move(rp); P.pcol = std::move(pcol); P.pvalv = std::move(pvalv); P.cri = std::move(cri); P.cval = std::move(cval);
-    ph.col_ptr_h = col_ptr;
     P.item_ptr = std::move(item_ptr); P.item_dst = std::move(item_dst); P.col_ptr = std::move(col_ptr); P.ishort = std::move(ishort); P.ilong = std::move(ilong);
     P.l2g_perm = std::move(l2g_perm);
     P.rs_ptr = std::move(rs_ptr); P.rs_idx = std::move(rs_idx); P.rs_val = std::move(rs_val);
@@ -951,11 +951,12 @@ int mlx_finalize(mlx_handle h)
     }
     // Dense tiles: 512-row chunks are the optimum when the handle's problems make >= ~1000 of them (profiles/r1_notes.md);
     // with FEW problems (the 64-partition job strong-scaled over 8 GPUs leaves 8 per GPU = 248 chunks for 256 CUs, one
-    // wave per SIMD where the pass needs two) the chunks shrink until about 1000 workgroups exist, down to 64 rows.
+    // wave per SIMD where the pass needs two) the chunks shrink until about 512 workgroups exist (1774 solves/s at that shape
+    // against 1617 with 512-row chunks; 1024 workgroups: 1670, the step's assembly of the partials then costs more), down to 64 rows.
     if (getenv("MLX_DENSE_RPB") == nullptr) {
         int64_t dense_rows = 0;
         for (auto &p : h->parts) if (p.dense) dense_rows += (int64_t)nl * p.l;
-        const int64_t want = getenv("MLX_DENSE_WGS") ? std::max(64, atoi(getenv("MLX_DENSE_WGS"))) : 1024;
+        const int64_t want = getenv("MLX_DENSE_WGS") ? std::max(64, atoi(getenv("MLX_DENSE_WGS"))) : 512;
         if (dense_rows > 0 && dense_rows / 512 < want) {
             int rpb = (int)std::max<int64_t>(64, std::min<int64_t>(512, (dense_rows / want + 15) / 16 * 16));
             for (auto &p : h->parts) if (p.dense && p.l >= 4096) {

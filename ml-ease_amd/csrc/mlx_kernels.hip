@@ -769,20 +769,19 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     // (three dependent latencies per round instead of per slice); items longer than the first packs continue in the deep loop
     constexpr int COL_B = 8, KP = HASVAL ? 1 : 2;
     const int zs = pa.rblk_rows;
-    // batches of COL_B CONSECUTIVE slices, dealt to the 16 waves round-robin (slices are sorted by length: every wave gets
-    // long and short ones): a batch's offsets are one load (lane u reads cs_ptr[s + u]) and lane broadcasts, then the
-    // destinations and first packs of all COL_B are fetched together
-    for (int sb = s0 + wave * COL_B; sb < s1; sb += 16 * COL_B) {
+    // (slice s0 + wave + 16 t: slices are sorted by length, so this deals the long ones evenly; batches of consecutive slices
+    // per wave -- one offset load instead of 16 -- put a hot unit's 16 long slices on 2 waves: 196 -> 278 us)
+    for (int sb = s0 + wave; sb < s1; sb += 16 * COL_B) {
         int base[COL_B], L4[COL_B], dst[COL_B];
         double a[COL_B];
-        const int pv = cs_ptr[min(sb + min(lane, COL_B), s1)];
 #pragma unroll
         for (int u = 0; u < COL_B; u++) {
-            const int sl = sb + u;
-            base[u] = __builtin_amdgcn_readlane(pv, u);
-            const int nx = __builtin_amdgcn_readlane(pv, u + 1);
+            const int sl = sb + 16 * u;
+            const int sc = min(sl, s1 - 1);
+            base[u] = __builtin_amdgcn_readfirstlane(cs_ptr[sc]);
+            const int nx = __builtin_amdgcn_readfirstlane(cs_ptr[sc + 1]);
             L4[u] = (sl < s1) ? (nx - base[u]) >> 8 : 0;
-            const int dl = item_dst[min(sl, s1 - 1) * 64 + lane];            // unconditional, clamped
+            const int dl = item_dst[sc * 64 + lane];                          // unconditional, clamped
             dst[u] = (sl < s1) ? dl : -1;
             a[u] = 0.0;
         }
