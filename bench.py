@@ -431,6 +431,9 @@ def run_sparse(args, C):
     nloc = np.array([b.n_local for b in blocks])
     sched = EpsSchedule(admm)
     acc = dict(solves=0, cg=0, newton=0, pref=0, pdev=0, ticks=0, alg=0.0, rms=0.0, cms=0.0, sms=0.0, tms=0.0)
+    # every pass launch of this leg (finalize's c0 pass: one row + one column pass per partition, + warm-up + timed): what a
+    # rocprofv3 run of this command sees, used to turn its FETCH_SIZE / WRITE_SIZE sums into bytes per algorithmic byte
+    allrun = dict(alg=sum(2.0 * (4.0 * b.nnz + 8.0 * b.l + 8.0 * b.n_local) for b in blocks), ticks=1)
     fin = None
     for it in range(1, args.sparse_warmup + args.sparse_steps + 1):
         if it == args.sparse_warmup + 1:
@@ -440,6 +443,8 @@ def run_sparse(args, C):
         C["all_reduce"](eng.consensus_tensor())
         fin = eng.consensus_finish()
         sched.mindiff = fin.mindiff
+        allrun["alg"] += st.alg_bytes_dev
+        allrun["ticks"] += st.ticks
         if it > args.sparse_warmup:
             acc["solves"] += st.solves; acc["cg"] += st.cg_iters; acc["newton"] += st.newton_iters
             acc["pref"] += st.x_passes_ref; acc["pdev"] += st.x_passes_dev; acc["ticks"] += st.ticks
@@ -478,7 +483,14 @@ def run_sparse(args, C):
                         roof("k_step_a+b+c+commit", acc["sms"], 0.0,
                              "no algorithmic X bytes (SURVEY 8d counts the n-vector work as zero); streams ~13 x 8n bytes per problem and "
                              "tick = %.1f GB/s" % (step_model / max(1e-9, acc["sms"] * 1e-3) / 1e9))],
-           "last_maxdiff": fin.maxdiff}
+           "last_maxdiff": fin.maxdiff,
+           "all_launches": {"ticks_incl_c0_and_warmup": allrun["ticks"], "alg_bytes_row_plus_column": allrun["alg"]}}
+    tpath = os.path.join(ROOT, "profiles", "traffic_sparse.json")
+    if os.path.exists(tpath):
+        with open(tpath) as fh:
+            tj = json.load(fh)
+        res["traffic"] = {"source": "profiles/traffic_sparse.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `%s` (committed; not a counter read in this run)" % tj.get("command", ""),
+                          "hbm_bytes_per_alg_byte": tj.get("hbm_bytes_per_alg_byte"), "per_kernel": tj.get("per_kernel")}
     if args.sparse_cpu_sample > 0 and world == 1:
         import oracle_lib as ol
         ns = min(args.sparse_cpu_sample, len(blocks))
