@@ -4,6 +4,8 @@ The reference has no tests/goldens for this path ("parity unpinned"),
 held by: an independent NumPy restatement (<=1e-12 before the float32 writes), committed oracle
 outputs (regression), and mathematical properties that depend on neither implementation.
 """
+import os
+
 import numpy as np
 import pytest
 import scipy.optimize as so
@@ -347,3 +349,52 @@ def test_l1_and_lambda_map_c_vs_numpy(c1):
     z = oc.z()[0][0][:-1]
     w = 400.0 / 8.0
     assert np.any((np.abs(z) > 0) & (np.abs(z) <= w))
+
+
+def test_benchmark_data_generators_agree_bit_for_bit():
+    """tools/synth_data.py: the NumPy generator, its torch twin (what bench.py runs on the GPU; here on the CPU device) and the
+    C twin behind tools/make_ref_loglik.py (oracle/synth.c) build the dense benchmark rows from integer arithmetic only and
+    must produce identical float32 values and labels -- the committed oracle log-likelihood of BASELINE configs[1]
+    (tests/golden/c2_ref_loglik.json) is only meaningful for bench.py if they do."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import synth_data as sd
+    for row0, rows, nf, stride in ((0, 257, 1000, 1), (5, 300, 1000, 64), (1_000_000, 100, 333, 1)):
+        X, y = sd.dense_rows_np(row0, rows, nf, stride=stride)
+        Xc, yc = ol.synth_dense(row0, rows, nf, sd.dense_beta(nf), sd.SEED, stride=stride)
+        Xt, yt = sd.dense_rows_torch(torch, "cpu", row0, rows, nf, stride=stride)
+        assert np.array_equal(X, Xc) and np.array_equal(y, yc)
+        assert np.array_equal(X, Xt.numpy()) and np.array_equal(y, yt.numpy())
+    x = sd.dense_rows_np(0, 2000, 500)[0].astype(np.float64).ravel()
+    assert abs(x.mean()) < 5e-3 and abs(x.std() - 1.0) < 5e-3 and np.max(np.abs(x)) <= 6.0
+
+
+def test_reference_loglik_golden_is_consistent():
+    """tests/golden/c2_ref_loglik.json (tools/make_ref_loglik.py): 20 iterations, epsilon schedule of the driver loop, and a
+    spot check that the generator still produces the job it was computed on (first rows of partition 0)."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import synth_data as sd
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c2_ref_loglik.json")))
+    assert g["iterations"] == 20 and len(g["loglik_by_iteration"]) == 20 and g["ref_loglik"] == g["loglik_by_iteration"][-1]
+    assert g["epsilon_by_iteration"][0] == 0.01 and g["epsilon_by_iteration"][3] == ol.float_to_string_to_double(np.float32(0.01) / np.float32(10))
+    assert all(-0.36 < v < -0.33 for v in g["loglik_by_iteration"]) and "seed %d" % sd.SEED in g["generator"]
+
+
+def test_portable_math_and_the_verification_twin():
+    """ml-ease_amd/csrc/portable_math.h through the oracle twin liboracle_pm.so: same restatement, exp/log1p from +,-,*,/ only.
+    On config #1 the twin follows the plain oracle's trajectory and agrees to 1e-12 on the double z (the functions differ
+    from libm by <= 1 ulp); on the solve level it is the bit-exact partner of the HIP library's MLX_FAITHFUL mode (-m gpu)."""
+    from fixtures import load_c1
+    c1 = load_c1()
+    a = ol.OracleAdmm(c1.blocks, c1.n_global, [1.0], [1.0])
+    b = ol.OracleAdmm(c1.blocks, c1.n_global, [1.0], [1.0], pm=True)
+    for _ in range(3):
+        a.iterate(0.01, 1.0, nthreads=2)
+        b.iterate(0.01, 1.0, nthreads=2)
+        ca = [(s.newton_iters, s.cg_iters) for s in a.stats()]
+        cb = [(s.newton_iters, s.cg_iters) for s in b.stats()]
+        assert ca == cb
+        assert np.max(np.abs(a.z()[0] - b.z()[0])) <= 1e-12 * np.max(np.abs(a.z()[0]))

@@ -55,7 +55,7 @@ def main():
     alg = bs["all_launches"]["alg_bytes_row_plus_column"]
     per, tot_raw, tot_x2 = {}, 0.0, 0.0
     for key, label in (("k_rowpass_lds", "row pass"), ("k_colpass_lds", "column pass"), ("k_step_a", "step A"), ("k_step_b", "step B"),
-                       ("k_step_c", "step C"), ("k_step_commit", "step commit")):
+                       ("k_step_c(", "step C"), ("k_step_commit", "step commit")):
         kf = [k for k in fe if key in k]
         kw = [k for k in wr if key in k]
         f = sum(fe[k][1] for k in kf)
