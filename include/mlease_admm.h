@@ -195,10 +195,11 @@ int mlx_get_solve_counters(mlx_handle h, int32_t *out);
 /* ---- test log-likelihood per iteration (jobs/RegressionAdmmTrain.java:766-811, updateLogLikBestModel :812-845) ----
  * Upload the test rows once (the reference re-reads the first file under test.path, <= 1 000 000 rows, every
  * iteration): CSR with GLOBAL feature ids (-1 = name absent from the model: skipped as LinearModel.eval does,
- * models/LinearModel.java:251), val NULL for binary.feature, response[l] as read (1 / 0 / -1), weight[l] and
- * offset[l] as the doubles Util.getDoubleAvro yields (NULL = 1 / 0). */
+ * models/LinearModel.java:251), val[nnz] the feature values as the DOUBLES Util.getDoubleAvro yields (evalInstanceAvro does
+ * not cast them to float, models/LinearModel.java:530-534; only the training rows are, jobs/RegressionPrepare.java:145), NULL for
+ * binary.feature, response[l] as read (1 / 0 / -1), weight[l] and offset[l] likewise doubles (NULL = 1 / 0). */
 int mlx_set_test_data(mlx_handle h, int32_t l, int64_t nnz, const int64_t *row_ptr, const int32_t *global_idx,
-                      const float *val, const int8_t *response, const double *weight, const double *offset);
+                      const double *val, const int8_t *response, const double *weight, const double *offset);
 /* loglik_sum[n_lambda] = sum_i evalInstanceAvro(record_i, loglik=true, 1, ignore_value) with the CURRENT driver z
  * (double); the caller divides by its sum of weights n (:792-807). */
 int mlx_test_loglik(mlx_handle h, double *loglik_sum);
@@ -214,11 +215,11 @@ int mlx_solve_one(mlx_handle h, int32_t local_index, double *w, const double *pr
 /* ---- RegressionTest scoring (jobs/RegressionTest.java:147-175, the AdmmTestMapper) -----------------------------
  * pred[i] = (float) model.evalInstanceAvro(record_i, loglik = false, ignore_value) = (float)(offset_i + eval(features_i))
  * (models/LinearModel.java:241-257,491-541) for l rows in CSR form with GLOBAL feature ids (-1 = a name the model does
- * not hold: skipped), val NULL for binary.feature, offset NULL = 0. `model` is one record of the final-model /
+ * not hold: skipped), val as doubles (see mlx_set_test_data) or NULL for binary.feature, offset NULL = 0. `model` is one record of the final-model /
  * best-model file as dense float32 [n_global] (intercept last), exactly the values LinearModel reads back from avro.
  * Needs only mlx_create (no training partitions); sums run in record order, one thread per row. */
 int mlx_score_rows(mlx_handle h, int32_t n_global, const float *model, int32_t l, int64_t nnz, const int64_t *row_ptr,
-                   const int32_t *global_idx, const float *val, const double *offset, float *pred);
+                   const int32_t *global_idx, const double *val, const double *offset, float *pred);
 
 /* ---- posterior variance at the mode: the computePosteriorVar tail of LibLinear.train ----------
  * (liblinearfunc/LibLinear.java:221-228 with computePosteriorVar = true, body :314-337; the ADMM reducer passes false,

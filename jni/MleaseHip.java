@@ -103,7 +103,7 @@ public final class MleaseHip implements AutoCloseable
   public native void getSolveCounters(int[] out) throws IOException;                        // mlx_get_solve_counters
 
   // ---- test log-likelihood per iteration (RegressionAdmmTrain.java:766-845) ------------------------------------------
-  public native void setTestData(long[] rowPtr, int[] globalIdx, float[] valOrNull, byte[] response,
+  public native void setTestData(long[] rowPtr, int[] globalIdx, double[] valOrNull, byte[] response,
                                  double[] weightOrNull, double[] offsetOrNull) throws IOException;       // mlx_set_test_data
   public native void testLoglik(double[] loglikSumPerLambda) throws IOException;            // mlx_test_loglik
 
@@ -112,7 +112,7 @@ public final class MleaseHip implements AutoCloseable
   public native double[] solveOne(int localIndex, double[] w, double[] priorMeanOrNull, double[] priorVar,
                                   double epsilon, int maxIter, int[] counters4OrNull) throws IOException; // mlx_solve_one
   /** AdmmTestMapper.map (RegressionTest.java:147-175) for l rows; model = one final-model record, intercept last. */
-  public native void scoreRows(float[] modelInterceptLast, long[] rowPtr, int[] globalIdx, float[] valOrNull,
+  public native void scoreRows(float[] modelInterceptLast, long[] rowPtr, int[] globalIdx, double[] valOrNull,
                                double[] offsetOrNull, float[] pred) throws IOException;     // mlx_score_rows
   /** LibLinear.train(..., computePosteriorVar = true) tail (LibLinear.java:314-337); returns the Gram-kernel ms (0 if !full). */
   public native double posteriorVariance(int localIndex, double[] w, double[] priorVar, boolean full,

@@ -319,19 +319,19 @@ JFN(void, getSolveCounters)(JNIEnv *env, jobject self, jintArray out)
 }
 
 /* ---- test log-likelihood ---------------------------------------------------------------------------------------------- */
-JFN(void, setTestData)(JNIEnv *env, jobject self, jlongArray rowPtr, jintArray globalIdx, jfloatArray val, jbyteArray response,
+JFN(void, setTestData)(JNIEnv *env, jobject self, jlongArray rowPtr, jintArray globalIdx, jdoubleArray val, jbyteArray response,
                        jdoubleArray weight, jdoubleArray offset)
 {
     mlx_handle h = handle_of(env, self);
     const jsize l = (*env)->GetArrayLength(env, rowPtr) - 1;
     jlong *rp = PIN(jlong, Long, rowPtr);
     jint *gi = PIN(jint, Int, globalIdx);
-    jfloat *v = PIN(jfloat, Float, val);
+    jdouble *v = PIN(jdouble, Double, val);
     jbyte *r = PIN(jbyte, Byte, response);
     jdouble *w = PIN(jdouble, Double, weight), *o = PIN(jdouble, Double, offset);
     const int64_t nnz = (l >= 0 && rp) ? (int64_t)rp[l] : 0;
     int rc = mlx_set_test_data(h, (int32_t)l, nnz, (const int64_t *)rp, (const int32_t *)gi, v, (const int8_t *)r, w, o);
-    UNPIN_IN(Long, rowPtr, rp); UNPIN_IN(Int, globalIdx, gi); UNPIN_IN(Float, val, v); UNPIN_IN(Byte, response, r);
+    UNPIN_IN(Long, rowPtr, rp); UNPIN_IN(Int, globalIdx, gi); UNPIN_IN(Double, val, v); UNPIN_IN(Byte, response, r);
     UNPIN_IN(Double, weight, w); UNPIN_IN(Double, offset, o);
     throw_for(env, h, rc);
 }
@@ -362,19 +362,19 @@ JFN(jdoubleArray, solveOne)(JNIEnv *env, jobject self, jint localIndex, jdoubleA
     return arr;
 }
 
-JFN(void, scoreRows)(JNIEnv *env, jobject self, jfloatArray model, jlongArray rowPtr, jintArray globalIdx, jfloatArray val,
+JFN(void, scoreRows)(JNIEnv *env, jobject self, jfloatArray model, jlongArray rowPtr, jintArray globalIdx, jdoubleArray val,
                      jdoubleArray offset, jfloatArray pred)
 {
     mlx_handle h = handle_of(env, self);
     const jsize ng = (*env)->GetArrayLength(env, model);
     const jsize l = (*env)->GetArrayLength(env, rowPtr) - 1;
-    jfloat *m = PIN(jfloat, Float, model), *v = PIN(jfloat, Float, val), *p = PIN(jfloat, Float, pred);
+    jfloat *m = PIN(jfloat, Float, model), *p = PIN(jfloat, Float, pred);
     jlong *rp = PIN(jlong, Long, rowPtr);
     jint *gi = PIN(jint, Int, globalIdx);
-    jdouble *o = PIN(jdouble, Double, offset);
+    jdouble *o = PIN(jdouble, Double, offset), *v = PIN(jdouble, Double, val);
     const int64_t nnz = (l >= 0 && rp) ? (int64_t)rp[l] : 0;
     int rc = mlx_score_rows(h, (int32_t)ng, m, (int32_t)l, nnz, (const int64_t *)rp, (const int32_t *)gi, v, o, p);
-    UNPIN_IN(Float, model, m); UNPIN_IN(Float, val, v); UNPIN_OUT(Float, pred, p); UNPIN_IN(Long, rowPtr, rp);
+    UNPIN_IN(Float, model, m); UNPIN_IN(Double, val, v); UNPIN_OUT(Float, pred, p); UNPIN_IN(Long, rowPtr, rp);
     UNPIN_IN(Int, globalIdx, gi); UNPIN_IN(Double, offset, o);
     throw_for(env, h, rc);
 }

@@ -104,7 +104,7 @@ struct mlx_context {
 
     // test set (K15)
     int test_l = 0;
-    int64_t *t_rp = nullptr; int32_t *t_gi = nullptr; float *t_val = nullptr; int8_t *t_y = nullptr;
+    int64_t *t_rp = nullptr; int32_t *t_gi = nullptr; double *t_val = nullptr; int8_t *t_y = nullptr;
     double *t_wt = nullptr, *t_off = nullptr, *t_part = nullptr;
 
     ncclComm_t comm = nullptr;
@@ -1417,7 +1417,7 @@ int mlx_get_partition_model(mlx_handle h, int32_t local_index, int32_t lambda_in
 }
 
 int mlx_set_test_data(mlx_handle h, int32_t l, int64_t nnz, const int64_t *row_ptr, const int32_t *global_idx,
-                      const float *val, const int8_t *response, const double *weight, const double *offset)
+                      const double *val, const int8_t *response, const double *weight, const double *offset)
 {
     if (!h || !h->problem_set) return fail(h, MLX_ERR_INVALID, "mlx_set_problem first");
     if (l <= 0 || !row_ptr || (nnz > 0 && !global_idx) || !response) return fail(h, MLX_ERR_INVALID, "bad test data");
@@ -1523,7 +1523,7 @@ int mlx_solve_one(mlx_handle h, int32_t local_index, double *w, const double *pr
 }
 
 int mlx_score_rows(mlx_handle h, int32_t n_global, const float *model, int32_t l, int64_t nnz, const int64_t *row_ptr,
-                   const int32_t *global_idx, const float *val, const double *offset, float *pred)
+                   const int32_t *global_idx, const double *val, const double *offset, float *pred)
 {
     if (!h) return fail(h, MLX_ERR_INVALID, "no handle");
     if (n_global < 1 || !model || l < 0 || nnz < 0 || !row_ptr || (nnz > 0 && !global_idx) || !pred) return fail(h, MLX_ERR_INVALID, "bad arguments");
@@ -1544,11 +1544,11 @@ int mlx_score_rows(mlx_handle h, int32_t n_global, const float *model, int32_t l
         tmp.push_back(*q);
         return bytes == 0 || !src || hipMemcpyAsync(*q, src, bytes, hipMemcpyHostToDevice, h->stream) == hipSuccess;
     };
-    int64_t *d_rp; int32_t *d_gi; float *d_val = nullptr, *d_pred; double *d_off, *d_z;
+    int64_t *d_rp; int32_t *d_gi; float *d_pred; double *d_val = nullptr, *d_off, *d_z;
     bool ok = up((void **)&d_rp, row_ptr, sizeof(int64_t) * ((size_t)l + 1)) && up((void **)&d_gi, global_idx, sizeof(int32_t) * (size_t)nnz) &&
               up((void **)&d_off, off.data(), sizeof(double) * (size_t)l) && up((void **)&d_z, z.data(), sizeof(double) * (size_t)n_global) &&
               up((void **)&d_pred, nullptr, sizeof(float) * (size_t)l);
-    if (ok && val) ok = up((void **)&d_val, val, sizeof(float) * (size_t)nnz);
+    if (ok && val) ok = up((void **)&d_val, val, sizeof(double) * (size_t)nnz);
     if (!ok) { cleanup(); return fail(h, MLX_ERR_HIP, "mlx_score_rows: device allocation/copy failed"); }
     mlxk_score_rows(h->stream, l, d_rp, d_gi, d_val, d_off, d_z, base, d_pred);
     ok = hipMemcpyAsync(pred, d_pred, sizeof(float) * (size_t)l, hipMemcpyDeviceToHost, h->stream) == hipSuccess &&

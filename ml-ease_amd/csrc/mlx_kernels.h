@@ -44,7 +44,7 @@ void mlxk_z_update(hipStream_t st, int n_lambda, int n_global, int regularizer, 
                    float *z32, unsigned long long *diffbits);
 void mlxk_u_update(hipStream_t st, int nlocal, int n_lambda, int n_global, const float *UPX, const double *Z, float *u);
 void mlxk_test_loglik(hipStream_t st, int l, int n_lambda, int n_global, const int64_t *rp, const int32_t *gi,
-                      const float *val, const int8_t *y, const double *wt, const double *off, const double *Z, double *part);
+                      const double *val, const int8_t *y, const double *wt, const double *off, const double *Z, double *part);
 void mlxk_round_z(hipStream_t st, int64_t n, const double *Z, float *z32);
 
 // posterior variance (LibLinear.train computePosteriorVar): densify a CSR partition, weighted column sums, fp64-MFMA Gram
@@ -58,5 +58,5 @@ void mlxk_gram_f64(hipStream_t st, const float *X, int64_t ld, int l, const doub
 void mlxk_gram_finish(hipStream_t st, const double *P, int ksplit, int npad, int nf, const double *colsums, int64_t ld,
                       const double *pinv, double *H);
 // RegressionTest scoring: one float prediction per row
-void mlxk_score_rows(hipStream_t st, int l, const int64_t *rp, const int32_t *gi, const float *val, const double *off,
+void mlxk_score_rows(hipStream_t st, int l, const int64_t *rp, const int32_t *gi, const double *val, const double *off,
                      const double *z, double base, float *pred);

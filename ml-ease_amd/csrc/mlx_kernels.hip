@@ -2230,7 +2230,7 @@ k_outputs_present(const PartDev *__restrict__ parts, const ProbDev *__restrict__
 // ------------------------------------------------------------------------------------------------
 template <bool HASVAL>
 __global__ void __launch_bounds__(256)
-k_score_rows(int l, const int64_t *__restrict__ rp, const int32_t *__restrict__ gi, const float *__restrict__ val,
+k_score_rows(int l, const int64_t *__restrict__ rp, const int32_t *__restrict__ gi, const double *__restrict__ val,
              const double *__restrict__ off, const double *__restrict__ z, double base, float *__restrict__ pred)
 {
 #pragma clang fp contract(off)
@@ -2239,7 +2239,7 @@ k_score_rows(int l, const int64_t *__restrict__ rp, const int32_t *__restrict__ 
     double result = base;
     for (int64_t k = rp[row]; k < rp[row + 1]; k++) {
         const int g = gi[k];
-        if (g >= 0) result += z[g] * (HASVAL ? (double)val[k] : 1.0);
+        if (g >= 0) result += z[g] * (HASVAL ? val[k] : 1.0);
     }
     pred[row] = (float)(off[row] + result);
 }
@@ -2505,7 +2505,7 @@ k_u_update(int nlocal, int n_lambda, int n_global, const float *__restrict__ UPX
 template <bool HASVAL>
 __global__ void __launch_bounds__(256)
 k_test_loglik(int l, int n_lambda, int n_global, const int64_t *__restrict__ rp, const int32_t *__restrict__ gi,
-              const float *__restrict__ val, const int8_t *__restrict__ y, const double *__restrict__ wt,
+              const double *__restrict__ val, const int8_t *__restrict__ y, const double *__restrict__ wt,
               const double *__restrict__ off, const double *__restrict__ Z, double *__restrict__ part)
 {
     __shared__ double scratch[48];
@@ -2520,7 +2520,7 @@ k_test_loglik(int l, int n_lambda, int n_global, const int64_t *__restrict__ rp,
         double a = 0.0;
         for (int64_t k = k0 + gl; k < k1; k += G) {
             const int g = gi[k];
-            if (g >= 0) a += z[g] * (HASVAL ? (double)val[k] : 1.0);
+            if (g >= 0) a += z[g] * (HASVAL ? val[k] : 1.0);
         }
         a = group_allreduce_sum<G>(a);
         double ll[1] = {0.0};
@@ -2776,7 +2776,7 @@ void mlxk_u_update(hipStream_t st, int nlocal, int n_lambda, int n_global, const
 }
 
 void mlxk_test_loglik(hipStream_t st, int l, int n_lambda, int n_global, const int64_t *rp, const int32_t *gi,
-                      const float *val, const int8_t *y, const double *wt, const double *off, const double *Z, double *part)
+                      const double *val, const int8_t *y, const double *wt, const double *off, const double *Z, double *part)
 {
     const int gx = (l + 31) / 32;
     if (val) hipLaunchKernelGGL((k_test_loglik<true>), dim3(gx), dim3(256), 0, st, l, n_lambda, n_global, rp, gi, val, y, wt, off, Z, part);
@@ -2827,7 +2827,7 @@ void mlxk_gram_finish(hipStream_t st, const double *P, int ksplit, int npad, int
     hipLaunchKernelGGL(k_gram_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, P, ksplit, npad, nf, colsums, ld, pinv, H);
 }
 
-void mlxk_score_rows(hipStream_t st, int l, const int64_t *rp, const int32_t *gi, const float *val, const double *off,
+void mlxk_score_rows(hipStream_t st, int l, const int64_t *rp, const int32_t *gi, const double *val, const double *off,
                      const double *z, double base, float *pred)
 {
     const int gx = (l + 255) / 256;

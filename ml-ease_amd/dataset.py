@@ -261,7 +261,7 @@ class TestRows:
     __test__ = False
     row_ptr: np.ndarray          # int64 [l+1]
     global_idx: np.ndarray       # int32 [nnz]; -1 = feature name not in the training dictionary (skipped by eval)
-    val: Optional[np.ndarray]    # float32 [nnz] or None (binary.feature -> value 1.0, models/LinearModel.java:532-534)
+    val: Optional[np.ndarray]    # float64 [nnz] as Util.getDoubleAvro yields (NOT cast to float: models/LinearModel.java:530-534) or None (binary.feature -> 1.0)
     response: np.ndarray         # int8 [l] as read (1 / 0 / -1)
     weight: np.ndarray           # float64 [l]  Util.getDoubleAvro(record, "weight"), default 1
     offset: np.ndarray           # float64 [l]
@@ -287,7 +287,7 @@ def build_test_rows(records: Iterable[Dict[str, Any]], feature_names: Sequence[s
             term = "" if f.get("term") is None else str(f["term"])
             gi.append(index.get(feature_key(name, term), -1))
             if not binary_feature:
-                vv.append(np.float32(f["value"]))
+                vv.append(float(f["value"]))                 # evalInstanceAvro keeps the double (a float field widens exactly)
         rp.append(len(gi))
         ys.append(y)
         w = rec.get("weight")
@@ -302,5 +302,5 @@ def build_test_rows(records: Iterable[Dict[str, Any]], feature_names: Sequence[s
         os_.append(0.0 if o is None else float(o))
         if len(ys) >= max_rows:
             break
-    return TestRows(np.asarray(rp, np.int64), np.asarray(gi, np.int32), None if binary_feature else np.asarray(vv, np.float32),
+    return TestRows(np.asarray(rp, np.int64), np.asarray(gi, np.int32), None if binary_feature else np.asarray(vv, np.float64),
                     np.asarray(ys, np.int8), np.asarray(ws, np.float64), np.asarray(os_, np.float64), n)

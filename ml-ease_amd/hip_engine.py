@@ -262,7 +262,7 @@ class HipAdmmEngine:
         """Test rows in GLOBAL feature ids (-1 = not in the model); see mlx_set_test_data."""
         rp = np.ascontiguousarray(row_ptr, np.int64)
         gi = np.ascontiguousarray(global_idx, np.int32)
-        v = None if val is None else np.ascontiguousarray(val, np.float32)
+        v = None if val is None else np.ascontiguousarray(val, np.float64)
         y = np.ascontiguousarray(response, np.int8)
         w = None if weight is None else np.ascontiguousarray(weight, np.float64)
         o = None if offset is None else np.ascontiguousarray(offset, np.float64)
@@ -341,7 +341,7 @@ class HipScorer:
         m = np.ascontiguousarray(model32, np.float32)
         rp = np.ascontiguousarray(row_ptr, np.int64)
         gi = np.ascontiguousarray(global_idx, np.int32)
-        v = None if val is None else np.ascontiguousarray(val, np.float32)
+        v = None if val is None else np.ascontiguousarray(val, np.float64)
         o = None if offset is None else np.ascontiguousarray(offset, np.float64)
         out = np.empty(len(rp) - 1, np.float32)
         rc = self.L.mlx_score_rows(self.h, len(m), _p(m), len(rp) - 1, int(rp[-1]), _p(rp), _p(gi), _p(v), _p(o), _p(out))

@@ -74,7 +74,7 @@ double mlh_test_sizes(void *t, long long *out2)
 }
 const long long *mlh_test_rowptr(void *t) { return (const long long *)static_cast<TestRowsData *>(t)->row_ptr.data(); }
 const int *mlh_test_gidx(void *t) { return static_cast<TestRowsData *>(t)->gidx.data(); }
-const float *mlh_test_val(void *t) { auto &v = static_cast<TestRowsData *>(t)->val; return v.empty() ? nullptr : v.data(); }
+const double *mlh_test_val(void *t) { auto &v = static_cast<TestRowsData *>(t)->val; return v.empty() ? nullptr : v.data(); }
 const signed char *mlh_test_response(void *t) { return (const signed char *)static_cast<TestRowsData *>(t)->response.data(); }
 const double *mlh_test_weight(void *t) { return static_cast<TestRowsData *>(t)->weight.data(); }
 const double *mlh_test_offset(void *t) { return static_cast<TestRowsData *>(t)->offset.data(); }

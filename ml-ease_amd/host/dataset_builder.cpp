@@ -443,7 +443,7 @@ TestRowsData build_test_rows(const std::string &first_file, const Dataset &ds, b
                 t.gidx.push_back(g == ds.gindex.end() ? -1 : g->second);
                 if (!binary_feature) {
                     if (std::isnan(f.second)) throw std::runtime_error("value is null");
-                    t.val.push_back((float)f.second);
+                    t.val.push_back(f.second);
                 }
             }
             t.row_ptr.push_back((int64_t)t.gidx.size());

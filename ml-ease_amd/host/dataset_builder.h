@@ -201,7 +201,7 @@ class DatasetBuilder {
 struct TestRowsData {                   // jobs/RegressionAdmmTrain.java:766-811 inputs, GLOBAL feature ids
     std::vector<int64_t> row_ptr{0};
     std::vector<int32_t> gidx;
-    std::vector<float> val;
+    std::vector<double> val;             // as Util.getDoubleAvro yields: evalInstanceAvro does not cast to float (models/LinearModel.java:530-534)
     std::vector<int8_t> response;
     std::vector<double> weight, offset;
     double n = 0;                       // sum of Double.parseDouble(weight.toString())

@@ -141,7 +141,7 @@ int run_job(const JobConfig &props)
     struct Row { size_t raw_off, raw_len, f0, f1; double offset; };
     std::vector<Row> rows;
     std::vector<uint8_t> raw;
-    std::vector<std::pair<std::string, float>> feats;
+    std::vector<std::pair<std::string, double>> feats;
     read_input_rows(input, "", !binary, [&](InputRow &r) {
         const int y = resolve_response(r);                                                       // evalInstanceAvro :497-499
         if (y != 1 && y != 0 && y != -1) throw Fail("response = " + std::to_string(y));
@@ -149,7 +149,7 @@ int run_job(const JobConfig &props)
         raw.insert(raw.end(), r.raw, r.raw + r.raw_len);
         for (auto &f : r.feats) {
             if (!binary && std::isnan(f.second)) throw Fail("value is null");
-            feats.emplace_back(f.first, binary ? 1.0f : (float)f.second);
+            feats.emplace_back(f.first, binary ? 1.0 : f.second);
         }
         w.f1 = feats.size();
         rows.push_back(w);
@@ -165,7 +165,7 @@ int run_job(const JobConfig &props)
         for (size_t j = 0; j < m.names.size(); j++) index[m.names[j]] = (int32_t)j;              // later duplicates win like HashMap.put
         std::vector<int64_t> rp((size_t)l + 1, 0);
         std::vector<int32_t> gi(feats.size());
-        std::vector<float> val(binary ? 0 : feats.size());
+        std::vector<double> val(binary ? 0 : feats.size());     // doubles as evalInstanceAvro reads them (models/LinearModel.java:530-534)
         std::vector<double> off((size_t)l);
         for (int32_t i = 0; i < l; i++) {
             for (size_t k = rows[(size_t)i].f0; k < rows[(size_t)i].f1; k++) {

@@ -811,13 +811,13 @@ void orc_admm_get_stats(const orc_admm *a, orc_tron_stats *out)
  * for one model z (global index, intercept last): models/LinearModel.java:491-554 with eval :241-257;
  * called per record by testloglik, jobs/RegressionAdmmTrain.java:779-791. gidx < 0 = name not in the model. */
 double orc_test_loglik_sum(int n_global, const double *z, int l, const int64_t *row_ptr, const int32_t *gidx,
-                           const float *val, const int8_t *response, const double *weight, const double *offset)
+                           const double *val, const int8_t *response, const double *weight, const double *offset)
 {
     double total = 0.0;
     for (int i = 0; i < l; i++) {
         double result = -log(1 - 1 + 1 * exp(-z[n_global - 1]));          /* :243-244 */
         for (int64_t k = row_ptr[i]; k < row_ptr[i + 1]; k++)
-            if (gidx[k] >= 0) result += z[gidx[k]] * (val ? (double)val[k] : 1.0);   /* :249-255 */
+            if (gidx[k] >= 0) result += z[gidx[k]] * (val ? val[k] : 1.0);   /* :249-255 */
         double xbeta = (offset ? offset[i] : 0.0) + result;                /* :544 */
         double w = weight ? weight[i] : 1.0;
         if (response[i] == 1) total += -log1p(exp(-xbeta)) * w;            /* :545-552 */
@@ -830,13 +830,13 @@ double orc_test_loglik_sum(int n_global, const double *z, int l, const int64_t *
  * ignore_value) = (float)(offset + eval(keys, values, 1)) with eval of models/LinearModel.java:241-257 (result starts at
  * -log(1-1+1*exp(-intercept)), then += coef*value in record order; names the model does not hold, gidx < 0, are skipped).
  * z = the model as read from the final-model file (float32 widened), intercept last. */
-void orc_score_rows(int n_global, const double *z, int l, const int64_t *row_ptr, const int32_t *gidx, const float *val,
+void orc_score_rows(int n_global, const double *z, int l, const int64_t *row_ptr, const int32_t *gidx, const double *val,
                     const double *offset, float *pred)
 {
     for (int i = 0; i < l; i++) {
         double result = -log(1 - 1 + 1 * exp(-z[n_global - 1]));
         for (int64_t k = row_ptr[i]; k < row_ptr[i + 1]; k++)
-            if (gidx[k] >= 0) result += z[gidx[k]] * (val ? (double)val[k] : 1.0);
+            if (gidx[k] >= 0) result += z[gidx[k]] * (val ? val[k] : 1.0);
         pred[i] = (float)((offset ? offset[i] : 0.0) + result);
     }
 }

@@ -230,7 +230,7 @@ def test_loglik_sum(z, row_ptr, gidx, val, response, weight=None, offset=None) -
     z = np.ascontiguousarray(z, np.float64)
     rp = np.ascontiguousarray(row_ptr, np.int64)
     gi = np.ascontiguousarray(gidx, np.int32)
-    v = None if val is None else np.ascontiguousarray(val, np.float32)
+    v = None if val is None else np.ascontiguousarray(val, np.float64)
     y = np.ascontiguousarray(response, np.int8)
     w = None if weight is None else np.ascontiguousarray(weight, np.float64)
     o = None if offset is None else np.ascontiguousarray(offset, np.float64)
@@ -249,7 +249,7 @@ def score_rows(model32, row_ptr, gidx, val, offset=None) -> np.ndarray:
     z = np.ascontiguousarray(np.asarray(model32, np.float32).astype(np.float64))
     rp = np.ascontiguousarray(row_ptr, np.int64)
     gi = np.ascontiguousarray(gidx, np.int32)
-    v = None if val is None else np.ascontiguousarray(val, np.float32)
+    v = None if val is None else np.ascontiguousarray(val, np.float64)
     o = None if offset is None else np.ascontiguousarray(offset, np.float64)
     out = np.empty(len(rp) - 1, np.float32)
     lib().orc_score_rows(len(z), _p(z), len(rp) - 1, _p(rp), _p(gi), _p(v), _p(o), _p(out))

@@ -407,6 +407,14 @@ def test_test_loglik_kernel_vs_oracle(c1):
     got = eng.test_loglik_sums()
     want = ol.test_loglik_sum(eng.z()[0][1], b.row_ptr, gi, None, resp, None, None)
     assert abs(got[1] - want) <= 1e-11 * abs(want)
+    # test values are DOUBLES (models/LinearModel.java:530-534 does not cast them to float): values that are not float32
+    # numbers must enter the sum unrounded
+    vd = b.val.astype(np.float64) * (1.0 + 1e-9)
+    eng.set_test_data(b.row_ptr, gi, vd, resp, wt, off)
+    got = eng.test_loglik_sums()
+    want = ol.test_loglik_sum(eng.z()[0][0], b.row_ptr, gi, vd, resp, wt, off)
+    rounded = ol.test_loglik_sum(eng.z()[0][0], b.row_ptr, gi, vd.astype(np.float32), resp, wt, off)
+    assert abs(got[0] - want) <= 1e-12 * abs(want) and abs(rounded - want) > 1e-10 * abs(want)
 
 
 def _ragged_partitions():

@@ -46,7 +46,7 @@ def lib():
     L.mlh_test_free.argtypes = [C.c_void_p]
     L.mlh_test_sizes.restype = C.c_double
     L.mlh_test_sizes.argtypes = [C.c_void_p, C.c_void_p]
-    for nme, ty in (("rowptr", C.c_longlong), ("gidx", C.c_int), ("val", C.c_float), ("response", C.c_byte),
+    for nme, ty in (("rowptr", C.c_longlong), ("gidx", C.c_int), ("val", C.c_double), ("response", C.c_byte),
                     ("weight", C.c_double), ("offset", C.c_double)):
         f = getattr(L, "mlh_test_" + nme)
         f.restype = C.POINTER(ty)
