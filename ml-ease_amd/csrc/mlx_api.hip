@@ -252,7 +252,7 @@ void launch_step(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) { e0 = next_event(h, 3); e1 = next_event(h); hipEventRecord(e0, h->stream); }
     mlxk_tron_step(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->step_threads, h->d_done);
-    for (int which = 0; which < 4; which++)
+    for (int which = 0; which < 6; which++)
         mlxk_step_phase(h->stream, which, h->d_parts, h->d_probs, qcsr, nqc, h->step_ch, h->step_max_nwg, h->d_done);
     if (h->profiling) hipEventRecord(e1, h->stream);
 }

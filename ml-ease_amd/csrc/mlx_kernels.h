@@ -20,7 +20,7 @@ void mlxk_xpass_multi(hipStream_t st, const PartDev *parts, ProbDev *probs, cons
 void mlxk_tron_step(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int threads,
                     int *done_counter);
 // the same for CSR problems, split over column chunks of `ch` columns (max_nwg chunks for the widest problem):
-// four launches per tick, which = 0 (A), 1 (B), 2 (C), 3 (commit)
+// six launches per tick, which = 0 (A), 1 (reduce A), 2 (B), 3 (reduce B), 4 (C), 5 (commit)
 void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int ch,
                      int max_nwg, int *done_counter);
 // whole solves of small CSR problems in one launch (one workgroup per problem runs the tick loop)

@@ -1562,20 +1562,22 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, cons
 
 // ------------------------------------------------------------------------------------------------
 // Multi-workgroup TRON/CG step of the CSR tick path (bw/Tron.java:30-179, same statements as tron_step_body).
-// A tick's step is four launches -- A, B, C, commit -- because a CG step has two global reductions in sequence
+// A tick's step is six launches -- A, reduce, B, reduce, C, commit -- because a CG step has two global reductions in sequence
 // (alpha = rTr / d.Hd, then beta = r'.r' / rTr) and every coordinate update needs the scalar before it:
 //     A  Hd = d*pinv + X'c            partial d.Hd                    | EVAL: gradient candidate, sum t^2 pinv, |grad|^2
 //     B  s += alpha d ; r' = r - alpha Hd   partial |s|^2, |r'|^2 (+ the boundary sums s.d, s.s, d.d, speculatively)
 //                                                                     | EVAL: accept/reject, w/g copies, trcg prologue
 //     C  d = beta d + r'  (or the trust-region boundary step)  ;  at the end of trcg: w_new = w + s, partial g.s, s.r
+//     reduce  one small workgroup per problem adds the partials of A (B) in chunk order into ProbDev::totA (totB)
 //     commit  one workgroup per problem writes the problem's scalars (phase, f, delta, rTr, counters ...)
 // Each problem is cut into column chunks of `ch` columns, one 256-thread workgroup per chunk, so 128 problems of 35 K
 // columns are ~2 300 workgroups instead of 128. Reductions cross the KERNEL BOUNDARY only: every workgroup writes its
-// partial sums, and every workgroup of the next launch adds all of them in chunk order itself (a few hundred L2 hits) and
-// derives the same scalars from them -- fixed order, hence bit-reproducible, and no device-scope fence inside a kernel
-// (on this multi-XCD part a fence writes back / invalidates a whole L2: a last-arrival reduction with one fence per
-// workgroup ran the three phases at 1.3 TB/s). No scalar of ProbDev is written before the commit launch, so A, B and C
-// all see the tick's initial phase.
+// partial sums, a reduce launch adds them in chunk order -- fixed order, hence bit-reproducible -- and the next phase reads
+// the totals; no device-scope fence inside a kernel (on this multi-XCD part a fence writes back / invalidates a whole L2:
+// a last-arrival reduction with one fence per workgroup ran the three phases at 1.3 TB/s). Nothing a launch reads is
+// written in the same launch: A, B and C all see the tick's initial phase and scalars, the reduce launches write totA /
+// totB only, the commit launch the rest. (Having every workgroup of B and C re-add all the partials itself instead of the
+// reduce launches cost 40-44 % of those kernels.)
 // Norms are sqrt(sum v^2) of sums gathered inside the update loops (euclideanNorm's scaled form up to the last bits).
 // ------------------------------------------------------------------------------------------------
 #define STEP_T 256
@@ -1638,6 +1640,7 @@ k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
     if (!step_geom(pa, ch, G)) return;
     const int tid = threadIdx.x, n = G.n, nf = G.nf;
     const bool cg = (phase == PH_CG);
+    PT_INIT;
     // the intercept's column sum (the chunk that holds column nf) and the loss (chunk 0) come from the row pass's partials
     double csum_icpt = 0.0, loss = 0.0;
     if (G.j1 == n) csum_icpt = block_sum_array(pr.csump, pa.nblk, scratch);
@@ -1666,15 +1669,24 @@ k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
             mm[u] = cg ? 0.0 : m[jc];
             cc[u] = (phase == PH_EVAL0) ? c0[jc] : 0.0;
         }
-        double f0[STEP_XB];
+        // the first TWO slots of every column are fetched with the batch (most columns have one item per row block, i.e. one or
+        // two slots): a third dependent latency only for the few columns with more
+        double f0[STEP_XB], f1[STEP_XB];
 #pragma unroll
-        for (int u = 0; u < STEP_XB; u++) f0[u] = i1[u] > i0[u] ? segsum[i0[u]] : 0.0;
+        for (int u = 0; u < STEP_XB; u++) {
+            f0[u] = i1[u] > i0[u] ? segsum[i0[u]] : 0.0;
+            f1[u] = i1[u] > i0[u] + 1 ? segsum[i0[u] + 1] : 0.0;
+        }
 #pragma unroll
         for (int u = 0; u < STEP_XB; u++) {
             const int j = jb + u * STEP_T;
             if (j >= G.j1) continue;
             double xa = 0.0;                                   // slot order = (row block, segment) order
-            if (i1[u] > i0[u]) { xa += f0[u]; for (int it = i0[u] + 1; it < i1[u]; it++) xa += segsum[it]; }
+            if (i1[u] > i0[u]) {
+                xa += f0[u];
+                if (i1[u] > i0[u] + 1) xa += f1[u];
+                for (int it = i0[u] + 2; it < i1[u]; it++) xa += segsum[it];
+            }
             if (j == nf) xa = csum_icpt;
             if (cg) {
                 const double hd = vv[u] * pj[u] + xa;          // Hs[i] = (s[i]*priorVar_inv[i] + Hs[i]) * 1
@@ -1693,7 +1705,9 @@ k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
             }
         }
     }
+    PT_MARK(12);
     block_allreduce_sum<3>(acc, scratch);
+    PT_MARK(13);
     if (tid == 0) {
         double *__restrict__ px = pr.pA + G.wg * STEP_NP;
         px[0] = acc[0]; px[1] = acc[1]; px[2] = acc[2];
@@ -1808,8 +1822,6 @@ k_step_b(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
 {
 #pragma clang fp contract(off)
     __shared__ double scratch[96];
-    __shared__ double stage[STEP_T];
-    __shared__ double totA[4];
     ProbDev &pr = probs[qlist[blockIdx.y]];
     const int phase = pr.phase;
     if (phase == PH_DONE) return;
@@ -1817,7 +1829,9 @@ k_step_b(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
     StepGeom G;
     if (!step_geom(pa, ch, G)) return;
     const int tid = threadIdx.x;
-    step_gather<4>(pr.pA, G.nwg, totA, stage);
+    PT_INIT;
+    const double *totA = pr.totA;                             // k_step_reduce(A) wrote them; nobody writes them in this launch
+    PT_MARK(6);
     double *__restrict__ s = pr.s, *__restrict__ d = pr.d;
     const double *__restrict__ Hd = pr.Hd;
     if (phase == PH_CG) {
@@ -1849,6 +1863,7 @@ k_step_b(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
                 acc[4] += r1 * r1;
             }
         }
+        PT_MARK(7);
         block_allreduce_sum<5>(acc, scratch);
         if (tid == 0) {
             double *__restrict__ px = pr.pB + G.wg * STEP_NP;
@@ -1896,17 +1911,15 @@ k_step_c(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
 {
 #pragma clang fp contract(off)
     __shared__ double scratch[64];
-    __shared__ double stage[STEP_T];
-    __shared__ double totA[4], totB[5];
     ProbDev &pr = probs[qlist[blockIdx.y]];
     if (pr.phase != PH_CG) return;
     const PartDev &pa = parts[pr.part];
     StepGeom G;
     if (!step_geom(pa, ch, G)) return;
     const int tid = threadIdx.x;
-    step_gather<4>(pr.pA, G.nwg, totA, stage);
-    step_gather<5>(pr.pB, G.nwg, totB, stage);
-    const CgDecision D = cg_decide(pr, totA, totB);
+    PT_INIT;
+    PT_MARK(14);
+    const CgDecision D = cg_decide(pr, pr.totA, pr.totB);
     const bool boundary = D.boundary, end_cg = D.end_cg;
     const double nalpha = -D.alpha, alpha2 = D.alpha2, nalpha2 = -D.alpha2, beta = D.beta;
     double *__restrict__ s = pr.s, *__restrict__ d = pr.d;
@@ -1954,11 +1967,36 @@ k_step_c(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
             }
         }
     }
+    PT_MARK(15);
     if (!end_cg) return;
     block_allreduce_sum<3>(acc, scratch);
     if (tid == 0) {
         double *__restrict__ px = pr.pC + G.wg * STEP_NP;
         px[0] = acc[0]; px[1] = acc[1]; px[2] = acc[2];
+    }
+}
+
+// ---- reduce: one small workgroup per problem adds the partial sums of the phase just run (chunk order) into totA / totB,
+// so that the thousands of workgroups of the next phase read 4-5 doubles instead of each re-adding all the partials
+// (that prologue was 40 % of phase B and 44 % of phase C: in-kernel phase timing, profiles/r2_notes.md) -----------------
+__global__ void __launch_bounds__(STEP_T)
+k_step_reduce(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int ch, int which)
+{
+#pragma clang fp contract(off)
+    __shared__ double stage[STEP_T];
+    __shared__ double tot[STEP_NP];
+    ProbDev &pr = probs[qlist[blockIdx.x]];
+    const int phase = pr.phase;
+    if (phase == PH_DONE) return;
+    if (which == 1 && phase != PH_CG) return;                 // phase B leaves partial sums on CG ticks only
+    const PartDev &pa = parts[pr.part];
+    const int nwg = (pa.n_local + ch - 1) / ch;
+    if (which == 0) {
+        step_gather<4>(pr.pA, nwg, tot, stage);
+        if (threadIdx.x < 4) pr.totA[threadIdx.x] = tot[threadIdx.x];
+    } else {
+        step_gather<5>(pr.pB, nwg, tot, stage);
+        if (threadIdx.x < 5) pr.totB[threadIdx.x] = tot[threadIdx.x];
     }
 }
 
@@ -1969,16 +2007,15 @@ k_step_commit(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
 {
 #pragma clang fp contract(off)
     __shared__ double stage[STEP_T];
-    __shared__ double totA[4], totB[5], totC[3];
+    __shared__ double totC[3];
     ProbDev &pr = probs[qlist[blockIdx.x]];
     const int phase = pr.phase;
     if (phase == PH_DONE) return;
     const PartDev &pa = parts[pr.part];
     const int nwg = (pa.n_local + ch - 1) / ch;
-    step_gather<4>(pr.pA, nwg, totA, stage);
+    const double *totA = pr.totA;
     if (phase == PH_CG) {
-        step_gather<5>(pr.pB, nwg, totB, stage);
-        const CgDecision D = cg_decide(pr, totA, totB);
+        const CgDecision D = cg_decide(pr, pr.totA, pr.totB);
         if (D.end_cg) step_gather<3>(pr.pC, nwg, totC, stage);        // (uniform: every thread holds the same D)
         if (threadIdx.x != 0) return;
         if (!D.boundary) pr.rTr = D.rnew;
@@ -2677,10 +2714,14 @@ void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *p
 {
     if (nq <= 0) return;
     const dim3 grid((unsigned)max_nwg, (unsigned)nq);
-    if (which == 0) hipLaunchKernelGGL(k_step_a, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
-    else if (which == 1) hipLaunchKernelGGL(k_step_b, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
-    else if (which == 2) hipLaunchKernelGGL(k_step_c, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
-    else hipLaunchKernelGGL(k_step_commit, dim3((unsigned)nq), dim3(STEP_T), 0, st, parts, probs, qlist, ch, done_counter);
+    switch (which) {
+    case 0: hipLaunchKernelGGL(k_step_a, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch); break;
+    case 1: hipLaunchKernelGGL(k_step_reduce, dim3((unsigned)nq), dim3(STEP_T), 0, st, parts, probs, qlist, ch, 0); break;
+    case 2: hipLaunchKernelGGL(k_step_b, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch); break;
+    case 3: hipLaunchKernelGGL(k_step_reduce, dim3((unsigned)nq), dim3(STEP_T), 0, st, parts, probs, qlist, ch, 1); break;
+    case 4: hipLaunchKernelGGL(k_step_c, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch); break;
+    default: hipLaunchKernelGGL(k_step_commit, dim3((unsigned)nq), dim3(STEP_T), 0, st, parts, probs, qlist, ch, done_counter); break;
+    }
 }
 
 void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int first, bool hasval,
