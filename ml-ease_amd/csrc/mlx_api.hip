@@ -252,7 +252,7 @@ void launch_step(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) { e0 = next_event(h, 3); e1 = next_event(h); hipEventRecord(e0, h->stream); }
     mlxk_tron_step(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->step_threads, h->d_done);
-    for (int which = 0; which < 6; which++)
+    for (int which = 0; which < 4; which++)
         mlxk_step_phase(h->stream, which, h->d_parts, h->d_probs, qcsr, nqc, h->step_ch, h->step_max_nwg, h->d_done);
     if (h->profiling) hipEventRecord(e1, h->stream);
 }
@@ -1680,15 +1680,17 @@ int mlx_posterior_variance(mlx_handle h, int32_t local_index, const double *w, c
         mlxk_densify(h->stream, l, p.dev.rp, p.dev.ci, p.dev.val, Xtmp, ld);
         X = Xtmp;
     }
-    const int rows_per_chunk = 128, nchunk = (l + rows_per_chunk - 1) / rows_per_chunk;
-    double *d_part, *d_cs, *d_pinv;
-    if ((rc = talloc((void **)&d_part, sizeof(double) * 2 * ld * nchunk))) return rc;
-    if ((rc = talloc((void **)&d_cs, sizeof(double) * (2 * ld + 1)))) return rc;
+    double *d_pinv;
     if ((rc = talloc((void **)&d_pinv, sizeof(double) * n))) return rc;
     hipMemcpyAsync(d_pinv, pinv.data(), sizeof(double) * n, hipMemcpyHostToDevice, h->stream);
-    mlxk_hess_colsums(h->stream, X, ld, l, d_wd, d_part, nchunk, rows_per_chunk, d_cs);
     std::vector<double> out((size_t)n);
     if (!full) {
+        // (dense tiles; CSR partitions took the item path above)
+        const int rows_per_chunk = 128, nchunk = (l + rows_per_chunk - 1) / rows_per_chunk;
+        double *d_part, *d_cs;
+        if ((rc = talloc((void **)&d_part, sizeof(double) * 2 * ld * nchunk))) return rc;
+        if ((rc = talloc((void **)&d_cs, sizeof(double) * (2 * ld + 1)))) return rc;
+        mlxk_hess_colsums(h->stream, X, ld, l, d_wd, d_part, nchunk, rows_per_chunk, d_cs);
         // hessianDiagonal + 1/H (llf/LogisticRegressionL2.java:304-327, llf/LibLinear.java:331-334)
         std::vector<double> cs((size_t)(2 * ld + 1));
         hipMemcpyAsync(cs.data(), d_cs, sizeof(double) * cs.size(), hipMemcpyDeviceToHost, h->stream);
@@ -1696,7 +1698,8 @@ int mlx_posterior_variance(mlx_handle h, int32_t local_index, const double *w, c
         for (int j = 0; j < nf; j++) out[(size_t)j] = 1.0 / (pinv[(size_t)j] + cs[(size_t)(ld + j)]);
         out[(size_t)nf] = 1.0 / (pinv[(size_t)nf] + cs[(size_t)(2 * ld)]);
     } else {
-        const int nb = (nf + 127) / 128 > 0 ? (nf + 127) / 128 : 1, npad = nb * 128;
+        // the intercept is column nf of the Gram build itself (an implicit column of ones): nf + 1 columns in 128-column blocks
+        const int nb = (nf + 1 + 127) / 128, npad = nb * 128;
         std::vector<int> blocks;
         for (int bi = 0; bi < nb; bi++) for (int bj = 0; bj <= bi; bj++) { blocks.push_back(bi); blocks.push_back(bj); }
         const int nblocks = (int)blocks.size() / 2;
@@ -1711,9 +1714,9 @@ int mlx_posterior_variance(mlx_handle h, int32_t local_index, const double *w, c
         if ((rc = talloc((void **)&d_H, sizeof(double) * (size_t)n * n))) return rc;
         hipMemcpyAsync(d_blocks, blocks.data(), sizeof(int) * blocks.size(), hipMemcpyHostToDevice, h->stream);
         hipEventRecord(h->ev_t0, h->stream);
-        mlxk_gram_f64(h->stream, X, ld, l, d_wd, d_blocks, nblocks, ksplit, rows_per_split, d_P, npad);
+        mlxk_gram_f64(h->stream, X, ld, l, d_wd, d_blocks, nblocks, ksplit, rows_per_split, d_P, npad, nf);
         hipEventRecord(h->ev_t1, h->stream);
-        mlxk_gram_finish(h->stream, d_P, ksplit, npad, nf, d_cs, ld, d_pinv, d_H);
+        mlxk_gram_finish(h->stream, d_P, ksplit, npad, nf, d_pinv, d_H);
         std::vector<double> H((size_t)n * n), V;
         hipMemcpyAsync(H.data(), d_H, sizeof(double) * H.size(), hipMemcpyDeviceToHost, h->stream);
         if (hipStreamSynchronize(h->stream) != hipSuccess || hipGetLastError() != hipSuccess) { cleanup(); return fail(h, MLX_ERR_HIP, "posterior variance kernels failed"); }

@@ -20,7 +20,7 @@ void mlxk_xpass_multi(hipStream_t st, const PartDev *parts, ProbDev *probs, cons
 void mlxk_tron_step(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int threads,
                     int *done_counter);
 // the same for CSR problems, split over column chunks of `ch` columns (max_nwg chunks for the widest problem):
-// six launches per tick, which = 0 (A), 1 (reduce A), 2 (B), 3 (reduce B), 4 (C), 5 (commit)
+// four launches per tick, which = 0 (A), 1 (B), 2 (C), 3 (commit)
 void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int ch,
                      int max_nwg, int *done_counter);
 // whole solves of small CSR problems in one launch (one workgroup per problem runs the tick loop)
@@ -54,9 +54,8 @@ void mlxk_hess_colsums(hipStream_t st, const float *X, int64_t ld, int l, const 
 void mlxk_hess_diag_items(hipStream_t st, int n_items, const int32_t *item_ptr, const int32_t *item_dst, const int32_t *cri,
                           const float *cval, const double *wd, double *slots /* [n_slots] */);
 void mlxk_gram_f64(hipStream_t st, const float *X, int64_t ld, int l, const double *wd, const int *blocks_xy, int nblocks,
-                   int ksplit, int rows_per_split, double *P, int npad);
-void mlxk_gram_finish(hipStream_t st, const double *P, int ksplit, int npad, int nf, const double *colsums, int64_t ld,
-                      const double *pinv, double *H);
+                   int ksplit, int rows_per_split, double *P, int npad, int nf /* column nf = implicit ones (intercept) */);
+void mlxk_gram_finish(hipStream_t st, const double *P, int ksplit, int npad, int nf, const double *pinv, double *H);
 // RegressionTest scoring: one float prediction per row
 void mlxk_score_rows(hipStream_t st, int l, const int64_t *rp, const int32_t *gi, const double *val, const double *off,
                      const double *z, double base, float *pred);

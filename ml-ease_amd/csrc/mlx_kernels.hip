@@ -1562,22 +1562,20 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, cons
 
 // ------------------------------------------------------------------------------------------------
 // Multi-workgroup TRON/CG step of the CSR tick path (bw/Tron.java:30-179, same statements as tron_step_body).
-// A tick's step is six launches -- A, reduce, B, reduce, C, commit -- because a CG step has two global reductions in sequence
+// A tick's step is four launches -- A, B, C, commit -- because a CG step has two global reductions in sequence
 // (alpha = rTr / d.Hd, then beta = r'.r' / rTr) and every coordinate update needs the scalar before it:
 //     A  Hd = d*pinv + X'c            partial d.Hd                    | EVAL: gradient candidate, sum t^2 pinv, |grad|^2
 //     B  s += alpha d ; r' = r - alpha Hd   partial |s|^2, |r'|^2 (+ the boundary sums s.d, s.s, d.d, speculatively)
 //                                                                     | EVAL: accept/reject, w/g copies, trcg prologue
 //     C  d = beta d + r'  (or the trust-region boundary step)  ;  at the end of trcg: w_new = w + s, partial g.s, s.r
-//     reduce  one small workgroup per problem adds the partials of A (B) in chunk order into ProbDev::totA (totB)
 //     commit  one workgroup per problem writes the problem's scalars (phase, f, delta, rTr, counters ...)
 // Each problem is cut into column chunks of `ch` columns, one 256-thread workgroup per chunk, so 128 problems of 35 K
 // columns are ~2 300 workgroups instead of 128. Reductions cross the KERNEL BOUNDARY only: every workgroup writes its
-// partial sums, a reduce launch adds them in chunk order -- fixed order, hence bit-reproducible -- and the next phase reads
-// the totals; no device-scope fence inside a kernel (on this multi-XCD part a fence writes back / invalidates a whole L2:
-// a last-arrival reduction with one fence per workgroup ran the three phases at 1.3 TB/s). Nothing a launch reads is
-// written in the same launch: A, B and C all see the tick's initial phase and scalars, the reduce launches write totA /
-// totB only, the commit launch the rest. (Having every workgroup of B and C re-add all the partials itself instead of the
-// reduce launches cost 40-44 % of those kernels.)
+// partial sums, and every workgroup of the next launch adds all of them in chunk order itself (a few hundred L2 hits) and
+// derives the same scalars from them -- fixed order, hence bit-reproducible, and no device-scope fence inside a kernel
+// (on this multi-XCD part a fence writes back / invalidates a whole L2: a last-arrival reduction with one fence per
+// workgroup ran the three phases at 1.3 TB/s). No scalar of ProbDev is written before the commit launch, so A, B and C
+// all see the tick's initial phase.
 // Norms are sqrt(sum v^2) of sums gathered inside the update loops (euclideanNorm's scaled form up to the last bits).
 // ------------------------------------------------------------------------------------------------
 #define STEP_T 256
@@ -1640,7 +1638,6 @@ k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
     if (!step_geom(pa, ch, G)) return;
     const int tid = threadIdx.x, n = G.n, nf = G.nf;
     const bool cg = (phase == PH_CG);
-    PT_INIT;
     // the intercept's column sum (the chunk that holds column nf) and the loss (chunk 0) come from the row pass's partials
     double csum_icpt = 0.0, loss = 0.0;
     if (G.j1 == n) csum_icpt = block_sum_array(pr.csump, pa.nblk, scratch);
@@ -1705,9 +1702,7 @@ k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
             }
         }
     }
-    PT_MARK(12);
     block_allreduce_sum<3>(acc, scratch);
-    PT_MARK(13);
     if (tid == 0) {
         double *__restrict__ px = pr.pA + G.wg * STEP_NP;
         px[0] = acc[0]; px[1] = acc[1]; px[2] = acc[2];
@@ -1822,6 +1817,8 @@ k_step_b(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
 {
 #pragma clang fp contract(off)
     __shared__ double scratch[96];
+    __shared__ double stage[STEP_T];
+    __shared__ double totA[4];
     ProbDev &pr = probs[qlist[blockIdx.y]];
     const int phase = pr.phase;
     if (phase == PH_DONE) return;
@@ -1829,9 +1826,7 @@ k_step_b(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
     StepGeom G;
     if (!step_geom(pa, ch, G)) return;
     const int tid = threadIdx.x;
-    PT_INIT;
-    const double *totA = pr.totA;                             // k_step_reduce(A) wrote them; nobody writes them in this launch
-    PT_MARK(6);
+    step_gather<4>(pr.pA, G.nwg, totA, stage);
     double *__restrict__ s = pr.s, *__restrict__ d = pr.d;
     const double *__restrict__ Hd = pr.Hd;
     if (phase == PH_CG) {
@@ -1863,7 +1858,6 @@ k_step_b(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
                 acc[4] += r1 * r1;
             }
         }
-        PT_MARK(7);
         block_allreduce_sum<5>(acc, scratch);
         if (tid == 0) {
             double *__restrict__ px = pr.pB + G.wg * STEP_NP;
@@ -1911,15 +1905,17 @@ k_step_c(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
 {
 #pragma clang fp contract(off)
     __shared__ double scratch[64];
+    __shared__ double stage[STEP_T];
+    __shared__ double totA[4], totB[5];
     ProbDev &pr = probs[qlist[blockIdx.y]];
     if (pr.phase != PH_CG) return;
     const PartDev &pa = parts[pr.part];
     StepGeom G;
     if (!step_geom(pa, ch, G)) return;
     const int tid = threadIdx.x;
-    PT_INIT;
-    PT_MARK(14);
-    const CgDecision D = cg_decide(pr, pr.totA, pr.totB);
+    step_gather<4>(pr.pA, G.nwg, totA, stage);
+    step_gather<5>(pr.pB, G.nwg, totB, stage);
+    const CgDecision D = cg_decide(pr, totA, totB);
     const bool boundary = D.boundary, end_cg = D.end_cg;
     const double nalpha = -D.alpha, alpha2 = D.alpha2, nalpha2 = -D.alpha2, beta = D.beta;
     double *__restrict__ s = pr.s, *__restrict__ d = pr.d;
@@ -1967,36 +1963,11 @@ k_step_c(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
             }
         }
     }
-    PT_MARK(15);
     if (!end_cg) return;
     block_allreduce_sum<3>(acc, scratch);
     if (tid == 0) {
         double *__restrict__ px = pr.pC + G.wg * STEP_NP;
         px[0] = acc[0]; px[1] = acc[1]; px[2] = acc[2];
-    }
-}
-
-// ---- reduce: one small workgroup per problem adds the partial sums of the phase just run (chunk order) into totA / totB,
-// so that the thousands of workgroups of the next phase read 4-5 doubles instead of each re-adding all the partials
-// (that prologue was 40 % of phase B and 44 % of phase C: in-kernel phase timing, profiles/r2_notes.md) -----------------
-__global__ void __launch_bounds__(STEP_T)
-k_step_reduce(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int ch, int which)
-{
-#pragma clang fp contract(off)
-    __shared__ double stage[STEP_T];
-    __shared__ double tot[STEP_NP];
-    ProbDev &pr = probs[qlist[blockIdx.x]];
-    const int phase = pr.phase;
-    if (phase == PH_DONE) return;
-    if (which == 1 && phase != PH_CG) return;                 // phase B leaves partial sums on CG ticks only
-    const PartDev &pa = parts[pr.part];
-    const int nwg = (pa.n_local + ch - 1) / ch;
-    if (which == 0) {
-        step_gather<4>(pr.pA, nwg, tot, stage);
-        if (threadIdx.x < 4) pr.totA[threadIdx.x] = tot[threadIdx.x];
-    } else {
-        step_gather<5>(pr.pB, nwg, tot, stage);
-        if (threadIdx.x < 5) pr.totB[threadIdx.x] = tot[threadIdx.x];
     }
 }
 
@@ -2007,15 +1978,16 @@ k_step_commit(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
 {
 #pragma clang fp contract(off)
     __shared__ double stage[STEP_T];
-    __shared__ double totC[3];
+    __shared__ double totA[4], totB[5], totC[3];
     ProbDev &pr = probs[qlist[blockIdx.x]];
     const int phase = pr.phase;
     if (phase == PH_DONE) return;
     const PartDev &pa = parts[pr.part];
     const int nwg = (pa.n_local + ch - 1) / ch;
-    const double *totA = pr.totA;
+    step_gather<4>(pr.pA, nwg, totA, stage);
     if (phase == PH_CG) {
-        const CgDecision D = cg_decide(pr, pr.totA, pr.totB);
+        step_gather<5>(pr.pB, nwg, totB, stage);
+        const CgDecision D = cg_decide(pr, totA, totB);
         if (D.end_cg) step_gather<3>(pr.pC, nwg, totC, stage);        // (uniform: every thread holds the same D)
         if (threadIdx.x != 0) return;
         if (!D.boundary) pr.rTr = D.rnew;
@@ -2370,8 +2342,10 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 template <int KU>
 __global__ void __launch_bounds__(512)
 k_gram_f64(const float *__restrict__ X, int64_t ld, int l, const double *__restrict__ wd, const int2 *__restrict__ blocks,
-           int rows_per_split, double *__restrict__ P, int npad)
+           int rows_per_split, double *__restrict__ P, int npad, int nf)
 {
+    // Column nf of the Gram matrix is an IMPLICIT column of ones (the intercept: H[nf][c] = sum_i wd_i x_ic, H[nf][nf] = sum_i
+    // wd_i, llf/LogisticRegressionL2.java:259-297), so the intercept's row costs no pass of its own.
     // 8 waves = two groups of 4: each group owns one row split of the same 128 x 128 block, so that two waves share every
     // SIMD (one wave per SIMD reaches only ~45 % of the f64 MFMA rate, two reach 98 %: tools/mfma_f64_probe.hip)
     const int2 bb = blocks[blockIdx.x];
@@ -2389,6 +2363,8 @@ k_gram_f64(const float *__restrict__ X, int64_t ld, int l, const double *__restr
     const int cma = m0 + 4 * ii, cna = n0 + 4 * ii;
     const bool vm = cma < ld, vn = cna < ld;
     const int cm = vm ? cma : 0, cn = vn ? cna : 0;
+    const int oa = nf - cma, ob = nf - cna;                  // which of the lane's 4 columns (if any) is the ones column
+    const bool aq = cma <= nf;                                // the lane's A columns reach into [0, nf]
     float4 ca[KU], cb[KU], na[KU], nb[KU];      // operands of the current / the next 4 KU rows
     double cq[KU], nq[KU];
     auto fetch = [&](int r) {
@@ -2396,7 +2372,7 @@ k_gram_f64(const float *__restrict__ X, int64_t ld, int l, const double *__restr
         for (int u = 0; u < KU; u++) {
             const int row = r + 4 * u + kk;
             const int rc = min(row, l - 1);
-            nq[u] = (row < r1 && vm) ? wd[rc] : 0.0;
+            nq[u] = (row < r1 && aq) ? wd[rc] : 0.0;
             const float *__restrict__ xr = X + (int64_t)rc * ld;
             na[u] = *reinterpret_cast<const float4 *>(xr + cm);
             nb[u] = *reinterpret_cast<const float4 *>(xr + cn);
@@ -2410,9 +2386,14 @@ k_gram_f64(const float *__restrict__ X, int64_t ld, int l, const double *__restr
 #pragma unroll
         for (int u = 0; u < KU; u++) {
             const double qq = cq[u];
-            const double a[4] = {qq * (double)ca[u].x, qq * (double)ca[u].y, qq * (double)ca[u].z, qq * (double)ca[u].w};
-            const double b[4] = {vn ? (double)cb[u].x : 0.0, vn ? (double)cb[u].y : 0.0, vn ? (double)cb[u].z : 0.0,
-                                 vn ? (double)cb[u].w : 0.0};
+            const double xa[4] = {(double)ca[u].x, (double)ca[u].y, (double)ca[u].z, (double)ca[u].w};
+            const double xb[4] = {(double)cb[u].x, (double)cb[u].y, (double)cb[u].z, (double)cb[u].w};
+            double a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                a[t] = qq * (t == oa ? 1.0 : (vm ? xa[t] : 0.0));
+                b[t] = t == ob ? 1.0 : (vn ? xb[t] : 0.0);
+            }
 #pragma unroll
             for (int mt = 0; mt < 4; mt++)
 #pragma unroll
@@ -2435,22 +2416,15 @@ k_gram_f64(const float *__restrict__ X, int64_t ld, int l, const double *__restr
 // H[n][n] (n = nf + 1, row-major): feature block from the partial Gram matrices (lower triangle, mirrored), the intercept's
 // row/column from the column sums, 1/priorVar on the diagonal (llf/LogisticRegressionL2.java:259,293-296)
 __global__ void __launch_bounds__(256)
-k_gram_finish(const double *__restrict__ P, int ksplit, int npad, int nf, const double *__restrict__ colsums, int64_t ld,
-              const double *__restrict__ pinv, double *__restrict__ H)
+k_gram_finish(const double *__restrict__ P, int ksplit, int npad, int nf, const double *__restrict__ pinv, double *__restrict__ H)
 {
     const int n = nf + 1;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (int64_t)n * n) return;
     const int m = (int)(idx / n), c = (int)(idx % n);
-    double v;
-    if (m == nf && c == nf) v = colsums[2 * ld];
-    else if (m == nf) v = colsums[c];
-    else if (c == nf) v = colsums[m];
-    else {
-        const int hi = max(m, c), lo = min(m, c);
-        v = 0.0;
-        for (int k = 0; k < ksplit; k++) v += P[((int64_t)k * npad + hi) * npad + lo];
-    }
+    const int hi = max(m, c), lo = min(m, c);               // (row / column nf = the implicit ones column of the Gram build)
+    double v = 0.0;
+    for (int k = 0; k < ksplit; k++) v += P[((int64_t)k * npad + hi) * npad + lo];
     if (m == c) v = pinv[m] + v;
     H[idx] = v;
 }
@@ -2714,14 +2688,10 @@ void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *p
 {
     if (nq <= 0) return;
     const dim3 grid((unsigned)max_nwg, (unsigned)nq);
-    switch (which) {
-    case 0: hipLaunchKernelGGL(k_step_a, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch); break;
-    case 1: hipLaunchKernelGGL(k_step_reduce, dim3((unsigned)nq), dim3(STEP_T), 0, st, parts, probs, qlist, ch, 0); break;
-    case 2: hipLaunchKernelGGL(k_step_b, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch); break;
-    case 3: hipLaunchKernelGGL(k_step_reduce, dim3((unsigned)nq), dim3(STEP_T), 0, st, parts, probs, qlist, ch, 1); break;
-    case 4: hipLaunchKernelGGL(k_step_c, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch); break;
-    default: hipLaunchKernelGGL(k_step_commit, dim3((unsigned)nq), dim3(STEP_T), 0, st, parts, probs, qlist, ch, done_counter); break;
-    }
+    if (which == 0) hipLaunchKernelGGL(k_step_a, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
+    else if (which == 1) hipLaunchKernelGGL(k_step_b, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
+    else if (which == 2) hipLaunchKernelGGL(k_step_c, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
+    else hipLaunchKernelGGL(k_step_commit, dim3((unsigned)nq), dim3(STEP_T), 0, st, parts, probs, qlist, ch, done_counter);
 }
 
 void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int first, bool hasval,
@@ -2855,17 +2825,16 @@ void mlxk_hess_diag_items(hipStream_t st, int n_items, const int32_t *item_ptr, 
 }
 
 void mlxk_gram_f64(hipStream_t st, const float *X, int64_t ld, int l, const double *wd, const int *blocks_xy, int nblocks,
-                   int ksplit, int rows_per_split, double *P, int npad)
+                   int ksplit, int rows_per_split, double *P, int npad, int nf)
 {
     hipLaunchKernelGGL((k_gram_f64<4>), dim3(nblocks, ksplit / 2), dim3(512), 0, st, X, ld, l, wd,
-                       reinterpret_cast<const int2 *>(blocks_xy), rows_per_split, P, npad);
+                       reinterpret_cast<const int2 *>(blocks_xy), rows_per_split, P, npad, nf);
 }
 
-void mlxk_gram_finish(hipStream_t st, const double *P, int ksplit, int npad, int nf, const double *colsums, int64_t ld,
-                      const double *pinv, double *H)
+void mlxk_gram_finish(hipStream_t st, const double *P, int ksplit, int npad, int nf, const double *pinv, double *H)
 {
     const int64_t tot = (int64_t)(nf + 1) * (nf + 1);
-    hipLaunchKernelGGL(k_gram_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, P, ksplit, npad, nf, colsums, ld, pinv, H);
+    hipLaunchKernelGGL(k_gram_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, P, ksplit, npad, nf, pinv, H);
 }
 
 void mlxk_score_rows(hipStream_t st, int l, const int64_t *rp, const int32_t *gi, const double *val, const double *off,

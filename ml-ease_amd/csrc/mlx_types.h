@@ -89,7 +89,6 @@ struct ProbDev {
     double *rb[2];
     int32_t rsel;
     double *pA, *pB, *pC;  // [n_step_wg][STEP_NP] each
-    double totA[4], totB[5];   // chunk-ordered totals of phase A's / B's partial sums (k_step_reduce writes them between the phases)
     double gsq;            // sum g_j^2 at the last accepted point (= rTr of the next trcg call)
     double snorm;          // ||s|| at the end of the last trcg call
     double *wd[2];         // [l] wt_i * D_i at the accepted / trial point
