@@ -1666,24 +1666,15 @@ k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
             mm[u] = cg ? 0.0 : m[jc];
             cc[u] = (phase == PH_EVAL0) ? c0[jc] : 0.0;
         }
-        // the first TWO slots of every column are fetched with the batch (most columns have one item per row block, i.e. one or
-        // two slots): a third dependent latency only for the few columns with more
-        double f0[STEP_XB], f1[STEP_XB];
+        double f0[STEP_XB];
 #pragma unroll
-        for (int u = 0; u < STEP_XB; u++) {
-            f0[u] = i1[u] > i0[u] ? segsum[i0[u]] : 0.0;
-            f1[u] = i1[u] > i0[u] + 1 ? segsum[i0[u] + 1] : 0.0;
-        }
+        for (int u = 0; u < STEP_XB; u++) f0[u] = i1[u] > i0[u] ? segsum[i0[u]] : 0.0;
 #pragma unroll
         for (int u = 0; u < STEP_XB; u++) {
             const int j = jb + u * STEP_T;
             if (j >= G.j1) continue;
             double xa = 0.0;                                   // slot order = (row block, segment) order
-            if (i1[u] > i0[u]) {
-                xa += f0[u];
-                if (i1[u] > i0[u] + 1) xa += f1[u];
-                for (int it = i0[u] + 2; it < i1[u]; it++) xa += segsum[it];
-            }
+            if (i1[u] > i0[u]) { xa += f0[u]; for (int it = i0[u] + 1; it < i1[u]; it++) xa += segsum[it]; }
             if (j == nf) xa = csum_icpt;
             if (cg) {
                 const double hd = vv[u] * pj[u] + xa;          // Hs[i] = (s[i]*priorVar_inv[i] + Hs[i]) * 1
