@@ -19,7 +19,7 @@ Extra top-level keys of the same JSON line:
                 (it starts from the GPU's state after the warm-up iterations), one thread per partition solve
   parity_check  the GPU re-run of exactly those iterations against the oracle's result
   time_to_ref_loglik  metric (ii): full run from z = 0, test log-likelihood per iteration against the ORACLE's
-                committed 20-iteration value (tests/golden/c2_ref_loglik.json, tools/make_ref_loglik.py)
+                committed 20-iteration value (tests/golden/c2_ref_loglik.json, tests/golden/make_ref_loglik.py)
   sparse        BASELINE configs[2] (N = 1) / configs[3] (N > 1): one-hot 10M x 100K, 20 nnz/row, 256 / 1024
                 partitions, binary.feature, with per-kernel rooflines (row pass, column pass, TRON/CG step)
 """
@@ -320,7 +320,7 @@ def loglik_run(args, C, eng, P, nf, N, rows_total):
             gj = json.load(fh)
         if len(gj["loglik_by_iteration"]) >= args.loglik_iters:
             ref = gj["loglik_by_iteration"][args.loglik_iters - 1]
-            ref_src = "tests/golden/c2_ref_loglik.json: oracle/admm_oracle.c after ADMM iteration %d of the same job (tools/make_ref_loglik.py)" % args.loglik_iters
+            ref_src = "tests/golden/c2_ref_loglik.json: oracle/admm_oracle.c after ADMM iteration %d of the same job (tests/golden/make_ref_loglik.py)" % args.loglik_iters
     res = {"test_rows": lt, "iterations": args.loglik_iters, "seconds_all_iterations": round(walls[-1], 4),
            "loglik_by_iteration": [round(v, 8) for v in lls]}
     if ref is not None:

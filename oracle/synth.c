@@ -1,7 +1,7 @@
 /* synth.c -- C generator of the dense benchmark data (BASELINE configs[1]); TEST INFRASTRUCTURE like the rest of oracle/.
  * Same integer construction as tools/synth_data.py (NumPy) and its torch twin: element (r, c) is an Irwin-Hall(12)
  * variate from twelve 16-bit chunks of three 64-bit counter hashes, (sum - 6*65535) / 65536, so all three generators
- * give identical float32 values; used by tools/make_ref_loglik.py to build the full 1M x 1K job on the CPU quickly. */
+ * give identical float32 values; used by tests/golden/make_ref_loglik.py to build the full 1M x 1K job on the CPU quickly. */
 #include <math.h>
 #include <stdint.h>
 

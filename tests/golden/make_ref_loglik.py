@@ -6,9 +6,10 @@ job -- 1 000 000 rows x 1000 features, 64 partitions by row % 64, lambda = 1 (rh
 driver's liblinear-epsilon schedule -- and records the mean test log-likelihood of the consensus model after every
 iteration on 100 000 held-out rows (jobs/RegressionAdmmTrain.java:766-811). bench.py's metric (ii), "ADMM wall-clock
 to the reference log-likelihood", uses the LAST value as its target; the data come from the integer generator of
-tools/synth_data.py, which bench.py reproduces bit for bit on the GPU.
+tools/synth_data.py, which bench.py reproduces bit for bit on the GPU. (Fixture generator: lives beside the fixture, like
+make_golden_c1.py; it is the only place outside tests/, smoke() and bench.py's CPU legs that runs the oracle.)
 
-    python tools/make_ref_loglik.py [--threads 8]          (about 25 GB of host memory, ~1 core-hour)
+    python tests/golden/make_ref_loglik.py [--threads 8]          (about 25 GB of host memory, ~1 core-hour)
 """
 import argparse
 import json
@@ -18,7 +19,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for _p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
     if _p not in sys.path:
         sys.path.insert(0, _p)

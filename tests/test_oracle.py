@@ -353,7 +353,7 @@ def test_l1_and_lambda_map_c_vs_numpy(c1):
 
 def test_benchmark_data_generators_agree_bit_for_bit():
     """tools/synth_data.py: the NumPy generator, its torch twin (what bench.py runs on the GPU; here on the CPU device) and the
-    C twin behind tools/make_ref_loglik.py (oracle/synth.c) build the dense benchmark rows from integer arithmetic only and
+    C twin behind tests/golden/make_ref_loglik.py (oracle/synth.c) build the dense benchmark rows from integer arithmetic only and
     must produce identical float32 values and labels -- the committed oracle log-likelihood of BASELINE configs[1]
     (tests/golden/c2_ref_loglik.json) is only meaningful for bench.py if they do."""
     import sys
@@ -371,7 +371,7 @@ def test_benchmark_data_generators_agree_bit_for_bit():
 
 
 def test_reference_loglik_golden_is_consistent():
-    """tests/golden/c2_ref_loglik.json (tools/make_ref_loglik.py): 20 iterations, epsilon schedule of the driver loop, and a
+    """tests/golden/c2_ref_loglik.json (tests/golden/make_ref_loglik.py): 20 iterations, epsilon schedule of the driver loop, and a
     spot check that the generator still produces the job it was computed on (first rows of partition 0)."""
     import json
     import sys

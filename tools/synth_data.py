@@ -3,7 +3,7 @@
 Dense (configs[1], "C2"): element (row r, column c) of the 1M x 1K matrix is an Irwin-Hall(12) variate built from
 INTEGER arithmetic only -- twelve 16-bit chunks of three 64-bit counter hashes, summed, centred and divided by 2^16
 (mean 0, variance 1 - 2^-32, |x| <= 6) -- so the torch-on-GPU generator bench.py uses, the NumPy generator the tests
-use and the C generator behind the committed reference log-likelihood (tools/make_ref_loglik.py) produce the same
+use and the C generator behind the committed reference log-likelihood (tests/golden/make_ref_loglik.py) produce the same
 float32 values. Labels: y = +1 iff u_r < sigmoid(x_r . beta* + b) with u_r a 53-bit hash uniform; beta* = 0.1 * IH12,
 b = -1. (The fp64 dot product is summed in a different order by rocBLAS, OpenBLAS and the C loop: a label can differ
 only when u_r is within ~1e-15 of the threshold.)
