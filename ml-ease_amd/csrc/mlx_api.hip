@@ -83,6 +83,9 @@ struct mlx_context {
     int *d_plist = nullptr; int np_csr = 0; // first problem of every CSR partition
     int step_threads = 256;
     int step_ch = 2048, step_max_nwg = 1;   // multi-workgroup CSR step: columns per workgroup, chunks of the widest CSR problem
+    bool step_fused = false;                // phases A+B+C in one launch (k_step_fused)
+    unsigned step_seq = 0;                  // its launch sequence number (the exchanges' flag value; never 0)
+    int *d_stepctl = nullptr;               // [0] ticket counter [1] error flag
 
     double *d_Z = nullptr;
     float *d_z32 = nullptr, *d_u = nullptr, *d_B = nullptr, *d_UPX = nullptr;
@@ -253,8 +256,14 @@ void launch_step(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) { e0 = next_event(h, 3); e1 = next_event(h); hipEventRecord(e0, h->stream); }
     mlxk_tron_step(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->step_threads, h->d_done);
-    for (int which = 0; which < 4; which++)
-        mlxk_step_phase(h->stream, which, h->d_parts, h->d_probs, qcsr, nqc, h->step_ch, h->step_max_nwg, h->d_done);
+    if (h->step_fused) {
+        if (++h->step_seq == 0) h->step_seq = 1;
+        mlxk_step_fused(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->step_max_nwg, h->step_seq, h->d_stepctl);
+        mlxk_step_phase(h->stream, 3, h->d_parts, h->d_probs, qcsr, nqc, h->step_ch, h->step_max_nwg, h->d_done, h->d_stepctl);
+    } else {
+        for (int which = 0; which < 4; which++)
+            mlxk_step_phase(h->stream, which, h->d_parts, h->d_probs, qcsr, nqc, h->step_ch, h->step_max_nwg, h->d_done, h->d_stepctl);
+    }
     if (h->profiling) hipEventRecord(e1, h->stream);
 }
 
@@ -308,6 +317,14 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
     }
     HIPCHECK(h, hipStreamSynchronize(h->stream));
     HIPCHECK(h, hipGetLastError());
+    if (h->step_fused && nqc > 0) {
+        int ctl[2] = {0, 0};
+        HIPCHECK(h, hipMemcpy(ctl, h->d_stepctl, sizeof ctl, hipMemcpyDeviceToHost));
+        if (ctl[1] != 0) {
+            hipMemset(h->d_stepctl, 0, 2 * sizeof(int));
+            return fail(h, MLX_ERR_HIP, "fused TRON step: an in-launch exchange timed out (unset MLX_STEP_FUSED to run the three-launch step)");
+        }
+    }
     if (ticks_out) *ticks_out = ticks;
     return MLX_OK;
 }
@@ -1041,6 +1058,9 @@ int mlx_finalize(mlx_handle h)
         while ((max_nlocal_csr + ch - 1) / ch > 256) ch *= 2;
         h->step_ch = ch;
         h->step_max_nwg = (max_nlocal_csr + ch - 1) / ch;
+        // MLX_STEP_FUSED=1 (opt-in, measured slower -- profiles/r2_notes.md): phases A+B+C in one launch with in-launch exchanges
+        const char *fe = getenv("MLX_STEP_FUSED");
+        h->step_fused = ch == 2048 && h->step_max_nwg <= 256 && fe && atoi(fe) == 1;
     }
 
     // problems (+1 scratch for mlx_solve_one)
@@ -1051,7 +1071,7 @@ int mlx_finalize(mlx_handle h)
     auto step_nwg = [&](int n_local) { return (size_t)((n_local + h->step_ch - 1) / h->step_ch); };
     auto vec_bytes = [&](int n_local, int l, int64_t plen, int nblk, bool dense) {
         return 8 * carve_size((size_t)n_local) + (dense ? 2 : 3) * carve_size((size_t)l) + carve_size((size_t)plen) + 2 * carve_size((size_t)nblk) +
-               (dense ? 0 : carve_size((size_t)n_local) + 3 * carve_size(step_nwg(n_local) * STEP_NP)) +
+               (dense ? 0 : carve_size((size_t)n_local) + 3 * carve_size(step_nwg(n_local) * STEP_NP) + carve_size(16)) +
                (h->faithful ? carve_size((size_t)l) + carve_size((size_t)n_local) : 0);
     };
     const int scratch_blk = std::max(h->maxblk_dense, h->maxblk_csr);
@@ -1074,6 +1094,7 @@ int mlx_finalize(mlx_handle h)
             pr.coef = carve((size_t)l);
             pr.rb[0] = pr.r; pr.rb[1] = carve((size_t)n_local);
             pr.pA = carve(step_nwg(n_local) * STEP_NP); pr.pB = carve(step_nwg(n_local) * STEP_NP); pr.pC = carve(step_nwg(n_local) * STEP_NP);
+            pr.xs = carve(16);
         }
         if (h->faithful) { pr.rowtmp = carve((size_t)l); pr.c0f = carve((size_t)n_local); }
         pr.parts = carve((size_t)plen);
@@ -1100,6 +1121,8 @@ int mlx_finalize(mlx_handle h)
 
     if ((rc = dev_alloc(h, &h->d_done, 1))) return rc;
     HIPCHECK(h, hipMemset(h->d_done, 0, sizeof(int)));
+    if ((rc = dev_alloc(h, &h->d_stepctl, 2))) return rc;
+    HIPCHECK(h, hipMemset(h->d_stepctl, 0, 2 * sizeof(int)));
 
     // c0 = X' t0: one EVAL pass at w = 0 on the first problem of every partition
     std::vector<int> qfirst_d, qfirst_c, qfirst_all;

@@ -22,7 +22,9 @@ void mlxk_tron_step(hipStream_t st, const PartDev *parts, ProbDev *probs, const 
 // the same for CSR problems, split over column chunks of `ch` columns (max_nwg chunks for the widest problem):
 // four launches per tick, which = 0 (A), 1 (B), 2 (C), 3 (commit)
 void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int ch,
-                     int max_nwg, int *done_counter);
+                     int max_nwg, int *done_counter, int *ctl);
+// phases A+B+C in one launch with in-launch exchanges (ch == 2048, max_nwg <= 256); ctl: [0] ticket counter, [1] error flag
+void mlxk_step_fused(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int max_nwg, unsigned seq, int *ctl);
 // whole solves of small CSR problems in one launch (one workgroup per problem runs the tick loop)
 void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int first, bool hasval,
                       int max_ticks, int *done_counter, int lds_doubles, bool faithful);

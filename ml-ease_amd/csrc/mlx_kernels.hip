@@ -1585,7 +1585,20 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, cons
 
 // chunk-ordered totals of the previous launch's partial sums px[nwg][STEP_NP] -> tot[NP] (LDS); the loads run in
 // parallel (one partial per thread), the additions sequentially per column
-template <int NP>
+// agent-scope (cross-XCD coherent) relaxed accesses: served at the memory side, no cache maintenance -- the only accesses the
+// fused step's exchanges use for data another workgroup of the SAME launch wrote
+__device__ __forceinline__ void st_coh(double *p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_coh(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT));
+}
+
+template <int NP, bool COH = false>
 __device__ __forceinline__ void step_gather(const double *__restrict__ px, int nwg, double *tot /* LDS [NP] */,
                                             double *stage /* LDS [STEP_T] */)
 {
@@ -1596,7 +1609,7 @@ __device__ __forceinline__ void step_gather(const double *__restrict__ px, int n
     for (int w0 = 0; w0 < nwg; w0 += WPR) {
         const int w = w0 + tid / STEP_NP, k = tid % STEP_NP;
         __syncthreads();
-        stage[tid] = (w < nwg && k < NP) ? px[w * STEP_NP + k] : 0.0;
+        stage[tid] = (w < nwg && k < NP) ? (COH ? ld_coh(px + w * STEP_NP + k) : px[w * STEP_NP + k]) : 0.0;
         __syncthreads();
         if (tid < NP) {
             const int cnt = min(WPR, nwg - w0);
@@ -1962,17 +1975,305 @@ k_step_c(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
     }
 }
 
+// ---- phases A, B and C in ONE launch (opt-in experiment, MLX_STEP_FUSED=1; measured SLOWER, profiles/r2_notes.md) --------
+// The three phase kernels run at the HBM roofline of their ~13 n-vector streams per CG tick (A 4.5, B 6, C 3); what is
+// left to gain is the streams themselves. k_step_fused keeps a workgroup's 2048 columns of d, Hd and r' in registers from
+// phase A to phase C, so Hd is never written, d is read once instead of three times and r' is written once: ~8.5 streams.
+// The two reductions in between become EXCHANGES inside the launch, built so that no cache maintenance is needed (a
+// device-scope fence per workgroup writes back / invalidates a whole XCD's L2 -- profiles/r2_notes.md):
+//   * the only data one workgroup reads from another inside the launch are the partial sums and the totals, and those go
+//     through agent-scope relaxed atomics (st_coh / ld_coh: served at the memory side);
+//   * a workgroup publishes its partials, waits for the stores to be acknowledged (s_waitcnt vmcnt(0)), then bumps the
+//     problem's arrival counter; the workgroup whose bump returns nwg-1 adds all partials in chunk order (the same
+//     step_gather the commit launch uses, so both derive bit-identical scalars), publishes the totals, waits, then the
+//     launch's sequence number as the flag; every other workgroup polls the flag (one lane, s_sleep between polls);
+//   * forward progress: workgroups take their (problem, chunk) from a ticket counter in the order they START, so every
+//     chunk a spinning workgroup waits for either runs already or is dispatched before any later work -- no deadlock as
+//     long as one problem's chunks (<= 256) fit on the chip together, which 256 CUs guarantee;
+//   * a poll that does not see its flag within ~2 s raises ctl[1]; the commit launch then stops every problem and the host
+//     fails the solve -- a logic error must not hang the device.
+// The arithmetic, its order and the partial sums are those of k_step_a/b/c: results are bit-identical between the two paths
+// (tests/test_gpu_parity.py::test_fused_step_is_bit_identical_to_the_three_launch_step). It loses because an exchange is
+// ~6 dependent trips to the memory side (~10 us) and the registers hold only ~1.5 M of the job's 18 M columns at a time
+// (152 VGPRs, 3 workgroups per CU): a workgroup lives ~35 us for ~5 us of streaming. C3 step 440 vs 295 us per tick.
+// ------------------------------------------------------------------------------------------------
+#define FUSE_CPT 8                          // columns per thread, all register resident
+#define FUSE_CH (FUSE_CPT * STEP_T)         // 2048 columns per workgroup
+#define FUSE_SPIN_LIMIT (1 << 22)
+
+// xs: [0] arrivals A (u32) [1] arrivals B (u32) [2] flag A (u64) [3] flag B (u64) [4..7] totals A [8..12] totals B
+template <int NP>
+__device__ __forceinline__ void step_exchange(double (&v)[NP], double *__restrict__ px_mine, const double *__restrict__ px_all,
+                                              int nwg, double *__restrict__ xs, int which, unsigned seq, double *shtot,
+                                              double *stage, int *sh_last, int *__restrict__ ctl)
+{
+    const int tid = threadIdx.x;
+    unsigned *cnt = reinterpret_cast<unsigned *>(xs + which);
+    unsigned long long *flag = reinterpret_cast<unsigned long long *>(xs + 2 + which);
+    double *tot = xs + 4 + which * 4;
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < NP; k++) st_coh(px_mine + k, v[k]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *sh_last = (old == (unsigned)nwg - 1u) ? 1 : 0;
+    }
+    __syncthreads();
+    if (*sh_last) {                                                   // (uniform)
+        step_gather<NP, true>(px_all, nwg, shtot, stage);
+        if (tid == 0) {
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int k = 0; k < NP; k++) st_coh(tot + k, shtot[k]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(flag, (unsigned long long)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)seq) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > FUSE_SPIN_LIMIT) { __hip_atomic_store(ctl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < NP; k++) shtot[k] = ld_coh(tot + k);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < NP; k++) v[k] = shtot[k];
+}
+
+__global__ void __launch_bounds__(STEP_T)
+k_step_fused(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int max_nwg,
+             unsigned seq, int *__restrict__ ctl)
+{
+#pragma clang fp contract(off)
+    __shared__ double scratch[96];
+    __shared__ double stage[STEP_T];
+    __shared__ double shtot[STEP_NP];
+    __shared__ int sh_i[2];
+    const int tid = threadIdx.x;
+    if (tid == 0) sh_i[0] = atomicAdd(ctl, 1);                        // start order = logical order
+    __syncthreads();
+    const int ticket = sh_i[0];
+    ProbDev &pr = probs[qlist[ticket / max_nwg]];
+    const int phase = pr.phase;
+    if (phase == PH_DONE) return;
+    const PartDev &pa = parts[pr.part];
+    const int n = pa.n_local, nf = pa.n_feat;
+    const int wg = ticket % max_nwg, j0 = wg * FUSE_CH, nwg = (n + FUSE_CH - 1) / FUSE_CH;
+    if (j0 >= n) return;
+    const int j1 = min(n, j0 + FUSE_CH);
+    const bool cg = (phase == PH_CG);
+    double csum_icpt = 0.0, loss = 0.0;
+    if (j1 == n) csum_icpt = block_sum_array(pr.csump, pa.nblk, scratch);
+    if (wg == 0 && !cg) loss = block_sum_array(pr.lossp, pa.nblk, scratch);
+    const double *__restrict__ segsum = pr.parts;
+    const int32_t *__restrict__ cptr = pa.col_ptr;
+    const double *__restrict__ m = pr.m;
+    const double *__restrict__ c0 = pa.c0;
+    const double *__restrict__ pvec = pr.pinv_vec;
+    const double pscal = pr.pinv;
+    double *__restrict__ s = pr.s, *__restrict__ d = pr.d;
+    double *__restrict__ Hd = pr.Hd;
+    const double *__restrict__ v = cg ? pr.d : pr.w_new;
+
+    // ---- phase A: vv = d (CG) or w_new (EVAL), hd = Hd / gradient candidate -- both stay in registers
+    double vv[FUSE_CPT], hd[FUSE_CPT];
+    double accA[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int h = 0; h < FUSE_CPT; h += STEP_XB) {
+        int i0[STEP_XB], i1[STEP_XB];
+        double mm[STEP_XB], pj[STEP_XB], cc[STEP_XB], f0[STEP_XB];
+#pragma unroll
+        for (int u = 0; u < STEP_XB; u++) {
+            const int j = j0 + tid + (h + u) * STEP_T;
+            const int jc = min(j, j1 - 1);
+            const bool col = j < nf;
+            const int jf = min(jc, max(nf - 1, 0));
+            i0[u] = (col && nf > 0) ? cptr[jf] : 0; i1[u] = (col && nf > 0) ? cptr[jf + 1] : 0;
+            vv[h + u] = v[jc];
+            pj[u] = pvec ? pvec[jc] : pscal;
+            mm[u] = cg ? 0.0 : m[jc];
+            cc[u] = (phase == PH_EVAL0) ? c0[jc] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < STEP_XB; u++) f0[u] = i1[u] > i0[u] ? segsum[i0[u]] : 0.0;
+#pragma unroll
+        for (int u = 0; u < STEP_XB; u++) {
+            const int j = j0 + tid + (h + u) * STEP_T;
+            hd[h + u] = 0.0;
+            if (j >= j1) continue;
+            double xa = 0.0;                                   // slot order = (row block, segment) order
+            if (i1[u] > i0[u]) { xa += f0[u]; for (int it = i0[u] + 1; it < i1[u]; it++) xa += segsum[it]; }
+            if (j == nf) xa = csum_icpt;
+            if (cg) {
+                const double hv = vv[h + u] * pj[u] + xa;      // Hs[i] = (s[i]*priorVar_inv[i] + Hs[i]) * 1
+                hd[h + u] = hv;
+                accA[0] += vv[h + u] * hv;
+            } else {
+                const double t = vv[h + u] - mm[u];
+                accA[0] += t * t * pj[u];                      // fun :187-188
+                const double hv = t * pj[u] + xa;              // grad :224 (multiplier 1)
+                hd[h + u] = hv;
+                Hd[j] = hv;
+                accA[1] += hv * hv;
+                if (phase == PH_EVAL0) {
+                    const double g0 = (0.0 - mm[u]) * pj[u] + cc[u];      // grad(0)
+                    accA[2] += g0 * g0;
+                }
+            }
+        }
+    }
+    {
+        double a3[3] = {accA[0], accA[1], accA[2]};
+        block_allreduce_sum<3>(a3, scratch);
+        accA[0] = a3[0]; accA[1] = a3[1]; accA[2] = a3[2];
+        accA[3] = loss;                                        // chunk 0 carries the loss, the others add 0
+    }
+    step_exchange<4>(accA, pr.pA + wg * STEP_NP, pr.pA, nwg, pr.xs, 0, seq, shtot, stage, sh_i + 1, ctl);
+
+    if (!cg) {
+        // ---- PH_EVAL0 / PH_EVAL: phase B of the unfused step, with w_new and the gradient candidate still in registers
+        const EvalDecision D = eval_decide(pr, phase, accA);
+        double *__restrict__ w = pr.w, *__restrict__ w_new = pr.w_new, *__restrict__ g = pr.g;
+        double *__restrict__ r0 = pr.rb[0];
+        if (!(D.copy_w || D.copy_g || D.start)) return;
+#pragma unroll
+        for (int h = 0; h < FUSE_CPT; h += STEP_XB) {
+            double gv[STEP_XB], wv[STEP_XB];
+#pragma unroll
+            for (int u = 0; u < STEP_XB; u++) {
+                const int jc = min(j0 + tid + (h + u) * STEP_T, j1 - 1);
+                gv[u] = D.copy_g ? 0.0 : g[jc];
+                wv[u] = (D.nullstep && !D.copy_w) ? w[jc] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < STEP_XB; u++) {
+                const int j = j0 + tid + (h + u) * STEP_T;
+                if (j >= j1) continue;
+                if (D.copy_w) w[j] = vv[h + u];
+                if (D.copy_g) g[j] = hd[h + u];
+                if (D.start) {
+                    // trcg prologue (:133-141): s = 0, r = -g, d = r
+                    const double gj = D.copy_g ? hd[h + u] : gv[u];
+                    const double rj = -gj;
+                    s[j] = 0.0; r0[j] = rj; d[j] = rj;
+                    // the CG loop exits at once with s = 0: the (null) step is evaluated like any other
+                    if (D.nullstep) w_new[j] = (D.copy_w ? vv[h + u] : wv[u]) + 1.0 * 0.0;
+                }
+            }
+        }
+        return;
+    }
+
+    // ---- phase B (CG): s += alpha d ; r' = r - alpha Hd (kept in registers and written to the other residual buffer)
+    const double alpha = pr.rTr / accA[0], nalpha = -alpha;
+    const double *__restrict__ rc = pr.rb[pr.rsel];
+    double *__restrict__ rn = pr.rb[pr.rsel ^ 1];
+    double r1[FUSE_CPT];
+    double accB[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int h = 0; h < FUSE_CPT; h += STEP_XB) {
+        double sv[STEP_XB], rv[STEP_XB];
+#pragma unroll
+        for (int u = 0; u < STEP_XB; u++) {
+            const int jc = min(j0 + tid + (h + u) * STEP_T, j1 - 1);
+            sv[u] = s[jc]; rv[u] = rc[jc];
+        }
+#pragma unroll
+        for (int u = 0; u < STEP_XB; u++) {
+            const int j = j0 + tid + (h + u) * STEP_T;
+            r1[h + u] = 0.0;
+            if (j >= j1) continue;
+            const double dv = vv[h + u];
+            const double s1 = sv[u] + alpha * dv;                      // daxpy(alpha, d, s)
+            s[j] = s1;
+            accB[0] += s1 * s1;
+            const double sb = s1 + nalpha * dv;                        // the boundary case steps back first (:153)
+            accB[1] += sb * dv;
+            accB[2] += sb * sb;
+            accB[3] += dv * dv;
+            const double rr = rv[u] + nalpha * hd[h + u];              // daxpy(-alpha, Hd, r)
+            r1[h + u] = rr;
+            rn[j] = rr;
+            accB[4] += rr * rr;
+        }
+    }
+    block_allreduce_sum<5>(accB, scratch);
+    step_exchange<5>(accB, pr.pB + wg * STEP_NP, pr.pB, nwg, pr.xs, 1, seq, shtot, stage, sh_i + 1, ctl);
+
+    // ---- phase C
+    const CgDecision D = cg_decide(pr, accA, accB);
+    const bool boundary = D.boundary, end_cg = D.end_cg;
+    const double alpha2 = D.alpha2, nalpha2 = -D.alpha2, beta = D.beta;
+    const double *__restrict__ w = pr.w, *__restrict__ g = pr.g;
+    double *__restrict__ w_new = pr.w_new;
+    double accC[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int h = 0; h < FUSE_CPT; h += STEP_XB) {
+        double sv[STEP_XB], rv[STEP_XB], wv[STEP_XB], gv[STEP_XB];
+#pragma unroll
+        for (int u = 0; u < STEP_XB; u++) {
+            const int jc = min(j0 + tid + (h + u) * STEP_T, j1 - 1);
+            sv[u] = (boundary || end_cg) ? s[jc] : 0.0;                // (this thread's own store of phase B)
+            rv[u] = boundary ? rc[jc] : 0.0;
+            wv[u] = end_cg ? w[jc] : 0.0;
+            gv[u] = end_cg ? g[jc] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < STEP_XB; u++) {
+            const int j = j0 + tid + (h + u) * STEP_T;
+            if (j >= j1) continue;
+            const double dv = vv[h + u];
+            double sf = sv[u], rf = r1[h + u];
+            if (boundary) {
+                const double sb = sv[u] + nalpha * dv;                 // daxpy(-alpha, d, s)
+                sf = sb + alpha2 * dv;                                 // daxpy(alpha', d, s)
+                s[j] = sf;
+                rf = rv[u] + nalpha2 * hd[h + u];                      // daxpy(-alpha', Hd, r)
+                rn[j] = rf;
+            } else {
+                double dj = dv;
+                if (beta != 1.0) dj = dj * beta;                       // scale(beta, d)
+                d[j] = dj + 1.0 * r1[h + u];                           // daxpy(one, r, d)
+            }
+            if (end_cg) {
+                // back in tron(): w_new = w + s, gs, prered (:69-73)
+                w_new[j] = wv[u] + 1.0 * sf;
+                accC[0] += gv[u] * sf;
+                accC[1] += sf * rf;
+                accC[2] += sf * sf;
+            }
+        }
+    }
+    if (!end_cg) return;
+    block_allreduce_sum<3>(accC, scratch);
+    if (tid == 0) {
+        double *__restrict__ px = pr.pC + wg * STEP_NP;
+        px[0] = accC[0]; px[1] = accC[1]; px[2] = accC[2];
+    }
+}
+
 // ---- commit: one workgroup per problem writes the scalars of the tick ---------------------------------------------
 __global__ void __launch_bounds__(STEP_T)
 k_step_commit(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int ch,
-              int *__restrict__ done_counter)
+              int *__restrict__ done_counter, int *__restrict__ ctl)
 {
 #pragma clang fp contract(off)
     __shared__ double stage[STEP_T];
     __shared__ double totA[4], totB[5], totC[3];
     ProbDev &pr = probs[qlist[blockIdx.x]];
     const int phase = pr.phase;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl[0] = 0;             // the fused step's ticket counter, for the next tick
     if (phase == PH_DONE) return;
+    if (ctl[1] != 0) {
+        // an exchange of the fused step timed out: nothing of this tick can be trusted -- stop every problem, the host reports it
+        if (threadIdx.x == 0) { pr.status = ST_NAN; pr.phase = PH_DONE; atomicAdd(done_counter, 1); }
+        return;
+    }
     const PartDev &pa = parts[pr.part];
     const int nwg = (pa.n_local + ch - 1) / ch;
     step_gather<4>(pr.pA, nwg, totA, stage);
@@ -2675,14 +2976,21 @@ void mlxk_tron_step(hipStream_t st, const PartDev *parts, ProbDev *probs, const 
 }
 
 void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int ch,
-                     int max_nwg, int *done_counter)
+                     int max_nwg, int *done_counter, int *ctl)
 {
     if (nq <= 0) return;
     const dim3 grid((unsigned)max_nwg, (unsigned)nq);
     if (which == 0) hipLaunchKernelGGL(k_step_a, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
     else if (which == 1) hipLaunchKernelGGL(k_step_b, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
     else if (which == 2) hipLaunchKernelGGL(k_step_c, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
-    else hipLaunchKernelGGL(k_step_commit, dim3((unsigned)nq), dim3(STEP_T), 0, st, parts, probs, qlist, ch, done_counter);
+    else hipLaunchKernelGGL(k_step_commit, dim3((unsigned)nq), dim3(STEP_T), 0, st, parts, probs, qlist, ch, done_counter, ctl);
+}
+
+// phases A, B and C in one launch (ch must be FUSE_CH = 2048 and max_nwg <= 256); the commit launch follows as before
+void mlxk_step_fused(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int max_nwg, unsigned seq, int *ctl)
+{
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(k_step_fused, dim3((unsigned)max_nwg * (unsigned)nq), dim3(STEP_T), 0, st, parts, probs, qlist, max_nwg, seq, ctl);
 }
 
 void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int first, bool hasval,

@@ -811,6 +811,40 @@ def test_lambda_sweep_shared_x_passes(binary, nlam, monkeypatch):
     eng2.close()
 
 
+@pytest.mark.parametrize("kind", ["onehot", "valued-multilambda", "wide"])
+def test_fused_step_is_bit_identical_to_the_three_launch_step(kind, monkeypatch):
+    """The CSR tick path's TRON/CG step in ONE launch (MLX_STEP_FUSED=1, opt-in because it measured slower: k_step_fused keeps
+    d, Hd and r' in registers between the phases, the two reductions are in-launch exchanges over agent-scope atomics)
+    against the three phase launches of the default path: same arithmetic, same order, same partial sums -> every counter
+    equal and every output bit-identical, on problems of 1 chunk, a few chunks and ~35 chunks per problem, with lambdas
+    finishing at different ticks."""
+    from fixtures import onehot_blocks
+    monkeypatch.setenv("MLX_NO_SMALL", "1")
+    if kind == "onehot":
+        pd, lam, rho, iters = onehot_blocks(160000, 4), [1.0], [1.0], 5
+    elif kind == "wide":
+        pd, lam, rho, iters = synth_sparse(31, 3000, 9000, 25, 3, binary=True), [0.3, 30.0], [1.0, 1.0], 4
+    else:
+        pd, lam, rho, iters = synth_sparse(11, 6000, 300, 12, 3, weights=True, offsets=True), [0.05, 1.0, 100.0], [1.0, 1.0, 1.0], 4
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("MLX_STEP_FUSED", fused)
+        eng = make_engine(pd, lam, rho)
+        rec = []
+        for it in range(iters):
+            eng.iterate(0.01 if it < 2 else 0.001)
+            rec.append((eng.solve_counters().copy(), eng.z()[0].copy(),
+                        [eng.partition_model(k, li)[0].copy() for k in range(len(pd.blocks)) for li in range(len(lam))]))
+        outs.append(rec)
+        eng.close()
+    for it, (a, b) in enumerate(zip(*outs)):
+        assert np.array_equal(a[0], b[0]), "iteration %d: counters differ" % (it + 1)
+        assert np.array_equal(a[1], b[1]), "iteration %d: z differs" % (it + 1)
+        for x, y in zip(a[2], b[2]):
+            assert np.array_equal(x, y), "iteration %d: a partition model differs" % (it + 1)
+    assert outs[0][-1][0][:, 2].sum() > 0
+
+
 @pytest.mark.parametrize("kind", ["onehot", "valued"])
 def test_order_faithful_mode_is_bit_identical_to_the_oracle(kind, monkeypatch):
     """MLX_FAITHFUL=1: library column ids = the partition's first-seen order, one thread per row / per UNSPLIT
