@@ -112,21 +112,37 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # MLX_BENCH_SHARE_GPU=1 (test mode, never a measurement): every rank uses device 0 and the collectives run over gloo
+    # through host staging -- lets ONE GPU execute the whole N>1 control flow of this file (sharding, exchange, reductions).
+    share = os.environ.get("MLX_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:          # under torch.distributed.run also at N=1 (RCCL path)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     stream = torch.cuda.current_stream().cuda_stream
+
+    def _collective(t, op):
+        if share:
+            c = t.cpu()
+            dist.all_reduce(c, op=op)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=op)
 
     def all_reduce(t):
         # The library runs on its own HIP stream and is blocking, so the buffer is complete when we get here; the
         # collective runs on RCCL's stream, ordered against torch's current stream only. Wait for it on the host
         # before the library's next kernels (consensus_finish) read the summed buffer.
         if dist is not None:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            _collective(t, dist.ReduceOp.SUM)
             torch.cuda.current_stream().synchronize()
 
     def barrier():
@@ -138,14 +154,14 @@ def main():
         if dist is None:
             return x
         t = torch.tensor([x], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        _collective(t, dist.ReduceOp.MAX)
         return float(t.item())
 
     def reduce_sum(xs):
         if dist is None:
             return [float(x) for x in xs]
         t = torch.tensor(list(xs), device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        _collective(t, dist.ReduceOp.SUM)
         return [float(x) for x in t.tolist()]
 
     ctx = dict(torch=torch, dev=dev, dist=dist, world=world, rank=rank, local_rank=local_rank, stream=stream, admm=admm,
@@ -162,6 +178,8 @@ def main():
             else:
                 out["sparse"] = sp
     if rank == 0:
+        if share:
+            out["test_mode"] = "MLX_BENCH_SHARE_GPU=1: all ranks on ONE device, collectives over gloo -- control-flow check, not a measurement"
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
@@ -476,7 +494,7 @@ def run_sparse(args, C):
            "nnz": int(nnz), "rows_per_partition": rows, "n_local_mean": n_mean, "gen_s": round(tgen, 1), "upload_s": round(tup, 1),
            "x_passes_ref_per_s": round(tot_pref / dt, 1), "x_passes_dev_per_s": round(tot_pdev / dt, 1),
            "ticks_per_step": acc["ticks"] / args.sparse_steps, "cg_per_solve": round(acc["cg"] / max(1, acc["solves"]), 2),
-           "whole_step": {"alg_bytes_per_s_GB": round(tot_alg / dt / 1e9, 1), "frac_of_hbm_peak": round(tot_alg / dt / 1e9 / HBM_PEAK_GBS, 4),
+           "whole_step": {"alg_bytes_per_s_GB": round(tot_alg / dt / 1e9, 1), "frac_of_hbm_peak": round(tot_alg / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
                           "definition": "sum over solves of device passes x B_pass (SURVEY 8d) / wall time of the timed iterations"},
            "roofline": [roof("k_rowpass_lds<binary>", acc["rms"], half, "B_pass = nnz*4 + 8l + 8n per active problem"),
                         roof("k_colpass_lds<binary>", acc["cms"], half, "B_pass = nnz*4 + 8l + 8n per active problem"),
