@@ -6,6 +6,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -114,6 +118,8 @@ struct mlx_context {
     ncclComm_t comm = nullptr;
     int comm_nranks = 1;
     bool comm_always = false;              // MLX_COMM_ALWAYS=1: run the collective also at nranks == 1 (tests)
+    std::shared_ptr<struct LocalComm> lcomm;   // MLX_COMM_LOCAL=1 (tests): in-process exchange between handles on one device
+    int lrank = 0;
 
     mlx_stats last{};
 };
@@ -1318,21 +1324,65 @@ int mlx_admm_consensus_finish(mlx_handle h, mlx_stats *stats)
     return MLX_OK;
 }
 
+// MLX_COMM_LOCAL=1 (test mode): RCCL refuses two ranks on one device, so a host with ONE GPU could never run its
+// several-handles-in-one-process logic (one thread + one handle per device, `gpus=0,1,...` of mlease_admm_train). With the
+// switch set, mlx_comm_init joins an in-process communicator keyed by the unique id instead, and the exchange sums the
+// ranks' buffers in rank order through host memory. Never used unless the switch is set.
+struct LocalComm {
+    int nranks = 0, arrived = 0, gen = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::vector<double>> buf;
+    void barrier()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        const int g = gen;
+        if (++arrived == nranks) { arrived = 0; gen++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return gen != g; });
+    }
+};
+static std::mutex g_lcomm_mu;
+static std::map<std::string, std::weak_ptr<LocalComm>> g_lcomms;
+
+static int local_allreduce(mlx_handle h, size_t count)
+{
+    LocalComm &c = *h->lcomm;
+    std::vector<double> &mine = c.buf[(size_t)h->lrank];
+    mine.resize(count);
+    if (hipMemcpyAsync(mine.data(), h->d_cons, count * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) { c.barrier(); c.barrier(); return -1; }
+    c.barrier();
+    std::vector<double> sum(count, 0.0);
+    for (int r = 0; r < c.nranks; r++) {
+        const std::vector<double> &b = c.buf[(size_t)r];
+        if (b.size() != count) continue;
+        for (size_t i = 0; i < count; i++) sum[i] += b[i];
+    }
+    c.barrier();                                              // nobody overwrites its buffer before everybody has read it
+    if (hipMemcpyAsync(h->d_cons, sum.data(), count * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+    return 0;
+}
+
 // The exchange step of one iteration: ncclAllReduce(SUM) of [xbar | ubar] over the handle's communicator. The local
 // solve's status rides along in one extra slot, so that a rank whose solve failed still JOINS the collective (the others
 // would block in it forever otherwise) and every rank learns that the iteration failed: the reference aborts the whole
 // job when any reducer throws (jobs/RegressionAdmmTrain.java:713-716 -> job failure at :357).
 static int exchange(mlx_handle h, int local_rc, const char *what)
 {
-    if (h->comm && (h->comm_nranks > 1 || h->comm_always)) {
+    if ((h->comm || h->lcomm) && (h->comm_nranks > 1 || h->comm_always)) {
         const size_t cnt = 2 * (size_t)h->n_lambda * h->n_global;
         const double flag = local_rc ? 1.0 : 0.0;
         double total = 0.0;
         if (hipMemcpyAsync(h->d_cons + cnt, &flag, sizeof flag, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess)
             return local_rc ? local_rc : fail(h, MLX_ERR_HIP, "%s: status upload failed", what);
-        ncclResult_t r = ncclAllReduce(h->d_cons, h->d_cons, cnt + 1, ncclDouble, ncclSum, h->comm, h->stream);
-        if (r != ncclSuccess) return local_rc ? local_rc : fail(h, MLX_ERR_COMM, "ncclAllReduce failed: %s", ncclGetErrorString(r));
+        if (h->lcomm) {
+            if (local_allreduce(h, cnt + 1) != 0) return local_rc ? local_rc : fail(h, MLX_ERR_HIP, "%s: local exchange failed", what);
+        } else {
+            ncclResult_t r = ncclAllReduce(h->d_cons, h->d_cons, cnt + 1, ncclDouble, ncclSum, h->comm, h->stream);
+            if (r != ncclSuccess) return local_rc ? local_rc : fail(h, MLX_ERR_COMM, "ncclAllReduce failed: %s", ncclGetErrorString(r));
+        }
         if (hipMemcpyAsync(&total, h->d_cons + cnt, sizeof total, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess)
             return local_rc ? local_rc : fail(h, MLX_ERR_HIP, "%s: status download failed", what);
@@ -1834,7 +1884,18 @@ int mlx_comm_get_unique_id(char out[MLX_UNIQUE_ID_BYTES])
 int mlx_comm_init(mlx_handle h, const char unique_id[MLX_UNIQUE_ID_BYTES], int32_t nranks, int32_t rank)
 {
     if (!h) return MLX_ERR_INVALID;
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(h, MLX_ERR_INVALID, "mlx_comm_init: rank %d of %d", rank, nranks);
     hipSetDevice(h->device);
+    if (getenv("MLX_COMM_LOCAL") && atoi(getenv("MLX_COMM_LOCAL")) != 0) {
+        std::lock_guard<std::mutex> lk(g_lcomm_mu);
+        const std::string key(unique_id, MLX_UNIQUE_ID_BYTES);
+        std::shared_ptr<LocalComm> c = g_lcomms[key].lock();
+        if (!c) { c = std::make_shared<LocalComm>(); c->nranks = nranks; c->buf.resize((size_t)nranks); g_lcomms[key] = c; }
+        if (c->nranks != nranks) return fail(h, MLX_ERR_COMM, "mlx_comm_init: local communicator has %d ranks, not %d", c->nranks, nranks);
+        h->lcomm = c; h->lrank = rank; h->comm_nranks = nranks;
+        h->comm_always = getenv("MLX_COMM_ALWAYS") != nullptr && atoi(getenv("MLX_COMM_ALWAYS")) != 0;
+        return MLX_OK;
+    }
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof id);
     ncclResult_t r = ncclCommInitRank(&h->comm, nranks, id, rank);

@@ -259,6 +259,37 @@ def test_cli_mean_model_warm_start(tmp_path, c1):
 
 
 @pytest.mark.gpu
+def test_cli_several_handles_in_one_process(tmp_path, c1):
+    """`gpus=0,0,0` with MLX_COMM_LOCAL=1: mlease_admm_train's multi-device logic -- partition k -> handle k mod G, one thread per
+    handle for comm init / warm start / every iteration, the exchange inside mlx_naive_init and mlx_admm_iterate, test
+    loglik and z from handle 0 -- runs on ONE GPU (the in-process communicator stands in for RCCL, which refuses two ranks on
+    one device). The models must equal the one-handle run's (the partial sums associate differently: 1e-5, not bits)."""
+    subprocess.check_call(["make", "-C", HOST, "-s"])
+    recs = c1_raw_records(c1)
+    avro_io.write_container(str(tmp_path / "in" / "part-00000.avro"), PIG_SCHEMA, recs, codec="deflate")
+    avro_io.write_container(str(tmp_path / "test" / "part-00000.avro"), PIG_SCHEMA, recs[:200], codec="null")
+    outs = {}
+    for tag, gpus in (("one", "0"), ("three", "0,0,0")):
+        job = tmp_path / (tag + ".job")
+        job.write_text("input.paths=%s\noutput.base.path=%s\ntest.path=%s\nnum.blocks=8\nlambda=1.0,10\nnum.iters=6\nregularizer=2\n"
+                       "map.key=pkey\ninitialize.boost.rate=2.0\ngpus=%s\n" % (tmp_path / "in", tmp_path / ("out_" + tag), tmp_path / "test", gpus))
+        env = dict(os.environ, MLX_COMM_LOCAL="1")
+        r = subprocess.run([os.path.join(HOST, "mlease_admm_train"), str(job)], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = (admm.read_linear_models(str(tmp_path / ("out_" + tag) / "final-model" / "part-r-00000.avro"), c1.feature_names),
+                     [avro_io.read_records(str(tmp_path / ("out_" + tag) / "sample-test-loglik" / ("iteration-%d.avro" % i))) for i in range(0, 7)],
+                     r.stderr)
+    assert list(outs["one"][0]) == list(outs["three"][0]) == ["1.0", "10.0"]
+    for key, want in outs["one"][0].items():
+        got = outs["three"][0][key].astype(np.float64)
+        err = np.abs(got - want) / np.maximum(np.abs(want), 1e-2 * np.max(np.abs(want)))
+        assert np.max(err) <= 1e-5, (key, float(np.max(err)))
+    for a, b in zip(outs["one"][1], outs["three"][1]):
+        assert [x["lambda"] for x in a] == [x["lambda"] for x in b]
+        assert np.allclose([x["testLoglik"] for x in a], [x["testLoglik"] for x in b], rtol=0, atol=1e-6)
+
+
+@pytest.mark.gpu
 def test_cli_regression_test_matches_python_mirror(tmp_path, c1):
     """`mlease_regression_test job` (native host + mlx_score_rows) == admm.regression_test over the oracle scorer: same
     files, same schema, same float32 predictions in the same order; input records copied through unchanged."""
