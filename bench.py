@@ -37,6 +37,7 @@ for _p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle"), os.p
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_MATRIX_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet, fp64 matrix (v_mfma_f64_*); the in-image guide lists no fp64 figure
 ROWS, NFEAT, PARTS = 1_000_000, 1000, 64           # BASELINE configs[1]
 SP_ROWS, SP_PARTS_1GPU, SP_PARTS_MULTI = 10_000_000, 256, 1024     # configs[2] / configs[3]
 
@@ -68,6 +69,24 @@ def mem_available_gb():
     return 0.0
 
 
+def usable_cores():
+    """Cores this process can really use: os.cpu_count() capped by the scheduler affinity and by the cgroup CPU quota (the GPU
+    box shows 256 CPUs but grants the container 16 cores' worth of time: more threads than that are only throttled)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, period = fh.read().split()[:2]
+            if q != "max" and int(period) > 0:
+                n = min(n, max(1, -(-int(q) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +102,7 @@ def main():
     ap.add_argument("--loglik-iters", type=int, default=20, help="ADMM iterations of the time-to-reference-loglik run (0 = skip)")
     ap.add_argument("--test-rows", type=int, default=100000)
     ap.add_argument("--no-sparse", action="store_true", help="skip the configs[2]/[3] leg")
+    ap.add_argument("--no-gram", action="store_true", help="skip the fp64-MFMA Gram measurement (posterior covariance of one partition)")
     ap.add_argument("--sparse-only", action="store_true", help="run only the sparse leg (development / profiling)")
     ap.add_argument("--sparse-steps", type=int, default=3)
     ap.add_argument("--sparse-warmup", type=int, default=1)
@@ -296,10 +316,37 @@ def run_dense(args, C):
                "roofline": roof,
                "time_to_ref_loglik": loglik,
                "all_launches": {"xpass_launches_incl_c0_and_warmup": allrun["launches"], "alg_bytes": allrun["alg_bytes"]}}
+        if not args.no_gram:
+            out["gram"] = gram_leg(eng, rows, nf)
         if want_cpu:
             cpu_leg(args, C, eng, out, sample, snap, eps_used, step_times, nf, N)
     eng.close()
     return out
+
+
+def gram_leg(eng, rows, nf):
+    """north_star's "MFMA utilisation for the dense Gram path": the fp64-MFMA build of X'DX (full posterior covariance at the
+    current consensus, llf/LibLinear.java:314-337 -> mlx_posterior_variance) on one partition of the job, outside the timed
+    region. Flops: executed = the lower-triangle 128x128 blocks the kernel computes (intercept = an implicit ones column);
+    algorithmic = the reference's triangle loop 2 * l * n(n+1)/2."""
+    w = np.ascontiguousarray(eng.z()[0][0], np.float64)
+    pv = np.ones(nf + 1)
+    ms, wall = [], []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        _, _, m = eng.posterior_variance(0, w, pv, True)
+        wall.append(time.perf_counter() - t0)
+        ms.append(m)
+    nb = (nf + 1 + 127) // 128
+    flops_exec = 2.0 * (nb * (nb + 1) // 2) * 128 * 128 * rows
+    flops_alg = 1.0 * rows * (nf + 1) * (nf + 2)
+    best = min(ms)
+    return {"kernel": "k_gram_f64 (v_mfma_f64_16x16x4_f64)", "bound": "mfma", "workload": "X'DX of one %d x %d partition + intercept column" % (rows, nf),
+            "achieved": round(flops_exec / best / 1e9, 2), "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(flops_exec / best / 1e9 / FP64_MATRIX_PEAK_TFLOPS, 4), "achieved_algorithmic": round(flops_alg / best / 1e9, 2),
+            "kernel_ms": [round(x, 4) for x in ms], "wall_s_incl_threaded_host_cholesky_inverse": [round(x, 3) for x in wall],
+            "peak_source": "AMD MI355X datasheet fp64 matrix rate (SURVEY 8d); not in the in-image guide",
+            "note": "off the ADMM path: the solve is matrix-free (DESIGN 4); this is where the reference builds the dense Hessian"}
 
 
 def loglik_run(args, C, eng, P, nf, N, rows_total):
@@ -380,7 +427,7 @@ def cpu_leg(args, C, eng, out, sample, snap, eps_used, step_times, nf, N):
     del blocks
     sample.clear()
     oc.set_state(Z0, u0)
-    threads = min(os.cpu_count() or 1, N)
+    threads = min(usable_cores(), N)
     solves = passes = 0
     cnts = []
     t0 = time.perf_counter()
@@ -411,7 +458,7 @@ def cpu_leg(args, C, eng, out, sample, snap, eps_used, step_times, nf, N):
                            "sample": "oracle/admm_oracle.c (-O2, fp64, one thread per partition solve) on ALL %d partitions of the "
                                      "job, ADMM iterations %d..%d (started from the GPU's z/u after iteration %d, same epsilon "
                                      "schedule), %.1f s wall" % (N, it0 + 1, it0 + kc, it0, cdt),
-                           "x_passes_ref_per_s": round(passes / cdt, 2), "host_cores_available": os.cpu_count()}
+                           "x_passes_ref_per_s": round(passes / cdt, 2), "host_cpus_listed": os.cpu_count(), "host_cores_usable": usable_cores()}
     g_solves = sum(s[1] for s in step_times[:kc])
     g_time = sum(s[0] for s in step_times[:kc])
     g_pass = sum(s[2] for s in step_times[:kc])
@@ -513,7 +560,7 @@ def run_sparse(args, C):
         import oracle_lib as ol
         ns = min(args.sparse_cpu_sample, len(blocks))
         oc = ol.OracleAdmm(blocks[:ns], ng, [1.0], [1.0], num_blocks=Ptot)
-        threads = min(os.cpu_count() or 1, ns)
+        threads = min(usable_cores(), ns)
         t0 = time.perf_counter()
         oc.solve_local(0.01, 1.0, nthreads=threads)
         cdt = time.perf_counter() - t0

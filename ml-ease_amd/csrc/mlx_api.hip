@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <string>
 #include <thread>
@@ -1635,14 +1636,15 @@ int mlx_score_rows(mlx_handle h, int32_t n_global, const float *model, int32_t l
 namespace {
 // org.apache.commons:commons-math3:3.2 CholeskyDecomposition (default thresholds: relative symmetry 1e-15, absolute
 // positivity 1e-10) + getSolver().getInverse(), the call sequence of llf/LibLinear.java:321-325, from the published
-// algorithm. A (n x n, row-major) is overwritten by L^T; X receives the inverse. 0 ok, -1 not symmetric, -2 not SPD.
+// algorithm. A (n x n, row-major; its lower triangle is zeroed) is factorised in a work copy; X receives the inverse.
+// 0 ok, -1 not symmetric, -2 not positive definite, -3 out of memory.
 //
 // Threaded without touching the arithmetic: every matrix element sees the same operations in the same order as the
 // sequential loops (so the result is bit-identical for any thread count). Factorisation: in step i the rows q > i are
 // updated independently of each other (ltQ[p] -= ltI[q] * ltI[p]) once row i is scaled -- rows dealt round-robin, two
 // barriers per step. The two triangular solves act on the columns of X independently -- each thread owns a column range
-// and runs both sweeps over it without any synchronisation. (1001 x 1001: 0.17 s single-threaded -> ~15 ms on 16 cores.)
-struct SpinBarrier {
+// and runs both sweeps over it without any synchronisation.
+struct alignas(128) SpinBarrier {      // own cache lines: threads spinning on one barrier must not slow another's arrivals
     explicit SpinBarrier(int n) : n_(n) {}
     void wait()
     {
@@ -1657,14 +1659,32 @@ struct SpinBarrier {
         }
     }
     const int n_;
-    std::atomic<int> count_{0}, gen_{0};
+    alignas(64) std::atomic<int> count_{0};
+    alignas(64) std::atomic<int> gen_{0};
 };
+
+// cores this process may really use: the hardware count capped by the cgroup CPU quota (a container on a 256-core host
+// may be allowed 16 cores' worth of time; more runnable threads than that only get throttled)
+int effective_cpus()
+{
+    int hw = (int)std::thread::hardware_concurrency();
+    if (hw < 1) hw = 1;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64] = {0};
+        long long period = 0;
+        if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const long long quota = atoll(q);
+            if (quota > 0) hw = std::min<long long>(hw, std::max<long long>(1, (quota + period - 1) / period));
+        }
+        fclose(f);
+    }
+    return hw;
+}
 
 int cholesky_threads(int n)
 {
     if (const char *e = getenv("MLX_CHOL_THREADS")) return std::max(1, std::min(atoi(e), std::max(n, 1)));
-    const int hw = (int)std::thread::hardware_concurrency();
-    return std::max(1, std::min({16, hw > 0 ? hw : 1, n / 64}));
+    return std::max(1, std::min({32, effective_cpus(), n / 32}));
 }
 
 int cholesky_inverse(int n, std::vector<double> &A, std::vector<double> &X)
@@ -1677,14 +1697,34 @@ int cholesky_inverse(int n, std::vector<double> &A, std::vector<double> &X)
             A[j * N + i] = 0;
         }
     const int T = cholesky_threads(n);
-    X.assign(N * N, 0.0);
-    for (size_t i = 0; i < N; i++) X[i * N + i] = 1.0;
-    SpinBarrier bar(T);
-    std::atomic<int> bad{0};
-    double *Ap = A.data(), *Xp = X.data();
-    auto work = [&](int t) {
+    // the factorisation synchronises twice per row: beyond a few threads the barriers cost more than the rows they split;
+    // the solves do not synchronise at all and take every thread
+    const int TF = std::min(T, 4);
+    // Work copies with 64-byte aligned rows (row stride a multiple of 8 doubles) and thread-owned column ranges cut at
+    // multiples of 8: with the caller's stride (n = 1001) neighbouring threads shared a cache line in every row, and the
+    // line bounced on each of the n^2 row updates (8 threads were slower than 4).
+    const size_t LD = (N + 7) / 8 * 8;
+    const size_t bytes = (LD * N * sizeof(double) + 63) / 64 * 64;
+    double *Ap = static_cast<double *>(aligned_alloc(64, bytes)), *Xp = static_cast<double *>(aligned_alloc(64, bytes));
+    if (!Ap || !Xp) { free(Ap); free(Xp); return -3; }
+    memset(Xp, 0, bytes);
+    for (size_t i = 0; i < N; i++) {
+        memcpy(Ap + i * LD, A.data() + i * N, N * sizeof(double));
+        for (size_t k = N; k < LD; k++) Ap[i * LD + k] = 0.0;
+        Xp[i * LD + i] = 1.0;
+    }
+    SpinBarrier bar(TF);
+    alignas(64) std::atomic<int> bad{0};
+    auto run = [](int nt, const std::function<void(int)> &fn) {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; t++) th.emplace_back(fn, t);
+        fn(0);
+        for (auto &x : th) x.join();
+    };
+    // phase 1: the factorisation on TF threads (spinning barriers: nobody else is runnable meanwhile)
+    run(TF, [&](int t) {
         for (size_t i = 0; i < N; i++) {
-            double *ltI = Ap + i * N;
+            double *ltI = Ap + i * LD;
             if (t == 0) {
                 if (ltI[i] <= 1.0e-10) bad.store(1, std::memory_order_relaxed);
                 else {
@@ -1694,47 +1734,56 @@ int cholesky_inverse(int n, std::vector<double> &A, std::vector<double> &X)
                 }
             }
             bar.wait();
-            if (bad.load(std::memory_order_relaxed)) return;
-            for (size_t q = N - 1 - (size_t)t; q > i && q < N; q -= (size_t)T) {
-                double *ltQ = Ap + q * N;
+            if (bad.load(std::memory_order_relaxed)) break;
+            for (size_t q = N - 1 - (size_t)t; q > i && q < N; q -= (size_t)TF) {
+                double *ltQ = Ap + q * LD;
                 const double f = ltI[q];
                 for (size_t p = q; p < N; p++) ltQ[p] -= f * ltI[p];
             }
             bar.wait();
         }
-        // this thread's columns of X through both sweeps, in strips narrow enough that a strip (N rows) stays in its L2
-        const size_t t0 = N * (size_t)t / (size_t)T, t1 = N * ((size_t)t + 1) / (size_t)T;
+    });
+    // phase 2: both triangular sweeps, every thread on its own columns of X (a multiple of 8, cache-line aligned), in strips
+    // narrow enough that a strip (N rows) stays in its L2
+    if (!bad.load()) run(T, [&](int t) {
+        const size_t nb8 = LD / 8;
+        const size_t t0 = nb8 * (size_t)t / (size_t)T * 8, t1 = std::min(N, nb8 * ((size_t)t + 1) / (size_t)T * 8);
         const size_t W = std::max<size_t>(8, std::min<size_t>(64, (32768 / std::max<size_t>(N, 1)) / 8 * 8));
+        std::vector<double> S(N * W);                                  // the strip, contiguous: rows of W doubles
         for (size_t k0 = t0; k0 < t1; k0 += W) {
-            const size_t k1 = std::min(t1, k0 + W);
+            const size_t k1 = std::min(t1, k0 + W), w = k1 - k0;
+            for (size_t i = 0; i < N; i++) memcpy(&S[i * W], Xp + i * LD + k0, w * sizeof(double));
             for (size_t j = 0; j < N; j++) {                          // L Y = I
-                const double *lJ = Ap + j * N;
+                const double *lJ = Ap + j * LD;
                 const double lJJ = lJ[j];
-                double *xJ = Xp + j * N;
-                for (size_t k = k0; k < k1; k++) xJ[k] /= lJJ;
+                double *xJ = &S[j * W];
+                for (size_t k = 0; k < w; k++) xJ[k] /= lJJ;
                 for (size_t i = j + 1; i < N; i++) {
-                    double *xI = Xp + i * N;
+                    double *xI = &S[i * W];
                     const double lJI = lJ[i];
-                    for (size_t k = k0; k < k1; k++) xI[k] -= xJ[k] * lJI;
+                    for (size_t k = 0; k < w; k++) xI[k] -= xJ[k] * lJI;
                 }
             }
             for (size_t jj = N; jj-- > 0;) {                          // L^T X = Y
-                const double lJJ = Ap[jj * N + jj];
-                double *xJ = Xp + jj * N;
-                for (size_t k = k0; k < k1; k++) xJ[k] /= lJJ;
+                const double lJJ = Ap[jj * LD + jj];
+                double *xJ = &S[jj * W];
+                for (size_t k = 0; k < w; k++) xJ[k] /= lJJ;
                 for (size_t i = 0; i < jj; i++) {
-                    double *xI = Xp + i * N;
-                    const double lIJ = Ap[i * N + jj];
-                    for (size_t k = k0; k < k1; k++) xI[k] -= xJ[k] * lIJ;
+                    double *xI = &S[i * W];
+                    const double lIJ = Ap[i * LD + jj];
+                    for (size_t k = 0; k < w; k++) xI[k] -= xJ[k] * lIJ;
                 }
             }
+            for (size_t i = 0; i < N; i++) memcpy(Xp + i * LD + k0, &S[i * W], w * sizeof(double));
         }
-    };
-    std::vector<std::thread> th;
-    for (int t = 1; t < T; t++) th.emplace_back(work, t);
-    work(0);
-    for (auto &x : th) x.join();
-    return bad.load() ? -2 : 0;
+    });
+    const int rc = bad.load() ? -2 : 0;
+    if (rc == 0) {
+        X.resize(N * N);
+        for (size_t i = 0; i < N; i++) memcpy(X.data() + i * N, Xp + i * LD, N * sizeof(double));
+    }
+    free(Ap); free(Xp);
+    return rc;
 }
 }  // namespace
 
@@ -1859,6 +1908,7 @@ int mlx_posterior_variance(mlx_handle h, int32_t local_index, const double *w, c
         if (hipStreamSynchronize(h->stream) != hipSuccess || hipGetLastError() != hipSuccess) { cleanup(); return fail(h, MLX_ERR_HIP, "posterior variance kernels failed"); }
         if (gram_ms) { float ms = 0; hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1); *gram_ms = ms; }
         const int cr = cholesky_inverse(n, H, V);
+        if (cr == -3) { cleanup(); return fail(h, MLX_ERR_INVALID, "posterior covariance: out of host memory for the %d x %d factorisation", n, n); }
         if (cr != 0) { cleanup(); return fail(h, MLX_ERR_MODEL_FITTING, cr == -1 ? "Hessian is not symmetric (NonSymmetricMatrixException)" : "Hessian is not positive definite (NonPositiveDefiniteMatrixException)"); }
         for (int j = 0; j < n; j++) out[(size_t)j] = V[(size_t)j * n + j];
         if (post_var_matrix)
