@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--features", type=int, default=NFEAT)
     ap.add_argument("--partitions", type=int, default=PARTS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=2, help="ADMM iterations of the CPU-baseline leg (the first timed ones)")
+    ap.add_argument("--cpu-iters", type=int, default=4, help="ADMM iterations of the CPU-baseline leg (the first timed ones)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP events")
     ap.add_argument("--loglik-iters", type=int, default=20, help="ADMM iterations of the time-to-reference-loglik run (0 = skip)")
     ap.add_argument("--test-rows", type=int, default=100000)
