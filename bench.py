@@ -444,10 +444,21 @@ def cpu_leg(args, C, eng, out, sample, snap, eps_used, step_times, nf, N):
     same = True
     C["torch"].cuda.synchronize()
     tg = time.perf_counter()
+    per_it = []
+    only_last_accept = True        # every mismatch = same TRON iterations and CG steps, `accepted` (and with it the passes) off by one
     for i, e in enumerate(eps):
         eng.solve_local(e, 1.0)
         eng.consensus_finish()
-        same = same and bool(np.array_equal(eng.solve_counters(), cnts[i]))
+        gc = eng.solve_counters()
+        eq = np.all(gc == cnts[i], axis=1)
+        same = same and bool(eq.all())
+        bad = np.nonzero(~eq)[0]
+        for k in bad:
+            dlt = gc[k].astype(np.int64) - cnts[i][k].astype(np.int64)
+            only_last_accept = only_last_accept and dlt[0] == 0 and dlt[2] == 0 and abs(int(dlt[1])) == 1 and dlt[3] == dlt[1]
+        per_it.append({"iteration": it0 + i + 1, "liblinear_epsilon": e, "partitions_with_equal_counters": int(eq.sum()),
+                       "first_mismatches_[partition,gpu(newton,accepted,cg,passes),cpu(...)]":
+                           [[int(k), [int(x) for x in gc[k]], [int(x) for x in cnts[i][k]]] for k in bad[:4]]})
     gdt = time.perf_counter() - tg
     z = eng.z()[1][0].astype(np.float64)
     floor = 1e-4 * float(np.max(np.abs(z_orc)))
@@ -470,7 +481,14 @@ def cpu_leg(args, C, eng, out, sample, snap, eps_used, step_times, nf, N):
     out["parity_check"] = {"what": "GPU vs oracle, all %d partitions (%d x %d each), ADMM iterations %d..%d from the same state" % (
                                N, out["config"]["rows"] // N, nf, it0 + 1, it0 + kc),
                            "max_rel_err_z": err, "rel_err_floor": "1e-4 * max|z|", "tolerance": 1e-5, "tron_counters_equal": same,
-                           "bit_identical_float32_fraction": round(ident, 4)}
+                           "bit_identical_float32_fraction": round(ident, 4),
+                           "counters_equal_through_iteration": next((x["iteration"] - 1 for x in per_it if x["partitions_with_equal_counters"] < N), it0 + kc),
+                           "mismatch_kind": None if same else (
+                               "accept/reject of the LAST TRON step only (same TRON iterations, same CG steps): at liblinear epsilon <= 1e-7 the solve "
+                               "ends on bw/Tron.java:115-122's |actred|, |prered| <= 1e-12 |f| tests, where actred = f - fnew is the rounding "
+                               "noise of two 15 625-term sums and its comparison with eta0 * prered (:102) depends on the summation order"
+                               if only_last_accept else "other (see per_iteration)"),
+                           "per_iteration": per_it}
 
 
 # ======================================================================================================================

@@ -99,6 +99,22 @@ def onehot_blocks(rows, partitions, seed=5, fields=20, levels=5000):
     return PartitionedData(blocks, [str(i) for i in range(ng - 1)], partitions)
 
 
+def dense_blocks(rows, nfeat, partitions, seed=9):
+    """BASELINE configs[1]-style data in the small: dense N(0,1) float32 features handed over as CSR rows with every column present
+    (the library turns such a partition into a dense tile; the verification mode keeps it CSR)."""
+    rng = np.random.default_rng(seed)
+    beta = rng.normal(0, 0.1, nfeat)
+    blocks = []
+    per = rows // partitions
+    for k in range(partitions):
+        X = rng.normal(0, 1, (per, nfeat)).astype(np.float32)
+        y = np.where(rng.random(per) < 1 / (1 + np.exp(-(X.astype(np.float64) @ beta - 1.0))), 1, -1).astype(np.int8)
+        blocks.append(PartitionBlock(k, per, nfeat + 1, np.arange(0, (per + 1) * nfeat, nfeat, dtype=np.int64),
+                                     np.tile(np.arange(nfeat, dtype=np.int32), per), X.reshape(-1), y,
+                                     np.ones(per, np.float32), np.zeros(per, np.float32), np.arange(nfeat + 1, dtype=np.int32)))
+    return PartitionedData(blocks, [str(i + 1) for i in range(nfeat)], partitions)
+
+
 def permute_rows(b, seed=0):
     """Same partition, rows in another order (the reference's row order within a reducer key is unspecified)."""
     rng = np.random.default_rng(seed)

@@ -845,6 +845,47 @@ def test_fused_step_is_bit_identical_to_the_three_launch_step(kind, monkeypatch)
     assert outs[0][-1][0][:, 2].sum() > 0
 
 
+def test_tight_epsilon_differences_are_summation_order_only(monkeypatch):
+    """Under the driver's epsilon schedule the liblinear epsilon reaches 1e-7 by ADMM iteration 9 and keeps falling; from there
+    a solve ends on bw/Tron.java:115-122 (|actred|, |prered| <= 1e-12 |f|), where actred = f - fnew is the rounding noise of two
+    l-term sums, so whether the LAST step is accepted (:102, actred > eta0 * prered) depends on the summation order. On dense
+    data (configs[1] in the small) through epsilon 1e-11:
+      * the order-faithful mode stays counter-equal and bit-identical to the oracle twin in that regime too;
+      * the product path (dense tile kernels) agrees in TRON iterations and CG steps of every solve, may differ in `accepted` of
+        the last step by one (and in the passes by that one gradient), and its coefficients stay within 1e-5."""
+    from fixtures import dense_blocks
+    pd = dense_blocks(16000, 300, 4)
+    eps = [10.0 ** -k for k in range(2, 12)]
+    lam, rho = [1.0], [1.0]
+    oc = ol.OracleAdmm(pd.blocks, pd.n_global, lam, rho, pm=True)
+    monkeypatch.setenv("MLX_FAITHFUL", "1")
+    engf = make_engine(pd, lam, rho)
+    monkeypatch.delenv("MLX_FAITHFUL")
+    eng = make_engine(pd, lam, rho)                    # dense-enough CSR -> dense tiles: the headline kernels
+    oc2 = ol.OracleAdmm(pd.blocks, pd.n_global, lam, rho)
+    accept_diffs = 0
+    for it, e in enumerate(eps):
+        engf.iterate(e)
+        oc.iterate(e, 1.0, nthreads=4)
+        assert np.array_equal(engf.solve_counters(), _counters(oc)), "verification mode, epsilon %g: counters differ" % e
+        assert np.array_equal(engf.z()[0], oc.z()[0]), "verification mode, epsilon %g: z not bit-identical" % e
+        for k in range(len(pd.blocks)):
+            for a, b in zip(engf.partition_model(k, 0), oc.partition_model(k, 0)):
+                assert np.array_equal(a, b), "verification mode, epsilon %g, partition %d" % (e, k)
+        eng.iterate(e)
+        oc2.iterate(e, 1.0, nthreads=4)
+        gc, cc = eng.solve_counters().astype(np.int64), _counters(oc2).astype(np.int64)
+        d = gc - cc
+        assert np.all(d[:, 0] == 0) and np.all(d[:, 2] == 0), "epsilon %g: TRON iterations / CG steps differ: %s vs %s" % (e, gc, cc)
+        assert np.all(np.abs(d[:, 1]) <= 1) and np.all(d[:, 3] == d[:, 1]), "epsilon %g: %s vs %s" % (e, gc, cc)
+        if e >= 1e-6:
+            assert np.all(d == 0), "epsilon %g: counters differ above the noise regime: %s vs %s" % (e, gc, cc)
+        accept_diffs += int(np.abs(d[:, 1]).sum())
+        assert_coef_close(eng.z()[1][0], oc2.z()[1][0], "epsilon %g" % e)
+    print("accept/reject differences of the last step in the noise regime: %d of %d solves" % (accept_diffs, 4 * len(eps)))
+    engf.close(); eng.close()
+
+
 @pytest.mark.parametrize("kind", ["onehot", "valued"])
 def test_order_faithful_mode_is_bit_identical_to_the_oracle(kind, monkeypatch):
     """MLX_FAITHFUL=1: library column ids = the partition's first-seen order, one thread per row / per UNSPLIT
