@@ -103,8 +103,8 @@ struct mlx_context {
     unsigned long long *h_diff = nullptr;  // pinned [n_lambda]
     hipEvent_t ev_batch[2] = {nullptr, nullptr};
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
-    std::vector<hipEvent_t> ev_pool;        // profiling: event pairs, pair i brackets launches of kind ev_kind[i]
-    std::vector<int> ev_kind;               // 0 dense X pass, 1 CSR row pass, 2 CSR column pass, 3 TRON/CG step
+    std::vector<hipEvent_t> ev_pool;        // profiling: a chain of marks; the interval from mark i to mark i+1 belongs to ev_kind[i]
+    std::vector<int> ev_kind;               // 0 dense X pass, 1 CSR row pass, 2 CSR column pass, 3 TRON/CG step, -1 not a launch
     size_t ev_used = 0;
     // scratch vectors of the solve_one problem
     double *sc_vec[8] = {nullptr}, *sc_pinv = nullptr;
@@ -219,26 +219,27 @@ int upload_row_meta(mlx_handle h, PartHost &ph, int32_t l, const int8_t *y, cons
     return MLX_OK;
 }
 
-hipEvent_t next_event(mlx_handle h, int kind = -1)
+// Profiling mark: ONE event in front of every launch class of a tick (and one closing a batch of ticks); consecutive marks
+// give the class durations. (A pair of events around every launch cost 0.7 ms per ADMM iteration on a handle of 8 dense
+// problems -- 15 % of it; the chain halves that.)
+void mark(mlx_handle h, int kind)
 {
-    if (kind >= 0) h->ev_kind.push_back(kind);
+    if (!h->profiling) return;
     if (h->ev_used == h->ev_pool.size()) {
         hipEvent_t e;
         hipEventCreate(&e);
         h->ev_pool.push_back(e);
     }
-    return h->ev_pool[h->ev_used++];
+    h->ev_kind.push_back(kind);
+    hipEventRecord(h->ev_pool[h->ev_used++], h->stream);
 }
 
 // One X pass over every unfinished problem of the given lists (+ optional event bracket).
 int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int nqc)
 {
     auto bracket = [&](int kind, auto &&launch) -> int {
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (h->profiling) { e0 = next_event(h, kind); e1 = next_event(h); hipEventRecord(e0, h->stream); }
-        const int rc = launch();
-        if (h->profiling) hipEventRecord(e1, h->stream);
-        return rc;
+        mark(h, kind);
+        return launch();
     };
     if (nqd > 0 && bracket(0, [&] { return mlxk_xpass_dense(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->maxblk_dense, h->max_nfeat_dense, h->n_lambda == 1); }))
         return fail(h, MLX_ERR_INVALID, "dense tile wider than 2048 features is not supported; use the CSR form");
@@ -260,8 +261,7 @@ int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
 // The TRON/CG step of one tick: one workgroup per dense problem; three column-chunked launches + a commit for the CSR problems.
 void launch_step(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int nqc)
 {
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (h->profiling) { e0 = next_event(h, 3); e1 = next_event(h); hipEventRecord(e0, h->stream); }
+    mark(h, 3);
     mlxk_tron_step(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->step_threads, h->d_done);
     if (h->step_fused) {
         if (++h->step_seq == 0) h->step_seq = 1;
@@ -271,7 +271,6 @@ void launch_step(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
         for (int which = 0; which < 4; which++)
             mlxk_step_phase(h->stream, which, h->d_parts, h->d_probs, qcsr, nqc, h->step_ch, h->step_max_nwg, h->d_done, h->d_stepctl);
     }
-    if (h->profiling) hipEventRecord(e1, h->stream);
 }
 
 // Drive ticks until `count` problems starting at `first` are DONE.
@@ -311,6 +310,7 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
             launch_step(h, qdense, nqd, qcsr, nqc);
             ticks++;
         }
+        mark(h, -1);
         HIPCHECK(h, hipMemcpyAsync(&h->h_done[slot], h->d_done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(h, hipEventRecord(h->ev_batch[slot], h->stream));
         if (have_prev) {
@@ -1277,10 +1277,10 @@ static int collect_solve_stats(mlx_handle h, int64_t ticks, mlx_stats *stats)
     if (h->profiling) {
         double acc[4] = {0, 0, 0, 0};
         int64_t cnt[4] = {0, 0, 0, 0};
-        for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+        for (size_t i = 0; i + 1 < h->ev_used; i++) {
             float m2 = 0;
-            const int kind = h->ev_kind[i / 2];
-            if (hipEventElapsedTime(&m2, h->ev_pool[i], h->ev_pool[i + 1]) == hipSuccess) { acc[kind] += m2; cnt[kind]++; }
+            const int kind = h->ev_kind[i];
+            if (kind >= 0 && hipEventElapsedTime(&m2, h->ev_pool[i], h->ev_pool[i + 1]) == hipSuccess) { acc[kind] += m2; cnt[kind]++; }
         }
         s.xpass_ms = acc[0] + acc[1] + acc[2];
         s.rowpass_ms = acc[1]; s.colpass_ms = acc[2]; s.step_ms = acc[3];
