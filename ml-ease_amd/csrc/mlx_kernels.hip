@@ -723,6 +723,7 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
             }
         }
     }
+    PT_MARK(6);
     block_allreduce_sum<2>(red, scratch);
     if (tid == 0) { pr.lossp[c] = red[0]; pr.csump[c] = red[1]; }
     PT_MARK(5);
