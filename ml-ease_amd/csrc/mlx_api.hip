@@ -89,6 +89,7 @@ struct mlx_context {
     int step_threads = 256;
     int step_ch = 2048, step_max_nwg = 1;   // multi-workgroup CSR step: columns per workgroup, chunks of the widest CSR problem
     bool step_fused = false;                // phases A+B+C in one launch (k_step_fused)
+    int cold_groups = 0;                    // > 0: row groups of the widest partition with cold column slices (k_rowcold launch)
     unsigned step_seq = 0;                  // its launch sequence number (the exchanges' flag value; never 0)
     int *d_stepctl = nullptr;               // [0] ticket counter [1] error flag
 
@@ -253,7 +254,7 @@ int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
                                      h->max_cunits, h->max_rblk_rows, h->max_row_lds, h->row_ngc, h->row_multi, which);
                     return 0;
                 }
-                return mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_short, h->max_long, h->rowgroup, h->csr_hasval, h->csr_sell, h->max_cunits, h->max_rblk_rows, h->max_row_lds, h->row_ngc, h->n_lambda == 1, which);
+                return mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_short, h->max_long, h->rowgroup, h->csr_hasval, h->csr_sell, h->max_cunits, h->max_rblk_rows, h->max_row_lds, h->row_ngc, h->n_lambda == 1, which, h->cold_groups);
             });
     return MLX_OK;
 }
@@ -973,6 +974,13 @@ int mlx_finalize(mlx_handle h)
             p.dev.rows_per_blk = p.rows_per_blk; p.dev.nblk = p.nblk;
             h->max_row_lds = std::max(h->max_row_lds, p.slw);
         }
+        // The cold column slices as their own launch in front of the row pass when its workgroups are the big ones (128 row
+        // groups, 8 per wave: config #3 row pass 242 vs 261 us per tick); with short chunks the extra launch costs more than it
+        // saves (configs[3] per-GPU shape 51.5 vs 49 us). MLX_COLD_SEP=1 / 0 forces it on / off.
+        const char *ce = getenv("MLX_COLD_SEP");
+        h->cold_groups = 0;
+        if ((ce ? atoi(ce) != 0 : ngc >= 128) && !h->row_multi)
+            for (auto &p : h->parts) if (!p.dense && p.n_cs > 1) h->cold_groups = std::max(h->cold_groups, p.n_rgroups);
     }
     // Dense tiles: 512-row chunks are the optimum when the handle's problems make >= ~1000 of them (profiles/r1_notes.md);
     // with FEW problems (the 64-partition job strong-scaled over 8 GPUs leaves 8 per GPU = 248 chunks for 256 CUs, one

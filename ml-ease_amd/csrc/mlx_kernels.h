@@ -11,7 +11,8 @@ int mlxk_xpass_dense(hipStream_t st, const PartDev *parts, ProbDev *probs, const
                      int max_nfeat, bool stream_once);
 int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
                    int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cunits, int max_rblk_rows, int row_slw, int row_ngc, bool stream_once,
-                   int which /* 1 = row pass, 2 = column pass, 3 = both */);
+                   int which /* 1 = row pass, 2 = column pass, 3 = both */,
+                   int cold_groups /* > 0: the row pass's cold slices run as their own launch (k_rowcold) over that many row groups */);
 // Shared-X passes of a lambda sweep (n_lambda <= 8): one workgroup per (partition, piece) carries all lambdas; plist = first
 // problem of every CSR partition. row_multi false = only the column pass has a shared form for these partitions.
 void mlxk_xpass_multi(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *plist, int np, int nl, int R, int maxblk,

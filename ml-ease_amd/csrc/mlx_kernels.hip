@@ -614,7 +614,8 @@ __device__ __forceinline__ void sell_gather_round(double *a, const uint16_t *__r
 #endif
 template <bool HASVAL, bool NT, int GPW>
 __global__ void __launch_bounds__(1024)
-k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx)
+k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx,
+              int cold_sep)
 {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) double vs[];      // [slw + 1]: the staged hot slice, then the zero slot
@@ -654,7 +655,10 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     PT_MARK(0);
     __syncthreads();
     PT_MARK(1);
-    for (int sl = 0; sl < ncs; sl++) {
+    // cold_sep: the cold slices' sums were left in coef[] by k_rowcold (launched just before); only the hot slice runs here
+    const int nsl = cold_sep ? 1 : ncs;
+    const bool add_cold = cold_sep && ncs > 1;
+    for (int sl = 0; sl < nsl; sl++) {
         // block offsets of this wave's GPW consecutive groups: one load, then lane broadcasts (wave-uniform scalars)
         const int32_t *__restrict__ ptr = pa.rs_ptr + (int64_t)sl * ngr + g0;
         const int pv = ptr[min(wg0 + min(lane, GPW), gcount)];
@@ -692,7 +696,7 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     for (int i0 = 0; i0 < GPW; i0 += EH) {
         int rowi[EH];
         bool ok[EH];
-        double wdv0[EH];
+        double wdv0[EH], zc[EH];
         float offv[EH], wtv[EH];
         int yv[EH];
 #pragma unroll
@@ -701,6 +705,7 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
             ok[i] = (wg0 + i0 + i < gcount) && row < l;
             rowi[i] = min(row, l - 1);
             wdv0[i] = cg ? wdcur[rowi[i]] : 0.0;
+            zc[i] = add_cold ? coef[rowi[i]] : 0.0;
             offv[i] = cg ? 0.f : pa.off[rowi[i]];
             wtv[i] = cg ? 0.f : pa.wt[rowi[i]];
             yv[i] = cg ? 0 : (int)pa.y[rowi[i]];
@@ -708,7 +713,7 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
 #pragma unroll
         for (int i = 0; i < EH; i++) {
             if (ok[i]) {
-                const double t = acc[i0 + i] + vb;
+                const double t = (add_cold ? acc[i0 + i] + zc[i] : acc[i0 + i]) + vb;
                 double cf;
                 if (cg) {
                     cf = wdv0[i] * t;
@@ -727,6 +732,57 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     block_allreduce_sum<2>(red, scratch);
     if (tid == 0) { pr.lossp[c] = red[0]; pr.csump[c] = red[1]; }
     PT_MARK(5);
+}
+
+// The cold column slices of the row pass as a launch of their own (12 % of the entries of the one-hot configs, but 27 % of
+// the fused kernel's time: two dependent L2 latencies per round on a workgroup that owns a whole CU's LDS). Here they run
+// at full occupancy -- 256-thread workgroups, no LDS, a wave owns 4 consecutive row groups and a lane one row of each --
+// and leave a row's cold sum (entries in ascending column id) in coef[row]; k_rowpass_lds adds it to the row's hot sum.
+template <bool HASVAL, bool NT>
+__global__ void __launch_bounds__(256)
+k_rowcold(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx)
+{
+#pragma clang fp contract(off)
+    int pi_, bx_;
+    if (!xcd_map(nq, gx, pi_, bx_)) return;
+    ProbDev &pr = probs[qlist[pi_]];
+    const int phase = pr.phase;
+    if (phase == PH_DONE) return;
+    const PartDev &pa = parts[pr.part];
+    const int ncs = pa.n_cs, ngr = pa.n_rgroups, slw = pa.slw, l = pa.l;
+    if (!pa.sell || ncs <= 1) return;
+    constexpr int GC = 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g0 = bx_ * (4 * GC) + wave * GC;
+    if (g0 >= ngr) return;
+    const int gcount = min(GC, ngr - g0);
+    const double *__restrict__ v = (phase == PH_CG) ? pr.d : pr.w_new;
+    const uint16_t *__restrict__ rs_idx = pa.rs_idx;
+    const float *__restrict__ rs_val = pa.rs_val;
+    double acc[GC];
+#pragma unroll
+    for (int i = 0; i < GC; i++) acc[i] = 0.0;
+    for (int sl = 1; sl < ncs; sl++) {
+        const int32_t *__restrict__ ptr = pa.rs_ptr + (int64_t)sl * ngr + g0;
+        const int pv = ptr[min(lane, gcount)];
+        int base[GC], L4[GC];
+        int kmax = 0;
+#pragma unroll
+        for (int i = 0; i < GC; i++) {
+            base[i] = __builtin_amdgcn_readlane(pv, i);
+            const int nx = __builtin_amdgcn_readlane(pv, i + 1);
+            L4[i] = (i < gcount) ? (nx - base[i]) >> 8 : 0;
+            kmax = max(kmax, L4[i]);
+        }
+        const double *__restrict__ src = v + slw + (int64_t)(sl - 1) * 65535;
+        for (int k = 0; k < kmax; k++) sell_gather_round<HASVAL, NT, GC>(acc, rs_idx, rs_val, base, L4, k, lane, src);
+    }
+    double *__restrict__ coef = pr.coef;
+#pragma unroll
+    for (int i = 0; i < GC; i++) {
+        const int row = (g0 + i) * 64 + lane;
+        if (i < gcount && row < l) coef[row] = acc[i];
+    }
 }
 
 // Column pass with the row coefficients in LDS. One workgroup = (problem, work unit): the unit's row block of `coef`
@@ -2887,7 +2943,8 @@ static void launch_rowpass(hipStream_t st, const PartDev *parts, ProbDev *probs,
 }
 
 int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
-                   int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cunits, int max_rblk_rows, int row_slw, int row_ngc, bool stream_once, int which)
+                   int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cunits, int max_rblk_rows, int row_slw, int row_ngc, bool stream_once, int which,
+                   int cold_groups)
 {
     const bool do_row = which & 1, do_col = which & 2;
     if (nq <= 0) return 0;
@@ -2905,9 +2962,11 @@ int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const i
 #undef SETLDS
             attr_set = true;
         }
-#define LAUNCH_ROW(HV, NTF, GP) hipLaunchKernelGGL((k_rowpass_lds<HV, NTF, GP>), dim3(XGRID(nq, maxblk)), dim3(1024), lds_row, st, parts, probs, qlist, nq, maxblk)
+#define LAUNCH_ROW(HV, NTF, GP) hipLaunchKernelGGL((k_rowpass_lds<HV, NTF, GP>), dim3(XGRID(nq, maxblk)), dim3(1024), lds_row, st, parts, probs, qlist, nq, maxblk, cold_groups > 0 ? 1 : 0)
 #define LAUNCH_SELL(HV, NTF)                                                                                                                   \
         do {                                                                                                                                   \
+            if (do_row && cold_groups > 0)                                                                                                     \
+                hipLaunchKernelGGL((k_rowcold<HV, NTF>), dim3(XGRID(nq, (cold_groups + 15) / 16)), dim3(256), 0, st, parts, probs, qlist, nq, (cold_groups + 15) / 16); \
             if (do_row) switch (row_ngc) {                                                                                                     \
                 case 16: LAUNCH_ROW(HV, NTF, 1); break;                                                                                        \
                 case 32: LAUNCH_ROW(HV, NTF, 2); break;                                                                                        \

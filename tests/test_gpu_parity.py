@@ -811,6 +811,76 @@ def test_lambda_sweep_shared_x_passes(binary, nlam, monkeypatch):
     eng2.close()
 
 
+@pytest.mark.parametrize("binary", [True, False])
+def test_cold_column_slices_as_their_own_launch(binary, monkeypatch):
+    """The row pass gathers the hot column slice from LDS and the cold slices from L2; by default the cold slices run as a
+    launch of their own in front of it (k_rowcold: full occupancy instead of two dependent latencies per round on a
+    workgroup that owns a CU's LDS) and the row kernel adds the row's cold sum to its hot sum. MLX_COLD_SEP=0 keeps them
+    inside the row kernel. Both must follow the oracle's trajectory (MLX_SLW=128 makes most of these columns cold)."""
+    monkeypatch.setenv("MLX_NO_SMALL", "1")
+    monkeypatch.setenv("MLX_SLW", "128")
+    pd = synth_sparse(37, 5000, 900, 16, 3, binary=binary, weights=not binary, offsets=not binary)
+    lam, rho = [0.2, 5.0], [1.0, 1.0]
+    oc = ol.OracleAdmm(pd.blocks, pd.n_global, lam, rho)
+    engs = []
+    for sep in ("1", "0"):
+        monkeypatch.setenv("MLX_COLD_SEP", sep)
+        engs.append(make_engine(pd, lam, rho))
+    for it in range(4):
+        oc.iterate(0.01, 1.0, nthreads=4)
+        for sep, eng in zip(("1", "0"), engs):
+            eng.iterate(0.01)
+            assert np.array_equal(eng.solve_counters(), _counters(oc)), "MLX_COLD_SEP=%s iteration %d" % (sep, it + 1)
+            for li in range(len(lam)):
+                assert_coef_close(eng.z()[1][li], oc.z()[1][li], "MLX_COLD_SEP=%s lambda %g iteration %d" % (sep, lam[li], it + 1), floor=1e-2)
+    for eng in engs:
+        eng.close()
+
+
+def test_two_cold_slices_on_wide_partitions(monkeypatch):
+    """~80 000 local valued features with a 64-column hot slice: two cold slices (65 535 columns + the rest). Separate launch and
+    inside the row kernel both follow the oracle (counters equal, coefficients within 1e-5 of it)."""
+    from mlease_amd.dataset import PartitionBlock, PartitionedData
+    monkeypatch.setenv("MLX_SLW", "64")
+    monkeypatch.setenv("MLX_NO_DENSIFY", "1")
+    rng = np.random.default_rng(77)
+    nfeat, rows, parts = 150000, 4000, 2
+    beta = rng.normal(0, 0.5, nfeat)
+    blocks = []
+    for k in range(parts):
+        rp, ci, val, y = [0], [], [], []
+        for i in range(rows):
+            cols = np.unique(rng.integers(0, nfeat, 30))
+            v = rng.normal(0, 1, len(cols)).astype(np.float32)
+            ci.append(cols); val.append(v); rp.append(rp[-1] + len(cols))
+            y.append(1 if rng.random() < 1 / (1 + np.exp(-(float(np.dot(beta[cols], v)) - 0.3))) else -1)
+        gcols = np.concatenate(ci)
+        uniq, inv = np.unique(gcols, return_inverse=True)
+        # per-row ascending local ids (np.unique keeps the order of the sorted global ids)
+        blocks.append(PartitionBlock(k, rows, len(uniq) + 1, np.asarray(rp, np.int64), inv.astype(np.int32), np.concatenate(val),
+                                     np.asarray(y, np.int8), rng.uniform(0.5, 2.0, rows).astype(np.float32), np.zeros(rows, np.float32),
+                                     np.concatenate([uniq.astype(np.int32), [nfeat]]).astype(np.int32)))
+    pd = PartitionedData(blocks, [str(i) for i in range(nfeat)], parts)
+    assert min(b.n_local for b in blocks) > 64 + 65535
+    oc = ol.OracleAdmm(pd.blocks, pd.n_global, [1.0], [1.0])
+    engs = []
+    for sep in ("1", "0"):
+        monkeypatch.setenv("MLX_COLD_SEP", sep)
+        engs.append(make_engine(pd, [1.0], [1.0]))
+    for it in range(3):
+        oc.iterate(0.01, 1.0, nthreads=2)
+        for sep, eng in zip(("1", "0"), engs):
+            eng.iterate(0.01)
+            assert np.array_equal(eng.solve_counters(), _counters(oc)), "MLX_COLD_SEP=%s iteration %d" % (sep, it + 1)
+            # (~1.5 entries per feature: the consensus of features seen by one partition only amplifies last-bit differences of
+            # the solves, hence 1e-4 here; a dropped or doubled cold entry would be an O(1) error and change the counters)
+            want = oc.z()[1][0].astype(np.float64)
+            err = np.abs(eng.z()[1][0].astype(np.float64) - want) / np.maximum(np.abs(want), 1e-2 * np.max(np.abs(want)))
+            assert np.max(err) <= 1e-4, "MLX_COLD_SEP=%s iteration %d: %.3e" % (sep, it + 1, np.max(err))
+    for eng in engs:
+        eng.close()
+
+
 @pytest.mark.parametrize("kind", ["onehot", "valued-multilambda", "wide"])
 def test_fused_step_is_bit_identical_to_the_three_launch_step(kind, monkeypatch):
     """The CSR tick path's TRON/CG step in ONE launch (MLX_STEP_FUSED=1, opt-in because it measured slower: k_step_fused keeps
