@@ -561,7 +561,7 @@ def run_sparse(args, C):
            "ticks_per_step": acc["ticks"] / args.sparse_steps, "cg_per_solve": round(acc["cg"] / max(1, acc["solves"]), 2),
            "whole_step": {"alg_bytes_per_s_GB": round(tot_alg / dt / 1e9, 1), "frac_of_hbm_peak": round(tot_alg / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
                           "definition": "sum over solves of device passes x B_pass (SURVEY 8d) / wall time of the timed iterations"},
-           "roofline": [roof("k_rowpass_lds<binary>", acc["rms"], half, "B_pass = nnz*4 + 8l + 8n per active problem"),
+           "roofline": [roof("k_rowcold + k_rowpass_lds<binary>", acc["rms"], half, "B_pass = nnz*4 + 8l + 8n per active problem; the cold column slices run as their own launch in front of the row kernel"),
                         roof("k_colpass_lds<binary>", acc["cms"], half, "B_pass = nnz*4 + 8l + 8n per active problem"),
                         roof("k_step_a+b+c+commit", acc["sms"], 0.0,
                              "no algorithmic X bytes (SURVEY 8d counts the n-vector work as zero); streams ~13 x 8n bytes per problem and "

@@ -54,13 +54,13 @@ def main():
     fe, wr = pmc_sums(os.path.join(src, "sparse_pmc_fetch.txt"), "FETCH_SIZE"), pmc_sums(os.path.join(src, "sparse_pmc_write.txt"), "WRITE_SIZE")
     alg = bs["all_launches"]["alg_bytes_row_plus_column"]
     per, tot_raw, tot_x2 = {}, 0.0, 0.0
-    for key, label in (("k_rowpass_lds", "row pass"), ("k_colpass_lds", "column pass"), ("k_step_a", "step A"), ("k_step_b", "step B"),
-                       ("k_step_c(", "step C"), ("k_step_commit", "step commit")):
-        kf = [k for k in fe if key in k]
-        kw = [k for k in wr if key in k]
+    for keys, label in ((("k_rowpass_lds", "k_rowcold"), "row pass"), (("k_colpass_lds",), "column pass"), (("k_step_a",), "step A"),
+                        (("k_step_b",), "step B"), (("k_step_c(",), "step C"), (("k_step_commit",), "step commit")):
+        kf = [k for k in fe if any(key in k for key in keys)]
+        kw = [k for k in wr if any(key in k for key in keys)]
         f = sum(fe[k][1] for k in kf)
         w = sum(wr[k][1] for k in kw)
-        n = sum(fe[k][0] for k in kf)
+        n = sum(fe[k][0] for k in kf if keys[0] in k)        # (the cold-slice launch in front of the row kernel is part of the row pass)
         per[label] = {"launches": n, "FETCH_SIZE_bytes": f, "WRITE_SIZE_bytes": w, "hbm_bytes_raw": f + w, "hbm_bytes_fetch_x2": 2 * f + w}
         tot_raw += f + w
         tot_x2 += 2 * f + w
