@@ -48,7 +48,7 @@ struct PartHost {
     bool sell = false;
     std::vector<int32_t> new2old;          // CSR partitions: library local id -> caller's local id (features only)
     std::vector<int32_t> col_ptr_h;        // CSR partitions: host copy of col_ptr (slots of each column)
-    int n_cs = 1, slw = 64, n_rgroups = 0, n_cslices = 0, n_rblk = 1, rblk_rows = 0, n_cunits = 0;
+    int n_cs = 1, n_hs = 1, slw = 64, n_rgroups = 0, n_cslices = 0, n_rblk = 1, rblk_rows = 0, n_cunits = 0;
     int nblk = 0, rows_per_blk = 0, n_items = 0, n_slots = 0, rowgroup = 64, pos = 0, neg = 0;
     PartDev dev{};
     double *c0 = nullptr;
@@ -636,10 +636,19 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
         const int ngr = (l + 63) / 64;
         const int slmax = getenv("MLX_SLW") ? std::max(64, atoi(getenv("MLX_SLW")) / 64 * 64) : ROW_SLICE_MAX_COLS;
         const int slw = std::max(64, (std::min(nf, slmax) + 63) / 64 * 64);
-        const int ncold = nf > slw ? (nf - slw + ROW_COLD_COLS - 1) / ROW_COLD_COLS : 0;
-        const int ncs_r = 1 + ncold;
-        ph.n_cs = ncs_r; ph.slw = slw; ph.n_rgroups = ngr;
-        auto slice_lo = [&](int sl) { return sl == 0 ? 0 : slw + (sl - 1) * ROW_COLD_COLS; };
+        // hot slices (each slw columns, staged in LDS one after the other), then cold slices of 65 535 columns (gathered from L2,
+        // which serves ~190 G random 8-byte requests/s chip-wide). A second hot slice pays when it leaves NO cold columns
+        // (configs[3] per-GPU shape, ~35 K local features: row pass 44 vs 49 us per tick); when cold columns remain either way
+        // (config #3, ~70 K) one more staging and ~1.3 mostly padded packs per row group cost what the saved gathers did
+        // (1 / 2 / 3 / 4 hot slices: 284 / 287 / 298 / 289 us). MLX_NHOT forces a count.
+        int nhs_want = getenv("MLX_NHOT") ? std::max(1, atoi(getenv("MLX_NHOT"))) : (nf <= 2 * slw ? 2 : 1);
+        if (n_lambda >= 2 && getenv("MLX_MULTI") != nullptr && atoi(getenv("MLX_MULTI")) != 0) nhs_want = 1;   // the shared row pass knows one
+        const int n_hs = std::max(1, std::min(nhs_want, (nf + slw - 1) / slw));
+        const int hot_cols = n_hs * slw;
+        const int ncold = nf > hot_cols ? (nf - hot_cols + ROW_COLD_COLS - 1) / ROW_COLD_COLS : 0;
+        const int ncs_r = n_hs + ncold;
+        ph.n_cs = ncs_r; ph.n_hs = n_hs; ph.slw = slw; ph.n_rgroups = ngr;
+        auto slice_lo = [&](int sl) { return sl <= n_hs ? (int64_t)sl * slw : (int64_t)hot_cols + (int64_t)(sl - n_hs) * ROW_COLD_COLS; };
         // entries of row r in slice s: [cut[r][s], cut[r][s+1]) of the row's (ascending) entries
         std::vector<int32_t> cut((size_t)l * (ncs_r + 1));
         for (int r = 0; r < l; r++) {
@@ -664,7 +673,7 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
         ph.sell = nnz > 0 && (double)padded <= 2.0 * (double)nnz + 4096.0 && padded < (int64_t)std::numeric_limits<int32_t>::max() &&
                   (int64_t)nnz + 64LL * ph.n_items < (int64_t)std::numeric_limits<int32_t>::max() / 2 && getenv("MLX_NO_SELL") == nullptr &&
                   !faithful;
-        if (ph.sell && ph.multi_R && ncs_r <= 2) {
+        if (ph.sell && ph.multi_R && ncs_r <= 2 && n_hs == 1) {
             // the shared row pass keeps a row group's packs in registers: <= 6 hot and <= 3 cold packs per group
             int mxh = 0, mxc = 0;
             for (int g = 0; g < ngr; g++) {
@@ -676,7 +685,7 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
         if (ph.sell) {
             rs_idx.assign((size_t)padded, (uint16_t)0xFFFF);
             if (val) rs_val.assign((size_t)padded, 0.f);
-            std::fill(rs_idx.begin(), rs_idx.begin() + rs_ptr[(size_t)ngr], (uint16_t)slw);      // the hot slice pads with the zero slot
+            std::fill(rs_idx.begin(), rs_idx.begin() + rs_ptr[(size_t)n_hs * ngr], (uint16_t)slw);   // hot slices pad with the zero slot
             for (int sl = 0; sl < ncs_r; sl++)
                 for (int r = 0; r < l; r++) {
                     const int32_t base = rs_ptr[(size_t)sl * ngr + (r >> 6)], lane = r & 63;
@@ -763,7 +772,7 @@ static int commit_csr(mlx_handle h, CsrPrep &P, int32_t l, int32_t n_local, int6
     if ((rc = dev_upload(h, &d_ilong, P.ilong.data(), P.ilong.size()))) return rc;
     if ((rc = dev_upload(h, &d_l2g, P.l2g_perm.data(), (size_t)n_local))) return rc;
     ph.dev.rp = d_rp; ph.dev.ci = d_ci; ph.dev.val = d_val; ph.dev.cri = d_cri; ph.dev.cval = d_cval;
-    ph.dev.sell = ph.sell ? 1 : 0; ph.dev.n_cs = ph.n_cs; ph.dev.slw = ph.slw; ph.dev.n_rgroups = ph.n_rgroups; ph.dev.n_cslices = ph.n_cslices;
+    ph.dev.sell = ph.sell ? 1 : 0; ph.dev.n_cs = ph.n_cs; ph.dev.n_hs = ph.n_hs; ph.dev.slw = ph.slw; ph.dev.n_rgroups = ph.n_rgroups; ph.dev.n_cslices = ph.n_cslices;
     if (ph.sell) {
         int32_t *d_a, *d_c, *d_e, *d_h;
         uint16_t *d_b, *d_d;
@@ -980,7 +989,7 @@ int mlx_finalize(mlx_handle h)
         const char *ce = getenv("MLX_COLD_SEP");
         h->cold_groups = 0;
         if ((ce ? atoi(ce) != 0 : ngc >= 128) && !h->row_multi)
-            for (auto &p : h->parts) if (!p.dense && p.n_cs > 1) h->cold_groups = std::max(h->cold_groups, p.n_rgroups);
+            for (auto &p : h->parts) if (!p.dense && p.n_cs > p.n_hs) h->cold_groups = std::max(h->cold_groups, p.n_rgroups);
     }
     // Dense tiles: 512-row chunks are the optimum when the handle's problems make >= ~1000 of them (profiles/r1_notes.md);
     // with FEW problems (the 64-partition job strong-scaled over 8 GPUs leaves 8 per GPU = 248 chunks for 256 CUs, one

@@ -635,7 +635,7 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     const double *__restrict__ wdcur = pr.wd[pr.dsel];
     double *__restrict__ wdnew = pr.wd[pr.dsel ^ 1];
     double *__restrict__ coef = pr.coef;
-    const int nf = pa.n_feat, slw = pa.slw, ncs = pa.n_cs, ngr = pa.n_rgroups, l = pa.l;
+    const int nf = pa.n_feat, slw = pa.slw, ncs = pa.n_cs, nhs = pa.n_hs, ngr = pa.n_rgroups, l = pa.l;
     const int g0 = c * (16 * GPW);
     const int gcount = min(16 * GPW, ngr - g0);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -645,25 +645,13 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     double acc[GPW];
 #pragma unroll
     for (int i = 0; i < GPW; i++) acc[i] = 0.0;
-    {
-        StageRegs SR;
-        const int cnt = min(slw, nf);
-        stage_fetch(SR, v, cnt, tid);                        // all loads of the slice in flight at once
-        stage_store(SR, vs, v, cnt, tid);
-        if (tid == 0) vs[slw] = 0.0;
-    }
-    PT_MARK(0);
-    __syncthreads();
-    PT_MARK(1);
-    // cold_sep: the cold slices' sums were left in coef[] by k_rowcold (launched just before); only the hot slice runs here
-    const int nsl = cold_sep ? 1 : ncs;
-    const bool add_cold = cold_sep && ncs > 1;
-    for (int sl = 0; sl < nsl; sl++) {
-        // block offsets of this wave's GPW consecutive groups: one load, then lane broadcasts (wave-uniform scalars)
+    // block offsets of this wave's GPW consecutive groups in slice sl: one load, then lane broadcasts (wave-uniform scalars)
+    int base[GPW], L4[GPW];
+    int kmax;
+    auto offsets = [&](int sl) {
         const int32_t *__restrict__ ptr = pa.rs_ptr + (int64_t)sl * ngr + g0;
         const int pv = ptr[min(wg0 + min(lane, GPW), gcount)];
-        int base[GPW], L4[GPW];
-        int kmax = 0;
+        kmax = 0;
 #pragma unroll
         for (int i = 0; i < GPW; i++) {
             base[i] = __builtin_amdgcn_readlane(pv, i);
@@ -671,14 +659,41 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
             L4[i] = (wg0 + i < gcount) ? (nx - base[i]) >> 8 : 0;
             kmax = max(kmax, L4[i]);
         }
-        PT_MARK(2);
-        if (sl == 0) {
-            constexpr int KP = HASVAL ? 1 : ROW_KP;
-            for (int k = 0; k < kmax; k += KP)
-                sell_lds_first<HASVAL, NT, GPW, KP>(acc, rs_idx, rs_val, base, L4, k, lane, vs, slw);
-            PT_MARK(3);
-        } else {
-            const double *__restrict__ src = v + slw + (int64_t)(sl - 1) * 65535;
+    };
+    auto stage = [&](int sl) {
+        // hot slice sl: columns [sl*slw, sl*slw + cnt) of the gathered vector, then the zero slot
+        StageRegs SR;
+        const int cnt = min(slw, nf - sl * slw);
+        stage_fetch(SR, v + (int64_t)sl * slw, cnt, tid);    // all loads of the slice in flight at once
+        stage_store(SR, vs, v + (int64_t)sl * slw, cnt, tid);
+        if (tid == 0) vs[slw] = 0.0;
+    };
+    constexpr int KP = HASVAL ? 1 : ROW_KP;
+    // ---- hot slice 0 (straight-line: the common case is this slice and nothing else in this kernel)
+    stage(0);
+    PT_MARK(0);
+    __syncthreads();
+    PT_MARK(1);
+    offsets(0);
+    PT_MARK(2);
+    for (int k = 0; k < kmax; k += KP)
+        sell_lds_first<HASVAL, NT, GPW, KP>(acc, rs_idx, rs_val, base, L4, k, lane, vs, slw);
+    PT_MARK(3);
+    // ---- further hot slices, staged one after the other
+    for (int sl = 1; sl < nhs; sl++) {
+        __syncthreads();                                     // every wave is done with the previous slice
+        stage(sl);
+        __syncthreads();
+        offsets(sl);
+        for (int k = 0; k < kmax; k += KP)
+            sell_lds_first<HASVAL, NT, GPW, KP>(acc, rs_idx, rs_val, base, L4, k, lane, vs, slw);
+    }
+    // ---- cold slices, unless k_rowcold (launched just before) left their sums in coef[]
+    const bool add_cold = cold_sep && ncs > nhs;
+    if (!cold_sep) {
+        for (int sl = nhs; sl < ncs; sl++) {
+            offsets(sl);
+            const double *__restrict__ src = v + (int64_t)nhs * slw + (int64_t)(sl - nhs) * 65535;
             // (GPW gathers x 4 in flight; 8 groups, or 4 valued ones, go in two halves: their 32 results do not fit beside the rest)
             constexpr int NIH = (GPW > 4 || (HASVAL && GPW > 2)) ? GPW / 2 : GPW;
             for (int k = 0; k < kmax; k++) {
@@ -749,8 +764,8 @@ k_rowcold(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
     const int phase = pr.phase;
     if (phase == PH_DONE) return;
     const PartDev &pa = parts[pr.part];
-    const int ncs = pa.n_cs, ngr = pa.n_rgroups, slw = pa.slw, l = pa.l;
-    if (!pa.sell || ncs <= 1) return;
+    const int ncs = pa.n_cs, nhs = pa.n_hs, ngr = pa.n_rgroups, slw = pa.slw, l = pa.l;
+    if (!pa.sell || ncs <= nhs) return;
     constexpr int GC = 4;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g0 = bx_ * (4 * GC) + wave * GC;
@@ -762,7 +777,7 @@ k_rowcold(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
     double acc[GC];
 #pragma unroll
     for (int i = 0; i < GC; i++) acc[i] = 0.0;
-    for (int sl = 1; sl < ncs; sl++) {
+    for (int sl = nhs; sl < ncs; sl++) {
         const int32_t *__restrict__ ptr = pa.rs_ptr + (int64_t)sl * ngr + g0;
         const int pv = ptr[min(lane, gcount)];
         int base[GC], L4[GC];
@@ -774,7 +789,7 @@ k_rowcold(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
             L4[i] = (i < gcount) ? (nx - base[i]) >> 8 : 0;
             kmax = max(kmax, L4[i]);
         }
-        const double *__restrict__ src = v + slw + (int64_t)(sl - 1) * 65535;
+        const double *__restrict__ src = v + (int64_t)nhs * slw + (int64_t)(sl - nhs) * 65535;
         for (int k = 0; k < kmax; k++) sell_gather_round<HASVAL, NT, GC>(acc, rs_idx, rs_val, base, L4, k, lane, src);
     }
     double *__restrict__ coef = pr.coef;

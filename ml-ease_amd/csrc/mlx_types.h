@@ -42,12 +42,13 @@ struct PartDev {
     const int32_t *items_long;   // real item ids with 65..SEG entries (one wave each)
     int32_t n_short, n_long;
     // Sliced-ELL copies for the LDS passes; sell != 0 when built (row-side padding <= 2x nnz).
-    // Row side: slice 0 = the slw most frequent columns (gathered from LDS), slices 1.. = 65 535 columns each (gathered from
-    // global memory), n_rgroups groups of 64 rows; block (s, g) at rs_ptr[s*n_rgroups + g] holds, in packs of 4 per lane,
+    // Row side: slices 0..n_hs-1 = the n_hs*slw most frequent columns, slw each (gathered from LDS), the later slices = 65 535
+    // columns each (gathered from global memory), n_rgroups groups of 64 rows; block (s, g) at rs_ptr[s*n_rgroups + g] holds, in packs of 4 per lane,
     // the slice-local uint16 column ids of the 64 rows' entries in slice s, padded with slw (slice 0: the LDS slot behind
     // the staged slice, which holds 0.0) / 0xFFFF (cold slices).
     int32_t sell;
     int32_t n_cs, slw, n_rgroups, n_cslices;
+    int32_t n_hs;              // the first n_hs row-side slices are hot (slw columns each, staged in LDS); the rest are cold
     int32_t rgroups_per_chunk; // row groups one row-pass workgroup owns (set at finalize); nblk = chunks
     const int32_t *rs_ptr;     // [n_cs*n_rgroups + 1] entry offsets
     const uint16_t *rs_idx;

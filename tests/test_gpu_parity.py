@@ -822,17 +822,21 @@ def test_cold_column_slices_as_their_own_launch(binary, monkeypatch):
     pd = synth_sparse(37, 5000, 900, 16, 3, binary=binary, weights=not binary, offsets=not binary)
     lam, rho = [0.2, 5.0], [1.0, 1.0]
     oc = ol.OracleAdmm(pd.blocks, pd.n_global, lam, rho)
+    # ... and with three hot slices staged one after the other in front of the cold one (MLX_NHOT=3; the default takes a second
+    # hot slice only when that leaves no cold columns)
+    modes = [("1", "1"), ("0", "1"), ("1", "3"), ("0", "3"), ("1", "7")]
     engs = []
-    for sep in ("1", "0"):
+    for sep, nhot in modes:
         monkeypatch.setenv("MLX_COLD_SEP", sep)
+        monkeypatch.setenv("MLX_NHOT", nhot)
         engs.append(make_engine(pd, lam, rho))
     for it in range(4):
         oc.iterate(0.01, 1.0, nthreads=4)
-        for sep, eng in zip(("1", "0"), engs):
+        for (sep, nhot), eng in zip(modes, engs):
             eng.iterate(0.01)
-            assert np.array_equal(eng.solve_counters(), _counters(oc)), "MLX_COLD_SEP=%s iteration %d" % (sep, it + 1)
+            assert np.array_equal(eng.solve_counters(), _counters(oc)), "MLX_COLD_SEP=%s MLX_NHOT=%s iteration %d" % (sep, nhot, it + 1)
             for li in range(len(lam)):
-                assert_coef_close(eng.z()[1][li], oc.z()[1][li], "MLX_COLD_SEP=%s lambda %g iteration %d" % (sep, lam[li], it + 1), floor=1e-2)
+                assert_coef_close(eng.z()[1][li], oc.z()[1][li], "MLX_COLD_SEP=%s MLX_NHOT=%s lambda %g iteration %d" % (sep, nhot, lam[li], it + 1), floor=1e-2)
     for eng in engs:
         eng.close()
 
