@@ -2,8 +2,9 @@
 // ADMM consensus. No library calls, no CUDA shims: HIP C++ for MI355X only.
 //
 // Execution model (DESIGN.md "Tick machine"): every (partition, lambda) problem advances in
-// lock-step TICKS. One tick = one pass over X for every unfinished problem (k_xpass_dense, or
-// k_rowpass_csr + k_colpass_csc) followed by k_tron_step, which owns all of Tron's control flow
+// lock-step TICKS. One tick = one pass over X for every unfinished problem (dense tiles: k_xpass_dense; sliced CSR
+// partitions: [k_rowcold +] k_rowpass_lds, then k_colpass_lds) followed by the TRON/CG step (dense: k_tron_step, one
+// workgroup per problem; CSR: k_step_a / b / c + k_step_commit over column chunks), which owns all of Tron's control flow
 // (bw/Tron.java:30-179) for its problem and decides what the next pass computes:
 //     PH_CG    pass computes  X' diag(wt*D) X d          (the Hv of llf/LogisticRegressionL2.java:231-248)
 //     PH_EVAL  pass computes  loss(w_new), D(w_new), X' t(w_new)  (fun + grad fused, :156-225)
