@@ -479,6 +479,20 @@ struct CsrPrep {
     }
 };
 
+// Hot slices of the row pass (columns of the gathered vector staged in LDS): width, count, columns covered.
+struct RowHot { int slw, n_hs, hot_cols; };
+static RowHot row_hot_cols(int nf, int n_lambda)
+{
+    RowHot R;
+    const int slmax = getenv("MLX_SLW") ? std::min(ROW_SLICE_MAX_COLS, std::max(64, atoi(getenv("MLX_SLW")) / 64 * 64)) : ROW_SLICE_MAX_COLS;
+    R.slw = std::max(64, (std::min(nf, slmax) + 63) / 64 * 64);
+    int nhs_want = getenv("MLX_NHOT") ? std::max(1, atoi(getenv("MLX_NHOT"))) : (nf <= 2 * R.slw ? 2 : 1);
+    if (n_lambda >= 2 && getenv("MLX_MULTI") != nullptr && atoi(getenv("MLX_MULTI")) != 0) nhs_want = 1;   // the shared row pass knows one
+    R.n_hs = std::max(1, std::min(nhs_want, (nf + R.slw - 1) / R.slw));
+    R.hot_cols = R.n_hs * R.slw;
+    return R;
+}
+
 static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t l, int32_t n_local, int64_t nnz,
                     const int64_t *row_ptr, const int32_t *col_idx, const float *val, const int8_t *y,
                     const int32_t *local_to_global, bool faithful, int n_lambda)
@@ -505,6 +519,22 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
         for (int j = 0; j < nf; j++) new2old[(size_t)j] = j;
         // (verification mode: the caller's first-seen order is kept, so a row's entries are summed in the reference's order)
         if (!faithful) std::stable_sort(new2old.begin(), new2old.end(), [&](int32_t a, int32_t b) { return cnt[(size_t)a] > cnt[(size_t)b]; });
+        // The COLD tail (the columns behind the hot slices of the row pass; ~1.8 entries each on the one-hot configs) is ordered
+        // by the row of a column's first entry instead: the 64 rows of a group then gather their first-seen cold columns from a
+        // few neighbouring cache lines of the vector (k_rowcold is bound by distinct lines per gather instruction, not by
+        // bytes), and the column pass reads the staged coefficients of those columns' items in ascending rows. Columns that
+        // need more packs per item stay in front so that the 64-item slices keep their fill. MLX_NO_COLD_ORDER=1: A/B switch.
+        const int hot_cols = row_hot_cols(nf, n_lambda).hot_cols;
+        if (!faithful && nf > hot_cols && getenv("MLX_NO_COLD_ORDER") == nullptr) {
+            std::vector<int32_t> first((size_t)nf, std::numeric_limits<int32_t>::max());
+            for (int i = l - 1; i >= 0; i--)
+                for (int64_t k = row_ptr[i]; k < row_ptr[i + 1]; k++) first[(size_t)col_idx[k]] = i;
+            std::stable_sort(new2old.begin() + hot_cols, new2old.end(), [&](int32_t a, int32_t b) {
+                const int pa = (cnt[(size_t)a] + 3) / 4, pb = (cnt[(size_t)b] + 3) / 4;
+                if (pa != pb) return pa > pb;
+                return first[(size_t)a] < first[(size_t)b];
+            });
+        }
         for (int j = 0; j < nf; j++) newid[(size_t)new2old[(size_t)j]] = j;
     }
     std::vector<int32_t> pcol((size_t)nnz), l2g_perm((size_t)n_local);
@@ -546,7 +576,7 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
     // padded to a multiple of 64 items. cri/cval are re-ordered into item order so item_ptr is monotone.
     // (verification mode: one row block, unsplit columns -- a column's sum then runs over its rows in ascending order, XTv's order)
     const int seg = faithful ? std::numeric_limits<int32_t>::max() : (getenv("MLX_SEG") ? atoi(getenv("MLX_SEG")) : CSC_SEG);
-    int rbmax = faithful ? std::numeric_limits<int32_t>::max() - 64 : (getenv("MLX_RBMAX") ? atoi(getenv("MLX_RBMAX")) : RBLK_MAX_ROWS);
+    int rbmax = faithful ? std::numeric_limits<int32_t>::max() - 64 : (getenv("MLX_RBMAX") ? std::min(RBLK_MAX_ROWS, std::max(64, atoi(getenv("MLX_RBMAX")))) : RBLK_MAX_ROWS);
     // lambda sweeps of 2..8 lambdas: the shared column pass keeps the block's coefficients of R = 2 / 4 / 8 lambdas in LDS at once
     // (opt-in, MLX_MULTI=1: measured SLOWER than the per-problem passes sharing the streams through L2 -- the passes are not
     // bound by the index stream, and R times shorter row blocks multiply the column items; profiles/r2_notes.md)
@@ -634,17 +664,15 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
     std::vector<float> rs_val, cs_val;
     {
         const int ngr = (l + 63) / 64;
-        const int slmax = getenv("MLX_SLW") ? std::max(64, atoi(getenv("MLX_SLW")) / 64 * 64) : ROW_SLICE_MAX_COLS;
-        const int slw = std::max(64, (std::min(nf, slmax) + 63) / 64 * 64);
+        const RowHot RH = row_hot_cols(nf, n_lambda);
+        const int slw = RH.slw;
         // hot slices (each slw columns, staged in LDS one after the other), then cold slices of 65 535 columns (gathered from L2,
         // which serves ~190 G random 8-byte requests/s chip-wide). A second hot slice pays when it leaves NO cold columns
         // (configs[3] per-GPU shape, ~35 K local features: row pass 44 vs 49 us per tick); when cold columns remain either way
         // (config #3, ~70 K) one more staging and ~1.3 mostly padded packs per row group cost what the saved gathers did
         // (1 / 2 / 3 / 4 hot slices: 284 / 287 / 298 / 289 us). MLX_NHOT forces a count.
-        int nhs_want = getenv("MLX_NHOT") ? std::max(1, atoi(getenv("MLX_NHOT"))) : (nf <= 2 * slw ? 2 : 1);
-        if (n_lambda >= 2 && getenv("MLX_MULTI") != nullptr && atoi(getenv("MLX_MULTI")) != 0) nhs_want = 1;   // the shared row pass knows one
-        const int n_hs = std::max(1, std::min(nhs_want, (nf + slw - 1) / slw));
-        const int hot_cols = n_hs * slw;
+        const int n_hs = RH.n_hs;
+        const int hot_cols = RH.hot_cols;
         const int ncold = nf > hot_cols ? (nf - hot_cols + ROW_COLD_COLS - 1) / ROW_COLD_COLS : 0;
         const int ncs_r = n_hs + ncold;
         ph.n_cs = ncs_r; ph.n_hs = n_hs; ph.slw = slw; ph.n_rgroups = ngr;

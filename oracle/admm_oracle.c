@@ -36,6 +36,7 @@
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+#endif
 
 #ifdef ORC_PORTABLE_MATH
 /* Verification twin (liboracle_pm.so): exp / log1p from the +,-,*,/ implementations that the HIP library's order-faithful
@@ -44,7 +45,17 @@
 #define exp pm_exp
 #define log1p pm_log1p
 #endif
+
+/* which exp / log1p this build evaluates: tests assert "portable" on liboracle_pm.so and "libm" on liboracle.so, so a
+ * twin built without -DORC_PORTABLE_MATH (or with the define lost behind another guard) cannot pass for the other */
+const char *orc_math_kind(void)
+{
+#ifdef ORC_PORTABLE_MATH
+    return "portable";
+#else
+    return "libm";
 #endif
+}
 
 typedef struct { int index; double value; } orc_node;   /* bw/FeatureNode.java */
 

@@ -58,6 +58,7 @@ def main():
     e = np.float32(0.01)
     mindiff = 99999999.0
     lls, eps_used, diffs, counters = [], [], [], []
+    z32_it, Z_it, cnt_it = [], [], []
     for it in range(1, args.iters + 1):
         if it > 1 and mindiff < 0.001:
             e = np.float32(e / np.float32(10))
@@ -69,6 +70,8 @@ def main():
         st = oc.stats()
         lls.append(ll); eps_used.append(eps); diffs.append(maxdiff)
         counters.append([int(sum(s.newton_iters for s in st)), int(sum(s.cg_iters for s in st)), int(sum(s.x_passes for s in st))])
+        z32_it.append(oc.z()[1][0].copy()); Z_it.append(Z.copy())
+        cnt_it.append(np.array([(s.newton_iters, s.accepted, s.cg_iters, s.x_passes) for s in st], np.int32))
         print("iteration %2d: eps %g maxdiff %.6g loglik %.10f (%.0f s)" % (it, eps, maxdiff, ll, time.time() - t1), file=sys.stderr)
     out = {"what": "oracle/admm_oracle.c on BASELINE configs[1]: %d x %d, %d partitions (row %% %d), lambda=1, rho=1; "
                    "mean test loglik of z after each ADMM iteration on %d held-out rows" % (args.rows, NFEAT, PARTS, PARTS, TEST_ROWS),
@@ -79,6 +82,10 @@ def main():
            "z32_final_sha1": __import__("hashlib").sha1(oc.z()[1].tobytes()).hexdigest()}
     with open(args.out, "w") as fh:
         json.dump(out, fh, indent=1)
+    # the consensus after every iteration (float32 as the final-model file holds it, and the driver's double) and every
+    # solve's TRON counters: bench.py compares its full 20-iteration run against these, iteration by iteration
+    np.savez_compressed(os.path.splitext(args.out)[0].replace("c2_ref_loglik", "c2_ref_z") + ".npz",
+                        z32=np.stack(z32_it), Z=np.stack(Z_it), counters=np.stack(cnt_it))
     print("wrote", args.out, file=sys.stderr)
 
 

@@ -42,6 +42,10 @@ def lib(pm: bool = False):
             build(force=True)
         L = C.CDLL(path)
         vp, i32, f64, f32 = C.c_void_p, C.c_int, C.c_double, C.c_float
+        L.orc_math_kind.restype = C.c_char_p
+        kind = L.orc_math_kind().decode()
+        if kind != ("portable" if pm else "libm"):     # a twin whose -DORC_PORTABLE_MATH got lost must not pass for the other
+            raise RuntimeError("%s evaluates %s exp/log1p" % (path, kind))
         L.orc_dataset_create.restype = vp
         L.orc_dataset_create.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp]
         L.orc_dataset_destroy.argtypes = [vp]

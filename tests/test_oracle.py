@@ -398,3 +398,19 @@ def test_portable_math_and_the_verification_twin():
         cb = [(s.newton_iters, s.cg_iters) for s in b.stats()]
         assert ca == cb
         assert np.max(np.abs(a.z()[0] - b.z()[0])) <= 1e-12 * np.max(np.abs(a.z()[0]))
+
+
+def test_verification_twin_keeps_its_math_without_openmp(tmp_path):
+    """The -DORC_PORTABLE_MATH block must not depend on -fopenmp (round-2 finding: it sat inside `#ifdef _OPENMP`, so a twin
+    built without OpenMP silently evaluated libm). Build both variants without OpenMP and ask them."""
+    import ctypes
+    import subprocess
+    odir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    for flag, want in (([], b"libm"), (["-DORC_PORTABLE_MATH"], b"portable")):
+        so = str(tmp_path / ("o_%s.so" % want.decode()))
+        subprocess.check_call(["gcc", "-O0", "-fPIC", "-std=c11", "-ffp-contract=off", "-shared", "-I" + os.path.join(odir, "..", "ml-ease_amd", "csrc"),
+                               *flag, "-o", so, os.path.join(odir, "admm_oracle.c"), os.path.join(odir, "synth.c"), "-lm"])
+        L = ctypes.CDLL(so)
+        L.orc_math_kind.restype = ctypes.c_char_p
+        assert L.orc_math_kind() == want
+    assert ol.lib(False).orc_math_kind() == b"libm" and ol.lib(True).orc_math_kind() == b"portable"
