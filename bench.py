@@ -21,7 +21,10 @@ Extra top-level keys of the same JSON line:
   time_to_ref_loglik  metric (ii): full run from z = 0, test log-likelihood per iteration against the ORACLE's
                 committed 20-iteration value (tests/golden/c2_ref_loglik.json, tests/golden/make_ref_loglik.py)
   sparse        BASELINE configs[2] (N = 1) / configs[3] (N > 1): one-hot 10M x 100K, 20 nnz/row, 256 / 1024
-                partitions, binary.feature, with per-kernel rooflines (row pass, column pass, TRON/CG step)
+                partitions, binary.feature, with per-kernel rooflines (row pass, column pass, TRON/CG step), its own
+                cpu_baseline (same timed iterations, from the GPU's state) and parity_check (order-faithful mode vs the
+                oracle twin; product path vs oracle beside the oracle's own row-permutation spread)
+  lambda_sweep  BASELINE configs[4], per-GPU shape: 128 partitions x 9 765 rows x 8 lambdas (rho = 10 above lambda = 100)
 """
 import argparse
 import json
@@ -104,11 +107,17 @@ def main():
     ap.add_argument("--no-sparse", action="store_true", help="skip the configs[2]/[3] leg")
     ap.add_argument("--no-gram", action="store_true", help="skip the fp64-MFMA Gram measurement (posterior covariance of one partition)")
     ap.add_argument("--sparse-only", action="store_true", help="run only the sparse leg (development / profiling)")
-    ap.add_argument("--sparse-steps", type=int, default=3)
+    ap.add_argument("--sparse-steps", type=int, default=5)
     ap.add_argument("--sparse-warmup", type=int, default=1)
     ap.add_argument("--sparse-rows", type=int, default=SP_ROWS)
     ap.add_argument("--sparse-partitions", type=int, default=0, help="0 = 256 at one GPU, 1024 sharded otherwise")
-    ap.add_argument("--sparse-cpu-sample", type=int, default=16, help="partitions of the sparse CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the configs[4] lambda-sweep leg")
+    ap.add_argument("--sweep-only", action="store_true", help="run only the lambda-sweep leg (development / profiling)")
+    ap.add_argument("--sweep-partitions", type=int, default=128, help="partitions per GPU of the lambda-sweep leg")
+    ap.add_argument("--sweep-steps", type=int, default=3)
+    ap.add_argument("--sweep-warmup", type=int, default=1)
+    ap.add_argument("--sweep-cpu-sample", type=int, default=8, help="partitions (x 8 lambdas) of the lambda-sweep CPU / parity sample (0 = skip)")
+    ap.add_argument("--sparse-cpu-sample", type=int, default=64, help="partitions of the sparse CPU-baseline / parity sample (0 = skip)")
     args = ap.parse_args()
 
     # stdout must carry exactly ONE line (the JSON): anything a library prints to fd 1 (RCCL prints a version banner
@@ -188,15 +197,22 @@ def main():
                sd=sd, HipAdmmEngine=HipAdmmEngine, all_reduce=all_reduce, barrier=barrier, reduce_max=reduce_max,
                reduce_sum=reduce_sum)
     out = {}
-    if not args.sparse_only:
+    if not (args.sparse_only or args.sweep_only):
         out = run_dense(args, ctx)
-    if not args.no_sparse:
+    if not (args.no_sparse or args.sweep_only):
         sp = run_sparse(args, ctx)
         if rank == 0:
             if args.sparse_only:
                 out = sp
             else:
                 out["sparse"] = sp
+    if not (args.no_sweep or args.sparse_only):
+        sw = run_lambda_sweep(args, ctx)
+        if rank == 0:
+            if args.sweep_only:
+                out = sw
+            else:
+                out["lambda_sweep"] = sw
     if rank == 0:
         if share:
             out["test_mode"] = "MLX_BENCH_SHARE_GPU=1: all ranks on ONE device, collectives over gloo -- control-flow check, not a measurement"
@@ -270,6 +286,7 @@ def run_dense(args, C):
     dt = C["reduce_max"](time.perf_counter() - t0)
     tot_solves, tot_pref, tot_pdev, tot_cg, tot_newton = C["reduce_sum"](
         [acc["solves"], acc["passes_ref"], acc["passes_dev"], acc["cg"], acc["newton"]])
+    z32_end = eng.z()[1].copy()            # the consensus as the final-model file would hold it (identical on every rank)
 
     # ---- metric (ii): ADMM wall-clock to the reference test log-likelihood: a full run from z = u = 0 with
     # the per-iteration test loglik (jobs/RegressionAdmmTrain.java:766-845) on the 100 000 held-out rows; the target is
@@ -312,7 +329,8 @@ def run_dense(args, C):
                         "x_passes_ref_per_s": round(tot_pref / dt, 2), "x_passes_dev_per_s": round(tot_pdev / dt, 2),
                         "passes_ref_per_solve": round(tot_pref / max(1.0, tot_solves), 2),
                         "passes_dev_per_solve": round(tot_pdev / max(1.0, tot_solves), 2), "ticks": acc["ticks"],
-                        "last_maxdiff": fin.maxdiff},
+                        "last_maxdiff": fin.maxdiff,
+                        "z32_sha1_after_timed_steps": __import__("hashlib").sha1(z32_end.tobytes()).hexdigest()},
                "roofline": roof,
                "time_to_ref_loglik": loglik,
                "all_launches": {"xpass_launches_incl_c0_and_warmup": allrun["launches"], "alg_bytes": allrun["alg_bytes"]}}
@@ -366,20 +384,35 @@ def loglik_run(args, C, eng, P, nf, N, rows_total):
     eng.set_state(np.zeros((1, nf + 1)), np.zeros((P, 1, nf + 1), np.float32))
     sched = EpsSchedule(admm)
     lls, walls = [], []
+    default_job = (rows_total == ROWS and nf == NFEAT and N == PARTS and lt == 100000)
+    zpath = os.path.join(ROOT, "tests", "golden", "c2_ref_z.npz")
+    gz = np.load(zpath) if (rank == 0 and default_job and os.path.exists(zpath)) else None
+    zcmp = []                      # per iteration: this run's consensus and counters against the oracle's committed run
     C["barrier"]()
     tl0 = time.perf_counter()
-    for _ in range(args.loglik_iters):
-        eng.solve_local(sched.next(), 1.0)
+    for it in range(args.loglik_iters):
+        eps = sched.next()
+        eng.solve_local(eps, 1.0)
         C["all_reduce"](eng.consensus_tensor())
         sched.mindiff = eng.consensus_finish().mindiff
         if rank == 0:
             lls.append(float(eng.test_loglik_sums()[0]) / lt)
         walls.append(time.perf_counter() - tl0)
+        if gz is not None and it < len(gz["z32"]):          # (host-side bookkeeping: its time is taken out of the clock below)
+            tb = time.perf_counter()
+            z32 = eng.z()[1][0]
+            zo = gz["z32"][it].astype(np.float64)
+            rel = float(np.max(np.abs(z32.astype(np.float64) - zo) / np.maximum(np.abs(zo), 1e-4 * np.max(np.abs(zo)))))
+            rec = {"iteration": it + 1, "liblinear_epsilon": eps, "max_rel_err_z32": rel,
+                   "bit_identical_float32_fraction": round(float(np.mean(z32 == gz["z32"][it])), 4)}
+            if C["world"] == 1:
+                rec["partitions_with_equal_counters"] = int(np.all(eng.solve_counters() == gz["counters"][it], axis=1).sum())
+            zcmp.append(rec)
+            tl0 += time.perf_counter() - tb
     if rank != 0:
         return None
     ref, ref_src = None, None
     gpath = os.path.join(ROOT, "tests", "golden", "c2_ref_loglik.json")
-    default_job = (rows_total == ROWS and nf == NFEAT and N == PARTS and lt == 100000)
     if os.path.exists(gpath) and default_job:
         with open(gpath) as fh:
             gj = json.load(fh)
@@ -402,6 +435,20 @@ def loglik_run(args, C, eng, P, nf, N, rows_total):
                     "abs_diff_to_oracle_by_iteration_max": max(abs(a - b) for a, b in zip(lls, gj["loglik_by_iteration"])),
                     "reached_at_iteration": None if reached is None else reached + 1,
                     "seconds_to_ref_loglik": None if reached is None else round(walls[reached], 4)})
+        if zcmp:
+            # the consensus of EVERY iteration of this run against the oracle's run of the same job (tests/golden/c2_ref_z.npz):
+            # the liblinear epsilon falls from 1e-2 to 1e-18 over the 20 iterations, so this covers the noise regime too
+            import hashlib
+            final = zcmp[-1]
+            res["vs_oracle_run"] = {
+                "source": "tests/golden/c2_ref_z.npz (oracle/admm_oracle.c, tests/golden/make_ref_loglik.py): z32 and the 64 solves' TRON counters after every iteration",
+                "tolerance": 1e-5, "rel_err_floor": "1e-4 * max|z|",
+                "max_rel_err_z32_over_iterations": max(r["max_rel_err_z32"] for r in zcmp),
+                "final_iteration": final["iteration"], "final_max_rel_err_z32": final["max_rel_err_z32"],
+                "z32_final_identical": (hashlib.sha1(eng.z()[1].tobytes()).hexdigest() == gj.get("z32_final_sha1")) if len(zcmp) == gj["iterations"] else None,
+                "smallest_epsilon_compared": min(r["liblinear_epsilon"] for r in zcmp),
+                "iterations_with_all_counters_equal": sum(1 for r in zcmp if r.get("partitions_with_equal_counters") == N) if C["world"] == 1 else None,
+                "per_iteration": zcmp}
     else:
         res.update({"ref_loglik": None, "ref_source": "no committed oracle value for this job shape"})
     return res
@@ -492,9 +539,68 @@ def cpu_leg(args, C, eng, out, sample, snap, eps_used, step_times, nf, N):
 
 
 # ======================================================================================================================
+def sparse_timed_run(args, C, eng, blocks, lam, warmup, steps, snapshot):
+    """warmup + steps ADMM iterations of a one-hot job with the driver's epsilon schedule; HIP-event sums per launch class.
+    snapshot=True also keeps the state the first timed iteration starts from (outside the timed region)."""
+    sched = EpsSchedule(C["admm"])
+    nl, P = len(lam), len(blocks)
+    acc = dict(solves=0, cg=0, newton=0, pref=0, pdev=0, ticks=0, alg=0.0, rms=0.0, cms=0.0, sms=0.0, tms=0.0)
+    # every pass launch of this leg (finalize's c0 pass: one row + one column pass per partition, + warm-up + timed): what a
+    # rocprofv3 run of this command sees, used to turn its FETCH_SIZE / WRITE_SIZE sums into bytes per algorithmic byte
+    allrun = dict(alg=sum(2.0 * (4.0 * b.nnz + 8.0 * b.l + 8.0 * b.n_local) for b in blocks), ticks=1)
+    fin, snap, eps_all, step_s = None, None, [], []
+    tstart = time.perf_counter()
+    for it in range(1, warmup + steps + 1):
+        if it == warmup + 1:
+            if snapshot:
+                if warmup > 0:
+                    snap = (eng.z()[0].copy(), np.stack([np.stack([eng.partition_model(i, li)[2] for li in range(nl)]) for i in range(P)]))
+                else:
+                    snap = (np.zeros((nl, eng.n_global)), np.zeros((P, nl, eng.n_global), np.float32))
+            C["barrier"]()
+            tstart = time.perf_counter()
+        eps = sched.next()
+        eps_all.append(eps)
+        ts = time.perf_counter()
+        st = eng.solve_local(eps, 1.0)
+        C["all_reduce"](eng.consensus_tensor())
+        fin = eng.consensus_finish()
+        sched.mindiff = fin.mindiff
+        allrun["alg"] += st.alg_bytes_dev
+        allrun["ticks"] += st.ticks
+        if it > warmup:
+            step_s.append(time.perf_counter() - ts)
+            acc["solves"] += st.solves; acc["cg"] += st.cg_iters; acc["newton"] += st.newton_iters
+            acc["pref"] += st.x_passes_ref; acc["pdev"] += st.x_passes_dev; acc["ticks"] += st.ticks
+            acc["alg"] += st.alg_bytes_dev; acc["tms"] += st.total_ms
+            acc["rms"] += st.rowpass_ms; acc["cms"] += st.colpass_ms; acc["sms"] += st.step_ms
+    C["barrier"]()
+    dt = C["reduce_max"](time.perf_counter() - tstart)
+    return acc, allrun, dt, fin, snap, eps_all, step_s
+
+
+def sparse_rooflines(acc, dt, n_mean, row_kernel, col_kernel):
+    # SURVEY 8(d): one X pass over one partition moves B_pass = nnz*4 + 8 l + 8 n bytes (binary.feature: no value array);
+    # the library counts 2 passes (row + column) per tick and active problem in alg_bytes_dev
+    half = acc["alg"] / 2.0
+
+    def roof(kernel, ms, alg_bytes, note):
+        a = alg_bytes / max(1e-9, ms * 1e-3) / 1e9
+        return {"kernel": kernel, "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(a / HBM_PEAK_GBS, 4), "ms": round(ms, 3), "share_of_step": round(ms / (dt * 1e3), 4),
+                "us_per_tick": round(1e3 * ms / max(1, acc["ticks"]), 1), "alg_bytes": alg_bytes, "note": note}
+
+    step_model = 13.0 * 8.0 * n_mean * (acc["pdev"] / 2.0)        # 13 n-vector streams per problem and tick (DESIGN 4)
+    return [roof(row_kernel, acc["rms"], half, "B_pass = nnz*4 + 8l + 8n per active problem; the cold column slices run as their own launch in front of the row kernel"),
+            roof(col_kernel, acc["cms"], half, "B_pass = nnz*4 + 8l + 8n per active problem"),
+            roof("k_step_a+b+c+commit", acc["sms"], 0.0,
+                 "no algorithmic X bytes (SURVEY 8d counts the n-vector work as zero); streams ~13 x 8n bytes per problem and "
+                 "tick = %.1f GB/s" % (step_model / max(1e-9, acc["sms"] * 1e-3) / 1e9))]
+
+
 def run_sparse(args, C):
     """BASELINE configs[2] at one GPU (256 partitions), configs[3] sharded (1024 partitions, k -> rank k mod N)."""
-    world, rank, sd, admm = C["world"], C["rank"], C["sd"], C["admm"]
+    world, rank, sd = C["world"], C["rank"], C["sd"]
     from mlease_amd.dataset import PartitionBlock
     Ptot = args.sparse_partitions or (SP_PARTS_1GPU if world == 1 else SP_PARTS_MULTI)
     rows = args.sparse_rows // Ptot
@@ -512,83 +618,241 @@ def run_sparse(args, C):
     tup = time.time() - t0
     nnz = sum(b.nnz for b in blocks)
     nloc = np.array([b.n_local for b in blocks])
-    sched = EpsSchedule(admm)
-    acc = dict(solves=0, cg=0, newton=0, pref=0, pdev=0, ticks=0, alg=0.0, rms=0.0, cms=0.0, sms=0.0, tms=0.0)
-    # every pass launch of this leg (finalize's c0 pass: one row + one column pass per partition, + warm-up + timed): what a
-    # rocprofv3 run of this command sees, used to turn its FETCH_SIZE / WRITE_SIZE sums into bytes per algorithmic byte
-    allrun = dict(alg=sum(2.0 * (4.0 * b.nnz + 8.0 * b.l + 8.0 * b.n_local) for b in blocks), ticks=1)
-    fin = None
-    for it in range(1, args.sparse_warmup + args.sparse_steps + 1):
-        if it == args.sparse_warmup + 1:
-            C["barrier"]()
-            tstart = time.perf_counter()
-        st = eng.solve_local(sched.next(), 1.0)
-        C["all_reduce"](eng.consensus_tensor())
-        fin = eng.consensus_finish()
-        sched.mindiff = fin.mindiff
-        allrun["alg"] += st.alg_bytes_dev
-        allrun["ticks"] += st.ticks
-        if it > args.sparse_warmup:
-            acc["solves"] += st.solves; acc["cg"] += st.cg_iters; acc["newton"] += st.newton_iters
-            acc["pref"] += st.x_passes_ref; acc["pdev"] += st.x_passes_dev; acc["ticks"] += st.ticks
-            acc["alg"] += st.alg_bytes_dev; acc["tms"] += st.total_ms
-            acc["rms"] += st.rowpass_ms; acc["cms"] += st.colpass_ms; acc["sms"] += st.step_ms
-    C["barrier"]()
-    dt = C["reduce_max"](time.perf_counter() - tstart)
+    want_checks = world == 1 and args.sparse_cpu_sample > 0
+    acc, allrun, dt, fin, snap, eps_all, step_s = sparse_timed_run(args, C, eng, blocks, [1.0], args.sparse_warmup, args.sparse_steps, want_checks)
     tot_solves, tot_pref, tot_pdev, tot_alg = C["reduce_sum"]([acc["solves"], acc["pref"], acc["pdev"], acc["alg"]])
-    if rank != 0:
-        eng.close()
-        return None
-    # one X pass over one partition moves B_pass = nnz*4 + 8 l + 8 n bytes (binary.feature: no value array);
-    # the library counts 2 passes (row + column) per tick and active problem in alg_bytes_dev
-    half = acc["alg"] / 2.0
-    n_mean = float(nloc.mean())
-
-    def roof(kernel, ms, alg_bytes, note):
-        a = alg_bytes / max(1e-9, ms * 1e-3) / 1e9
-        return {"kernel": kernel, "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(a / HBM_PEAK_GBS, 4), "ms": round(ms, 3), "share_of_step": round(ms / (dt * 1e3), 4),
-                "us_per_tick": round(1e3 * ms / max(1, acc["ticks"]), 1), "alg_bytes": alg_bytes, "note": note}
-
-    step_model = 13.0 * 8.0 * n_mean * (acc["pdev"] / 2.0)        # 13 n-vector streams per problem and tick
-    res = {"workload": "BASELINE configs[%d]: synthetic one-hot %d rows x %d binary features (20 fields x 5000 Zipf(1.1) levels, 20 nnz/row), "
-                       "%d partitions%s, lambda=1, rho=1" % (2 if world == 1 else 3, rows * Ptot, ng - 1, Ptot,
-                                                             " sharded k -> rank k mod %d" % world if world > 1 else ""),
-           "value": round(tot_solves / dt, 2), "unit": "solves/s", "n_gpus": world, "steps": args.sparse_steps, "warmup": args.sparse_warmup,
-           "ms_per_step": round(dt * 1e3 / args.sparse_steps, 3),
-           "nnz": int(nnz), "rows_per_partition": rows, "n_local_mean": n_mean, "gen_s": round(tgen, 1), "upload_s": round(tup, 1),
-           "x_passes_ref_per_s": round(tot_pref / dt, 1), "x_passes_dev_per_s": round(tot_pdev / dt, 1),
-           "ticks_per_step": acc["ticks"] / args.sparse_steps, "cg_per_solve": round(acc["cg"] / max(1, acc["solves"]), 2),
-           "whole_step": {"alg_bytes_per_s_GB": round(tot_alg / dt / 1e9, 1), "frac_of_hbm_peak": round(tot_alg / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
-                          "definition": "sum over solves of device passes x B_pass (SURVEY 8d) / wall time of the timed iterations"},
-           "roofline": [roof("k_rowcold + k_rowpass_lds<binary>", acc["rms"], half, "B_pass = nnz*4 + 8l + 8n per active problem; the cold column slices run as their own launch in front of the row kernel"),
-                        roof("k_colpass_lds<binary>", acc["cms"], half, "B_pass = nnz*4 + 8l + 8n per active problem"),
-                        roof("k_step_a+b+c+commit", acc["sms"], 0.0,
-                             "no algorithmic X bytes (SURVEY 8d counts the n-vector work as zero); streams ~13 x 8n bytes per problem and "
-                             "tick = %.1f GB/s" % (step_model / max(1e-9, acc["sms"] * 1e-3) / 1e9))],
-           "last_maxdiff": fin.maxdiff,
-           "all_launches": {"ticks_incl_c0_and_warmup": allrun["ticks"], "alg_bytes_row_plus_column": allrun["alg"]}}
-    tpath = os.path.join(ROOT, "profiles", "traffic_sparse.json")
-    if os.path.exists(tpath):
-        with open(tpath) as fh:
-            tj = json.load(fh)
-        res["traffic"] = {"source": "profiles/traffic_sparse.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `%s` (committed; not a counter read in this run)" % tj.get("command", ""),
-                          "hbm_bytes_per_alg_byte": tj.get("hbm_bytes_per_alg_byte"), "per_kernel": tj.get("per_kernel")}
-    if args.sparse_cpu_sample > 0 and world == 1:
-        import oracle_lib as ol
-        ns = min(args.sparse_cpu_sample, len(blocks))
-        oc = ol.OracleAdmm(blocks[:ns], ng, [1.0], [1.0], num_blocks=Ptot)
-        threads = min(usable_cores(), ns)
-        t0 = time.perf_counter()
-        oc.solve_local(0.01, 1.0, nthreads=threads)
-        cdt = time.perf_counter() - t0
-        ps = sum(s.x_passes for s in oc.stats())
-        res["cpu_baseline"] = {"value": round(ns / cdt, 3), "unit": "solves/s", "cores": threads, "kind": "port",
-                               "sample": "oracle/admm_oracle.c on %d of the %d partitions, the solves of ADMM iteration 1 (z = u = 0, "
-                                         "epsilon 0.01), %.1f s wall" % (ns, Ptot, cdt),
-                               "x_passes_ref_per_s": round(ps / cdt, 1)}
+    res = None
+    if rank == 0:
+        n_mean = float(nloc.mean())
+        res = {"workload": "BASELINE configs[%d]: synthetic one-hot %d rows x %d binary features (20 fields x 5000 Zipf(1.1) levels, 20 nnz/row), "
+                           "%d partitions%s, lambda=1, rho=1" % (2 if world == 1 else 3, rows * Ptot, ng - 1, Ptot,
+                                                                 " sharded k -> rank k mod %d" % world if world > 1 else ""),
+               "value": round(tot_solves / dt, 2), "unit": "solves/s", "n_gpus": world, "steps": args.sparse_steps, "warmup": args.sparse_warmup,
+               "ms_per_step": round(dt * 1e3 / args.sparse_steps, 3), "liblinear_epsilon_by_iteration": eps_all,
+               "nnz": int(nnz), "rows_per_partition": rows, "n_local_mean": n_mean, "gen_s": round(tgen, 1), "upload_s": round(tup, 1),
+               "x_passes_ref_per_s": round(tot_pref / dt, 1), "x_passes_dev_per_s": round(tot_pdev / dt, 1),
+               "ticks_per_step": acc["ticks"] / args.sparse_steps, "cg_per_solve": round(acc["cg"] / max(1, acc["solves"]), 2),
+               "whole_step": {"alg_bytes_per_s_GB": round(tot_alg / dt / 1e9, 1), "frac_of_hbm_peak": round(tot_alg / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
+                              "definition": "sum over solves of device passes x B_pass (SURVEY 8d) / wall time of the timed iterations"},
+               "roofline": sparse_rooflines(acc, dt, n_mean, "k_rowcold + k_rowpass_lds<binary>", "k_colpass_lds<binary>"),
+               "last_maxdiff": fin.maxdiff,
+               "all_launches": {"ticks_incl_c0_and_warmup": allrun["ticks"], "alg_bytes_row_plus_column": allrun["alg"]}}
+        tpath = os.path.join(ROOT, "profiles", "traffic_sparse.json")
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            res["traffic"] = {"source": "profiles/traffic_sparse.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `%s` (committed; not a counter read in this run)" % tj.get("command", ""),
+                              "hbm_bytes_per_alg_byte": tj.get("hbm_bytes_per_alg_byte"), "per_kernel": tj.get("per_kernel")}
+        if want_checks:
+            sparse_checks(args, C, eng, blocks, ng, Ptot, snap, eps_all, step_s, res)
     eng.close()
     return res
+
+
+LS_LAMBDAS = [0.1, 0.3, 1.0, 3.0, 10.0, 30.0, 100.0, 300.0]
+
+
+def run_lambda_sweep(args, C):
+    """BASELINE configs[4]: the 8-lambda sweep on the one-hot data, 1024 partitions of 9 765 rows over 8 GPUs -- here the per-GPU
+    share: 128 partitions x 8 lambdas = 1024 problems per GPU (N GPUs: 128 N partitions, k -> rank k mod N; one GPU runs its share
+    as a closed 128-block job). rho follows the reference's table (1 up to lambda = 100, 10 above: jobs/RegressionAdmmTrain.java:
+    174-181). The reference replicates every row once per lambda through the shuffle (:553-568); here a partition's rows are
+    uploaded once and its 8 problems run side by side on one XCD, sharing the index streams through that L2."""
+    world, rank, sd = C["world"], C["rank"], C["sd"]
+    from mlease_amd.dataset import PartitionBlock
+    Ptot = args.sweep_partitions * world
+    rows = SP_ROWS // 1024
+    lam = LS_LAMBDAS
+    rho = [1.0 if l <= 100 else 10.0 for l in lam]
+    mine = [k for k in range(Ptot) if k % world == rank]
+    blocks, ng = [], None
+    for k in mine:
+        rp, ci, y, l2g, ng = sd.onehot_partition(k, rows)
+        blocks.append(PartitionBlock(k, rows, len(l2g), rp, ci, None, y, np.ones(rows, np.float32), np.zeros(rows, np.float32), l2g))
+    eng = C["HipAdmmEngine"](ng, lam, rho, Ptot, device=C["local_rank"], stream=C["stream"], profiling=True)
+    eng.add_partitions(blocks)
+    eng.finalize()
+    want_checks = world == 1 and args.sweep_cpu_sample > 0
+    acc, allrun, dt, fin, snap, eps_all, step_s = sparse_timed_run(args, C, eng, blocks, lam, args.sweep_warmup, args.sweep_steps, want_checks)
+    tot_solves, tot_pref, tot_pdev, tot_alg = C["reduce_sum"]([acc["solves"], acc["pref"], acc["pdev"], acc["alg"]])
+    res = None
+    if rank == 0:
+        n_mean = float(np.mean([b.n_local for b in blocks]))
+        res = {"workload": "BASELINE configs[4], per-GPU shape: one-hot %d partitions x %d rows (~%d local features) x %d lambdas %s, rho %s%s" % (
+                   Ptot, rows, int(n_mean), len(lam), lam, rho, " sharded k -> rank k mod %d" % world if world > 1 else
+                   " (the share one of 8 GPUs holds of the 1024-partition job, run as a closed %d-block job)" % Ptot),
+               "value": round(tot_solves / dt, 2), "unit": "solves/s", "n_gpus": world, "steps": args.sweep_steps, "warmup": args.sweep_warmup,
+               "ms_per_step": round(dt * 1e3 / args.sweep_steps, 3), "problems_per_gpu": len(blocks) * len(lam),
+               "liblinear_epsilon_by_iteration": eps_all,
+               "x_passes_ref_per_s": round(tot_pref / dt, 1), "x_passes_dev_per_s": round(tot_pdev / dt, 1),
+               "ticks_per_step": acc["ticks"] / args.sweep_steps, "cg_per_solve": round(acc["cg"] / max(1, acc["solves"]), 2),
+               "whole_step": {"alg_bytes_per_s_GB": round(tot_alg / dt / 1e9, 1), "frac_of_hbm_peak": round(tot_alg / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
+                              "definition": "sum over (partition, lambda) solves of device passes x B_pass (SURVEY 8d: every problem's pass counted in full, "
+                                            "although the 8 problems of a partition share its index stream) / wall time of the timed iterations"},
+               "roofline": sparse_rooflines(acc, dt, n_mean, "k_rowpass_lds<binary> (two hot slices, no cold columns at this width)", "k_colpass_lds<binary>"),
+               "x_sharing": "per-problem passes; the 8 lambda problems of a partition are scheduled on one XCD and share the uint16 index streams through "
+                            "its L2 (the one-workgroup-per-partition form that reads them once was measured slower: profiles/r2_notes.md, "
+                            "tests/test_gpu_parity.py::test_lambda_sweep_shared_x_passes keeps it bit-comparable)",
+               "last_maxdiff": fin.maxdiff, "last_mindiff": fin.mindiff}
+        if want_checks:
+            sparse_checks(args, C, eng, blocks, ng, Ptot, snap, eps_all, step_s, res, lam=lam, rho=rho, warm=args.sweep_warmup,
+                          ns=args.sweep_cpu_sample, full=False)
+    eng.close()
+    return res
+
+
+def _rel_err(a, ref):
+    """max |a - ref| / max(|ref|, 1e-4 max|ref|) per row of two [k, n] arrays (float64)."""
+    a, ref = a.astype(np.float64), ref.astype(np.float64)
+    fl = 1e-4 * np.max(np.abs(ref), axis=1, keepdims=True)
+    return np.max(np.abs(a - ref) / np.maximum(np.abs(ref), np.maximum(fl, 1e-300)), axis=1)
+
+
+def sparse_checks(args, C, eng, blocks, ng, Ptot, snap, eps_all, step_s, res, lam=(1.0,), rho=(1.0,), warm=None, ns=None, full=True):
+    """cpu_baseline + parity_check of the sparse leg (outside every timed region), on the partitions of the job itself:
+      (c) cpu_baseline: the oracle on `--sparse-cpu-sample` partitions for the SAME timed iterations, each solve started from the
+          GPU's own state at that iteration (z, u_k: the solves of one iteration are independent given the state);
+      (b) product path, solve level: the GPU's beta_k of those solves against the oracle's, beside the oracle's distance to
+          ITSELF on row-permuted partitions (an order Hadoop does not define, llf/LibLinearDataset.java:467-478);
+      (a) order-faithful mode (MLX_FAITHFUL=1) against the oracle twin (portable exp/log1p) on 8 of them: counters equal and
+          every float32 output bit-identical;
+      (b') product path, ADMM level: the first 8 partitions as a closed 8-block job from z = 0: |z_gpu - z_oracle| next to
+          |z_oracle(perm) - z_oracle| per iteration."""
+    import oracle_lib as ol
+    from fixtures import permute_rows
+    HipAdmmEngine = C["HipAdmmEngine"]
+    P = len(blocks)
+    lam, rho, nl = list(lam), list(rho), len(lam)
+    ns = min(args.sparse_cpu_sample if ns is None else ns, P)
+    nv = min(8, ns)
+    warm = args.sparse_warmup if warm is None else warm
+    eps_timed = eps_all[warm:]
+    Z0, u0 = snap
+    threads = min(usable_cores(), ns)
+
+    def cnts(o):
+        return np.array([(s.newton_iters, s.accepted, s.cg_iters, s.x_passes) for s in o.stats()], np.int32)
+
+    # the GPU on the timed iterations again, keeping state and results of the sample partitions (bit-reproducible runs)
+    eng.set_state(Z0, u0)
+    recs = []
+    Zi, ui = Z0, u0[:ns].copy()
+    for e in eps_timed:
+        eng.solve_local(e, 1.0)
+        pm = [eng.partition_model(k, li) for k in range(ns) for li in range(nl)]          # problem order: partition-major
+        gc = eng.solve_counters()[:ns * nl].copy()
+        eng.consensus_finish()
+        recs.append((Zi, ui, e, np.stack([m[0] for m in pm]), np.stack([m[1] for m in pm]), gc))
+        Zi = eng.z()[0].copy()
+        ui = np.stack([np.stack([eng.partition_model(k, li)[2] for li in range(nl)]) for k in range(ns)])
+    # (c) + (b): oracle and row-permuted oracle from the same states
+    oc = ol.OracleAdmm(blocks[:ns], ng, lam, rho, num_blocks=Ptot)
+    ocp = ol.OracleAdmm([permute_rows(b, 7 + i) for i, b in enumerate(blocks[:nv])], ng, lam, rho, num_blocks=Ptot)
+    threads = min(usable_cores(), ns * nl)
+    cdt, solves, passes = 0.0, 0, 0
+    per_it, ob_all = [], []
+    for i, (Zs, us, e, gb, gupx, gc) in enumerate(recs):
+        oc.set_state(Zs, us)
+        t0 = time.perf_counter()
+        oc.solve_local(e, 1.0, nthreads=threads)
+        cdt += time.perf_counter() - t0
+        cc = cnts(oc)
+        solves += ns * nl
+        passes += int(cc[:, 3].sum())
+        ob = np.stack([oc.partition_model(k, li)[0] for k in range(ns) for li in range(nl)])
+        ob_all.append(ob)
+        ocp.set_state(Zs, us[:nv])
+        ocp.solve_local(e, 1.0, nthreads=min(threads, nv * nl))
+        pb = np.stack([ocp.partition_model(k, li)[0] for k in range(nv) for li in range(nl)])
+        eg, ep = _rel_err(gb, ob), _rel_err(pb, ob[:nv * nl])
+        per_it.append({"iteration": warm + i + 1, "liblinear_epsilon": e,
+                       "gpu_vs_oracle": {"solves": ns * nl, "equal_counters": int(np.all(gc == cc, axis=1).sum()),
+                                         "within_1e-5": int((eg <= 1e-5).sum()), "median_rel_err_beta": float(np.median(eg)),
+                                         "max_rel_err_beta": float(eg.max()),
+                                         "max_abs_err_beta": float(np.max(np.abs(gb.astype(np.float64) - ob))),
+                                         "bit_identical_float32_fraction": round(float(np.mean(gb == ob)), 4)},
+                       "oracle_rowperm_vs_oracle": {"solves": nv * nl, "equal_counters": int(np.all(cnts(ocp) == cc[:nv * nl], axis=1).sum()),
+                                                    "within_1e-5": int((ep <= 1e-5).sum()), "median_rel_err_beta": float(np.median(ep)),
+                                                    "max_rel_err_beta": float(ep.max()),
+                                                    "max_abs_err_beta": float(np.max(np.abs(pb.astype(np.float64) - ob[:nv * nl]))),
+                                                    "bit_identical_float32_fraction": round(float(np.mean(pb == ob[:nv * nl])), 4)},
+                       "max_abs_beta": float(np.max(np.abs(ob)))})
+    v = solves / cdt
+    g_rate = P * nl * len(step_s) / sum(step_s)
+    res["cpu_baseline"] = {"value": round(v, 3), "unit": "solves/s", "cores": threads, "kind": "port",
+                           "sample": "oracle/admm_oracle.c (-O2, fp64, one thread per (partition, lambda) solve) on %d of the %d partitions%s, the SAME ADMM "
+                                     "iterations as the timed ones (%d..%d), every solve started from the GPU's z / u_k at that iteration, %.1f s wall" % (
+                                         ns, P, " x %d lambdas" % nl if nl > 1 else "", warm + 1, warm + len(recs), cdt),
+                           "x_passes_ref_per_s": round(passes / cdt, 1), "host_cpus_listed": os.cpu_count(), "host_cores_usable": usable_cores()}
+    res["gpu_over_cpu"] = {"same_iterations": [warm + 1, warm + len(recs)], "solves_per_s": round(g_rate / v, 2),
+                           "gpu_solves_per_s": round(g_rate, 2), "cpu_seconds": round(cdt, 2)}
+    worst_g = max(r["gpu_vs_oracle"]["max_rel_err_beta"] for r in per_it)
+    worst_p = max(r["oracle_rowperm_vs_oracle"]["max_rel_err_beta"] for r in per_it)
+    res["parity_check"] = {
+        "what": "partitions of the timed job (%d rows x ~%d local features each), ADMM iterations %d..%d, every solve from the GPU's state at "
+                "that iteration" % (blocks[0].l, int(np.mean([b.n_local for b in blocks[:ns]])), warm + 1, warm + len(recs)),
+        "tolerance": 1e-5, "rel_err_floor": "1e-4 * max|beta_k|",
+        "product_path_solve_level": {"max_rel_err_beta_gpu_vs_oracle": worst_g, "max_rel_err_beta_oracle_rowperm_vs_oracle": worst_p,
+                                     "per_iteration": per_it},
+        "reading": "the product path sums in another order than the reference, and on this data the reference itself moves by the same order of "
+                   "magnitude when its rows are permuted (chaotic TRON trajectories at a 1e-2 stopping tolerance, DESIGN 5); the order-faithful "
+                   "mode shows the kernels compute the reference's arithmetic bit for bit"}
+    if not full:
+        return
+    # (a) order-faithful mode vs the oracle twin, same states
+    os.environ["MLX_FAITHFUL"] = "1"
+    try:
+        engf = HipAdmmEngine(ng, [1.0], [1.0], Ptot, device=C["local_rank"], stream=C["stream"])
+        engf.add_partitions(blocks[:nv])
+        engf.finalize()
+    finally:
+        del os.environ["MLX_FAITHFUL"]
+    ocf = ol.OracleAdmm(blocks[:nv], ng, [1.0], [1.0], num_blocks=Ptot, pm=True)
+    fa = {"partitions": nv, "iterations": [warm + 1, warm + len(recs)], "solves": 0, "solves_with_equal_counters": 0,
+          "solves_bit_identical_beta_and_uplusx": 0, "bit_identical_float32_fraction": 1.0, "gpu_seconds": 0.0}
+    ident = []
+    for (Zs, us, e, _, _, _) in recs:
+        engf.set_state(Zs, us[:nv])
+        t0 = time.perf_counter()
+        engf.solve_local(e, 1.0)
+        fa["gpu_seconds"] += time.perf_counter() - t0
+        ocf.set_state(Zs, us[:nv])
+        ocf.solve_local(e, 1.0, nthreads=min(threads, nv))
+        fc, occ = engf.solve_counters(), cnts(ocf)
+        for k in range(nv):
+            fb, fu, _ = engf.partition_model(k, 0)
+            obb, ou, _ = ocf.partition_model(k, 0)
+            fa["solves"] += 1
+            fa["solves_with_equal_counters"] += int(np.array_equal(fc[k], occ[k]))
+            fa["solves_bit_identical_beta_and_uplusx"] += int(np.array_equal(fb, obb) and np.array_equal(fu, ou))
+            ident.append(float(np.mean(fb == obb)))
+    fa["bit_identical_float32_fraction"] = round(float(np.mean(ident)), 6)
+    fa["gpu_seconds"] = round(fa["gpu_seconds"], 2)
+    engf.close()
+    # (b') closed 8-block job from z = 0 with the driver's epsilon schedule
+    sub = blocks[:nv]
+    engs = HipAdmmEngine(ng, [1.0], [1.0], nv, device=C["local_rank"], stream=C["stream"])
+    engs.add_partitions(sub)
+    engs.finalize()
+    ocs = ol.OracleAdmm(sub, ng, [1.0], [1.0])
+    ocsp = ol.OracleAdmm([permute_rows(b, 1007 + i) for i, b in enumerate(sub)], ng, [1.0], [1.0])
+    sched = EpsSchedule(C["admm"])
+    run = []
+    for it in range(1, len(eps_all) + 1):
+        e = sched.next()
+        mo = ocs.iterate(e, 1.0, nthreads=min(threads, nv))
+        ocsp.iterate(e, 1.0, nthreads=min(threads, nv))
+        engs.iterate(e)
+        sched.mindiff = mo[1]
+        zo, zg, zp = ocs.z()[0][0], engs.z()[0][0], ocsp.z()[0][0]
+        run.append({"iteration": it, "liblinear_epsilon": e, "max_abs_z_gpu_minus_oracle": float(np.max(np.abs(zg - zo))),
+                    "max_abs_z_oracle_rowperm_minus_oracle": float(np.max(np.abs(zp - zo))), "max_abs_z": float(np.max(np.abs(zo))),
+                    "counters_equal_gpu": int(np.all(engs.solve_counters() == cnts(ocs), axis=1).sum()),
+                    "counters_equal_rowperm": int(np.all(cnts(ocsp) == cnts(ocs), axis=1).sum())})
+    engs.close()
+    res["parity_check"]["order_faithful_mode_vs_oracle_twin"] = fa
+    res["parity_check"]["product_path_admm_level_closed_%d_block_job" % nv] = run
+
 
 
 if __name__ == "__main__":

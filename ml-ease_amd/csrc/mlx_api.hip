@@ -120,7 +120,10 @@ struct mlx_context {
     ncclComm_t comm = nullptr;
     int comm_nranks = 1;
     bool comm_always = false;              // MLX_COMM_ALWAYS=1: run the collective also at nranks == 1 (tests)
-    std::shared_ptr<struct LocalComm> lcomm;   // MLX_COMM_LOCAL=1 (tests): in-process exchange between handles on one device
+#ifdef MLX_EXPERIMENTAL
+    std::shared_ptr<struct LocalComm> lcomm;   // MLX_COMM_LOCAL=1 (experimental build, tests): in-process exchange between handles on one device
+#endif
+    bool has_lcomm = false;
     int lrank = 0;
 
     mlx_stats last{};
@@ -249,11 +252,15 @@ int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
     if (nqc > 0)
         for (int which = 1; which <= 2; which++)
             bracket(which, [&] {
+#ifdef MLX_EXPERIMENTAL
                 if (multi && (which == 2 || h->row_multi)) {
                     mlxk_xpass_multi(h->stream, h->d_parts, h->d_probs, h->d_plist, h->np_csr, h->n_lambda, h->multi_R, h->maxblk_csr, h->csr_hasval,
                                      h->max_cunits, h->max_rblk_rows, h->max_row_lds, h->row_ngc, h->row_multi, which);
                     return 0;
                 }
+#else
+                (void)multi;
+#endif
                 return mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_short, h->max_long, h->rowgroup, h->csr_hasval, h->csr_sell, h->max_cunits, h->max_rblk_rows, h->max_row_lds, h->row_ngc, h->n_lambda == 1, which, h->cold_groups);
             });
     return MLX_OK;
@@ -264,14 +271,16 @@ void launch_step(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
 {
     mark(h, 3);
     mlxk_tron_step(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->step_threads, h->d_done);
+#ifdef MLX_EXPERIMENTAL
     if (h->step_fused) {
         if (++h->step_seq == 0) h->step_seq = 1;
         mlxk_step_fused(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->step_max_nwg, h->step_seq, h->d_stepctl);
         mlxk_step_phase(h->stream, 3, h->d_parts, h->d_probs, qcsr, nqc, h->step_ch, h->step_max_nwg, h->d_done, h->d_stepctl);
-    } else {
-        for (int which = 0; which < 4; which++)
-            mlxk_step_phase(h->stream, which, h->d_parts, h->d_probs, qcsr, nqc, h->step_ch, h->step_max_nwg, h->d_done, h->d_stepctl);
+        return;
     }
+#endif
+    for (int which = 0; which < 4; which++)
+        mlxk_step_phase(h->stream, which, h->d_parts, h->d_probs, qcsr, nqc, h->step_ch, h->step_max_nwg, h->d_done, h->d_stepctl);
 }
 
 // Drive ticks until `count` problems starting at `first` are DONE.
@@ -364,7 +373,11 @@ int finish_part(mlx_handle h, PartHost &ph)
 // =================================================================================================
 extern "C" {
 
-const char *mlx_version(void) { return "mlease_hip gfx950 r1 (" __DATE__ ")"; }
+#ifdef MLX_EXPERIMENTAL
+const char *mlx_version(void) { return "mlease_hip gfx950 r3 +experimental (" __DATE__ ")"; }
+#else
+const char *mlx_version(void) { return "mlease_hip gfx950 r3 (" __DATE__ ")"; }
+#endif
 
 const char *mlx_last_error(mlx_handle h) { return h ? h->err.c_str() : g_err_nohandle.c_str(); }
 
@@ -987,6 +1000,11 @@ int mlx_finalize(mlx_handle h)
     // Sliced CSR partitions: the row chunk of one row-pass workgroup (a range of 64-row groups; the sliced layout does not
     // depend on it). Every workgroup stages the whole gathered vector once, slice by slice, so chunks are as long as the
     // handle's total work allows: about three workgroups per CU over all problems, 16..128 groups (1 024..8 192 rows).
+#ifndef MLX_EXPERIMENTAL
+    for (const char *sw : {"MLX_MULTI", "MLX_STEP_FUSED"})
+        if (getenv(sw) && atoi(getenv(sw)) != 0)
+            return fail(h, MLX_ERR_INVALID, "%s needs the experimental build (libmlease_hip_exp.so); the product library does not contain that code", sw);
+#endif
     h->csr_sell = true;
     for (auto &p : h->parts) if (!p.dense) h->csr_sell = h->csr_sell && p.sell;
     if (h->csr_sell && nl >= 2) {
@@ -1370,6 +1388,8 @@ int mlx_admm_consensus_finish(mlx_handle h, mlx_stats *stats)
     return MLX_OK;
 }
 
+#ifdef MLX_EXPERIMENTAL
+// (experimental build only: libmlease_hip_exp.so)
 // MLX_COMM_LOCAL=1 (test mode): RCCL refuses two ranks on one device, so a host with ONE GPU could never run its
 // several-handles-in-one-process logic (one thread + one handle per device, `gpus=0,1,...` of mlease_admm_train). With the
 // switch set, mlx_comm_init joins an in-process communicator keyed by the unique id instead, and the exchange sums the
@@ -1409,6 +1429,7 @@ static int local_allreduce(mlx_handle h, size_t count)
         hipStreamSynchronize(h->stream) != hipSuccess) return -1;
     return 0;
 }
+#endif
 
 // The exchange step of one iteration: ncclAllReduce(SUM) of [xbar | ubar] over the handle's communicator. The local
 // solve's status rides along in one extra slot, so that a rank whose solve failed still JOINS the collective (the others
@@ -1416,16 +1437,19 @@ static int local_allreduce(mlx_handle h, size_t count)
 // job when any reducer throws (jobs/RegressionAdmmTrain.java:713-716 -> job failure at :357).
 static int exchange(mlx_handle h, int local_rc, const char *what)
 {
-    if ((h->comm || h->lcomm) && (h->comm_nranks > 1 || h->comm_always)) {
+    if ((h->comm || h->has_lcomm) && (h->comm_nranks > 1 || h->comm_always)) {
         const size_t cnt = 2 * (size_t)h->n_lambda * h->n_global;
         const double flag = local_rc ? 1.0 : 0.0;
         double total = 0.0;
         if (hipMemcpyAsync(h->d_cons + cnt, &flag, sizeof flag, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess)
             return local_rc ? local_rc : fail(h, MLX_ERR_HIP, "%s: status upload failed", what);
+#ifdef MLX_EXPERIMENTAL
         if (h->lcomm) {
             if (local_allreduce(h, cnt + 1) != 0) return local_rc ? local_rc : fail(h, MLX_ERR_HIP, "%s: local exchange failed", what);
-        } else {
+        } else
+#endif
+        {
             ncclResult_t r = ncclAllReduce(h->d_cons, h->d_cons, cnt + 1, ncclDouble, ncclSum, h->comm, h->stream);
             if (r != ncclSuccess) return local_rc ? local_rc : fail(h, MLX_ERR_COMM, "ncclAllReduce failed: %s", ncclGetErrorString(r));
         }
@@ -1982,14 +2006,18 @@ int mlx_comm_init(mlx_handle h, const char unique_id[MLX_UNIQUE_ID_BYTES], int32
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(h, MLX_ERR_INVALID, "mlx_comm_init: rank %d of %d", rank, nranks);
     hipSetDevice(h->device);
     if (getenv("MLX_COMM_LOCAL") && atoi(getenv("MLX_COMM_LOCAL")) != 0) {
+#ifndef MLX_EXPERIMENTAL
+        return fail(h, MLX_ERR_INVALID, "MLX_COMM_LOCAL needs the experimental build (libmlease_hip_exp.so): the product library exchanges over RCCL only");
+#else
         std::lock_guard<std::mutex> lk(g_lcomm_mu);
         const std::string key(unique_id, MLX_UNIQUE_ID_BYTES);
         std::shared_ptr<LocalComm> c = g_lcomms[key].lock();
         if (!c) { c = std::make_shared<LocalComm>(); c->nranks = nranks; c->buf.resize((size_t)nranks); g_lcomms[key] = c; }
         if (c->nranks != nranks) return fail(h, MLX_ERR_COMM, "mlx_comm_init: local communicator has %d ranks, not %d", c->nranks, nranks);
-        h->lcomm = c; h->lrank = rank; h->comm_nranks = nranks;
+        h->lcomm = c; h->has_lcomm = true; h->lrank = rank; h->comm_nranks = nranks;
         h->comm_always = getenv("MLX_COMM_ALWAYS") != nullptr && atoi(getenv("MLX_COMM_ALWAYS")) != 0;
         return MLX_OK;
+#endif
     }
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof id);

@@ -870,256 +870,9 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Shared-X passes for lambda sweeps (BASELINE configs[4]: the reference replicates every row once per lambda through the
-// shuffle, jobs/RegressionAdmmTrain.java:553-568). One workgroup = (PARTITION, piece of it) and carries ALL of the
-// partition's lambda problems, so the index / value streams -- the dominant traffic -- are read ONCE per tick:
-//   * row pass: the packs of the wave's rows are loaded into registers once, then for every unfinished lambda the hot
-//     slice of ITS vector is staged in LDS and the same packs drive the gathers (hot from LDS, cold from L2);
-//   * column pass: the row blocks are R times shorter (R = the lambda count rounded up to 2, 4 or 8) so that the block's
-//     coefficients of ALL lambdas sit in LDS side by side; every pack is loaded once and feeds R running sums.
-// Each lambda keeps its own phase (CG / EVAL / DONE), vectors and outputs: per problem the arithmetic and its order are
-// exactly those of the single-lambda kernels, finished lambdas are skipped.
-// ------------------------------------------------------------------------------------------------
-#define RM_MAXH 6      // hot packs per row group held in registers (24 entries per row)
-#define RM_MAXC 3      // cold packs per row group (12 entries per row); partitions beyond either run the per-problem row pass
-template <bool HASVAL, bool NT, int GPW>
-__global__ void __launch_bounds__(1024)
-k_rowpass_multi(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ plist, int np, int gx, int nl)
-{
-#pragma clang fp contract(off)
-    extern __shared__ __attribute__((aligned(16))) double vs[];      // [slw + 1]: the staged hot slice of one lambda, then the zero slot
-    __shared__ double scratch[48];
-    int pi_, bx_;
-    if (!xcd_map(np, gx, pi_, bx_)) return;
-    const int q0 = plist[pi_];
-    const PartDev &pa = parts[probs[q0].part];
-    const int c = bx_;
-    if (c >= pa.nblk) return;
-    const int nf = pa.n_feat, slw = pa.slw, ngr = pa.n_rgroups, l = pa.l;
-    const int g0 = c * (16 * GPW);
-    const int gcount = min(16 * GPW, ngr - g0);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wg0 = wave * GPW;
-    const uint16_t *__restrict__ rs_idx = pa.rs_idx;
-    const float *__restrict__ rs_val = pa.rs_val;
-    const bool has_cold = pa.n_cs > 1;
-    // ---- the wave's packs, once: hot block offsets from slice 0, cold ones from slice 1 (n_cs <= 2 is a launch condition)
-    int nh[GPW], nc[GPW];
-    u2v_t qh[GPW][RM_MAXH], qc[GPW][RM_MAXC];
-    f4v_t xh[GPW][RM_MAXH], xc[GPW][RM_MAXC];
-    {
-        const int32_t *__restrict__ ptr = pa.rs_ptr + g0;
-        const int pv = ptr[min(wg0 + min(lane, GPW), gcount)];
-        const int pw = has_cold ? ptr[ngr + min(wg0 + min(lane, GPW), gcount)] : 0;
-        const unsigned zz = (unsigned)slw | ((unsigned)slw << 16);
-#pragma unroll
-        for (int i = 0; i < GPW; i++) {
-            const bool on = wg0 + i < gcount;
-            const int bh = __builtin_amdgcn_readlane(pv, i), bc = __builtin_amdgcn_readlane(pw, i);
-            nh[i] = on ? (__builtin_amdgcn_readlane(pv, i + 1) - bh) >> 8 : 0;
-            nc[i] = (on && has_cold) ? (__builtin_amdgcn_readlane(pw, i + 1) - bc) >> 8 : 0;
-#pragma unroll
-            for (int p = 0; p < RM_MAXH; p++) {
-                const int kk = max(min(p, nh[i] - 1), 0);
-                qh[i][p] = pack_load<NT>(rs_idx, bh, kk, lane);
-                if (HASVAL) xh[i][p] = pack_load_val<NT>(rs_val, bh, kk, lane);
-                if (p >= nh[i]) { qh[i][p].x = zz; qh[i][p].y = zz; }
-            }
-#pragma unroll
-            for (int p = 0; p < RM_MAXC; p++) {
-                const int kk = max(min(p, nc[i] - 1), 0);
-                qc[i][p] = pack_load<NT>(rs_idx, bc, kk, lane);
-                if (HASVAL) xc[i][p] = pack_load_val<NT>(rs_val, bc, kk, lane);
-                if (p >= nc[i]) { qc[i][p].x = 0xFFFFFFFFu; qc[i][p].y = 0xFFFFFFFFu; }
-            }
-        }
-    }
-    for (int li = 0; li < nl; li++) {
-        ProbDev &pr = probs[q0 + li];
-        const int phase = pr.phase;
-        if (phase == PH_DONE) continue;                       // (uniform over the workgroup)
-        const bool cg = (phase == PH_CG);
-        const double *__restrict__ v = cg ? pr.d : pr.w_new;
-        const double *__restrict__ wdcur = pr.wd[pr.dsel];
-        double *__restrict__ wdnew = pr.wd[pr.dsel ^ 1];
-        double *__restrict__ coef = pr.coef;
-        __syncthreads();                                      // the previous lambda's readers are done
-        {
-            StageRegs SR;
-            const int cnt = min(slw, nf);
-            stage_fetch(SR, v, cnt, tid);
-            stage_store(SR, vs, v, cnt, tid);
-            if (tid == 0) vs[slw] = 0.0;
-        }
-        __syncthreads();
-        double acc[GPW];
-        const double *__restrict__ src = v + slw;             // cold ids are relative to the end of the hot slice
-        // The packs are loop invariant, and so would be the 4 LDS / global offsets derived from each: hoisted out of the lambda
-        // loop they cost 4 more registers per pack and spill. Opaque copies keep only the packs alive across iterations.
-#pragma unroll
-        for (int i = 0; i < GPW; i++) {
-#pragma unroll
-            for (int p = 0; p < RM_MAXH; p++) asm volatile("" : "+v"(qh[i][p].x), "+v"(qh[i][p].y));
-#pragma unroll
-            for (int p = 0; p < RM_MAXC; p++) asm volatile("" : "+v"(qc[i][p].x), "+v"(qc[i][p].y));
-        }
-#pragma unroll
-        for (int i = 0; i < GPW; i++) {
-            double a = 0.0;
-#pragma unroll
-            for (int p = 0; p < RM_MAXH; p++)
-                if (p < nh[i]) a = pack_sum<HASVAL>(a, qh[i][p], xh[i][p], vs);
-            // cold gathers of the group: all loads first (clamped, unconditional), then the adds in entry order
-            double cv[RM_MAXC][4];
-#pragma unroll
-            for (int p = 0; p < RM_MAXC; p++) {
-                const unsigned id[4] = {qc[i][p].x & 0xFFFFu, qc[i][p].x >> 16, qc[i][p].y & 0xFFFFu, qc[i][p].y >> 16};
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const double g = has_cold ? src[id[e] == 0xFFFFu ? 0u : id[e]] : 0.0;
-                    cv[p][e] = id[e] == 0xFFFFu ? 0.0 : g;
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < RM_MAXC; p++)
-                if (p < nc[i]) {
-                    a = a + (HASVAL ? cv[p][0] * (double)xc[i][p].x : cv[p][0]);
-                    a = a + (HASVAL ? cv[p][1] * (double)xc[i][p].y : cv[p][1]);
-                    a = a + (HASVAL ? cv[p][2] * (double)xc[i][p].z : cv[p][2]);
-                    a = a + (HASVAL ? cv[p][3] * (double)xc[i][p].w : cv[p][3]);
-                }
-            acc[i] = a;
-            asm volatile("" ::: "memory");                    // one group's gathers at a time (their results would not fit twice)
-        }
-        const double vb = v[nf];
-        double red[2] = {0.0, 0.0};
-#pragma unroll
-        for (int i = 0; i < GPW; i++) {
-            const int row = (g0 + wg0 + i) * 64 + lane;
-            const bool ok = (wg0 + i < gcount) && row < l;
-            const int rc = min(row, l - 1);
-            const double wdv0 = cg ? wdcur[rc] : 0.0;
-            const float offv = cg ? 0.f : pa.off[rc];
-            const float wtv = cg ? 0.f : pa.wt[rc];
-            const int yv = cg ? 0 : (int)pa.y[rc];
-            if (ok) {
-                const double t = acc[i] + vb;
-                double cf;
-                if (cg) {
-                    cf = wdv0 * t;
-                } else {
-                    double loss, wdv;
-                    row_eval(t + (double)offv, yv, (double)wtv, loss, wdv, cf);
-                    wdnew[rc] = wdv;
-                    red[0] += loss;
-                }
-                coef[rc] = cf;
-                red[1] += cf;
-            }
-        }
-        block_allreduce_sum<2>(red, scratch);
-        if (tid == 0) { pr.lossp[c] = red[0]; pr.csump[c] = red[1]; }
-    }
-}
-
-// Column pass for R lambdas at once: LDS holds the block's coefficients of lambda li at cf[li * (rblk_rows + 1) ...], each
-// region followed by its zero slot. COL_MB item slices per wave and round; a pack is loaded once and adds into R sums.
-template <bool HASVAL, bool NT, int R>
-__global__ void __launch_bounds__(1024)
-k_colpass_multi(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ plist, int np, int gx, int nl)
-{
-#pragma clang fp contract(off)
-    extern __shared__ __attribute__((aligned(16))) double cf[];
-    int pi_, bx_;
-    if (!xcd_map(np, gx, pi_, bx_)) return;
-    const int q0 = plist[pi_];
-    const PartDev &pa = parts[probs[q0].part];
-    if (bx_ >= pa.n_cunits) return;
-    const int blk = pa.cw_blk[bx_];
-    const int s0 = pa.cw_slice[bx_], s1 = pa.cw_slice[bx_ + 1];
-    const int rbr = pa.rblk_rows, reg = rbr + 1;
-    const int r0 = blk * rbr;
-    const int nr = min(rbr, pa.l - r0);
-    bool act[R];
-    double *outp[R];
-    bool any = false;
-#pragma unroll
-    for (int li = 0; li < R; li++) {
-        act[li] = li < nl && probs[q0 + min(li, nl - 1)].phase != PH_DONE;
-        outp[li] = probs[q0 + min(li, nl - 1)].parts;
-        any = any || act[li];
-    }
-    if (!any) return;
-#pragma unroll
-    for (int li = 0; li < R; li++) {
-        if (act[li]) {
-            StageRegs SR;
-            const double *__restrict__ src = probs[q0 + li].coef + r0;      // r0 is a multiple of 64: 16-byte aligned pairs
-            stage_fetch(SR, src, nr, threadIdx.x);
-            stage_store(SR, cf + li * reg, src, nr, threadIdx.x);
-        }
-        if (threadIdx.x == 0) cf[li * reg + rbr] = 0.0;
-    }
-    __syncthreads();
-    const uint16_t *__restrict__ cs_idx = pa.cs_idx;
-    const float *__restrict__ cs_val = pa.cs_val;
-    const int32_t *__restrict__ cs_ptr = pa.cs_ptr;
-    const int32_t *__restrict__ item_dst = pa.item_dst;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    constexpr int COL_MB = R >= 8 ? 2 : (R >= 4 ? 4 : 8);
-    const unsigned zz = (unsigned)rbr | ((unsigned)rbr << 16);
-    for (int sb = s0 + wave; sb < s1; sb += 16 * COL_MB) {
-        int base[COL_MB], L4[COL_MB], dst[COL_MB];
-        u2v_t q0v[COL_MB];
-        f4v_t x0v[COL_MB];
-#pragma unroll
-        for (int u = 0; u < COL_MB; u++) {
-            const int sl = sb + 16 * u;
-            const int sc = min(sl, s1 - 1);
-            base[u] = __builtin_amdgcn_readfirstlane(cs_ptr[sc]);
-            const int nx = __builtin_amdgcn_readfirstlane(cs_ptr[sc + 1]);
-            L4[u] = (sl < s1) ? (nx - base[u]) >> 8 : 0;
-            dst[u] = (sl < s1) ? item_dst[sc * 64 + lane] : -1;
-        }
-#pragma unroll
-        for (int u = 0; u < COL_MB; u++) {
-            q0v[u] = pack_load<NT>(cs_idx, base[u], 0, lane);
-            if (HASVAL) x0v[u] = pack_load_val<NT>(cs_val, base[u], 0, lane);
-            if (L4[u] < 1) { q0v[u].x = zz; q0v[u].y = zz; }
-        }
-#pragma unroll
-        for (int u = 0; u < COL_MB; u++) {
-            double a[R];
-#pragma unroll
-            for (int li = 0; li < R; li++) a[li] = act[li] ? pack_sum<HASVAL>(0.0, q0v[u], x0v[u], cf + li * reg) : 0.0;
-            // long items: LSUM packs in flight, every pack feeds the R sums
-            constexpr int LSUM = HASVAL ? 2 : 4;
-            for (int k = 1; k < L4[u]; k += LSUM) {
-                u2v_t q[LSUM];
-                f4v_t xv[LSUM];
-#pragma unroll
-                for (int t = 0; t < LSUM; t++) {
-                    const int kk = min(k + t, L4[u] - 1);
-                    q[t] = pack_load<NT>(cs_idx, base[u], kk, lane);
-                    if (HASVAL) xv[t] = pack_load_val<NT>(cs_val, base[u], kk, lane);
-                    if (k + t >= L4[u]) { q[t].x = zz; q[t].y = zz; }
-                }
-#pragma unroll
-                for (int li = 0; li < R; li++)
-                    if (act[li]) {
-#pragma unroll
-                        for (int t = 0; t < LSUM; t++) a[li] = pack_sum<HASVAL>(a[li], q[t], xv[t], cf + li * reg);
-                    }
-            }
-            if (dst[u] >= 0) {
-#pragma unroll
-                for (int li = 0; li < R; li++)
-                    if (act[li]) outp[li][dst[u]] = a[li];
-            }
-        }
-    }
-}
+#ifdef MLX_EXPERIMENTAL
+#include "mlx_experimental_passes.inc"   // shared-X passes of lambda sweeps (MLX_MULTI=1): measured slower, kept out of the product
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // per-iteration problem setup: warm start z~, prior mean z~ - u_k on the partition's local index set
@@ -2048,287 +1801,9 @@ k_step_c(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
     }
 }
 
-// ---- phases A, B and C in ONE launch (opt-in experiment, MLX_STEP_FUSED=1; measured SLOWER, profiles/r2_notes.md) --------
-// The three phase kernels run at the HBM roofline of their ~13 n-vector streams per CG tick (A 4.5, B 6, C 3); what is
-// left to gain is the streams themselves. k_step_fused keeps a workgroup's 2048 columns of d, Hd and r' in registers from
-// phase A to phase C, so Hd is never written, d is read once instead of three times and r' is written once: ~8.5 streams.
-// The two reductions in between become EXCHANGES inside the launch, built so that no cache maintenance is needed (a
-// device-scope fence per workgroup writes back / invalidates a whole XCD's L2 -- profiles/r2_notes.md):
-//   * the only data one workgroup reads from another inside the launch are the partial sums and the totals, and those go
-//     through agent-scope relaxed atomics (st_coh / ld_coh: served at the memory side);
-//   * a workgroup publishes its partials, waits for the stores to be acknowledged (s_waitcnt vmcnt(0)), then bumps the
-//     problem's arrival counter; the workgroup whose bump returns nwg-1 adds all partials in chunk order (the same
-//     step_gather the commit launch uses, so both derive bit-identical scalars), publishes the totals, waits, then the
-//     launch's sequence number as the flag; every other workgroup polls the flag (one lane, s_sleep between polls);
-//   * forward progress: workgroups take their (problem, chunk) from a ticket counter in the order they START, so every
-//     chunk a spinning workgroup waits for either runs already or is dispatched before any later work -- no deadlock as
-//     long as one problem's chunks (<= 256) fit on the chip together, which 256 CUs guarantee;
-//   * a poll that does not see its flag within ~2 s raises ctl[1]; the commit launch then stops every problem and the host
-//     fails the solve -- a logic error must not hang the device.
-// The arithmetic, its order and the partial sums are those of k_step_a/b/c: results are bit-identical between the two paths
-// (tests/test_gpu_parity.py::test_fused_step_is_bit_identical_to_the_three_launch_step). It loses because an exchange is
-// ~6 dependent trips to the memory side (~10 us) and the registers hold only ~1.5 M of the job's 18 M columns at a time
-// (152 VGPRs, 3 workgroups per CU): a workgroup lives ~35 us for ~5 us of streaming. C3 step 440 vs 295 us per tick.
-// ------------------------------------------------------------------------------------------------
-#define FUSE_CPT 8                          // columns per thread, all register resident
-#define FUSE_CH (FUSE_CPT * STEP_T)         // 2048 columns per workgroup
-#define FUSE_SPIN_LIMIT (1 << 22)
-
-// xs: [0] arrivals A (u32) [1] arrivals B (u32) [2] flag A (u64) [3] flag B (u64) [4..7] totals A [8..12] totals B
-template <int NP>
-__device__ __forceinline__ void step_exchange(double (&v)[NP], double *__restrict__ px_mine, const double *__restrict__ px_all,
-                                              int nwg, double *__restrict__ xs, int which, unsigned seq, double *shtot,
-                                              double *stage, int *sh_last, int *__restrict__ ctl)
-{
-    const int tid = threadIdx.x;
-    unsigned *cnt = reinterpret_cast<unsigned *>(xs + which);
-    unsigned long long *flag = reinterpret_cast<unsigned long long *>(xs + 2 + which);
-    double *tot = xs + 4 + which * 4;
-    if (tid == 0) {
-#pragma unroll
-        for (int k = 0; k < NP; k++) st_coh(px_mine + k, v[k]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *sh_last = (old == (unsigned)nwg - 1u) ? 1 : 0;
-    }
-    __syncthreads();
-    if (*sh_last) {                                                   // (uniform)
-        step_gather<NP, true>(px_all, nwg, shtot, stage);
-        if (tid == 0) {
-            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int k = 0; k < NP; k++) st_coh(tot + k, shtot[k]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(flag, (unsigned long long)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    } else {
-        if (tid == 0) {
-            int spins = 0;
-            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)seq) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > FUSE_SPIN_LIMIT) { __hip_atomic_store(ctl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            }
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int k = 0; k < NP; k++) shtot[k] = ld_coh(tot + k);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int k = 0; k < NP; k++) v[k] = shtot[k];
-}
-
-__global__ void __launch_bounds__(STEP_T)
-k_step_fused(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int max_nwg,
-             unsigned seq, int *__restrict__ ctl)
-{
-#pragma clang fp contract(off)
-    __shared__ double scratch[96];
-    __shared__ double stage[STEP_T];
-    __shared__ double shtot[STEP_NP];
-    __shared__ int sh_i[2];
-    const int tid = threadIdx.x;
-    if (tid == 0) sh_i[0] = atomicAdd(ctl, 1);                        // start order = logical order
-    __syncthreads();
-    const int ticket = sh_i[0];
-    ProbDev &pr = probs[qlist[ticket / max_nwg]];
-    const int phase = pr.phase;
-    if (phase == PH_DONE) return;
-    const PartDev &pa = parts[pr.part];
-    const int n = pa.n_local, nf = pa.n_feat;
-    const int wg = ticket % max_nwg, j0 = wg * FUSE_CH, nwg = (n + FUSE_CH - 1) / FUSE_CH;
-    if (j0 >= n) return;
-    const int j1 = min(n, j0 + FUSE_CH);
-    const bool cg = (phase == PH_CG);
-    double csum_icpt = 0.0, loss = 0.0;
-    if (j1 == n) csum_icpt = block_sum_array(pr.csump, pa.nblk, scratch);
-    if (wg == 0 && !cg) loss = block_sum_array(pr.lossp, pa.nblk, scratch);
-    const double *__restrict__ segsum = pr.parts;
-    const int32_t *__restrict__ cptr = pa.col_ptr;
-    const double *__restrict__ m = pr.m;
-    const double *__restrict__ c0 = pa.c0;
-    const double *__restrict__ pvec = pr.pinv_vec;
-    const double pscal = pr.pinv;
-    double *__restrict__ s = pr.s, *__restrict__ d = pr.d;
-    double *__restrict__ Hd = pr.Hd;
-    const double *__restrict__ v = cg ? pr.d : pr.w_new;
-
-    // ---- phase A: vv = d (CG) or w_new (EVAL), hd = Hd / gradient candidate -- both stay in registers
-    double vv[FUSE_CPT], hd[FUSE_CPT];
-    double accA[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int h = 0; h < FUSE_CPT; h += STEP_XB) {
-        int i0[STEP_XB], i1[STEP_XB];
-        double mm[STEP_XB], pj[STEP_XB], cc[STEP_XB], f0[STEP_XB];
-#pragma unroll
-        for (int u = 0; u < STEP_XB; u++) {
-            const int j = j0 + tid + (h + u) * STEP_T;
-            const int jc = min(j, j1 - 1);
-            const bool col = j < nf;
-            const int jf = min(jc, max(nf - 1, 0));
-            i0[u] = (col && nf > 0) ? cptr[jf] : 0; i1[u] = (col && nf > 0) ? cptr[jf + 1] : 0;
-            vv[h + u] = v[jc];
-            pj[u] = pvec ? pvec[jc] : pscal;
-            mm[u] = cg ? 0.0 : m[jc];
-            cc[u] = (phase == PH_EVAL0) ? c0[jc] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < STEP_XB; u++) f0[u] = i1[u] > i0[u] ? segsum[i0[u]] : 0.0;
-#pragma unroll
-        for (int u = 0; u < STEP_XB; u++) {
-            const int j = j0 + tid + (h + u) * STEP_T;
-            hd[h + u] = 0.0;
-            if (j >= j1) continue;
-            double xa = 0.0;                                   // slot order = (row block, segment) order
-            if (i1[u] > i0[u]) { xa += f0[u]; for (int it = i0[u] + 1; it < i1[u]; it++) xa += segsum[it]; }
-            if (j == nf) xa = csum_icpt;
-            if (cg) {
-                const double hv = vv[h + u] * pj[u] + xa;      // Hs[i] = (s[i]*priorVar_inv[i] + Hs[i]) * 1
-                hd[h + u] = hv;
-                accA[0] += vv[h + u] * hv;
-            } else {
-                const double t = vv[h + u] - mm[u];
-                accA[0] += t * t * pj[u];                      // fun :187-188
-                const double hv = t * pj[u] + xa;              // grad :224 (multiplier 1)
-                hd[h + u] = hv;
-                Hd[j] = hv;
-                accA[1] += hv * hv;
-                if (phase == PH_EVAL0) {
-                    const double g0 = (0.0 - mm[u]) * pj[u] + cc[u];      // grad(0)
-                    accA[2] += g0 * g0;
-                }
-            }
-        }
-    }
-    {
-        double a3[3] = {accA[0], accA[1], accA[2]};
-        block_allreduce_sum<3>(a3, scratch);
-        accA[0] = a3[0]; accA[1] = a3[1]; accA[2] = a3[2];
-        accA[3] = loss;                                        // chunk 0 carries the loss, the others add 0
-    }
-    step_exchange<4>(accA, pr.pA + wg * STEP_NP, pr.pA, nwg, pr.xs, 0, seq, shtot, stage, sh_i + 1, ctl);
-
-    if (!cg) {
-        // ---- PH_EVAL0 / PH_EVAL: phase B of the unfused step, with w_new and the gradient candidate still in registers
-        const EvalDecision D = eval_decide(pr, phase, accA);
-        double *__restrict__ w = pr.w, *__restrict__ w_new = pr.w_new, *__restrict__ g = pr.g;
-        double *__restrict__ r0 = pr.rb[0];
-        if (!(D.copy_w || D.copy_g || D.start)) return;
-#pragma unroll
-        for (int h = 0; h < FUSE_CPT; h += STEP_XB) {
-            double gv[STEP_XB], wv[STEP_XB];
-#pragma unroll
-            for (int u = 0; u < STEP_XB; u++) {
-                const int jc = min(j0 + tid + (h + u) * STEP_T, j1 - 1);
-                gv[u] = D.copy_g ? 0.0 : g[jc];
-                wv[u] = (D.nullstep && !D.copy_w) ? w[jc] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < STEP_XB; u++) {
-                const int j = j0 + tid + (h + u) * STEP_T;
-                if (j >= j1) continue;
-                if (D.copy_w) w[j] = vv[h + u];
-                if (D.copy_g) g[j] = hd[h + u];
-                if (D.start) {
-                    // trcg prologue (:133-141): s = 0, r = -g, d = r
-                    const double gj = D.copy_g ? hd[h + u] : gv[u];
-                    const double rj = -gj;
-                    s[j] = 0.0; r0[j] = rj; d[j] = rj;
-                    // the CG loop exits at once with s = 0: the (null) step is evaluated like any other
-                    if (D.nullstep) w_new[j] = (D.copy_w ? vv[h + u] : wv[u]) + 1.0 * 0.0;
-                }
-            }
-        }
-        return;
-    }
-
-    // ---- phase B (CG): s += alpha d ; r' = r - alpha Hd (kept in registers and written to the other residual buffer)
-    const double alpha = pr.rTr / accA[0], nalpha = -alpha;
-    const double *__restrict__ rc = pr.rb[pr.rsel];
-    double *__restrict__ rn = pr.rb[pr.rsel ^ 1];
-    double r1[FUSE_CPT];
-    double accB[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int h = 0; h < FUSE_CPT; h += STEP_XB) {
-        double sv[STEP_XB], rv[STEP_XB];
-#pragma unroll
-        for (int u = 0; u < STEP_XB; u++) {
-            const int jc = min(j0 + tid + (h + u) * STEP_T, j1 - 1);
-            sv[u] = s[jc]; rv[u] = rc[jc];
-        }
-#pragma unroll
-        for (int u = 0; u < STEP_XB; u++) {
-            const int j = j0 + tid + (h + u) * STEP_T;
-            r1[h + u] = 0.0;
-            if (j >= j1) continue;
-            const double dv = vv[h + u];
-            const double s1 = sv[u] + alpha * dv;                      // daxpy(alpha, d, s)
-            s[j] = s1;
-            accB[0] += s1 * s1;
-            const double sb = s1 + nalpha * dv;                        // the boundary case steps back first (:153)
-            accB[1] += sb * dv;
-            accB[2] += sb * sb;
-            accB[3] += dv * dv;
-            const double rr = rv[u] + nalpha * hd[h + u];              // daxpy(-alpha, Hd, r)
-            r1[h + u] = rr;
-            rn[j] = rr;
-            accB[4] += rr * rr;
-        }
-    }
-    block_allreduce_sum<5>(accB, scratch);
-    step_exchange<5>(accB, pr.pB + wg * STEP_NP, pr.pB, nwg, pr.xs, 1, seq, shtot, stage, sh_i + 1, ctl);
-
-    // ---- phase C
-    const CgDecision D = cg_decide(pr, accA, accB);
-    const bool boundary = D.boundary, end_cg = D.end_cg;
-    const double alpha2 = D.alpha2, nalpha2 = -D.alpha2, beta = D.beta;
-    const double *__restrict__ w = pr.w, *__restrict__ g = pr.g;
-    double *__restrict__ w_new = pr.w_new;
-    double accC[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-    for (int h = 0; h < FUSE_CPT; h += STEP_XB) {
-        double sv[STEP_XB], rv[STEP_XB], wv[STEP_XB], gv[STEP_XB];
-#pragma unroll
-        for (int u = 0; u < STEP_XB; u++) {
-            const int jc = min(j0 + tid + (h + u) * STEP_T, j1 - 1);
-            sv[u] = (boundary || end_cg) ? s[jc] : 0.0;                // (this thread's own store of phase B)
-            rv[u] = boundary ? rc[jc] : 0.0;
-            wv[u] = end_cg ? w[jc] : 0.0;
-            gv[u] = end_cg ? g[jc] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < STEP_XB; u++) {
-            const int j = j0 + tid + (h + u) * STEP_T;
-            if (j >= j1) continue;
-            const double dv = vv[h + u];
-            double sf = sv[u], rf = r1[h + u];
-            if (boundary) {
-                const double sb = sv[u] + nalpha * dv;                 // daxpy(-alpha, d, s)
-                sf = sb + alpha2 * dv;                                 // daxpy(alpha', d, s)
-                s[j] = sf;
-                rf = rv[u] + nalpha2 * hd[h + u];                      // daxpy(-alpha', Hd, r)
-                rn[j] = rf;
-            } else {
-                double dj = dv;
-                if (beta != 1.0) dj = dj * beta;                       // scale(beta, d)
-                d[j] = dj + 1.0 * r1[h + u];                           // daxpy(one, r, d)
-            }
-            if (end_cg) {
-                // back in tron(): w_new = w + s, gs, prered (:69-73)
-                w_new[j] = wv[u] + 1.0 * sf;
-                accC[0] += gv[u] * sf;
-                accC[1] += sf * rf;
-                accC[2] += sf * sf;
-            }
-        }
-    }
-    if (!end_cg) return;
-    block_allreduce_sum<3>(accC, scratch);
-    if (tid == 0) {
-        double *__restrict__ px = pr.pC + wg * STEP_NP;
-        px[0] = accC[0]; px[1] = accC[1]; px[2] = accC[2];
-    }
-}
+#ifdef MLX_EXPERIMENTAL
+#include "mlx_experimental_step.inc"     // the three step phases in one launch (MLX_STEP_FUSED=1): measured slower
+#endif
 
 // ---- commit: one workgroup per problem writes the scalars of the tick ---------------------------------------------
 __global__ void __launch_bounds__(STEP_T)
@@ -3016,6 +2491,7 @@ int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const i
     return 0;
 }
 
+#ifdef MLX_EXPERIMENTAL
 // Shared-X passes of a lambda sweep: plist = first problem of every CSR partition (its n_lambda problems are consecutive)
 void mlxk_xpass_multi(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *plist, int np, int nl, int R, int maxblk,
                       bool hasval, int max_cunits, int max_rblk_rows, int row_slw, int row_ngc, bool row_multi, int which)
@@ -3044,6 +2520,7 @@ void mlxk_xpass_multi(hipStream_t st, const PartDev *parts, ProbDev *probs, cons
 #undef LCOL
     }
 }
+#endif
 
 void mlxk_tron_step(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int threads,
                     int *done_counter)
@@ -3062,12 +2539,14 @@ void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *p
     else hipLaunchKernelGGL(k_step_commit, dim3((unsigned)nq), dim3(STEP_T), 0, st, parts, probs, qlist, ch, done_counter, ctl);
 }
 
+#ifdef MLX_EXPERIMENTAL
 // phases A, B and C in one launch (ch must be FUSE_CH = 2048 and max_nwg <= 256); the commit launch follows as before
 void mlxk_step_fused(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int max_nwg, unsigned seq, int *ctl)
 {
     if (nq <= 0) return;
     hipLaunchKernelGGL(k_step_fused, dim3((unsigned)max_nwg * (unsigned)nq), dim3(STEP_T), 0, st, parts, probs, qlist, max_nwg, seq, ctl);
 }
+#endif
 
 void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int first, bool hasval,
                       int max_ticks, int *done_counter, int lds_doubles, bool faithful)

@@ -39,18 +39,23 @@ class MlxStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
-_lib = None
+EXP_LIB_PATH = os.path.join(_HERE, "csrc", "libmlease_hip_exp.so")    # the same sources + -DMLX_EXPERIMENTAL (csrc/Makefile): tests only
+_libs = {}
 
 
-def load_library():
-    """dlopen the in-tree HIP library; raises (never falls back) when it is missing."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load_library(experimental: Optional[bool] = None):
+    """dlopen the in-tree HIP library; raises (never falls back) when it is missing. experimental=True (or MLX_EXPERIMENTAL=1
+    in the environment when an engine is constructed) loads libmlease_hip_exp.so instead: the product code plus the
+    measured-slower / test-only pieces kept as evidence (fused step, shared-X lambda-sweep passes, in-process communicator)."""
+    if experimental is None:
+        experimental = os.environ.get("MLX_EXPERIMENTAL", "0") not in ("", "0")
+    path = EXP_LIB_PATH if experimental else LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise RuntimeError("HIP extension missing: %s (run `python -c 'import __graft_entry__ as g; g.build()'`); "
-                           "the MI355X path has no CPU fallback" % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+                           "the MI355X path has no CPU fallback" % path)
+    L = C.CDLL(path)
     vp, i32, i64, f64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_float
     L.mlx_version.restype = C.c_char_p
     L.mlx_last_error.restype = C.c_char_p
@@ -83,7 +88,7 @@ def load_library():
     L.mlx_score_rows.argtypes = [vp, i32, vp, i32, i64, vp, vp, vp, vp, vp]
     L.mlx_comm_get_unique_id.argtypes = [vp]
     L.mlx_comm_init.argtypes = [vp, vp, i32, i32]
-    _lib = L
+    _libs[path] = L
     return L
 
 

@@ -1,0 +1,141 @@
+"""N > 1 control flow on ONE GPU (-m gpu): what the first real 8-GPU run must not be the first execution of.
+
+  * bench.py under torch.distributed.run with 2 ranks sharing device 0 (MLX_BENCH_SHARE_GPU=1: collectives over gloo through
+    host staging) -- sharding k -> rank k mod N, the [xbar | ubar] exchange, the max / sum reductions of the report, the
+    sparse configs[3] leg and the lambda-sweep leg -- against the one-rank run of the same job, bit for bit on the dense job;
+  * the library's own exchange between several handles (what the Java host / the CLI's `gpus=0,1,..` use: mlx_comm_init +
+    mlx_admm_iterate), two handles on two threads over the in-process communicator of the experimental build, including a
+    rank whose solve fails (the status slot of the all-reduce: jobs/RegressionAdmmTrain.java:355-364 fails the whole job
+    when any reducer throws; utils/LinearModelUtils.java:77-84 refuses a mean over fewer models than num.blocks).
+"""
+import copy
+import json
+import os
+import socket
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+import mlease_amd  # noqa: F401
+from mlease_amd import dataset
+from mlease_amd.hip_engine import HipAdmmEngine
+from fixtures import load_c1
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _bench(cmd, env):
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stderr[-3000:], r.stdout[-500:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_bench_two_ranks_on_one_gpu_reproduce_the_one_rank_consensus():
+    flags = ["--steps", "3", "--warmup", "1", "--rows", "65536", "--partitions", "8", "--no-cpu-baseline", "--no-gram", "--loglik-iters", "3",
+             "--test-rows", "4096", "--sparse-rows", "160000", "--sparse-partitions", "8", "--sparse-steps", "2", "--sparse-warmup", "1",
+             "--sparse-cpu-sample", "0", "--sweep-partitions", "2", "--sweep-steps", "1", "--sweep-warmup", "1", "--sweep-cpu-sample", "0"]
+    # the dense chunking adapts to the work a handle holds; pinned here so that one rank with 8 partitions and two
+    # ranks with 4 each add the same partial sums in the same order
+    env = dict(os.environ, MLX_DENSE_RPB="256")
+    env.pop("MLX_BENCH_SHARE_GPU", None)
+    one = _bench([sys.executable, "bench.py"] + flags, env)
+    env2 = dict(env, MLX_BENCH_SHARE_GPU="1")
+    two = _bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                  "--master-port", str(_free_port()), "bench.py", "--gpus", "2"] + flags, env2)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and "test_mode" in two
+    assert two["config"]["partitions"] == 8 and two["config"]["partitions_per_gpu"] == 4 and two["scaling"] == "strong"
+    assert two["work"]["solves"] == one["work"]["solves"] == 24
+    assert two["work"]["last_maxdiff"] == one["work"]["last_maxdiff"]
+    assert two["work"]["z32_sha1_after_timed_steps"] == one["work"]["z32_sha1_after_timed_steps"]
+    assert two["time_to_ref_loglik"]["loglik_by_iteration"] == one["time_to_ref_loglik"]["loglik_by_iteration"]
+    # the sparse legs: same job sharded (the consensus sum associates differently and one-hot solves amplify that)
+    for leg, nprob in (("sparse", 8 * 2), ("lambda_sweep", None)):
+        assert two[leg]["n_gpus"] == 2 and two[leg]["value"] > 0 and one[leg]["value"] > 0
+    assert abs(two["sparse"]["last_maxdiff"] - one["sparse"]["last_maxdiff"]) <= 0.05 * abs(one["sparse"]["last_maxdiff"])
+    assert two["lambda_sweep"]["problems_per_gpu"] == 2 * 8
+
+
+def _run_ranks(engs, fn):
+    out, err = [None] * len(engs), [None] * len(engs)
+
+    def work(r):
+        try:
+            out[r] = fn(r, engs[r])
+        except Exception as e:          # noqa: BLE001 -- handed to the asserting thread
+            err[r] = e
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(len(engs))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in ts), "a rank is blocked in the exchange"
+    return out, err
+
+
+def _two_handles(blocks, n_global, lam, rho, monkeypatch):
+    monkeypatch.setenv("MLX_EXPERIMENTAL", "1")        # libmlease_hip_exp.so: the in-process communicator is not product code
+    monkeypatch.setenv("MLX_COMM_LOCAL", "1")
+    engs = []
+    for r in range(2):
+        e = HipAdmmEngine(n_global, lam, rho, len(blocks))
+        for b in blocks[r::2]:
+            e.add_partition(b)                          # partition k -> handle k mod 2
+        e.finalize()
+        engs.append(e)
+    uid = HipAdmmEngine.comm_unique_id()
+    _, err = _run_ranks(engs, lambda r, e: e.comm_init(uid, 2, r))
+    assert err == [None, None], err
+    return engs
+
+
+def test_two_handles_exchange_inside_the_library(monkeypatch):
+    c1 = load_c1()
+    lam, rho = [1.0, 10.0], [1.0, 1.0]
+    ref = HipAdmmEngine(c1.n_global, lam, rho, 8)
+    for b in c1.blocks:
+        ref.add_partition(b)
+    ref.finalize()
+    engs = _two_handles(c1.blocks, c1.n_global, lam, rho, monkeypatch)
+    ref.naive_init(0.01)
+    _, err = _run_ranks(engs, lambda r, e: e.naive_init(0.01))
+    assert err == [None, None], err
+    for it in range(4):
+        sref = ref.iterate(0.01)
+        out, err = _run_ranks(engs, lambda r, e: e.iterate(0.01))
+        assert err == [None, None], err
+        z0, z1, zr = engs[0].z()[0], engs[1].z()[0], ref.z()[0]
+        assert np.array_equal(z0, z1), "iteration %d: the two ranks hold different consensus models" % (it + 1)
+        # per-handle partial means summed in rank order vs one handle's sum over all 8: association only
+        assert np.max(np.abs(z0 - zr)) <= 1e-5 * np.max(np.abs(zr))
+        assert abs(out[0].maxdiff - sref.maxdiff) <= 1e-9 and out[0].maxdiff == out[1].maxdiff
+        assert out[0].solves + out[1].solves == sref.solves == 16
+    for e in engs + [ref]:
+        e.close()
+
+
+def test_two_handles_failed_rank_fails_both(monkeypatch):
+    """The partition with a NaN offset lives on rank 1: rank 1 reports its own failure, rank 0 -- whose solves were fine --
+    learns it from the status slot, and neither blocks."""
+    c1 = load_c1()
+    blocks = [copy.copy(b) for b in c1.blocks]
+    bad = copy.copy(blocks[3])
+    bad.offset = bad.offset.copy()
+    bad.offset[5] = np.nan
+    blocks[3] = bad
+    engs = _two_handles(blocks, c1.n_global, [1.0], [1.0], monkeypatch)
+    _, err = _run_ranks(engs, lambda r, e: e.iterate(0.01))
+    assert all(isinstance(e, dataset.ModelFittingError) for e in err), err
+    assert "another rank" in str(err[0]) and "another rank" not in str(err[1])
+    for e in engs:
+        e.close()

@@ -789,6 +789,7 @@ def test_lambda_sweep_shared_x_passes(binary, nlam, monkeypatch):
     lambda instead, jobs/RegressionAdmmTrain.java:553-568). Per problem the result must be the per-problem kernels' result:
     TRON/CG counters equal to the oracle's, coefficients within 1e-5, lambdas finishing at different ticks included."""
     monkeypatch.setenv("MLX_NO_SMALL", "1")
+    monkeypatch.setenv("MLX_EXPERIMENTAL", "1")             # libmlease_hip_exp.so: the product library does not contain these passes
     monkeypatch.setenv("MLX_MULTI", "1")                    # opt-in: measured slower than the per-problem passes (DESIGN 4)
     pd = synth_sparse(23, 9000, 400, 14, 3, binary=binary, weights=not binary, offsets=not binary)
     lam = [0.05, 0.3, 1.0, 3.0, 10.0, 30.0, 100.0, 300.0][:nlam]
@@ -804,6 +805,7 @@ def test_lambda_sweep_shared_x_passes(binary, nlam, monkeypatch):
     eng.close()
     # the same sweep on the (default) per-problem passes: same trajectories
     monkeypatch.delenv("MLX_MULTI")
+    monkeypatch.delenv("MLX_EXPERIMENTAL")                  # ... of the product library
     eng2 = make_engine(pd, lam, rho)
     for it in range(4):
         eng2.iterate(0.01)
@@ -894,6 +896,7 @@ def test_fused_step_is_bit_identical_to_the_three_launch_step(kind, monkeypatch)
     finishing at different ticks."""
     from fixtures import onehot_blocks
     monkeypatch.setenv("MLX_NO_SMALL", "1")
+    monkeypatch.setenv("MLX_EXPERIMENTAL", "1")             # k_step_fused lives in libmlease_hip_exp.so only
     if kind == "onehot":
         pd, lam, rho, iters = onehot_blocks(160000, 4), [1.0], [1.0], 5
     elif kind == "wide":

@@ -31,6 +31,23 @@ def test_abi_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.mlx_version()
 
 
+def test_product_library_holds_no_experimental_code():
+    """Round-2 finding: ~700 lines of opt-in, measured-slower or test-only code (fused step, shared-X lambda-sweep passes, the
+    in-process communicator) were compiled into the product library. They now live in csrc/mlx_experimental_*.inc / behind
+    MLX_EXPERIMENTAL and are built into libmlease_hip_exp.so only, which exports the same C-ABI."""
+    csrc = os.path.join(ROOT, "ml-ease_amd", "csrc")
+    prod = open(os.path.join(csrc, "libmlease_hip.so"), "rb").read()
+    exp = open(os.path.join(csrc, "libmlease_hip_exp.so"), "rb").read()
+    for name in (b"k_step_fused", b"k_colpass_multi", b"k_rowpass_multi", b"mlxk_step_fused", b"mlxk_xpass_multi", b"LocalComm"):
+        assert name not in prod, name
+        assert name in exp, name
+    assert b"experimental" not in hip_engine.load_library(False).mlx_version()
+    xl = hip_engine.load_library(True)
+    assert b"+experimental" in xl.mlx_version()
+    for sym in hip_engine.ABI_SYMBOLS:
+        assert hasattr(xl, sym), sym
+
+
 def test_threaded_cholesky_inverse_is_bit_identical_to_the_sequential_order():
     """The posterior covariance's host-side Cholesky + inverse (commons-math3's loops, llf/LibLinear.java:321-325) is
     threaded over rows / columns without changing any element's operation order: any thread count gives the same bits,

@@ -273,7 +273,9 @@ def test_cli_several_handles_in_one_process(tmp_path, c1):
         job = tmp_path / (tag + ".job")
         job.write_text("input.paths=%s\noutput.base.path=%s\ntest.path=%s\nnum.blocks=8\nlambda=1.0,10\nnum.iters=6\nregularizer=2\n"
                        "map.key=pkey\ninitialize.boost.rate=2.0\ngpus=%s\n" % (tmp_path / "in", tmp_path / ("out_" + tag), tmp_path / "test", gpus))
-        env = dict(os.environ, MLX_COMM_LOCAL="1")
+        # the in-process communicator is experimental-build code: the CLI is linked against libmlease_hip.so, so the
+        # experimental build under that name (csrc/exp/) is put first on the loader's path for this run
+        env = dict(os.environ, MLX_COMM_LOCAL="1", LD_LIBRARY_PATH=os.path.join(os.path.dirname(HOST), "csrc", "exp") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
         r = subprocess.run([os.path.join(HOST, "mlease_admm_train"), str(job)], capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[tag] = (admm.read_linear_models(str(tmp_path / ("out_" + tag) / "final-model" / "part-r-00000.avro"), c1.feature_names),
