@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--sweep-steps", type=int, default=3)
     ap.add_argument("--sweep-warmup", type=int, default=1)
     ap.add_argument("--sweep-cpu-sample", type=int, default=8, help="partitions (x 8 lambdas) of the lambda-sweep CPU / parity sample (0 = skip)")
-    ap.add_argument("--sparse-cpu-sample", type=int, default=64, help="partitions of the sparse CPU-baseline / parity sample (0 = skip)")
+    ap.add_argument("--sparse-cpu-sample", type=int, default=256, help="partitions of the sparse CPU-baseline / parity sample (0 = skip)")
     args = ap.parse_args()
 
     # stdout must carry exactly ONE line (the JSON): anything a library prints to fd 1 (RCCL prints a version banner
@@ -713,7 +713,8 @@ def sparse_checks(args, C, eng, blocks, ng, Ptot, snap, eps_all, step_s, res, la
       (c) cpu_baseline: the oracle on `--sparse-cpu-sample` partitions for the SAME timed iterations, each solve started from the
           GPU's own state at that iteration (z, u_k: the solves of one iteration are independent given the state);
       (b) product path, solve level: the GPU's beta_k of those solves against the oracle's, beside the oracle's distance to
-          ITSELF on row-permuted partitions (an order Hadoop does not define, llf/LibLinearDataset.java:467-478);
+          ITSELF on row-permuted partitions (an order Hadoop does not define; the features are renumbered in first-seen order of
+          the permuted rows, as the reference's own indexing would: llf/LibLinearDataset.java:467-482);
       (a) order-faithful mode (MLX_FAITHFUL=1) against the oracle twin (portable exp/log1p) on 8 of them: counters equal and
           every float32 output bit-identical;
       (b') product path, ADMM level: the first 8 partitions as a closed 8-block job from z = 0: |z_gpu - z_oracle| next to
@@ -747,7 +748,7 @@ def sparse_checks(args, C, eng, blocks, ng, Ptot, snap, eps_all, step_s, res, la
         ui = np.stack([np.stack([eng.partition_model(k, li)[2] for li in range(nl)]) for k in range(ns)])
     # (c) + (b): oracle and row-permuted oracle from the same states
     oc = ol.OracleAdmm(blocks[:ns], ng, lam, rho, num_blocks=Ptot)
-    ocp = ol.OracleAdmm([permute_rows(b, 7 + i) for i, b in enumerate(blocks[:nv])], ng, lam, rho, num_blocks=Ptot)
+    ocp = ol.OracleAdmm([permute_rows(b, 7 + i, relabel=True) for i, b in enumerate(blocks[:nv])], ng, lam, rho, num_blocks=Ptot)
     threads = min(usable_cores(), ns * nl)
     cdt, solves, passes = 0.0, 0, 0
     per_it, ob_all = [], []
@@ -835,7 +836,7 @@ def sparse_checks(args, C, eng, blocks, ng, Ptot, snap, eps_all, step_s, res, la
     engs.add_partitions(sub)
     engs.finalize()
     ocs = ol.OracleAdmm(sub, ng, [1.0], [1.0])
-    ocsp = ol.OracleAdmm([permute_rows(b, 1007 + i) for i, b in enumerate(sub)], ng, [1.0], [1.0])
+    ocsp = ol.OracleAdmm([permute_rows(b, 1007 + i, relabel=True) for i, b in enumerate(sub)], ng, [1.0], [1.0])
     sched = EpsSchedule(C["admm"])
     run = []
     for it in range(1, len(eps_all) + 1):

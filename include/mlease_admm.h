@@ -191,6 +191,11 @@ int mlx_get_partition_model(mlx_handle h, int32_t local_index, int32_t lambda_in
 /* Per-problem counters of the last solve: out[q*4 + {0,1,2,3}] = newton_iters, accepted, cg_iters,
  * x_passes_ref for q = local_index*n_lambda + lambda_index. */
 int mlx_get_solve_counters(mlx_handle h, int32_t *out);
+/* Dimensions a host needs to size (or check) its arrays: out[0..5] = n_global, n_lambda, partitions held by this handle,
+ * num.blocks, and -- for the local partition `local_index` (add order; -1: zeros) -- its n_local and its row count l.
+ * No reference counterpart: the Java code sizes everything by HashMap; the JNI glue (jni/mlease_jni.c) uses it to turn a
+ * wrongly sized Java array into an IllegalArgumentException instead of a native out-of-bounds access. */
+int mlx_get_dims(mlx_handle h, int32_t local_index, int32_t out[6]);
 
 /* ---- test log-likelihood per iteration (jobs/RegressionAdmmTrain.java:766-811, updateLogLikBestModel :812-845) ----
  * Upload the test rows once (the reference re-reads the first file under test.path, <= 1 000 000 rows, every

@@ -101,6 +101,8 @@ public final class MleaseHip implements AutoCloseable
                                        float[] uNextOrNull) throws IOException;             // mlx_get_partition_model
   /** out[q*4 + {0,1,2,3}] = newton, accepted, cg, xPassesRef for q = localIndex*nLambda + lambdaIndex. */
   public native void getSolveCounters(int[] out) throws IOException;                        // mlx_get_solve_counters
+  /** {nGlobal, nLambda, local partitions, num.blocks, nLocal and rows of partition localIndex (0, 0 for -1)}. */
+  public native int[] dims(int localIndexOrMinus1) throws IOException;                      // mlx_get_dims
 
   // ---- test log-likelihood per iteration (RegressionAdmmTrain.java:766-845) ------------------------------------------
   public native void setTestData(long[] rowPtr, int[] globalIdx, double[] valOrNull, byte[] response,

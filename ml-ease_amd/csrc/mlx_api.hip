@@ -1617,6 +1617,16 @@ int mlx_get_solve_counters(mlx_handle h, int32_t *out)
     return MLX_OK;
 }
 
+int mlx_get_dims(mlx_handle h, int32_t local_index, int32_t out[6])
+{
+    if (!h || !out) return fail(h, MLX_ERR_INVALID, "mlx_get_dims: NULL argument");
+    if (local_index < -1 || local_index >= (int32_t)h->parts.size()) return fail(h, MLX_ERR_INVALID, "local_index %d out of range", local_index);
+    out[0] = h->n_global; out[1] = h->n_lambda; out[2] = (int32_t)h->parts.size(); out[3] = h->num_blocks;
+    out[4] = local_index >= 0 ? h->parts[(size_t)local_index].n_local : 0;
+    out[5] = local_index >= 0 ? h->parts[(size_t)local_index].l : 0;
+    return MLX_OK;
+}
+
 int mlx_solve_one(mlx_handle h, int32_t local_index, double *w, const double *prior_mean, const double *prior_var,
                   double epsilon, int32_t max_iter, int32_t *counters4, double *f_out, double *gnorm_out, double *gnorm1_out)
 {

@@ -13,7 +13,9 @@
 //   * fun and grad share one pass; after a rejected step the trial D is discarded (wd double buffer);
 //   * grad(0)'s data term X' t0 is a per-partition constant (c0), computed once at upload.
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <stdint.h>
 
 #include "mlx_kernels.h"
@@ -2401,6 +2403,27 @@ __global__ void k_round_z(int64_t n, const double *__restrict__ Z, float *__rest
                                 (4 * NV * 256 + 16) * sizeof(double), st, parts, probs, qlist);                           \
     } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT DEVICE: with one handle + one thread per device in a
+// process (the CLI's gpus=0,1,..; a JVM host) every device needs its own call, and two threads must not race on the flag.
+// fn runs once per (launcher slot, device), under a lock; a failing call is reported (the launch that follows then fails loudly).
+template <typename F>
+static void per_device_once(int slot, F &&fn)
+{
+    static std::mutex mu;
+    static bool done[8][64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { fn(); return; }
+    std::lock_guard<std::mutex> lk(mu);
+    if (done[slot][dev]) return;
+    fn();
+    done[slot][dev] = true;
+}
+static void set_max_lds(const void *func, int bytes)
+{
+    const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) fprintf(stderr, "[mlease_hip] hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed: %s\n", bytes, hipGetErrorString(e));
+}
+
 int mlxk_xpass_dense(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
                      int max_nfeat, bool stream_once)
 {
@@ -2409,14 +2432,10 @@ int mlxk_xpass_dense(hipStream_t st, const PartDev *parts, ProbDev *probs, const
     else if (max_nfeat <= 512) LAUNCH_DENSE(2, 4);
     else if (max_nfeat <= 1024) LAUNCH_DENSE(4, 4);
     else if (max_nfeat <= 2048) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xpass_dense<8, 2, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (4 * 8 * 256 + 16) * (int)sizeof(double));
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xpass_dense<8, 2, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (4 * 8 * 256 + 16) * (int)sizeof(double));
-            attr_set = true;
-        }
+        per_device_once(0, [&] {
+            set_max_lds(reinterpret_cast<const void *>(&k_xpass_dense<8, 2, true>), (4 * 8 * 256 + 16) * (int)sizeof(double));
+            set_max_lds(reinterpret_cast<const void *>(&k_xpass_dense<8, 2, false>), (4 * 8 * 256 + 16) * (int)sizeof(double));
+        });
         LAUNCH_DENSE(8, 2);
     }
     else return -1;
@@ -2441,18 +2460,16 @@ int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const i
     if (nq <= 0) return 0;
     if (sell) {
         const size_t lds_col = ((size_t)max_rblk_rows + 1) * sizeof(double), lds_row = ((size_t)row_slw + 1) * sizeof(double);
-        static bool attr_set = false;
-        if (!attr_set) {
+        per_device_once(1, [&] {
 #define SETLDS(HV, NTF)                                                                                                                        \
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_colpass_lds<HV, NTF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); \
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowpass_lds<HV, NTF, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); \
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowpass_lds<HV, NTF, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); \
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowpass_lds<HV, NTF, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); \
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowpass_lds<HV, NTF, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512)
+            set_max_lds(reinterpret_cast<const void *>(&k_colpass_lds<HV, NTF>), 160 * 1024 - 64); \
+            set_max_lds(reinterpret_cast<const void *>(&k_rowpass_lds<HV, NTF, 1>), 160 * 1024 - 512); \
+            set_max_lds(reinterpret_cast<const void *>(&k_rowpass_lds<HV, NTF, 2>), 160 * 1024 - 512); \
+            set_max_lds(reinterpret_cast<const void *>(&k_rowpass_lds<HV, NTF, 4>), 160 * 1024 - 512); \
+            set_max_lds(reinterpret_cast<const void *>(&k_rowpass_lds<HV, NTF, 8>), 160 * 1024 - 512)
             SETLDS(true, true); SETLDS(true, false); SETLDS(false, true); SETLDS(false, false);
 #undef SETLDS
-            attr_set = true;
-        }
+        });
 #define LAUNCH_ROW(HV, NTF, GP) hipLaunchKernelGGL((k_rowpass_lds<HV, NTF, GP>), dim3(XGRID(nq, maxblk)), dim3(1024), lds_row, st, parts, probs, qlist, nq, maxblk, cold_groups > 0 ? 1 : 0)
 #define LAUNCH_SELL(HV, NTF)                                                                                                                   \
         do {                                                                                                                                   \
@@ -2498,17 +2515,15 @@ void mlxk_xpass_multi(hipStream_t st, const PartDev *parts, ProbDev *probs, cons
 {
     if (np <= 0) return;
     const size_t lds_col = (size_t)R * ((size_t)max_rblk_rows + 1) * sizeof(double), lds_row = ((size_t)row_slw + 1) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
+    per_device_once(2, [&] {
 #define SETM(HV)                                                                                                                              \
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_colpass_multi<HV, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); \
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_colpass_multi<HV, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); \
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_colpass_multi<HV, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)
+        set_max_lds(reinterpret_cast<const void *>(&k_colpass_multi<HV, false, 2>), 160 * 1024 - 64); \
+        set_max_lds(reinterpret_cast<const void *>(&k_colpass_multi<HV, false, 4>), 160 * 1024 - 64); \
+        set_max_lds(reinterpret_cast<const void *>(&k_colpass_multi<HV, false, 8>), 160 * 1024 - 64)
         SETM(true); SETM(false);
 #undef SETM
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rowpass_multi<false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        attr_set = true;
-    }
+        set_max_lds(reinterpret_cast<const void *>(&k_rowpass_multi<false, false, 1>), 160 * 1024 - 512);
+        });
     // (the shared row pass exists for binary.feature partitions, one row group per wave: its packs stay in registers across
     // the lambda loop, and a float4 of values per pack or a second group does not fit beside them)
     if ((which & 1) && row_multi && !hasval && row_ngc == 16)
@@ -2558,12 +2573,10 @@ void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, int 
     }
     // lds_doubles > 0: the work vectors of every problem fit in LDS (that many doubles for the largest) -> LDS-resident solve
     if (lds_doubles > 0) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_small<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_solve_small<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            attr_set = true;
-        }
+        per_device_once(3, [&] {
+            set_max_lds(reinterpret_cast<const void *>(&k_solve_small<true, true, false>), 150 * 1024);
+            set_max_lds(reinterpret_cast<const void *>(&k_solve_small<false, true, false>), 150 * 1024);
+        });
         const size_t bytes = (size_t)lds_doubles * sizeof(double);
         if (hasval) hipLaunchKernelGGL((k_solve_small<true, true, false>), dim3(nprob), dim3(1024), bytes, st, parts, probs + first, nprob, max_ticks, done_counter);
         else hipLaunchKernelGGL((k_solve_small<false, true, false>), dim3(nprob), dim3(1024), bytes, st, parts, probs + first, nprob, max_ticks, done_counter);

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "mlx_create", "mlx_destroy", "mlx_last_error", "mlx_set_stream", "mlx_set_profiling", "mlx_set_problem",
     "mlx_set_regularizer", "mlx_add_partition_csr", "mlx_add_partitions_csr", "mlx_add_partition_dense", "mlx_finalize", "mlx_set_state",
     "mlx_admm_iterate", "mlx_admm_solve_local", "mlx_naive_init", "mlx_naive_solve_local", "mlx_naive_finish", "mlx_consensus_buffer", "mlx_admm_consensus_finish", "mlx_get_z",
-    "mlx_get_partition_model", "mlx_get_solve_counters", "mlx_set_test_data", "mlx_test_loglik", "mlx_solve_one", "mlx_posterior_variance", "mlx_score_rows", "mlx_comm_get_unique_id", "mlx_comm_init",
+    "mlx_get_partition_model", "mlx_get_solve_counters", "mlx_get_dims", "mlx_set_test_data", "mlx_test_loglik", "mlx_solve_one", "mlx_posterior_variance", "mlx_score_rows", "mlx_comm_get_unique_id", "mlx_comm_init",
     "mlx_version",
 ]
 
@@ -81,6 +81,7 @@ def load_library(experimental: Optional[bool] = None):
     L.mlx_get_z.argtypes = [vp, vp, vp]
     L.mlx_get_partition_model.argtypes = [vp, i32, i32, vp, vp, vp]
     L.mlx_get_solve_counters.argtypes = [vp, vp]
+    L.mlx_get_dims.argtypes = [vp, i32, vp]
     L.mlx_set_test_data.argtypes = [vp, i32, i64, vp, vp, vp, vp, vp, vp]
     L.mlx_test_loglik.argtypes = [vp, vp]
     L.mlx_solve_one.argtypes = [vp, i32, vp, vp, vp, f64, i32, vp, vp, vp, vp]
@@ -277,6 +278,11 @@ class HipAdmmEngine:
         out = np.zeros(self.n_lambda, np.float64)
         self._ck(self.L.mlx_test_loglik(self.h, _p(out)))
         return out
+
+    def dims(self, local_index: int = -1) -> dict:
+        out = np.zeros(6, np.int32)
+        self._ck(self.L.mlx_get_dims(self.h, int(local_index), _p(out)))
+        return dict(zip(("n_global", "n_lambda", "partitions_local", "num_blocks", "n_local", "l"), (int(v) for v in out)))
 
     def solve_counters(self) -> np.ndarray:
         out = np.zeros((self.nlocal * self.n_lambda, 4), np.int32)

@@ -115,13 +115,48 @@ def dense_blocks(rows, nfeat, partitions, seed=9):
     return PartitionedData(blocks, [str(i + 1) for i in range(nfeat)], partitions)
 
 
-def permute_rows(b, seed=0):
-    """Same partition, rows in another order (the reference's row order within a reducer key is unspecified)."""
+def permute_rows(b, seed=0, relabel=False):
+    """Same partition, rows in another order (the reference's row order within a reducer key is unspecified).
+    relabel=True also renumbers the partition-local features the way the reference's indexing would for that row order:
+    ids in first-seen order (llf/LibLinearDataset.java:467-478), every row re-sorted by id (:481-482) -- so the oracle's
+    n-long dots and norms run in another order too, not only its row-order sums."""
     rng = np.random.default_rng(seed)
     perm = rng.permutation(b.l)
     lens = np.diff(b.row_ptr)
     rp = np.concatenate([[0], np.cumsum(lens[perm])]).astype(np.int64)
     starts = np.repeat(b.row_ptr[:-1][perm] - rp[:-1], lens[perm])
     idx = np.arange(rp[-1], dtype=np.int64) + starts
-    return PartitionBlock(b.partition_id, b.l, b.n_local, rp, b.col_idx[idx], None if b.val is None else b.val[idx],
-                          b.y[perm], b.weight[perm], b.offset[perm], b.local_to_global)
+    cols = b.col_idx[idx]
+    vals = None if b.val is None else b.val[idx]
+    l2g = b.local_to_global
+    if relabel:
+        nf = b.n_local - 1
+        uniq, first = np.unique(cols, return_index=True)
+        seen = uniq[np.argsort(first, kind="stable")]                    # features in first-seen order
+        rest = np.setdiff1d(np.arange(nf, dtype=cols.dtype), uniq)       # (never present: keep them behind)
+        order = np.concatenate([seen, rest]).astype(np.int64)
+        newid = np.empty(nf, np.int64)
+        newid[order] = np.arange(nf)
+        cols = newid[cols]
+        rowid = np.repeat(np.arange(b.l, dtype=np.int64), lens[perm])
+        srt = np.lexsort((cols, rowid))                                  # stable: duplicates keep their order
+        cols = cols[srt].astype(np.int32)
+        vals = None if vals is None else vals[srt]
+        l2g = np.concatenate([b.local_to_global[:nf][order], b.local_to_global[nf:]]).astype(np.int32)
+    return PartitionBlock(b.partition_id, b.l, b.n_local, rp, cols, vals, b.y[perm], b.weight[perm], b.offset[perm], l2g)
+
+
+def c1_raw_records(c1, with_key=True):
+    """The C1 fixture back as raw Pig-style records, rows interleaved across partitions like the original file."""
+    recs = []
+    maxl = max(b.l for b in c1.blocks)
+    for i in range(maxl):
+        for b in c1.blocks:
+            if i >= b.l:
+                continue
+            sl = slice(b.row_ptr[i], b.row_ptr[i + 1])
+            feats = [{"name": c1.feature_names[b.local_to_global[c]], "term": "", "value": float(v)}
+                     for c, v in zip(b.col_idx[sl], b.val[sl])]
+            recs.append({"features": feats, "offset": 0, "response": 1 if b.y[i] == 1 else 0, "weight": 1,
+                         "pkey": b.partition_id if with_key else None, "unused": None})
+    return recs

@@ -66,6 +66,8 @@ struct JNINativeInterface_ {
     jstring(JNICALL *NewStringUTF)(JNIEnv *env, const char *utf);
     jsize(JNICALL *GetArrayLength)(JNIEnv *env, jarray array);
     jobject(JNICALL *GetObjectArrayElement)(JNIEnv *env, jobjectArray array, jsize index);
+    jint(JNICALL *EnsureLocalCapacity)(JNIEnv *env, jint capacity);
+    void(JNICALL *DeleteLocalRef)(JNIEnv *env, jobject localRef);
     JNI_ARRAY_FNS(jbyte, Byte)
     JNI_ARRAY_FNS(jint, Int)
     JNI_ARRAY_FNS(jlong, Long)

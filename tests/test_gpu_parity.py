@@ -1028,7 +1028,7 @@ def test_onehot_admm_run_stays_within_the_reference_order_spread():
     train, test = pd.blocks[:8], pd.blocks[8]
     lam, rho = [1.0], [1.0]
     oc = ol.OracleAdmm(train, pd.n_global, lam, rho)
-    ops = [ol.OracleAdmm([permute_rows(b, sd + i) for i, b in enumerate(train)], pd.n_global, lam, rho) for sd in (7, 1007)]
+    ops = [ol.OracleAdmm([permute_rows(b, sd + i, relabel=True) for i, b in enumerate(train)], pd.n_global, lam, rho) for sd in (7, 1007)]
     eng = HipAdmmEngine(pd.n_global, lam, rho, 8)
     eng.add_partitions(train)
     eng.finalize()

@@ -72,20 +72,7 @@ def native_blocks(L, h, nb):
     return out
 
 
-def c1_raw_records(c1, with_key=True):
-    """The C1 fixture back as raw Pig-style records, rows interleaved across partitions like the original file."""
-    recs = []
-    maxl = max(b.l for b in c1.blocks)
-    for i in range(maxl):
-        for b in c1.blocks:
-            if i >= b.l:
-                continue
-            sl = slice(b.row_ptr[i], b.row_ptr[i + 1])
-            feats = [{"name": c1.feature_names[b.local_to_global[c]], "term": "", "value": float(v)}
-                     for c, v in zip(b.col_idx[sl], b.val[sl])]
-            recs.append({"features": feats, "offset": 0, "response": 1 if b.y[i] == 1 else 0, "weight": 1,
-                         "pkey": b.partition_id if with_key else None, "unused": None})
-    return recs
+from fixtures import c1_raw_records  # noqa: E402
 
 
 @pytest.fixture(scope="module")
