@@ -387,6 +387,10 @@ def loglik_run(args, C, eng, P, nf, N, rows_total):
     default_job = (rows_total == ROWS and nf == NFEAT and N == PARTS and lt == 100000)
     zpath = os.path.join(ROOT, "tests", "golden", "c2_ref_z.npz")
     gz = np.load(zpath) if (rank == 0 and default_job and os.path.exists(zpath)) else None
+    # the ORACLE's own spread: the same job with every partition's rows in another order (tests/golden/make_ref_loglik.py
+    # --permute-seed 11), an order the reference does not define
+    ppath = os.path.join(ROOT, "tests", "golden", "c2_ref_z_rowperm.npz")
+    gp = np.load(ppath) if (gz is not None and os.path.exists(ppath)) else None
     zcmp = []                      # per iteration: this run's consensus and counters against the oracle's committed run
     C["barrier"]()
     tl0 = time.perf_counter()
@@ -404,7 +408,14 @@ def loglik_run(args, C, eng, P, nf, N, rows_total):
             zo = gz["z32"][it].astype(np.float64)
             rel = float(np.max(np.abs(z32.astype(np.float64) - zo) / np.maximum(np.abs(zo), 1e-4 * np.max(np.abs(zo)))))
             rec = {"iteration": it + 1, "liblinear_epsilon": eps, "max_rel_err_z32": rel,
+                   "max_abs_err_over_max_abs_z": float(np.max(np.abs(z32.astype(np.float64) - zo)) / np.max(np.abs(zo))),
                    "bit_identical_float32_fraction": round(float(np.mean(z32 == gz["z32"][it])), 4)}
+            if gp is not None and it < len(gp["z32"]):
+                zp = gp["z32"][it].astype(np.float64)
+                rec["oracle_rowperm_vs_oracle"] = {
+                    "max_rel_err_z32": float(np.max(np.abs(zp - zo) / np.maximum(np.abs(zo), 1e-4 * np.max(np.abs(zo))))),
+                    "max_abs_err_over_max_abs_z": float(np.max(np.abs(zp - zo)) / np.max(np.abs(zo))),
+                    "partitions_with_equal_counters": int(np.all(gp["counters"][it] == gz["counters"][it], axis=1).sum())}
             if C["world"] == 1:
                 rec["partitions_with_equal_counters"] = int(np.all(eng.solve_counters() == gz["counters"][it], axis=1).sum())
             zcmp.append(rec)
@@ -444,6 +455,13 @@ def loglik_run(args, C, eng, P, nf, N, rows_total):
                 "source": "tests/golden/c2_ref_z.npz (oracle/admm_oracle.c, tests/golden/make_ref_loglik.py): z32 and the 64 solves' TRON counters after every iteration",
                 "tolerance": 1e-5, "rel_err_floor": "1e-4 * max|z|",
                 "max_rel_err_z32_over_iterations": max(r["max_rel_err_z32"] for r in zcmp),
+                "max_rel_err_z32_through_epsilon_1e-6": max([r["max_rel_err_z32"] for r in zcmp if r["liblinear_epsilon"] >= 9e-7] or [None]),
+                "max_abs_err_over_max_abs_z_over_iterations": max(r["max_abs_err_over_max_abs_z"] for r in zcmp),
+                "oracle_rowperm_max_rel_err_z32_over_iterations": (max(r["oracle_rowperm_vs_oracle"]["max_rel_err_z32"] for r in zcmp if "oracle_rowperm_vs_oracle" in r)
+                                                                   if any("oracle_rowperm_vs_oracle" in r for r in zcmp) else None),
+                "reading": "through epsilon 1e-6 every solve follows the oracle's trajectory and the float32 consensus is bit-identical; from 1e-7 on a solve ends on "
+                           "bw/Tron.java:115-122's noise-level tests and the accept/reject of its LAST step depends on the summation order (DESIGN 5) -- "
+                           "oracle_rowperm_vs_oracle is what the reference does to itself there when its rows come in another order",
                 "final_iteration": final["iteration"], "final_max_rel_err_z32": final["max_rel_err_z32"],
                 "z32_final_identical": (hashlib.sha1(eng.z()[1].tobytes()).hexdigest() == gj.get("z32_final_sha1")) if len(zcmp) == gj["iterations"] else None,
                 "smallest_epsilon_compared": min(r["liblinear_epsilon"] for r in zcmp),
@@ -540,23 +558,25 @@ def cpu_leg(args, C, eng, out, sample, snap, eps_used, step_times, nf, N):
 
 # ======================================================================================================================
 def sparse_timed_run(args, C, eng, blocks, lam, warmup, steps, snapshot):
-    """warmup + steps ADMM iterations of a one-hot job with the driver's epsilon schedule; HIP-event sums per launch class.
-    snapshot=True also keeps the state the first timed iteration starts from (outside the timed region)."""
+    """warmup + steps ADMM iterations of a one-hot job with the driver's epsilon schedule. The TIMED iterations run as a production
+    job does: no per-launch events, two tick streams. The per-class rooflines come from a REPLAY of exactly those iterations (from
+    the state the first of them started from; runs are bit-reproducible) with the library's per-launch-class HIP events on, which
+    also puts all ticks on one stream so that a class's duration is its own."""
     sched = EpsSchedule(C["admm"])
     nl, P = len(lam), len(blocks)
-    acc = dict(solves=0, cg=0, newton=0, pref=0, pdev=0, ticks=0, alg=0.0, rms=0.0, cms=0.0, sms=0.0, tms=0.0)
+    acc = dict(solves=0, cg=0, newton=0, pref=0, pdev=0, ticks=0, alg=0.0)
     # every pass launch of this leg (finalize's c0 pass: one row + one column pass per partition, + warm-up + timed): what a
     # rocprofv3 run of this command sees, used to turn its FETCH_SIZE / WRITE_SIZE sums into bytes per algorithmic byte
     allrun = dict(alg=sum(2.0 * (4.0 * b.nnz + 8.0 * b.l + 8.0 * b.n_local) for b in blocks), ticks=1)
     fin, snap, eps_all, step_s = None, None, [], []
+    eng.set_profiling(False)
     tstart = time.perf_counter()
     for it in range(1, warmup + steps + 1):
         if it == warmup + 1:
-            if snapshot:
-                if warmup > 0:
-                    snap = (eng.z()[0].copy(), np.stack([np.stack([eng.partition_model(i, li)[2] for li in range(nl)]) for i in range(P)]))
-                else:
-                    snap = (np.zeros((nl, eng.n_global)), np.zeros((P, nl, eng.n_global), np.float32))
+            if warmup > 0:
+                snap = (eng.z()[0].copy(), np.stack([np.stack([eng.partition_model(i, li)[2] for li in range(nl)]) for i in range(P)]))
+            else:
+                snap = (np.zeros((nl, eng.n_global)), np.zeros((P, nl, eng.n_global), np.float32))
             C["barrier"]()
             tstart = time.perf_counter()
         eps = sched.next()
@@ -572,30 +592,51 @@ def sparse_timed_run(args, C, eng, blocks, lam, warmup, steps, snapshot):
             step_s.append(time.perf_counter() - ts)
             acc["solves"] += st.solves; acc["cg"] += st.cg_iters; acc["newton"] += st.newton_iters
             acc["pref"] += st.x_passes_ref; acc["pdev"] += st.x_passes_dev; acc["ticks"] += st.ticks
-            acc["alg"] += st.alg_bytes_dev; acc["tms"] += st.total_ms
-            acc["rms"] += st.rowpass_ms; acc["cms"] += st.colpass_ms; acc["sms"] += st.step_ms
+            acc["alg"] += st.alg_bytes_dev
     C["barrier"]()
     dt = C["reduce_max"](time.perf_counter() - tstart)
-    return acc, allrun, dt, fin, snap, eps_all, step_s
+    # the replay with events
+    prof = dict(ticks=0, alg=0.0, pdev=0, rms=0.0, cms=0.0, sms=0.0, tms=0.0, wall=0.0, maxdiff=None)
+    eng.set_profiling(True)
+    eng.set_state(*snap)
+    C["barrier"]()
+    t0 = time.perf_counter()
+    for eps in eps_all[warmup:]:
+        st = eng.solve_local(eps, 1.0)
+        C["all_reduce"](eng.consensus_tensor())
+        f2 = eng.consensus_finish()
+        prof["ticks"] += st.ticks; prof["alg"] += st.alg_bytes_dev; prof["pdev"] += st.x_passes_dev; prof["tms"] += st.total_ms
+        prof["rms"] += st.rowpass_ms; prof["cms"] += st.colpass_ms; prof["sms"] += st.step_ms
+        prof["maxdiff"] = f2.maxdiff
+    C["barrier"]()
+    prof["wall"] = C["reduce_max"](time.perf_counter() - t0)
+    eng.set_profiling(False)
+    prof["reproduced_timed_run"] = bool(prof["maxdiff"] == fin.maxdiff and prof["ticks"] == acc["ticks"])
+    allrun["alg"] += prof["alg"]
+    allrun["ticks"] += prof["ticks"]
+    return acc, allrun, dt, fin, (snap if snapshot else None), eps_all, step_s, prof
 
 
-def sparse_rooflines(acc, dt, n_mean, row_kernel, col_kernel):
+def sparse_rooflines(prof, n_mean, row_kernel, col_kernel):
     # one X pass over one partition moves B_pass = nnz*4 + 8 l + 8 n bytes (binary.feature: no value array);
     # the library counts 2 passes (row + column) per tick and active problem in alg_bytes_dev
-    half = acc["alg"] / 2.0
+    half = prof["alg"] / 2.0
+    wall_ms = prof["wall"] * 1e3
 
     def roof(kernel, ms, alg_bytes, note):
         a = alg_bytes / max(1e-9, ms * 1e-3) / 1e9
         return {"kernel": kernel, "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(a / HBM_PEAK_GBS, 4), "ms": round(ms, 3), "share_of_step": round(ms / (dt * 1e3), 4),
-                "us_per_tick": round(1e3 * ms / max(1, acc["ticks"]), 1), "alg_bytes": alg_bytes, "note": note}
+                "frac": round(a / HBM_PEAK_GBS, 4), "ms": round(ms, 3), "share_of_replay": round(ms / wall_ms, 4),
+                "us_per_tick": round(1e3 * ms / max(1, prof["ticks"]), 1), "alg_bytes": alg_bytes, "note": note}
 
-    step_model = 13.0 * 8.0 * n_mean * (acc["pdev"] / 2.0)        # 13 n-vector streams per problem and tick
-    return [roof(row_kernel, acc["rms"], half, "B_pass = nnz*4 + 8l + 8n per active problem; the cold column slices run as their own launch in front of the row kernel"),
-            roof(col_kernel, acc["cms"], half, "B_pass = nnz*4 + 8l + 8n per active problem"),
-            roof("k_step_a+b+c+commit", acc["sms"], 0.0,
-                 "no algorithmic X bytes (SURVEY 8d counts the n-vector work as zero); streams ~13 x 8n bytes per problem and "
-                 "tick = %.1f GB/s" % (step_model / max(1e-9, acc["sms"] * 1e-3) / 1e9))]
+    step_model = 13.0 * 8.0 * n_mean * (prof["pdev"] / 2.0)        # 13 n-vector streams per problem and tick
+    return {"measured_in": "a replay of the timed iterations (same state, same epsilons; reproduced_timed_run = %s) with per-launch-class HIP events "
+                           "and ONE tick stream, %.1f ms wall against %s" % (prof["reproduced_timed_run"], wall_ms, "the timed run"),
+            "kernels": [roof(row_kernel, prof["rms"], half, "B_pass = nnz*4 + 8l + 8n per active problem; the cold column slices run as their own launch in front of the row kernel"),
+                        roof(col_kernel, prof["cms"], half, "B_pass = nnz*4 + 8l + 8n per active problem"),
+                        roof("k_step_a+b+c+commit", prof["sms"], 0.0,
+                             "no algorithmic X bytes (SURVEY 8d counts the n-vector work as zero); streams ~13 x 8n bytes per problem and "
+                             "tick = %.1f GB/s" % (step_model / max(1e-9, prof["sms"] * 1e-3) / 1e9))]}
 
 
 def run_sparse(args, C):
@@ -611,7 +652,7 @@ def run_sparse(args, C):
         rp, ci, y, l2g, ng = sd.onehot_partition(k, rows)
         blocks.append(PartitionBlock(k, rows, len(l2g), rp, ci, None, y, np.ones(rows, np.float32), np.zeros(rows, np.float32), l2g))
     tgen = time.time() - t0
-    eng = C["HipAdmmEngine"](ng, [1.0], [1.0], Ptot, device=C["local_rank"], stream=C["stream"], profiling=True)
+    eng = C["HipAdmmEngine"](ng, [1.0], [1.0], Ptot, device=C["local_rank"], stream=C["stream"])
     t0 = time.time()
     eng.add_partitions(blocks)
     eng.finalize()
@@ -619,7 +660,7 @@ def run_sparse(args, C):
     nnz = sum(b.nnz for b in blocks)
     nloc = np.array([b.n_local for b in blocks])
     want_checks = world == 1 and args.sparse_cpu_sample > 0
-    acc, allrun, dt, fin, snap, eps_all, step_s = sparse_timed_run(args, C, eng, blocks, [1.0], args.sparse_warmup, args.sparse_steps, want_checks)
+    acc, allrun, dt, fin, snap, eps_all, step_s, prof = sparse_timed_run(args, C, eng, blocks, [1.0], args.sparse_warmup, args.sparse_steps, want_checks)
     tot_solves, tot_pref, tot_pdev, tot_alg = C["reduce_sum"]([acc["solves"], acc["pref"], acc["pdev"], acc["alg"]])
     res = None
     if rank == 0:
@@ -634,7 +675,8 @@ def run_sparse(args, C):
                "ticks_per_step": acc["ticks"] / args.sparse_steps, "cg_per_solve": round(acc["cg"] / max(1, acc["solves"]), 2),
                "whole_step": {"alg_bytes_per_s_GB": round(tot_alg / dt / 1e9, 1), "frac_of_hbm_peak": round(tot_alg / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
                               "definition": "sum over solves of device passes x B_pass (SURVEY 8d) / wall time of the timed iterations"},
-               "roofline": sparse_rooflines(acc, dt, n_mean, "k_rowcold + k_rowpass_lds<binary>", "k_colpass_lds<binary>"),
+               "roofline": sparse_rooflines(prof, n_mean, "k_rowcold + k_rowpass_lds<binary>", "k_colpass_lds<binary>"),
+               "timed_run": "no per-launch events, two tick streams (library default)",
                "last_maxdiff": fin.maxdiff,
                "all_launches": {"ticks_incl_c0_and_warmup": allrun["ticks"], "alg_bytes_row_plus_column": allrun["alg"]}}
         tpath = os.path.join(ROOT, "profiles", "traffic_sparse.json")
@@ -669,11 +711,11 @@ def run_lambda_sweep(args, C):
     for k in mine:
         rp, ci, y, l2g, ng = sd.onehot_partition(k, rows)
         blocks.append(PartitionBlock(k, rows, len(l2g), rp, ci, None, y, np.ones(rows, np.float32), np.zeros(rows, np.float32), l2g))
-    eng = C["HipAdmmEngine"](ng, lam, rho, Ptot, device=C["local_rank"], stream=C["stream"], profiling=True)
+    eng = C["HipAdmmEngine"](ng, lam, rho, Ptot, device=C["local_rank"], stream=C["stream"])
     eng.add_partitions(blocks)
     eng.finalize()
     want_checks = world == 1 and args.sweep_cpu_sample > 0
-    acc, allrun, dt, fin, snap, eps_all, step_s = sparse_timed_run(args, C, eng, blocks, lam, args.sweep_warmup, args.sweep_steps, want_checks)
+    acc, allrun, dt, fin, snap, eps_all, step_s, prof = sparse_timed_run(args, C, eng, blocks, lam, args.sweep_warmup, args.sweep_steps, want_checks)
     tot_solves, tot_pref, tot_pdev, tot_alg = C["reduce_sum"]([acc["solves"], acc["pref"], acc["pdev"], acc["alg"]])
     res = None
     if rank == 0:
@@ -689,7 +731,8 @@ def run_lambda_sweep(args, C):
                "whole_step": {"alg_bytes_per_s_GB": round(tot_alg / dt / 1e9, 1), "frac_of_hbm_peak": round(tot_alg / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
                               "definition": "sum over (partition, lambda) solves of device passes x B_pass (SURVEY 8d: every problem's pass counted in full, "
                                             "although the 8 problems of a partition share its index stream) / wall time of the timed iterations"},
-               "roofline": sparse_rooflines(acc, dt, n_mean, "k_rowpass_lds<binary> (two hot slices, no cold columns at this width)", "k_colpass_lds<binary>"),
+               "roofline": sparse_rooflines(prof, n_mean, "k_rowpass_lds<binary> (two hot slices, no cold columns at this width)", "k_colpass_lds<binary>"),
+               "timed_run": "no per-launch events, two tick streams (library default)",
                "x_sharing": "per-problem passes; the 8 lambda problems of a partition are scheduled on one XCD and share the uint16 index streams through "
                             "its L2 (the one-workgroup-per-partition form that reads them once was measured slower: profiles/r2_notes.md, "
                             "tests/test_gpu_parity.py::test_lambda_sweep_shared_x_passes keeps it bit-comparable)",

@@ -89,6 +89,7 @@ struct mlx_context {
     int step_threads = 256;
     int step_ch = 2048, step_max_nwg = 1;   // multi-workgroup CSR step: columns per workgroup, chunks of the widest CSR problem
     bool step_fused = false;                // phases A+B+C in one launch (k_step_fused)
+    int step_group = 0;                     // problems per A/B/C launch group (0 = all in one): see launch_step
     int cold_groups = 0;                    // > 0: row groups of the widest partition with cold column slices (k_rowcold launch)
     unsigned step_seq = 0;                  // its launch sequence number (the exchanges' flag value; never 0)
     int *d_stepctl = nullptr;               // [0] ticket counter [1] error flag
@@ -103,6 +104,14 @@ struct mlx_context {
     int *h_done = nullptr;                 // pinned [2]
     unsigned long long *h_diff = nullptr;  // pinned [n_lambda]
     hipEvent_t ev_batch[2] = {nullptr, nullptr};
+    // second tick stream (MLX_STREAMS=2): the CSR problems are cut into two halves that tick independently, so that one half's
+    // latency-bound passes overlap the other half's bandwidth-bound step launches (run_ticks)
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_batch2[2] = {nullptr, nullptr}, ev_fork = nullptr, ev_join = nullptr;
+    int *h_done2 = nullptr;
+    int nstreams = 1;
+    bool anti_phase = false;                // MLX_STREAMS=3: the halves run half a tick apart, held there by cross-stream events
+    hipEvent_t ev_x[16] = {};
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
     std::vector<hipEvent_t> ev_pool;        // profiling: a chain of marks; the interval from mark i to mark i+1 belongs to ev_kind[i]
     std::vector<int> ev_kind;               // 0 dense X pass, 1 CSR row pass, 2 CSR column pass, 3 TRON/CG step, -1 not a launch
@@ -279,8 +288,14 @@ void launch_step(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
         return;
     }
 #endif
-    for (int which = 0; which < 4; which++)
-        mlxk_step_phase(h->stream, which, h->d_parts, h->d_probs, qcsr, nqc, h->step_ch, h->step_max_nwg, h->d_done, h->d_stepctl);
+    // Phases A, B, C run per GROUP of problems (A_g, B_g, C_g, then the next group), so that what one phase writes -- Hd, r', s --
+    // is still in the memory-side cache (256 MB Infinity Cache) when the next phase of the same group reads it; the phases of
+    // one problem depend only on that problem's partial sums. The commit stays one launch over all problems.
+    const int G = h->step_group > 0 ? h->step_group : std::max(nqc, 1);
+    for (int q0 = 0; q0 < nqc; q0 += G)
+        for (int which = 0; which < 3; which++)
+            mlxk_step_phase(h->stream, which, h->d_parts, h->d_probs, qcsr + q0, std::min(G, nqc - q0), h->step_ch, h->step_max_nwg, h->d_done, h->d_stepctl);
+    mlxk_step_phase(h->stream, 3, h->d_parts, h->d_probs, qcsr, nqc, h->step_ch, h->step_max_nwg, h->d_done, h->d_stepctl);
 }
 
 // Drive ticks until `count` problems starting at `first` are DONE.
@@ -314,23 +329,70 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
     int slot = 0;
     bool have_prev = false;
     int rc;
+    // two tick streams: the CSR list is cut in two (whole groups of 8 list positions, so the XCD placement of xcd_map is kept); the
+    // halves share nothing but the done counter
+    const bool two = h->nstreams == 2 && nqd == 0 && nqc >= 32 && !h->profiling;
+    const int nq0 = two ? (nqc / 2 + 7) / 8 * 8 : nqc;
+    hipStream_t sA = h->stream, sB = h->stream2;
+    if (two) {
+        h->h_done2[0] = h->h_done2[1] = 0;
+        HIPCHECK(h, hipEventRecord(h->ev_fork, sA));
+        HIPCHECK(h, hipStreamWaitEvent(sB, h->ev_fork, 0));
+    }
+    const bool anti = two && h->anti_phase;
+    int xk = 0;
+    auto xbar = [&]() {                                  // both streams wait for each other's work queued so far
+        hipEventRecord(h->ev_x[xk], sA); hipEventRecord(h->ev_x[xk + 1], sB);
+        hipStreamWaitEvent(sA, h->ev_x[xk + 1], 0); hipStreamWaitEvent(sB, h->ev_x[xk], 0);
+        xk = (xk + 2) % 16;
+    };
+    if (anti && (rc = launch_xpass(h, nullptr, 0, qcsr, nq0))) return rc;      // half 0 runs half a tick ahead
     for (;;) {
         for (int i = 0; i < batch; i++) {
-            if ((rc = launch_xpass(h, qdense, nqd, qcsr, nqc))) return rc;
-            launch_step(h, qdense, nqd, qcsr, nqc);
+            if (anti) {
+                // phase 1: step of half 0 beside the passes of half 1; phase 2: passes of half 0 (next tick) beside the step of half 1
+                xbar();
+                launch_step(h, nullptr, 0, qcsr, nq0);
+                h->stream = sB; rc = launch_xpass(h, nullptr, 0, qcsr + nq0, nqc - nq0); h->stream = sA;
+                if (rc) return rc;
+                xbar();
+                if ((rc = launch_xpass(h, nullptr, 0, qcsr, nq0))) return rc;
+                h->stream = sB; launch_step(h, nullptr, 0, qcsr + nq0, nqc - nq0); h->stream = sA;
+                ticks++;
+                continue;
+            }
+            if ((rc = launch_xpass(h, qdense, nqd, qcsr, nq0))) return rc;
+            launch_step(h, qdense, nqd, qcsr, nq0);
+            if (two) {
+                h->stream = sB;
+                rc = launch_xpass(h, nullptr, 0, qcsr + nq0, nqc - nq0);
+                if (!rc) launch_step(h, nullptr, 0, qcsr + nq0, nqc - nq0);
+                h->stream = sA;
+                if (rc) return rc;
+            }
             ticks++;
         }
         mark(h, -1);
-        HIPCHECK(h, hipMemcpyAsync(&h->h_done[slot], h->d_done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIPCHECK(h, hipEventRecord(h->ev_batch[slot], h->stream));
+        HIPCHECK(h, hipMemcpyAsync(&h->h_done[slot], h->d_done, sizeof(int), hipMemcpyDeviceToHost, sA));
+        HIPCHECK(h, hipEventRecord(h->ev_batch[slot], sA));
+        if (two) {
+            HIPCHECK(h, hipMemcpyAsync(&h->h_done2[slot], h->d_done, sizeof(int), hipMemcpyDeviceToHost, sB));
+            HIPCHECK(h, hipEventRecord(h->ev_batch2[slot], sB));
+        }
         if (have_prev) {
             HIPCHECK(h, hipEventSynchronize(h->ev_batch[slot ^ 1]));
-            if (getenv("MLX_TRACE")) fprintf(stderr, "[mlx] ticks=%lld done=%d/%d\n", (long long)(ticks - batch), h->h_done[slot ^ 1], count);
-            if (h->h_done[slot ^ 1] >= count) break;      // the batch just queued runs as no-ops
+            if (two) HIPCHECK(h, hipEventSynchronize(h->ev_batch2[slot ^ 1]));
+            const int done = two ? std::max(h->h_done[slot ^ 1], h->h_done2[slot ^ 1]) : h->h_done[slot ^ 1];
+            if (getenv("MLX_TRACE")) fprintf(stderr, "[mlx] ticks=%lld done=%d/%d\n", (long long)(ticks - batch), done, count);
+            if (done >= count) break;      // the batch just queued runs as no-ops
         }
         have_prev = true;
         slot ^= 1;
         if (ticks > TICK_CAP) return fail(h, MLX_ERR_MODEL_FITTING, "Model fitting error! solve did not terminate within %lld ticks", (long long)TICK_CAP);
+    }
+    if (two) {                                           // the first stream continues (outputs, means) after both halves
+        HIPCHECK(h, hipEventRecord(h->ev_join, sB));
+        HIPCHECK(h, hipStreamWaitEvent(sA, h->ev_join, 0));
     }
     HIPCHECK(h, hipStreamSynchronize(h->stream));
     HIPCHECK(h, hipGetLastError());
@@ -400,6 +462,21 @@ int mlx_create(int device_id, mlx_handle *out)
     h->own_stream = true;
     hipEventCreateWithFlags(&h->ev_batch[0], hipEventDisableTiming);
     hipEventCreateWithFlags(&h->ev_batch[1], hipEventDisableTiming);
+    // default: two tick streams (C3 5.1-5.2 k -> 5.4-5.5 k solves/s, 8 lambdas x 128 partitions 21.4 k -> 23.4 k; MLX_STREAMS=1: one).
+    // MLX_STREAMS=3 holds the halves half a tick apart with cross-stream events (passes of one beside the step of the other):
+    // measured SLOWER than one stream (4.88 k) -- the passes and the step do not complement each other, the gain of the free-running
+    // form is launch tails and gaps being filled (profiles/r3_notes.md).
+    h->nstreams = 2;
+    if (const char *se = getenv("MLX_STREAMS")) { h->nstreams = atoi(se) >= 2 ? 2 : 1; h->anti_phase = atoi(se) == 3; }
+    if (h->nstreams == 2) {
+        for (auto &e : h->ev_x) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess) h->nstreams = 1;
+        hipEventCreateWithFlags(&h->ev_batch2[0], hipEventDisableTiming);
+        hipEventCreateWithFlags(&h->ev_batch2[1], hipEventDisableTiming);
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
+        if (hipHostMalloc((void **)&h->h_done2, 2 * sizeof(int)) != hipSuccess) h->nstreams = 1;
+    }
     hipEventCreate(&h->ev_t0);
     hipEventCreate(&h->ev_t1);
     *out = h;
@@ -417,6 +494,12 @@ int mlx_destroy(mlx_handle h)
     if (h->h_diff) hipHostFree(h->h_diff);
     for (auto e : h->ev_pool) hipEventDestroy(e);
     for (auto e : h->ev_batch) if (e) hipEventDestroy(e);
+    for (auto e : h->ev_batch2) if (e) hipEventDestroy(e);
+    for (auto e : h->ev_x) if (e) hipEventDestroy(e);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
+    if (h->stream2) hipStreamDestroy(h->stream2);
+    if (h->h_done2) hipHostFree(h->h_done2);
     if (h->ev_t0) hipEventDestroy(h->ev_t0);
     if (h->ev_t1) hipEventDestroy(h->ev_t1);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -1129,6 +1212,7 @@ int mlx_finalize(mlx_handle h)
         h->step_ch = ch;
         h->step_max_nwg = (max_nlocal_csr + ch - 1) / ch;
         // MLX_STEP_FUSED=1 (opt-in, measured slower -- profiles/r2_notes.md): phases A+B+C in one launch with in-launch exchanges
+        if (const char *ge = getenv("MLX_STEP_GROUP")) h->step_group = std::max(0, atoi(ge));
         const char *fe = getenv("MLX_STEP_FUSED");
         h->step_fused = ch == 2048 && h->step_max_nwg <= 256 && fe && atoi(fe) == 1;
     }

@@ -178,6 +178,7 @@ int run_job(const JobConfig &props)
     if (devs.empty()) devs.push_back(0);
     const int G = (int)devs.size();
     std::vector<mlx_handle> hs((size_t)G, nullptr);
+    std::vector<std::vector<int32_t>> pids_of((size_t)G);          // handle g, local index (add order) -> partition id
     char uid[MLX_UNIQUE_ID_BYTES];
     if (G > 1 && mlx_comm_get_unique_id(uid) != MLX_OK) throw Fail(std::string("RCCL: ") + mlx_last_error(nullptr));
     for (int g = 0; g < G; g++) {
@@ -203,6 +204,7 @@ int run_job(const JobConfig &props)
                                      ds.binary ? nullptr : a_val.data(), a_y.data(), a_w.data(), a_o.data(), a_l2g.data()),
            "mlx_add_partitions_csr");
         ck(h, mlx_finalize(h), "mlx_finalize");
+        pids_of[(size_t)g] = a_pid;
     }
     if (G > 1) {
         std::vector<std::thread> th;
@@ -236,6 +238,7 @@ int run_job(const JobConfig &props)
         std::error_code ec;
         std::filesystem::remove_all(out + "/best-model", ec);
         std::filesystem::remove_all(out + "/sample-test-loglik", ec);
+        for (int it = 1; it <= niter; it++) std::filesystem::remove_all(out + "/iter-" + std::to_string(it), ec);
     }
     // ---- the loop (:278-497)
     double mindiff = 99999999;
@@ -276,6 +279,57 @@ int run_job(const JobConfig &props)
         for (auto &t : th) t.join();
         for (int g = 0; g < G; g++) ck(hs[(size_t)g], rcs[(size_t)g], what);
     };
+    // write.iter.files=true: the per-iteration files the reference leaves under output.base.path/iter-<i>/ (jobs/...:309-334; kept
+    // when remove.tmp.dir=false): u (the u_k every reducer of iteration i reads; an EMPTY model file at i = 1, :310-312),
+    // init-value (z as the solvers see it, float32) and, after the iteration, model: one RegressionTrainOutput record per reduce key
+    // "<lambda>#<partition>" with the reducer's beta_k and u_k + beta_k (:641-718, avro/RegressionTrainOutput.avsc:17-39).
+    // Vectors are written dense over the global feature list (the reference writes the keys of its HashMaps: absent ones read as 0).
+    const bool write_iter = props.get_bool("write.iter.files", false);
+    bool warm_start_done = false;                                   // z is the empty model before iteration 1 unless the mean-model warm start ran
+    std::vector<float> pm_b((size_t)ng), pm_x((size_t)ng), pm_u((size_t)ng);
+    auto reduce_key = [&](int li, int32_t pid) { return java_float_to_string(lam[(size_t)li]) + "#" + std::to_string(pid); };
+    auto write_iter_inputs = [&](int it) {
+        const std::string dir = out + "/iter-" + std::to_string(it);
+        {
+            AvroFileWriter w(dir + "/u/part-r-00000.avro", kLinearModelSchemaJson);
+            if (it > 1)
+                for (int g = 0; g < G; g++)
+                    for (size_t k = 0; k < pids_of[(size_t)g].size(); k++)
+                        for (int li = 0; li < nl; li++) {
+                            ck(hs[(size_t)g], mlx_get_partition_model(hs[(size_t)g], (int32_t)k, li, nullptr, nullptr, pm_u.data()), "mlx_get_partition_model");
+                            write_model_record(w, reduce_key(li, pids_of[(size_t)g][k]), pm_u.data(), ds);
+                        }
+            w.close();
+        }
+        ck(hs[0], mlx_get_z(hs[0], nullptr, zf.data()), "mlx_get_z");
+        AvroFileWriter w(dir + "/init-value/part-r-00000.avro", kLinearModelSchemaJson);
+        if (it > 1 || warm_start_done)
+            for (int li = 0; li < nl; li++) write_model_record(w, java_float_to_string(lam[(size_t)li]), zf.data() + (size_t)li * ng, ds);
+        w.close();
+    };
+    auto write_iter_models = [&](int it) {
+        AvroFileWriter w(out + "/iter-" + std::to_string(it) + "/model/part-r-00000.avro", kTrainOutputSchemaJson);
+        for (int g = 0; g < G; g++)
+            for (size_t k = 0; k < pids_of[(size_t)g].size(); k++)
+                for (int li = 0; li < nl; li++) {
+                    ck(hs[(size_t)g], mlx_get_partition_model(hs[(size_t)g], (int32_t)k, li, pm_b.data(), pm_x.data(), nullptr), "mlx_get_partition_model");
+                    w.put_string(reduce_key(li, pids_of[(size_t)g][k]));
+                    for (const float *v : {pm_b.data(), pm_x.data()}) {
+                        w.array_start(ng);
+                        w.put_string("(INTERCEPT)"); w.put_string(""); w.put_float(v[ng - 1]);
+                        for (int32_t j = 0; j + 1 < ng; j++) {
+                            const std::string &nm = ds.names[(size_t)j];
+                            size_t sep = nm.find('\x01');
+                            w.put_string(sep == std::string::npos ? nm : nm.substr(0, sep));
+                            w.put_string(sep == std::string::npos ? "" : nm.substr(sep + 1));
+                            w.put_float(v[j]);
+                        }
+                        w.array_end();
+                    }
+                    w.end_record();
+                }
+        w.close();
+    };
     const bool warm_start = boost > 0 && reg == 2;
     if (warm_start) {
         // Initialize z by the mean model (:236-276): RegressionNaiveTrain on the same partitions with the job's
@@ -287,6 +341,7 @@ int run_job(const JobConfig &props)
         solve_s += std::chrono::duration<double>(clk::now() - t0).count();
         fprintf(stderr, "[mlease] mean model initialised (liblinear epsilon %g)\n", ieps);
         if (test_loglik) update_loglik_best_model(0);                                        // :271-274
+        warm_start_done = true;
     }
     for (i = 1; i <= niter; i++) {
         float rate = 1.0f;
@@ -295,6 +350,7 @@ int run_job(const JobConfig &props)
         if (i > 1 && mindiff < 0.001 && !aggressive) liblinear_eps = liblinear_eps / 10;     // :338-341
         else if (aggressive && i > 5) liblinear_eps = liblinear_eps / 10;                    // :342-345
         const double eps = float_string_roundtrip(liblinear_eps);                            // :346,:620,:702
+        if (write_iter) write_iter_inputs(i);
         auto t0 = clk::now();
         std::vector<mlx_stats> st((size_t)G);
         on_all_devices("mlx_admm_iterate", [&](int g) { return mlx_admm_iterate(hs[(size_t)g], eps, rate, &st[(size_t)g]); });
@@ -303,6 +359,7 @@ int run_job(const JobConfig &props)
         mindiff = st[0].mindiff;
         fprintf(stderr, "[mlease] iteration %d: liblinear epsilon %s, max |z - z_prev| = %.6g, min = %.6g\n", i,
                 java_float_to_string(liblinear_eps).c_str(), maxdiff, mindiff);
+        if (write_iter) write_iter_models(i);
         if (test_loglik) update_loglik_best_model(i);
         if (maxdiff < epsilon && liblinear_eps <= 0.00001) break;                            // :493-496
     }

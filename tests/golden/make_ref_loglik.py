@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--rows", type=int, default=ROWS)
     ap.add_argument("--iters", type=int, default=ITERS)
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "c2_ref_loglik.json"))
+    ap.add_argument("--permute-seed", type=int, default=0,
+                    help="!= 0: every partition's rows in a seeded random order (an order Hadoop does not define) -> the oracle's OWN spread; "
+                         "write with --out tests/golden/c2_ref_loglik_rowperm.json (-> c2_ref_z_rowperm.npz beside it)")
     args = ap.parse_args()
     beta = sd.dense_beta(NFEAT)
     per = args.rows // PARTS
@@ -44,6 +47,9 @@ def main():
     t0 = time.time()
     for k in range(PARTS):
         X, y = ol.synth_dense(k, per, NFEAT, beta, sd.SEED, stride=PARTS)
+        if args.permute_seed:
+            perm = np.random.default_rng([args.permute_seed, k]).permutation(per)
+            X, y = np.ascontiguousarray(X[perm]), np.ascontiguousarray(y[perm])
         blocks.append(PartitionBlock(k, per, NFEAT + 1, np.arange(0, (per + 1) * NFEAT, NFEAT, dtype=np.int64),
                                      np.tile(np.arange(NFEAT, dtype=np.int32), per), X.reshape(-1), y,
                                      np.ones(per, np.float32), np.zeros(per, np.float32), np.arange(NFEAT + 1, dtype=np.int32)))
@@ -79,7 +85,7 @@ def main():
            "rows": args.rows, "features": NFEAT, "partitions": PARTS, "test_rows": TEST_ROWS, "iterations": args.iters,
            "loglik_by_iteration": lls, "ref_loglik": lls[-1], "epsilon_by_iteration": eps_used, "maxdiff_by_iteration": diffs,
            "newton_cg_xpasses_by_iteration": counters,
-           "z32_final_sha1": __import__("hashlib").sha1(oc.z()[1].tobytes()).hexdigest()}
+           "z32_final_sha1": __import__("hashlib").sha1(oc.z()[1].tobytes()).hexdigest(), "permute_seed": args.permute_seed}
     with open(args.out, "w") as fh:
         json.dump(out, fh, indent=1)
     # the consensus after every iteration (float32 as the final-model file holds it, and the driver's double) and every

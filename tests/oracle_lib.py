@@ -14,8 +14,9 @@ import numpy as np
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _ORACLE_DIR = os.path.join(_ROOT, "oracle")
-_LIB_PATH = os.path.join(_ORACLE_DIR, "liboracle.so")
-_LIB_PM_PATH = os.path.join(_ORACLE_DIR, "liboracle_pm.so")     # verification twin: portable exp/log1p (oracle/Makefile)
+_ASAN = os.environ.get("MLX_ASAN", "0") not in ("", "0")          # tools/run_asan.sh: the ASan + UBSan builds (make -C oracle asan)
+_LIB_PATH = os.path.join(_ORACLE_DIR, "liboracle_asan.so" if _ASAN else "liboracle.so")
+_LIB_PM_PATH = os.path.join(_ORACLE_DIR, "liboracle_pm_asan.so" if _ASAN else "liboracle_pm.so")     # verification twin: portable exp/log1p (oracle/Makefile)
 
 
 class TronStats(C.Structure):
@@ -27,7 +28,7 @@ class TronStats(C.Structure):
 def build(force: bool = False) -> str:
     srcs = [os.path.join(_ORACLE_DIR, f) for f in ("admm_oracle.c", "synth.c")]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
-        subprocess.check_call(["make", "-C", _ORACLE_DIR, "-s", "liboracle.so", "liboracle_pm.so"])
+        subprocess.check_call(["make", "-C", _ORACLE_DIR, "-s"] + (["asan"] if _ASAN else ["liboracle.so", "liboracle_pm.so"]))
     return _LIB_PATH
 
 

@@ -26,8 +26,9 @@ PIG_SCHEMA = {  # the writer schema shape of examples/sample-data.avro (Pig: eve
 
 
 def lib():
-    subprocess.check_call(["make", "-C", HOST, "-s", "libmlease_host.so"])
-    L = C.CDLL(os.path.join(HOST, "libmlease_host.so"))
+    name = "libmlease_host_asan.so" if os.environ.get("MLX_ASAN", "0") not in ("", "0") else "libmlease_host.so"    # tools/run_asan.sh
+    subprocess.check_call(["make", "-C", HOST, "-s", name])
+    L = C.CDLL(os.path.join(HOST, name))
     L.mlh_last_error.restype = C.c_char_p
     L.mlh_build.restype = C.c_void_p
     L.mlh_build.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_ulonglong, C.c_int, C.c_int]
@@ -216,6 +217,47 @@ def test_cli_end_to_end_matches_golden(tmp_path, c1):
     assert r2.returncode == 0, r2.stderr[-2000:]
     assert sorted(os.listdir(tmp_path / "out" / "best-model")) == best
     assert not os.path.exists(tmp_path / "out" / "sample-test-loglik" / "iteration-77.avro")
+
+
+@pytest.mark.gpu
+def test_cli_writes_the_iteration_files(tmp_path, c1):
+    """write.iter.files=true: iter-<i>/{u, init-value, model} as the reference leaves them (jobs/RegressionAdmmTrain.java:309-334,
+    reducer output avro/RegressionTrainOutput.avsc:17-39; keys "<lambda>" and "<lambda>#<partition>") -- checked against the committed
+    oracle golden of the same job: z entering iteration i, the reducers' beta_k / u_k + beta_k of iterations 1 and 2, and u_k."""
+    subprocess.check_call(["make", "-C", HOST, "-s"])
+    recs = c1_raw_records(c1)
+    avro_io.write_container(str(tmp_path / "in" / "part-00000.avro"), PIG_SCHEMA, recs, codec="deflate")
+    job = tmp_path / "iter.job"
+    job.write_text("input.paths=%s\noutput.base.path=%s\nnum.blocks=8\nlambda=1.0\nnum.iters=3\nregularizer=2\nmap.key=pkey\n"
+                   "write.iter.files=true\n" % (tmp_path / "in", tmp_path / "out"))
+    r = subprocess.run([os.path.join(HOST, "mlease_admm_train"), str(job)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    gold = load_c1_golden()
+    names = c1.feature_names
+
+    def close(a, want, what):
+        a, want = a.astype(np.float64), want.astype(np.float64)
+        err = np.abs(a - want) / np.maximum(np.abs(want), 1e-4 * np.max(np.abs(want)) + 1e-300)
+        assert np.max(err) <= 1e-5, (what, float(np.max(err)))
+
+    out = tmp_path / "out"
+    assert avro_io.read_records(str(out / "iter-1" / "u")) == [] and avro_io.read_records(str(out / "iter-1" / "init-value")) == []
+    for i in (2, 3):
+        z = admm.read_linear_models(str(out / ("iter-%d" % i) / "init-value" / "part-r-00000.avro"), names)
+        assert list(z) == ["1.0"]
+        close(z["1.0"], gold["Z"][i - 2][0].astype(np.float32), "init-value of iteration %d" % i)
+    for i in (1, 2):
+        recs_m = {r_["key"]: r_ for r_ in avro_io.read_records(str(out / ("iter-%d" % i) / "model"))}
+        assert sorted(recs_m) == sorted("1.0#%d" % k for k in range(8))
+        u_next = admm.read_linear_models(str(out / ("iter-%d" % (i + 1)) / "u" / "part-r-00000.avro"), names)
+        for k in range(8):
+            for field, gkey in (("model", "B_it%d" % i), ("uplusx", "UPX_it%d" % i)):
+                v = np.zeros(len(names) + 1, np.float32)
+                idx = {n: j for j, n in enumerate(names)}
+                for f in recs_m["1.0#%d" % k][field]:
+                    v[-1 if f["name"] == admm.INTERCEPT_NAME else idx[f["name"]]] = np.float32(f["value"])
+                close(v, gold[gkey][k, 0], "%s of partition %d, iteration %d" % (field, k, i))
+            close(u_next["1.0#%d" % k], gold["Unext_it%d" % i][k, 0], "u of partition %d entering iteration %d" % (k, i + 1))
 
 
 @pytest.mark.gpu

@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--lambdas", type=str, default="1.0")
     ap.add_argument("--cpu-sample", type=int, default=0)
+    ap.add_argument("--no-profile", action="store_true", help="no per-launch-class HIP events (needed for MLX_STREAMS=2)")
     ap.add_argument("--check", type=int, default=0, help="verify the first N partitions' models of iteration 1 against the oracle")
     args = ap.parse_args()
 
@@ -68,7 +69,7 @@ def main():
     tgen = time.time() - t0
     lam = sorted(float(x) for x in args.lambdas.split(","))
     rho = [1.0 if l <= 100 else 10.0 for l in lam]
-    eng = HipAdmmEngine(ng, lam, rho, args.partitions, profiling=True)
+    eng = HipAdmmEngine(ng, lam, rho, args.partitions, profiling=not args.no_profile)
     t0 = time.time()
     eng.add_partitions(blocks)
     eng.finalize()
