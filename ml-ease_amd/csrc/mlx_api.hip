@@ -2059,13 +2059,13 @@ int mlx_posterior_variance(mlx_handle h, int32_t local_index, const double *w, c
         int *d_blocks;
         double *d_P, *d_H;
         if ((rc = talloc((void **)&d_blocks, sizeof(int) * blocks.size()))) return rc;
-        if ((rc = talloc((void **)&d_P, sizeof(double) * (size_t)ksplit * npad * npad))) return rc;
+        if ((rc = talloc((void **)&d_P, sizeof(double) * (size_t)(ksplit / 2) * npad * npad))) return rc;   // one partial block per workgroup (= two row splits)
         if ((rc = talloc((void **)&d_H, sizeof(double) * (size_t)n * n))) return rc;
         hipMemcpyAsync(d_blocks, blocks.data(), sizeof(int) * blocks.size(), hipMemcpyHostToDevice, h->stream);
         hipEventRecord(h->ev_t0, h->stream);
         mlxk_gram_f64(h->stream, X, ld, l, d_wd, d_blocks, nblocks, ksplit, rows_per_split, d_P, npad, nf);
         hipEventRecord(h->ev_t1, h->stream);
-        mlxk_gram_finish(h->stream, d_P, ksplit, npad, nf, d_pinv, d_H);
+        mlxk_gram_finish(h->stream, d_P, ksplit / 2, npad, nf, d_pinv, d_H);
         std::vector<double> H((size_t)n * n), V;
         hipMemcpyAsync(H.data(), d_H, sizeof(double) * H.size(), hipMemcpyDeviceToHost, h->stream);
         if (hipStreamSynchronize(h->stream) != hipSuccess || hipGetLastError() != hipSuccess) { cleanup(); return fail(h, MLX_ERR_HIP, "posterior variance kernels failed"); }

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 #include <stdint.h>
 
 #include "mlx_kernels.h"
@@ -2189,10 +2190,15 @@ k_gram_f64(const float *__restrict__ X, int64_t ld, int l, const double *__restr
     // Column nf of the Gram matrix is an IMPLICIT column of ones (the intercept: H[nf][c] = sum_i wd_i x_ic, H[nf][nf] = sum_i
     // wd_i, llf/LogisticRegressionL2.java:259-297), so the intercept's row costs no pass of its own.
     // 8 waves = two groups of 4: each group owns one row split of the same 128 x 128 block, so that two waves share every
-    // SIMD (one wave per SIMD reaches only ~45 % of the f64 MFMA rate, two reach 98 %: tools/mfma_f64_probe.hip)
+    // SIMD (one wave per SIMD reaches only ~45 % of the f64 MFMA rate, two reach 98 %: tools/mfma_f64_probe.hip). The two
+    // groups' tiles are added through LDS at the end (group 1 parks its 4 x 64 x 64 accumulators there, group 0 adds its own
+    // and stores): one partial Gram block per WORKGROUP instead of one per group -- half the store traffic of the tail and half
+    // the partial matrices k_gram_finish adds.
+    extern __shared__ __attribute__((aligned(16))) double red[];     // [4 waves][16 tiles][4 regs][64 lanes] = 128 KiB
     const int2 bb = blocks[blockIdx.x];
     const int wave = (threadIdx.x >> 6) & 3, lane = threadIdx.x & 63;
-    const int split = blockIdx.y * 2 + (threadIdx.x >> 8);
+    const int grp = threadIdx.x >> 8;
+    const int split = blockIdx.y * 2 + grp;
     const int ii = lane & 15, kk = lane >> 4;
     const int m0 = bb.x * 128 + (wave >> 1) * 64, n0 = bb.y * 128 + (wave & 1) * 64;
     const int r0 = min(l, split * rows_per_split), r1 = min(l, r0 + rows_per_split);
@@ -2207,43 +2213,62 @@ k_gram_f64(const float *__restrict__ X, int64_t ld, int l, const double *__restr
     const int cm = vm ? cma : 0, cn = vn ? cna : 0;
     const int oa = nf - cma, ob = nf - cna;                  // which of the lane's 4 columns (if any) is the ones column
     const bool aq = cma <= nf;                                // the lane's A columns reach into [0, nf]
-    float4 ca[KU], cb[KU], na[KU], nb[KU];      // operands of the current / the next 4 KU rows
-    double cq[KU], nq[KU];
-    auto fetch = [&](int r) {
+    // EDGE = the block touches column nf (the ones column) or the padding behind it: only those blocks (8 of 36 at n = 1001) pay
+    // for the per-operand selects -- 96 v_cndmask per 64 MFMAs in the main loop of the one-size-fits-all form
+    auto run = [&](auto edge_tag) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        float4 ca[KU], cb[KU], na[KU], nb[KU];      // operands of the current / the next 4 KU rows
+        double cq[KU], nq[KU];
+        auto fetch = [&](int r) {
 #pragma unroll
-        for (int u = 0; u < KU; u++) {
-            const int row = r + 4 * u + kk;
-            const int rc = min(row, l - 1);
-            nq[u] = (row < r1 && aq) ? wd[rc] : 0.0;
-            const float *__restrict__ xr = X + (int64_t)rc * ld;
-            na[u] = *reinterpret_cast<const float4 *>(xr + cm);
-            nb[u] = *reinterpret_cast<const float4 *>(xr + cn);
+            for (int u = 0; u < KU; u++) {
+                const int row = r + 4 * u + kk;
+                const int rc = min(row, l - 1);
+                nq[u] = (row < r1 && (!EDGE || aq)) ? wd[rc] : 0.0;
+                const float *__restrict__ xr = X + (int64_t)rc * ld;
+                na[u] = *reinterpret_cast<const float4 *>(xr + cm);
+                nb[u] = *reinterpret_cast<const float4 *>(xr + cn);
+            }
+        };
+        if (r0 < r1) fetch(r0);
+        for (int r = r0; r < r1; r += 4 * KU) {
+#pragma unroll
+            for (int u = 0; u < KU; u++) { ca[u] = na[u]; cb[u] = nb[u]; cq[u] = nq[u]; }
+            if (r + 4 * KU < r1) fetch(r + 4 * KU);
+#pragma unroll
+            for (int u = 0; u < KU; u++) {
+                const double qq = cq[u];
+                const double xa[4] = {(double)ca[u].x, (double)ca[u].y, (double)ca[u].z, (double)ca[u].w};
+                const double xb[4] = {(double)cb[u].x, (double)cb[u].y, (double)cb[u].z, (double)cb[u].w};
+                double a[4], b[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    a[t] = EDGE ? qq * (t == oa ? 1.0 : (vm ? xa[t] : 0.0)) : qq * xa[t];
+                    b[t] = EDGE ? (t == ob ? 1.0 : (vn ? xb[t] : 0.0)) : xb[t];
+                }
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+                    for (int nt = 0; nt < 4; nt++)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+            }
         }
     };
-    if (r0 < r1) fetch(r0);
-    for (int r = r0; r < r1; r += 4 * KU) {
+    if ((bb.x + 1) * 128 > nf) run(std::true_type{});        // (bb.y <= bb.x: the column range is never further out than the row range)
+    else run(std::false_type{});
+    // group 1 -> LDS -> group 0 adds and stores
+    double *__restrict__ mine = red + (size_t)wave * 4096 + lane;
+    if (grp == 1) {
 #pragma unroll
-        for (int u = 0; u < KU; u++) { ca[u] = na[u]; cb[u] = nb[u]; cq[u] = nq[u]; }
-        if (r + 4 * KU < r1) fetch(r + 4 * KU);
+        for (int mt = 0; mt < 4; mt++)
 #pragma unroll
-        for (int u = 0; u < KU; u++) {
-            const double qq = cq[u];
-            const double xa[4] = {(double)ca[u].x, (double)ca[u].y, (double)ca[u].z, (double)ca[u].w};
-            const double xb[4] = {(double)cb[u].x, (double)cb[u].y, (double)cb[u].z, (double)cb[u].w};
-            double a[4], b[4];
+            for (int nt = 0; nt < 4; nt++)
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                a[t] = qq * (t == oa ? 1.0 : (vm ? xa[t] : 0.0));
-                b[t] = t == ob ? 1.0 : (vn ? xb[t] : 0.0);
-            }
-#pragma unroll
-            for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-                for (int nt = 0; nt < 4; nt++)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
-        }
+                for (int reg = 0; reg < 4; reg++) mine[((mt * 4 + nt) * 4 + reg) * 64] = acc[mt][nt][reg];
     }
-    double *__restrict__ out = P + (int64_t)split * npad * npad;
+    __syncthreads();
+    if (grp == 1) return;
+    double *__restrict__ out = P + (int64_t)blockIdx.y * npad * npad;
 #pragma unroll
     for (int mt = 0; mt < 4; mt++)
 #pragma unroll
@@ -2251,7 +2276,7 @@ k_gram_f64(const float *__restrict__ X, int64_t ld, int l, const double *__restr
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
                 const int row = m0 + 4 * (kk + 4 * reg) + mt, col = n0 + 4 * ii + nt;
-                out[(int64_t)row * npad + col] = acc[mt][nt][reg];
+                out[(int64_t)row * npad + col] = acc[mt][nt][reg] + mine[((mt * 4 + nt) * 4 + reg) * 64];
             }
 }
 
@@ -2694,7 +2719,8 @@ void mlxk_hess_diag_items(hipStream_t st, int n_items, const int32_t *item_ptr, 
 void mlxk_gram_f64(hipStream_t st, const float *X, int64_t ld, int l, const double *wd, const int *blocks_xy, int nblocks,
                    int ksplit, int rows_per_split, double *P, int npad, int nf)
 {
-    hipLaunchKernelGGL((k_gram_f64<4>), dim3(nblocks, ksplit / 2), dim3(512), 0, st, X, ld, l, wd,
+    per_device_once(4, [&] { set_max_lds(reinterpret_cast<const void *>(&k_gram_f64<4>), 4 * 4096 * (int)sizeof(double)); });
+    hipLaunchKernelGGL((k_gram_f64<4>), dim3(nblocks, ksplit / 2), dim3(512), 4 * 4096 * sizeof(double), st, X, ld, l, wd,
                        reinterpret_cast<const int2 *>(blocks_xy), rows_per_split, P, npad, nf);
 }
 

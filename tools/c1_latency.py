@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""BASELINE configs[0] (sample data, 8 partitions of 125 rows x 200 features, lambda = 1): wall time of 20 ADMM iterations with the
+driver's epsilon schedule on the GPU, split into solve_local / consensus_finish, against the C oracle on the host cores."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
+import mlease_amd  # noqa: F401
+from mlease_amd import admm
+from mlease_amd.hip_engine import HipAdmmEngine
+from fixtures import load_c1, load_c1_golden
+c1 = load_c1()
+gold = load_c1_golden()
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+best = None
+for rep in range(reps):
+    eng = HipAdmmEngine(c1.n_global, [1.0], [1.0], 8)
+    for b in c1.blocks:
+        eng.add_partition(b)
+    eng.finalize()
+    e, mind = np.float32(0.01), 99999999.0
+    ts, tf, ticks = [], [], []
+    t0 = time.perf_counter()
+    for it in range(1, 21):
+        if it > 1 and mind < 0.001:
+            e = np.float32(e / np.float32(10))
+        a = time.perf_counter()
+        st = eng.solve_local(admm.float_string_roundtrip(e), 1.0)
+        b = time.perf_counter()
+        fin = eng.consensus_finish()
+        c = time.perf_counter()
+        mind = fin.mindiff
+        ts.append(b - a); tf.append(c - b); ticks.append(st.ticks)
+    tot = time.perf_counter() - t0
+    ok = bool(np.array_equal(eng.z()[0], gold["Z"][-1])) if rep == 0 else None
+    if best is None or tot < best[0]:
+        best = (tot, sum(ts), sum(tf), ticks)
+    eng.close()
+print("C1 20 iterations: %.2f ms (solve_local %.2f, consensus_finish %.2f), ticks per iteration %s, z == golden (double, bit for bit): %s" % (
+    best[0] * 1e3, best[1] * 1e3, best[2] * 1e3, best[3], ok))
+if len(sys.argv) > 2:
+    import oracle_lib as ol
+    for th in (1, 8):
+        oc = ol.OracleAdmm(c1.blocks, c1.n_global, [1.0], [1.0])
+        t0 = time.perf_counter(); oc.run(20, nthreads=th); print("oracle %d threads: %.2f ms" % (th, (time.perf_counter() - t0) * 1e3))
