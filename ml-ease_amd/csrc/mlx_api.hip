@@ -559,6 +559,7 @@ struct CsrPrep {
     std::vector<int32_t> rp, pcol, cri, item_ptr, item_dst, col_ptr, ishort, ilong, l2g_perm, rs_ptr, cs_ptr, cw_blk, cw_slice;
     std::vector<uint16_t> rs_idx, cs_idx;
     std::vector<float> pvalv, cval, rs_val, cs_val;
+    std::vector<int32_t> rowperm;            // library row i = the caller's row rowperm[i] (empty: identity)
     bool hasval = false;
     int rc = MLX_OK;
     std::string error;
@@ -602,6 +603,7 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
         if (i && row_ptr[i] < row_ptr[i - 1]) return P.fail(MLX_ERR_INVALID, "row_ptr not monotone at %d", i);
         rp[i] = (int32_t)row_ptr[i];
     }
+    std::vector<int32_t> rowperm;            // library row order (see the cold-column block below); empty = the caller's
     for (int64_t k = 0; k < nnz; k++)
         if (col_idx[k] < 0 || col_idx[k] >= nf) return P.fail(MLX_ERR_INVALID, "col_idx[%lld]=%d out of [0,%d)", (long long)k, col_idx[k], nf);
     // Library-internal relabelling of the local ids: most frequent feature first (stable). The caller's local order
@@ -622,13 +624,60 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
         // need more packs per item stay in front so that the 64-item slices keep their fill. MLX_NO_COLD_ORDER=1: A/B switch.
         const int hot_cols = row_hot_cols(nf, n_lambda).hot_cols;
         if (!faithful && nf > hot_cols && getenv("MLX_NO_COLD_ORDER") == nullptr) {
-            std::vector<int32_t> first((size_t)nf, std::numeric_limits<int32_t>::max());
-            for (int i = l - 1; i >= 0; i--)
-                for (int64_t k = row_ptr[i]; k < row_ptr[i + 1]; k++) first[(size_t)col_idx[k]] = i;
+            // Rows and cold columns are ordered TOGETHER by a depth-first walk of the bipartite graph (rows x cold columns): a row
+            // is followed by the rows it shares a cold column with, a cold column is numbered when a row first reaches it. On the
+            // one-hot configs a cold column has 1..4 entries and a row ~2 cold entries: the walk makes not only a column's FIRST
+            // entry but most of its later ones fall next to their neighbours' (rows in the same 64-row group gather from the same few
+            // cache lines of the vector). The library's row order is as free as its column order: the reference defines neither
+            // (llf/LibLinearDataset.java:467-478); y / weight / offset are uploaded in the same order. MLX_COLD_ROWS=0 keeps the
+            // caller's row order (columns then numbered by first row).
+            std::vector<char> is_cold((size_t)nf, 0);
+            for (int j = hot_cols; j < nf; j++) is_cold[(size_t)new2old[(size_t)j]] = 1;
+            std::vector<int32_t> visit((size_t)nf, -1);
+            const bool walk = !(getenv("MLX_COLD_ROWS") && atoi(getenv("MLX_COLD_ROWS")) == 0);
+            if (walk) {
+                std::vector<int32_t> cstart((size_t)nf + 1, 0);
+                for (int64_t k = 0; k < nnz; k++) if (is_cold[(size_t)col_idx[k]]) cstart[(size_t)col_idx[k] + 1]++;
+                for (int j = 0; j < nf; j++) cstart[(size_t)j + 1] += cstart[(size_t)j];
+                std::vector<int32_t> crow((size_t)cstart[(size_t)nf]), fillp(cstart.begin(), cstart.end() - 1);
+                for (int i = 0; i < l; i++)
+                    for (int64_t k = row_ptr[i]; k < row_ptr[i + 1]; k++)
+                        if (is_cold[(size_t)col_idx[k]]) crow[(size_t)fillp[(size_t)col_idx[k]]++] = i;
+                std::vector<char> seen((size_t)l, 0);
+                std::vector<int32_t> stack;
+                rowperm.reserve((size_t)l);
+                int nvis = 0;
+                for (int seed = 0; seed < l; seed++) {
+                    if (seen[(size_t)seed]) continue;
+                    stack.push_back(seed);
+                    while (!stack.empty()) {
+                        const int r = stack.back();
+                        stack.pop_back();
+                        if (seen[(size_t)r]) continue;
+                        seen[(size_t)r] = 1;
+                        rowperm.push_back(r);
+                        for (int64_t k = row_ptr[r + 1] - 1; k >= row_ptr[r]; k--) {     // (reverse: the row's first cold column is walked first)
+                            const int32_t c = col_idx[k];
+                            if (!is_cold[(size_t)c]) continue;
+                            for (int32_t q = cstart[(size_t)c + 1] - 1; q >= cstart[(size_t)c]; q--)
+                                if (!seen[(size_t)crow[(size_t)q]]) stack.push_back(crow[(size_t)q]);
+                        }
+                        for (int64_t k = row_ptr[r]; k < row_ptr[r + 1]; k++) {
+                            const int32_t c = col_idx[k];
+                            if (is_cold[(size_t)c] && visit[(size_t)c] < 0) visit[(size_t)c] = nvis++;
+                        }
+                    }
+                }
+            } else {
+                int nvis = 0;
+                for (int i = 0; i < l; i++)
+                    for (int64_t k = row_ptr[i]; k < row_ptr[i + 1]; k++)
+                        if (is_cold[(size_t)col_idx[k]] && visit[(size_t)col_idx[k]] < 0) visit[(size_t)col_idx[k]] = nvis++;
+            }
             std::stable_sort(new2old.begin() + hot_cols, new2old.end(), [&](int32_t a, int32_t b) {
                 const int pa = (cnt[(size_t)a] + 3) / 4, pb = (cnt[(size_t)b] + 3) / 4;
-                if (pa != pb) return pa > pb;
-                return first[(size_t)a] < first[(size_t)b];
+                if (pa != pb) return pa > pb;                     // columns that need more packs per item stay in front
+                return visit[(size_t)a] < visit[(size_t)b];
             });
         }
         for (int j = 0; j < nf; j++) newid[(size_t)new2old[(size_t)j]] = j;
@@ -637,11 +686,17 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
     std::vector<float> pvalv(val ? (size_t)nnz : 0);
     for (int j = 0; j < nf; j++) l2g_perm[(size_t)j] = local_to_global[new2old[(size_t)j]];
     l2g_perm[(size_t)nf] = local_to_global[nf];
+    if (!rowperm.empty()) {                  // library rows: rp becomes the row pointer of the permuted rows
+        std::vector<int32_t> rpn((size_t)l + 1, 0);
+        for (int i = 0; i < l; i++) rpn[(size_t)i + 1] = rpn[(size_t)i] + (int32_t)(row_ptr[rowperm[(size_t)i] + 1] - row_ptr[rowperm[(size_t)i]]);
+        rp.swap(rpn);
+    }
     {
         std::vector<std::pair<int32_t, float>> rowbuf;
         for (int i = 0; i < l; i++) {
             rowbuf.clear();
-            for (int32_t k = rp[i]; k < rp[i + 1]; k++) rowbuf.emplace_back(newid[(size_t)col_idx[k]], val ? val[k] : 1.0f);
+            const int io = rowperm.empty() ? i : rowperm[(size_t)i];
+            for (int64_t k = row_ptr[io]; k < row_ptr[io + 1]; k++) rowbuf.emplace_back(newid[(size_t)col_idx[k]], val ? val[k] : 1.0f);
             std::stable_sort(rowbuf.begin(), rowbuf.end(), [](const std::pair<int32_t, float> &a, const std::pair<int32_t, float> &b) { return a.first < b.first; });
             for (size_t t = 0; t < rowbuf.size(); t++) {
                 pcol[(size_t)rp[i] + t] = rowbuf[t].first;
@@ -807,8 +862,10 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
             ph.row_multi_ok = mxh <= 6 && mxc <= 3;
         }
         if (ph.sell) {
-            rs_idx.assign((size_t)padded, (uint16_t)0xFFFF);
-            if (val) rs_val.assign((size_t)padded, 0.f);
+            // (+256 entries of padding behind the last block: a wave whose trailing groups do not exist issues its unconditional,
+            // clamped pack load at the END offset -- one 512-byte pack that must still be inside the allocation)
+            rs_idx.assign((size_t)padded + 256, (uint16_t)0xFFFF);
+            if (val) rs_val.assign((size_t)padded + 256, 0.f);
             std::fill(rs_idx.begin(), rs_idx.begin() + rs_ptr[(size_t)n_hs * ngr], (uint16_t)slw);   // hot slices pad with the zero slot
             for (int sl = 0; sl < ncs_r; sl++)
                 for (int r = 0; r < l; r++) {
@@ -831,8 +888,8 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
                 for (int t = s2 * 64; t < s2 * 64 + 64; t++) mx = std::max(mx, item_ptr[(size_t)t + 1] - item_ptr[(size_t)t]);
                 cs_ptr[(size_t)s2 + 1] = cs_ptr[(size_t)s2] + (mx + 3) / 4 * 256;
             }
-            cs_idx.assign((size_t)cs_ptr[(size_t)ncs], (uint16_t)RB);       // padding gathers the zero slot behind the block
-            if (val) cs_val.assign((size_t)cs_ptr[(size_t)ncs], 0.f);
+            cs_idx.assign((size_t)cs_ptr[(size_t)ncs] + 256, (uint16_t)RB);       // padding gathers the zero slot behind the block (+ one pack of slack, as above)
+            if (val) cs_val.assign((size_t)cs_ptr[(size_t)ncs] + 256, 0.f);
             for (int bk = 0; bk < nb; bk++) {
                 for (int it = blk_item0[(size_t)bk]; it < blk_item0[(size_t)bk + 1]; it++) {
                     const int32_t base = cs_ptr[(size_t)(it >> 6)], lane = it & 63;
@@ -867,6 +924,7 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
     P.rp = std::move(rp); P.pcol = std::move(pcol); P.pvalv = std::move(pvalv); P.cri = std::move(cri); P.cval = std::move(cval);
     P.item_ptr = std::move(item_ptr); P.item_dst = std::move(item_dst); P.col_ptr = std::move(col_ptr); P.ishort = std::move(ishort); P.ilong = std::move(ilong);
     P.l2g_perm = std::move(l2g_perm);
+    P.rowperm = std::move(rowperm);
     P.rs_ptr = std::move(rs_ptr); P.rs_idx = std::move(rs_idx); P.rs_val = std::move(rs_val);
     P.cs_ptr = std::move(cs_ptr); P.cs_idx = std::move(cs_idx); P.cs_val = std::move(cs_val);
     P.cw_blk = std::move(cw_blk); P.cw_slice = std::move(cw_slice);
@@ -916,6 +974,18 @@ static int commit_csr(mlx_handle h, CsrPrep &P, int32_t l, int32_t n_local, int6
     }
     ph.dev.items_short = d_ishort; ph.dev.items_long = d_ilong; ph.dev.n_short = ph.n_short; ph.dev.n_long = ph.n_long;
     ph.dev.item_ptr = d_item; ph.dev.item_dst = d_itemdst; ph.dev.col_ptr = d_colptr; ph.dev.n_slots = ph.n_slots; ph.dev.l2g = d_l2g; ph.dev.X = nullptr;
+    if (!P.rowperm.empty()) {
+        std::vector<int8_t> yp((size_t)l);
+        std::vector<float> wp(weight ? (size_t)l : 0), op(offset ? (size_t)l : 0);
+        for (int i = 0; i < l; i++) {
+            const int io = P.rowperm[(size_t)i];
+            yp[(size_t)i] = y[io];
+            if (weight) wp[(size_t)i] = weight[io];
+            if (offset) op[(size_t)i] = offset[io];
+        }
+        if ((rc = upload_row_meta(h, ph, l, yp.data(), weight ? wp.data() : nullptr, offset ? op.data() : nullptr, false))) return rc;
+        return finish_part(h, ph);
+    }
     if ((rc = upload_row_meta(h, ph, l, y, weight, offset, false))) return rc;
     return finish_part(h, ph);
 }
