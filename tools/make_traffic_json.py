@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copies the summaries of tools/profile_round2.sh from gpurun_out/prof_<tag>/ into profiles/<tag>_* and derives the
+"""Copies the summaries of tools/profile_round3.sh from gpurun_out/prof_<tag>/ into profiles/<tag>_* and derives the
 HBM-traffic ratios bench.py quotes:
 
     profiles/traffic.json          dense leg: (2 x FETCH_SIZE + WRITE_SIZE) of k_xpass_dense / its algorithmic bytes
@@ -31,7 +31,7 @@ def pmc_sums(path, counter):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
     for f in sorted(os.listdir(src)):
@@ -43,7 +43,7 @@ def main():
     kd = next(k for k in fe if "k_xpass_dense" in k)
     hbm = 2.0 * fe[kd][1] + wr[kd][1]
     alg = bd["all_launches"]["alg_bytes"]
-    json.dump({"kernel": "k_xpass_dense<4,4>", "command": "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --loglik-iters 0 --no-sparse --no-profile",
+    json.dump({"kernel": "k_xpass_dense<4,4>", "command": "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --loglik-iters 0 --no-sparse --no-sweep --no-profile",
                "launches": fe[kd][0], "FETCH_SIZE_bytes": fe[kd][1], "WRITE_SIZE_bytes": wr[kd][1],
                "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests at 64 B for wide coalesced reads; MI355X_MICROARCH.md, HBM section)",
                "hbm_bytes": hbm, "alg_bytes_same_launches": alg, "hbm_bytes_per_alg_byte": round(hbm / alg, 4),
