@@ -31,3 +31,164 @@ def test_every_abi_entry_point_is_bound_and_natives_match():
     assert natives == cfuncs, "natives without glue: %s ; glue without native: %s" % (sorted(natives - cfuncs), sorted(cfuncs - natives))
     # the error mapping of jobs/RegressionAdmmTrain.java:713-716 and utils/LinearModelUtils.java:80-83
     assert '"Model fitting error!"' in glue and '"Some models failed!"' in glue
+
+
+# ---- the glue EXECUTED without a JVM: tests/jni_stub/fake_env.c implements the JNIEnv entries it uses ---------------------------
+import ctypes as C
+
+import numpy as np
+import pytest
+
+PFX = "Java_com_linkedin_mlease_regression_gpu_MleaseHip_"
+
+
+@pytest.fixture(scope="module")
+def glue(tmp_path_factory):
+    """jni/mlease_jni.c + the fake JNIEnv in one shared library, linked against the in-tree libmlease_hip.so."""
+    so = str(tmp_path_factory.mktemp("jni") / "libjni_fake.so")
+    csrc = os.path.join(ROOT, "ml-ease_amd", "csrc")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-g", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-fPIC", "-shared",
+                           "-I", os.path.join(ROOT, "tests", "jni_stub"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "jni_stub", "fake_env.c"), GLUE, "-o", so,
+                           "-L", csrc, "-lmlease_hip", "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib"])
+    L = C.CDLL(so)
+    vp = C.c_void_p
+    L.fake_env.restype = vp
+    L.fake_new_array.restype = vp
+    L.fake_new_array.argtypes = [C.c_size_t, C.c_int32, vp]
+    L.fake_new_object_array.restype = vp
+    L.fake_new_object_array.argtypes = [C.c_int32]
+    L.fake_set_element.argtypes = [vp, C.c_int32, vp]
+    L.fake_array_data.restype = vp
+    L.fake_array_data.argtypes = [vp]
+    L.fake_array_len.argtypes = [vp]
+    L.fake_new_self.restype = vp
+    L.fake_new_self.argtypes = [C.c_int64]
+    L.fake_object_double.restype = C.c_double
+    L.fake_object_double.argtypes = [vp, C.c_int]
+    L.fake_exception_class.restype = C.c_char_p
+    L.fake_exception_message.restype = C.c_char_p
+    return L
+
+
+class _J:
+    """Helpers around the fake environment: numpy -> fake Java arrays, calling natives, reading the pending exception."""
+
+    def __init__(self, L):
+        self.L, self.env = L, C.c_void_p(L.fake_env())
+
+    def arr(self, a, dtype):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dtype)
+        return C.c_void_p(self.L.fake_new_array(a.itemsize, len(a), a.ctypes.data_as(C.c_void_p)))
+
+    def out(self, n, dtype):
+        return C.c_void_p(self.L.fake_new_array(np.dtype(dtype).itemsize, n, None))
+
+    def read(self, h, dtype):
+        n = self.L.fake_array_len(h)
+        return np.ctypeslib.as_array(C.cast(self.L.fake_array_data(h), C.POINTER(np.ctypeslib.as_ctypes_type(dtype))), shape=(n,)).copy()
+
+    def call(self, name, self_obj, *args, restype=None, argtypes=None):
+        f = getattr(self.L, PFX + name)
+        f.restype = restype
+        f.argtypes = [C.c_void_p, C.c_void_p] + list(argtypes or [C.c_void_p] * len(args))
+        self.L.fake_clear()
+        r = f(self.env, self_obj, *args)
+        return r, self.L.fake_exception_class().decode(), self.L.fake_exception_message().decode()
+
+
+def test_glue_rejects_wrongly_sized_arrays_before_touching_them(glue):
+    """Round-2 advisor finding: a short or null Java array became a native out-of-bounds access. Every native now checks its arrays
+    before pinning them; here with a NULL handle (no GPU needed: validation comes first)."""
+    J = _J(glue)
+    me = C.c_void_p(glue.fake_new_self(0))
+    rp = np.array([0, 2, 5], np.int64)                   # l = 2, nnz = 5
+    good = dict(ci=np.zeros(5, np.int32), y=np.array([1, -1], np.int8), l2g=np.arange(4, dtype=np.int32))
+    i32, vp = C.c_int32, C.c_void_p
+    sig = [i32, i32, vp, vp, vp, vp, vp, vp, vp]
+
+    def add(rowptr, ci, val, y, wt, off, l2g, n_local=4):
+        return J.call("addPartitionCsr", me, 0, n_local, J.arr(rowptr, np.int64), J.arr(ci, np.int32), J.arr(val, np.float32), J.arr(y, np.int8),
+                      J.arr(wt, np.float32), J.arr(off, np.float32), J.arr(l2g, np.int32), argtypes=sig)
+    for kw, frag in ((dict(rowptr=None), "rowPtr is null"), (dict(ci=good["ci"][:4]), "colIdx has 4 elements, 5 needed"),
+                     (dict(ci=None), "colIdx is null"), (dict(val=np.zeros(3, np.float32)), "val has 3"),
+                     (dict(y=good["y"][:1]), "y has 1 elements, 2 needed"), (dict(y=None), "y is null"),
+                     (dict(wt=np.ones(1, np.float32)), "weight has 1"), (dict(l2g=good["l2g"][:3]), "localToGlobal has 3 elements, 4 needed"),
+                     (dict(rowptr=np.array([0, 2, -1], np.int64)), "not a valid entry count")):
+        a = dict(rowptr=rp, ci=good["ci"], val=None, y=good["y"], wt=None, off=None, l2g=good["l2g"])
+        a.update(kw)
+        _, cls, msg = add(a["rowptr"], a["ci"], a["val"], a["y"], a["wt"], a["off"], a["l2g"])
+        assert cls == "java/lang/IllegalArgumentException" and frag in msg, (kw, cls, msg)
+        assert glue.fake_outstanding_pins() == 0
+    # well-formed arrays reach the library, which rejects the NULL handle (still an exception, not a crash)
+    _, cls, msg = add(rp, good["ci"], None, good["y"], None, None, good["l2g"])
+    assert cls != "" and glue.fake_outstanding_pins() == 0
+    # several partitions at once: the k-th entry is checked too
+    oa = lambda xs, dt: (lambda h: [glue.fake_set_element(h, i, J.arr(x, dt)) for i, x in enumerate(xs)] and h)(C.c_void_p(glue.fake_new_object_array(len(xs))))
+    _, cls, msg = J.call("addPartitionsCsr", me, J.arr([0, 1], np.int32), J.arr([4, 4], np.int32), oa([rp, rp], np.int64), oa([good["ci"], good["ci"][:2]], np.int32),
+                         None, oa([good["y"], good["y"]], np.int8), None, None, oa([good["l2g"], good["l2g"]], np.int32))
+    assert cls == "java/lang/IllegalArgumentException" and "colIdx[k] has 2 elements, 5 needed" in msg
+    assert glue.fake_outstanding_pins() == 0
+    # scoring and test rows
+    _, cls, msg = J.call("scoreRows", me, J.arr(np.zeros(4, np.float32), np.float32), J.arr(rp, np.int64), J.arr(good["ci"], np.int32), None, None,
+                         J.out(1, np.float32))
+    assert cls == "java/lang/IllegalArgumentException" and "pred has 1 elements, 2 needed" in msg
+    _, cls, msg = J.call("setTestData", me, J.arr(rp, np.int64), J.arr(good["ci"], np.int32), None, J.arr(good["y"][:1], np.int8), None, None)
+    assert cls == "java/lang/IllegalArgumentException" and "response has 1" in msg
+    _, cls, msg = J.call("setProblem", me, 10, J.arr([1.0, 2.0], np.float32), J.arr([1.0], np.float32), 8, 0, None,
+                         argtypes=[i32, vp, vp, i32, C.c_uint8, vp])
+    assert cls == "java/lang/IllegalArgumentException" and "rho has 1 elements, 2 needed" in msg
+
+
+@pytest.mark.gpu
+def test_glue_runs_the_sample_job_like_the_ctypes_engine(glue):
+    """The whole seam through the JNI natives (create -> setProblem -> addPartitionCsr x 8 -> finalizeProblem -> admmIterate x 3 -> getZ /
+    getPartitionModel / getSolveCounters / dims) on the C1 fixture: bit-identical to the ctypes engine, and result arrays of the wrong
+    size are refused."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import mlease_amd  # noqa: F401
+    from mlease_amd.hip_engine import HipAdmmEngine
+    from fixtures import load_c1
+    c1 = load_c1()
+    J = _J(glue)
+    i32, vp, f64, f32 = C.c_int32, C.c_void_p, C.c_double, C.c_float
+    h, cls, msg = J.call("create", None, 0, restype=C.c_int64, argtypes=[i32])
+    assert cls == "" and h, (cls, msg)
+    me = C.c_void_p(glue.fake_new_self(h))
+    ok = lambda r: (_ for _ in ()).throw(AssertionError(r[1:])) if r[1] else r[0]
+    ok(J.call("setProblem", me, c1.n_global, J.arr([1.0], np.float32), J.arr([1.0], np.float32), 8, 0, None, argtypes=[i32, vp, vp, i32, C.c_uint8, vp]))
+    for b in c1.blocks:
+        ok(J.call("addPartitionCsr", me, b.partition_id, b.n_local, J.arr(b.row_ptr, np.int64), J.arr(b.col_idx, np.int32), J.arr(b.val, np.float32),
+                  J.arr(b.y, np.int8), J.arr(b.weight, np.float32), J.arr(b.offset, np.float32), J.arr(b.local_to_global, np.int32),
+                  argtypes=[i32, i32, vp, vp, vp, vp, vp, vp, vp]))
+    ok(J.call("finalizeProblem", me))
+    d = J.read(C.c_void_p(ok(J.call("dims", me, 3, restype=vp, argtypes=[i32]))), np.int32)
+    assert list(d[:4]) == [c1.n_global, 1, 8, 8] and d[4] == c1.blocks[3].n_local and d[5] == c1.blocks[3].l
+    eng = HipAdmmEngine(c1.n_global, [1.0], [1.0], 8)
+    for b in c1.blocks:
+        eng.add_partition(b)
+    eng.finalize()
+    for _ in range(3):
+        st = C.c_void_p(ok(J.call("admmIterate", me, 0.01, 1.0, restype=vp, argtypes=[f64, f32])))
+        es = eng.iterate(0.01)
+        assert glue.fake_object_double(st, 0) == es.maxdiff                      # Stats.maxdiff (first double field set)
+    zd, zf = J.out(c1.n_global, np.float64), J.out(c1.n_global, np.float32)
+    ok(J.call("getZ", me, zd, zf))
+    assert np.array_equal(J.read(zd, np.float64), eng.z()[0][0]) and np.array_equal(J.read(zf, np.float32), eng.z()[1][0])
+    _, cls, msg = J.call("getZ", me, J.out(c1.n_global - 1, np.float64), None)
+    assert cls == "java/lang/IllegalArgumentException" and "zDouble has %d elements, %d needed" % (c1.n_global - 1, c1.n_global) in msg
+    b_, x_, u_ = (J.out(c1.n_global, np.float32) for _ in range(3))
+    ok(J.call("getPartitionModel", me, 5, 0, b_, x_, u_, argtypes=[i32, i32, vp, vp, vp]))
+    for got, want in zip((b_, x_, u_), eng.partition_model(5, 0)):
+        assert np.array_equal(J.read(got, np.float32), want)
+    cnt = J.out(8 * 4, np.int32)
+    ok(J.call("getSolveCounters", me, cnt))
+    assert np.array_equal(J.read(cnt, np.int32).reshape(8, 4), eng.solve_counters())
+    _, cls, msg = J.call("getSolveCounters", me, J.out(31, np.int32))
+    assert cls == "java/lang/IllegalArgumentException" and "out has 31 elements, 32 needed" in msg
+    assert glue.fake_outstanding_pins() == 0
+    J.call("destroy", None, C.c_int64(h), argtypes=[C.c_int64])
+    eng.close()
