@@ -867,7 +867,7 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
 #pragma unroll
         for (int u = 0; u < COL_B; u++) {
             if (L4[u] > KP) a[u] = sell_lds_sum<HASVAL, NT>(a[u], cs_idx, cs_val, base[u], KP, L4[u], lane, cf, zs);
-            if (dst[u] >= 0) out[dst[u]] = a[u];
+            if (dst[u] >= 0) out[dst[u]] = a[u];          // (plain store: phase A reads the slots from L2 right after; a streaming store cost the pass 13 %)
         }
         PT_MARK(11);
     }
@@ -1408,6 +1408,17 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, cons
 // Norms are sqrt(sum v^2) of sums gathered inside the update loops (euclideanNorm's scaled form up to the last bits).
 // ------------------------------------------------------------------------------------------------
 #define STEP_T 256
+// The step's n-vector streams are touched once per launch and not again before ~1 GB of other traffic has gone by: streaming
+// (non-temporal) loads and stores keep them from displacing the gathered vectors and index packs in L2 (config #3: step 316 -> 283 us per
+// tick, 5.06 k -> 5.29 k solves/s). NOT for what the next launch reads from L2: the column pass's slot stores and phase A's slot /
+// pointer loads as streaming accesses cost 13 % of the column pass and 10 % of phase A. -DMLX_STEP_NO_NT: A/B build.
+#ifdef MLX_STEP_NO_NT
+#define SLD(p) (*(p))
+#define SST(p, v) (*(p) = (v))
+#else
+#define SLD(p) __builtin_nontemporal_load(p)
+#define SST(p, v) __builtin_nontemporal_store((v), (p))
+#endif
 #ifndef STEP_XB
 #define STEP_XB 4      // columns per thread and round (independent loads in flight)
 #endif
@@ -1503,7 +1514,7 @@ k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
             const bool col = j < nf;
             const int jf = min(jc, max(nf - 1, 0));
             i0[u] = (col && nf > 0) ? cptr[jf] : 0; i1[u] = (col && nf > 0) ? cptr[jf + 1] : 0;
-            vv[u] = v[jc];
+            vv[u] = SLD(v + jc);
             pj[u] = pvec ? pvec[jc] : pscal;
             mm[u] = cg ? 0.0 : m[jc];
             cc[u] = (phase == PH_EVAL0) ? c0[jc] : 0.0;
@@ -1520,7 +1531,7 @@ k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
             if (j == nf) xa = csum_icpt;
             if (cg) {
                 const double hd = vv[u] * pj[u] + xa;          // Hs[i] = (s[i]*priorVar_inv[i] + Hs[i]) * 1
-                Hd[j] = hd;
+                SST(Hd + j, hd);
                 acc[0] += vv[u] * hd;
             } else {
                 const double t = vv[u] - mm[u];
@@ -1673,21 +1684,21 @@ k_step_b(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
 #pragma unroll
             for (int u = 0; u < STEP_XB; u++) {
                 const int jc = min(jb + u * STEP_T, G.j1 - 1);
-                dv[u] = d[jc]; sv[u] = s[jc]; rv[u] = rc[jc]; hv[u] = Hd[jc];
+                dv[u] = SLD(d + jc); sv[u] = SLD(s + jc); rv[u] = SLD(rc + jc); hv[u] = SLD(Hd + jc);
             }
 #pragma unroll
             for (int u = 0; u < STEP_XB; u++) {
                 const int j = jb + u * STEP_T;
                 if (j >= G.j1) continue;
                 const double s1 = sv[u] + alpha * dv[u];               // daxpy(alpha, d, s)
-                s[j] = s1;
+                SST(s + j, s1);
                 acc[0] += s1 * s1;
                 const double sb = s1 + nalpha * dv[u];                 // the boundary case steps back first (:153)
                 acc[1] += sb * dv[u];
                 acc[2] += sb * sb;
                 acc[3] += dv[u] * dv[u];
                 const double r1 = rv[u] + nalpha * hv[u];              // daxpy(-alpha, Hd, r)
-                rn[j] = r1;
+                SST(rn + j, r1);
                 acc[4] += r1 * r1;
             }
         }
@@ -1763,13 +1774,13 @@ k_step_c(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
 #pragma unroll
         for (int u = 0; u < STEP_XB; u++) {
             const int jc = min(jb + u * STEP_T, G.j1 - 1);
-            dv[u] = d[jc];
-            r1[u] = boundary ? 0.0 : rn[jc];
-            sv[u] = (boundary || end_cg) ? s[jc] : 0.0;
-            hv[u] = boundary ? Hd[jc] : 0.0;
-            rv[u] = boundary ? rc[jc] : 0.0;
-            wv[u] = end_cg ? w[jc] : 0.0;
-            gv[u] = end_cg ? g[jc] : 0.0;
+            dv[u] = SLD(d + jc);
+            r1[u] = boundary ? 0.0 : SLD(rn + jc);
+            sv[u] = (boundary || end_cg) ? SLD(s + jc) : 0.0;
+            hv[u] = boundary ? SLD(Hd + jc) : 0.0;
+            rv[u] = boundary ? SLD(rc + jc) : 0.0;
+            wv[u] = end_cg ? SLD(w + jc) : 0.0;
+            gv[u] = end_cg ? SLD(g + jc) : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < STEP_XB; u++) {
