@@ -723,7 +723,7 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
             const int row = (g0 + wg0 + i0 + i) * 64 + lane;
             ok[i] = (wg0 + i0 + i < gcount) && row < l;
             rowi[i] = min(row, l - 1);
-            wdv0[i] = cg ? wdcur[rowi[i]] : 0.0;
+            wdv0[i] = cg ? __builtin_nontemporal_load(wdcur + rowi[i]) : 0.0;      // (read once per tick)
             zc[i] = add_cold ? coef[rowi[i]] : 0.0;
             offv[i] = cg ? 0.f : pa.off[rowi[i]];
             wtv[i] = cg ? 0.f : pa.wt[rowi[i]];
@@ -857,7 +857,7 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
             base[u] = __builtin_amdgcn_readfirstlane(cs_ptr[sc]);
             const int nx = __builtin_amdgcn_readfirstlane(cs_ptr[sc + 1]);
             L4[u] = (sl < s1) ? (nx - base[u]) >> 8 : 0;
-            const int dl = item_dst[sc * 64 + lane];                          // unconditional, clamped
+            const int dl = __builtin_nontemporal_load(item_dst + sc * 64 + lane);   // unconditional, clamped; read once per tick
             dst[u] = (sl < s1) ? dl : -1;
             a[u] = 0.0;
         }
