@@ -14,7 +14,9 @@ partition k -> rank k mod N (64/N per GPU), the consensus means [xbar | ubar] al
 backend "nccl"). --scaling weak keeps 64 partitions per GPU (num.blocks = 64 N).
 
 Extra top-level keys of the same JSON line:
-  roofline      dominant kernel of the headline (k_xpass_dense): algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak
+  roofline      dominant kernel of the headline (k_xpass_dense): algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak. The
+                timed iterations run as a production job does (no per-launch events; two tick streams); the events live in a
+                replay of exactly those iterations from the same state (`measured_in`, `reproduced_timed_run`)
   cpu_baseline  the C oracle on the host cores, ALL 64 partitions, the SAME ADMM iterations as the first timed ones
                 (it starts from the GPU's state after the warm-up iterations), one thread per partition solve
   parity_check  the GPU re-run of exactly those iterations against the oracle's result
@@ -231,7 +233,7 @@ def run_dense(args, C):
     rows = rows_total // N                                                  # rows per partition (row % N assignment)
     mine = [k for k in range(N) if k % world == rank]                       # partition k -> rank k mod G
     P = len(mine)
-    eng = C["HipAdmmEngine"](nf + 1, [1.0], [1.0], N, device=C["local_rank"], stream=C["stream"], profiling=not args.no_profile)
+    eng = C["HipAdmmEngine"](nf + 1, [1.0], [1.0], N, device=C["local_rank"], stream=C["stream"])
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     if want_cpu and mem_available_gb() < 48:
         want_cpu = False
@@ -271,10 +273,9 @@ def run_dense(args, C):
 
     for _ in range(args.warmup):
         step(False)
-    snap = None
-    if want_cpu:                       # the state every timed iteration starts from (outside the timed region)
-        snap = (eng.z()[0].copy(), np.stack([eng.partition_model(i, 0)[2] for i in range(P)])[:, None, :].copy(),
-                sched.e, sched.mindiff, sched.it)
+    # the state every timed iteration starts from (outside the timed region): for the CPU leg and for the replay with events
+    snap = (eng.z()[0].copy(), np.stack([eng.partition_model(i, 0)[2] for i in range(P)])[:, None, :].copy(),
+            sched.e, sched.mindiff, sched.it)
     C["barrier"]()
     t0 = time.perf_counter()
     step_times = []
@@ -287,6 +288,29 @@ def run_dense(args, C):
     tot_solves, tot_pref, tot_pdev, tot_cg, tot_newton = C["reduce_sum"](
         [acc["solves"], acc["passes_ref"], acc["passes_dev"], acc["cg"], acc["newton"]])
     z32_end = eng.z()[1].copy()            # the consensus as the final-model file would hold it (identical on every rank)
+    # ---- roofline of the dominant kernel: the timed iterations ran as a production job does (no per-launch events; the library then
+    # ticks two halves of the problems on two streams, so that one half's TRON step -- one workgroup per problem -- runs beside the
+    # other half's pass). The HIP events that time k_xpass_dense live in a REPLAY of exactly those iterations from the same state
+    # (bit-reproducible; `reproduced_timed_run`), where events keep every launch on one stream so that a duration is the kernel's own.
+    prof = None
+    if not args.no_profile:
+        prof = dict(alg_bytes=0.0, xpass_ms=0.0, launches=0, ticks=0, wall=0.0)
+        eng.set_state(snap[0], snap[1])
+        eng.set_profiling(True)
+        C["barrier"]()
+        tp = time.perf_counter()
+        f2 = None
+        for eps in eps_used[args.warmup:args.warmup + args.steps]:
+            st2 = eng.solve_local(eps, 1.0)
+            C["all_reduce"](eng.consensus_tensor())
+            f2 = eng.consensus_finish()
+            prof["alg_bytes"] += st2.alg_bytes_dev; prof["xpass_ms"] += st2.xpass_ms; prof["launches"] += st2.xpass_launches; prof["ticks"] += st2.ticks
+            allrun["alg_bytes"] += st2.alg_bytes_dev
+            allrun["launches"] += st2.ticks
+        C["barrier"]()
+        prof["wall"] = C["reduce_max"](time.perf_counter() - tp)
+        eng.set_profiling(False)
+        prof["reproduced"] = bool(f2 is not None and f2.maxdiff == fin.maxdiff and prof["ticks"] == acc["ticks"] and np.array_equal(eng.z()[1], z32_end))
 
     # ---- metric (ii): ADMM wall-clock to the reference test log-likelihood: a full run from z = u = 0 with
     # the per-iteration test loglik (jobs/RegressionAdmmTrain.java:766-845) on the 100 000 held-out rows; the target is
@@ -299,22 +323,27 @@ def run_dense(args, C):
     if rank == 0:
         value = tot_solves / dt
         roof = None
-        if acc["xpass_ms"] > 0:
-            achieved = acc["alg_bytes"] / (acc["xpass_ms"] * 1e-3) / 1e9
+        if prof is not None and prof["xpass_ms"] > 0:
+            achieved = prof["alg_bytes"] / (prof["xpass_ms"] * 1e-3) / 1e9
             traffic, tsrc = None, None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as fh:
                     tj = json.load(fh)
-                traffic = tj["hbm_bytes_per_alg_byte"] * acc["alg_bytes"] / max(1, acc["launches"])
+                traffic = tj["hbm_bytes_per_alg_byte"] * prof["alg_bytes"] / max(1, prof["launches"])
                 tsrc = "profiles/traffic.json: (2 x FETCH_SIZE + WRITE_SIZE) / algorithmic bytes = %.4f from the committed rocprofv3 " \
                        "--pmc passes of `%s`, times this run's algorithmic bytes per launch (not a counter read in this run)" % (
                            tj["hbm_bytes_per_alg_byte"], tj.get("command", "bench.py"))
             roof = {"bound": "hbm", "kernel": "k_xpass_dense<4,4>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
-                    "alg_bytes_per_launch": acc["alg_bytes"] / max(1, acc["launches"]),
-                    "avg_launch_ms": acc["xpass_ms"] / max(1, acc["launches"]), "launches": acc["launches"],
-                    "xpass_share_of_step": round(acc["xpass_ms"] / (dt * 1e3), 4)}
+                    "alg_bytes_per_launch": prof["alg_bytes"] / max(1, prof["launches"]),
+                    "avg_launch_ms": prof["xpass_ms"] / max(1, prof["launches"]), "launches": prof["launches"],
+                    "xpass_share_of_replay": round(prof["xpass_ms"] / (prof["wall"] * 1e3), 4),
+                    "replay_ms_per_step": round(prof["wall"] * 1e3 / args.steps, 3), "timed_ms_per_step": round(dt * 1e3 / args.steps, 3),
+                    "reproduced_timed_run": prof["reproduced"],
+                    "measured_in": "a replay of the %d timed iterations (same state, same epsilons; reproduced_timed_run = %s) with the library's per-launch "
+                                   "HIP events on its own stream and ONE tick stream: %.3f ms per iteration there against %.3f ms in the timed run "
+                                   "(no events, two tick streams)" % (args.steps, prof["reproduced"], prof["wall"] * 1e3 / args.steps, dt * 1e3 / args.steps)}
         out = {"metric": "partition Newton-solves/sec (ADMM L2-LR, dense 1Mx1K, 64 partitions)",
                "value": round(value, 3), "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": args.scaling,

@@ -331,8 +331,13 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
     int rc;
     // two tick streams: the CSR list is cut in two (whole groups of 8 list positions, so the XCD placement of xcd_map is kept); the
     // halves share nothing but the done counter
-    const bool two = h->nstreams == 2 && nqd == 0 && nqc >= 32 && !h->profiling;
-    const int nq0 = two ? (nqc / 2 + 7) / 8 * 8 : nqc;
+    // (dense lists too: the step of a dense tick is one workgroup per problem -- 21 us during which most of the chip idles; with
+    // two halves it runs beside the other half's pass. Mixed dense + CSR handles stay on one stream.)
+    const bool two_csr = h->nstreams == 2 && nqd == 0 && nqc >= 32 && !h->profiling;
+    const bool two_dense = h->nstreams == 2 && nqc == 0 && nqd >= 4 && !h->profiling && !h->anti_phase;
+    const bool two = two_csr || two_dense;
+    const int nq0 = two_csr ? (nqc / 2 + 7) / 8 * 8 : nqc;
+    const int nd0 = two_dense ? (nqd + 1) / 2 : nqd;
     hipStream_t sA = h->stream, sB = h->stream2;
     if (two) {
         h->h_done2[0] = h->h_done2[1] = 0;
@@ -361,12 +366,12 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
                 ticks++;
                 continue;
             }
-            if ((rc = launch_xpass(h, qdense, nqd, qcsr, nq0))) return rc;
-            launch_step(h, qdense, nqd, qcsr, nq0);
+            if ((rc = launch_xpass(h, qdense, nd0, qcsr, nq0))) return rc;
+            launch_step(h, qdense, nd0, qcsr, nq0);
             if (two) {
                 h->stream = sB;
-                rc = launch_xpass(h, nullptr, 0, qcsr + nq0, nqc - nq0);
-                if (!rc) launch_step(h, nullptr, 0, qcsr + nq0, nqc - nq0);
+                rc = launch_xpass(h, qdense + nd0, nqd - nd0, qcsr + nq0, nqc - nq0);
+                if (!rc) launch_step(h, qdense + nd0, nqd - nd0, qcsr + nq0, nqc - nq0);
                 h->stream = sA;
                 if (rc) return rc;
             }
