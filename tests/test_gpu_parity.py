@@ -1062,3 +1062,60 @@ def test_onehot_admm_run_stays_within_the_reference_order_spread():
     assert max(dgs) <= 1e-2 * scale, msg
     assert max(lgs) <= max(4.0 * max(lps), 2e-4), msg
     eng.close()
+
+
+@pytest.mark.parametrize("kind", ["sparse", "dense"])
+def test_two_tick_streams_are_bit_identical_to_one(kind, monkeypatch):
+    """Round 3: the problem list is cut into two halves that tick independently on two HIP streams (MLX_STREAMS, default 2; the
+    halves share nothing but the done counter). Every output must equal the one-stream run bit for bit -- on the CSR tick kernels
+    (>= 32 problems: 17 partitions x 2 lambdas) and on dense tiles (>= 4 problems)."""
+    monkeypatch.setenv("MLX_NO_SMALL", "1")
+    if kind == "sparse":
+        pd, lam, rho = synth_sparse(41, 6800, 500, 10, 17, binary=True), [0.3, 3.0], [1.0, 1.0]
+    else:
+        from fixtures import dense_blocks
+        pd, lam, rho = dense_blocks(6 * 4200, 96, 6), [1.0], [1.0]
+    outs = []
+    for ns in ("1", "2"):
+        monkeypatch.setenv("MLX_STREAMS", ns)
+        eng = make_engine(pd, lam, rho)
+        rec = []
+        for it in range(4):
+            st = eng.iterate(0.01 if it < 2 else 1e-4)
+            rec.append((eng.solve_counters().copy(), eng.z()[0].copy(), st.maxdiff,
+                        [eng.partition_model(k, li)[1].copy() for k in range(len(pd.blocks)) for li in range(len(lam))]))
+        outs.append(rec)
+        eng.close()
+    for it, (a, b) in enumerate(zip(*outs)):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2], "iteration %d" % (it + 1)
+        assert all(np.array_equal(x, y) for x, y in zip(a[3], b[3])), "iteration %d: a partition's u + beta differs" % (it + 1)
+    assert outs[0][-1][0][:, 2].sum() > 0
+
+
+def test_row_and_cold_column_order_does_not_change_the_solve(monkeypatch):
+    """Round 3: rows and cold columns are renumbered together by a depth-first walk (a locality matter for the cold gathers); with
+    the walk, with the cold columns numbered by first row only (MLX_COLD_ROWS=0) and with the round-2 frequency order
+    (MLX_NO_COLD_ORDER=1) a well-conditioned sparse job must follow the oracle's trajectory and agree within 1e-5 -- with
+    weights and offsets, which travel with their rows. MLX_SLW=128 makes most columns cold; MLX_ROW_NG=128 + MLX_COLD_SEP=1 runs
+    the 128-group row workgroups and the separate cold launch the big configs use."""
+    monkeypatch.setenv("MLX_NO_SMALL", "1")
+    monkeypatch.setenv("MLX_SLW", "128")
+    monkeypatch.setenv("MLX_ROW_NG", "128")
+    monkeypatch.setenv("MLX_COLD_SEP", "1")
+    pd = synth_sparse(57, 9000, 1500, 14, 3, binary=False, weights=True, offsets=True)
+    lam, rho = [0.5, 8.0], [1.0, 1.0]
+    oc = ol.OracleAdmm(pd.blocks, pd.n_global, lam, rho)
+    for it in range(4):
+        oc.iterate(0.01, 1.0, nthreads=4)
+    for env in ({}, {"MLX_COLD_ROWS": "0"}, {"MLX_NO_COLD_ORDER": "1"}):
+        for k in ("MLX_COLD_ROWS", "MLX_NO_COLD_ORDER"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = make_engine(pd, lam, rho)
+        for it in range(4):
+            eng.iterate(0.01)
+        assert np.array_equal(eng.solve_counters(), _counters(oc)), env
+        for li in range(2):
+            assert_coef_close(eng.z()[1][li], oc.z()[1][li], "%s lambda %d" % (env, li), floor=1e-2)
+        eng.close()
