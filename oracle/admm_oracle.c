@@ -15,7 +15,12 @@
  * This file is therefore pinned only by (a) line-by-line review against the
  * reference files cited on every function, (b) agreement to <=1e-12 with an
  * independent NumPy restatement (oracle/admm_numpy.py), (c) mathematical pins
- * in tests/ (finite differences, KKT at exit, approach to the centralised optimum).
+ * in tests/ (finite differences, KKT at exit, approach to the centralised optimum), and (d) -- the closest thing to the reference
+ * this image can run -- the C++ liblinear the reference's vendored Java port derives from, reached through scikit-learn's
+ * `liblinear` solver: where the objectives coincide (prior mean 0, variance 1, bias last and penalised) the TRON trajectories
+ * agree in iteration counts and to ~1e-15 in the coefficients at every tolerance (tests/test_oracle.py::
+ * test_oracle_tron_follows_c_liblinear_through_scikit_learn). tools/make_java_golden.sh pins it to the Java itself wherever a JDK
+ * exists (tests/test_java_golden.py).
  *
  * Path aliases used in citations (all under /root/reference/src/main/java/):
  *   bw/   = de/bwaldvogel/liblinear/

@@ -1119,3 +1119,23 @@ def test_row_and_cold_column_order_does_not_change_the_solve(monkeypatch):
         for li in range(2):
             assert_coef_close(eng.z()[1][li], oc.z()[1][li], "%s lambda %d" % (env, li), floor=1e-2)
         eng.close()
+
+
+def test_hip_solve_follows_c_liblinear_through_scikit_learn(c1):
+    """The LibLinear.train seam of the HIP library (mlx_solve_one) against scikit-learn's `liblinear` solver -- the C++ liblinear whose
+    Java port the reference vendors -- where the two objectives are the same function (prior mean 0, prior variance 1 = C 1, bias
+    feature last and penalised): equal Newton iteration counts and coefficients within 1e-9 at loose and tight tolerances. An
+    implementation neither this repository nor its oracle shares code with (tests/test_oracle.py pins the oracle the same way)."""
+    sk = pytest.importorskip("sklearn.linear_model")
+    import scipy.sparse as sps
+    eng = make_engine(c1, [1.0], [1.0])
+    for k in (0, 3, 6):
+        b = c1.blocks[k]
+        X = sps.csr_matrix((b.val.astype(np.float64), b.col_idx, b.row_ptr), shape=(b.l, b.n_local - 1))
+        for tol in (1e-2, 1e-5):
+            clf = sk.LogisticRegression(penalty="l2", C=1.0, solver="liblinear", tol=tol, fit_intercept=True, intercept_scaling=1.0, max_iter=10000).fit(X, b.y)
+            w_sk = np.concatenate([clf.coef_[0], clf.intercept_])
+            w, cnt, _ = eng.solve_one(k, np.zeros(b.n_local), np.zeros(b.n_local), np.ones(b.n_local), tol)
+            assert int(clf.n_iter_[0]) == cnt[0] == cnt[1], (k, tol, clf.n_iter_, cnt)
+            assert np.max(np.abs(w - w_sk)) <= 1e-9 * max(1.0, np.max(np.abs(w_sk))), (k, tol, float(np.max(np.abs(w - w_sk))))
+    eng.close()

@@ -414,3 +414,42 @@ def test_verification_twin_keeps_its_math_without_openmp(tmp_path):
         L.orc_math_kind.restype = ctypes.c_char_p
         assert L.orc_math_kind() == want
     assert ol.lib(False).orc_math_kind() == b"libm" and ol.lib(True).orc_math_kind() == b"portable"
+
+
+def test_oracle_tron_follows_c_liblinear_through_scikit_learn():
+    """An independent pin of the TRON core (R3-R9 of SURVEY 8a), short of running the Java: scikit-learn's `liblinear` solver IS the C++
+    liblinear whose Java port the reference vendors (de.bwaldvogel.liblinear), primal L2-regularised logistic regression (solver 0).
+    With prior mean 0, prior variance 1 (= C 1), the bias feature appended last with value 1 and penalised like the rest
+    (intercept_scaling 1) the two objectives are the same function, so the whole trust-region trajectory must coincide: equal Newton
+    iteration counts and coefficients to ~1e-15 at EVERY tolerance -- including 0.01, where the result is whatever the trajectory has
+    reached. Also with per-row weights (scikit-learn's liblinear multiplies the loss by sample_weight, as llf/LogisticRegressionL2.java
+    :166-182 does by weight[i]) and on binary one-hot rows; and at another C the minimisers agree at a tight tolerance."""
+    sk = pytest.importorskip("sklearn.linear_model")
+    import scipy.sparse as sps
+    from fixtures import load_c1, onehot_blocks
+    c1 = load_c1()
+    rng = np.random.default_rng(3)
+    # (tolerance per case: on the sample data the trajectories agree to the last bits; on one-hot rows the C library's unrolled BLAS
+    # dot products -- another summation order than the Java port's plain loops -- are amplified to ~1e-6 at the loose tolerance,
+    # the order sensitivity DESIGN section 5 is about, here between liblinear's own two language versions)
+    cases = [(c1.blocks[0], None, 1e-12), (c1.blocks[3], None, 1e-12),
+             (c1.blocks[5], rng.uniform(0.5, 2.0, c1.blocks[5].l).astype(np.float32), 1e-12),
+             (onehot_blocks(3000, 1, levels=40).blocks[0], None, 1e-5)]
+    for b, wt, rtol in cases:
+        nf = b.n_local - 1
+        vals = np.ones(len(b.col_idx)) if b.val is None else b.val.astype(np.float64)
+        X = sps.csr_matrix((vals, b.col_idx, b.row_ptr), shape=(b.l, nf))
+        od = ol.OracleDataset(b.l, b.n_local, b.row_ptr, b.col_idx, b.val, b.y, b.weight if wt is None else wt, b.offset)
+        for tol in (1e-2, 1e-4, 1e-8):
+            clf = sk.LogisticRegression(penalty="l2", C=1.0, solver="liblinear", tol=tol, fit_intercept=True, intercept_scaling=1.0, max_iter=10000)
+            clf.fit(X, b.y, sample_weight=None if wt is None else wt.astype(np.float64))
+            w_sk = np.concatenate([clf.coef_[0], clf.intercept_])
+            w, st = od.train(np.zeros(b.n_local), np.zeros(b.n_local), np.ones(b.n_local), tol)
+            assert int(clf.n_iter_[0]) == st.newton_iters == st.accepted, (tol, clf.n_iter_, st.newton_iters, st.accepted)
+            assert np.max(np.abs(w - w_sk)) <= rtol * max(1.0, np.max(np.abs(w))), (tol, float(np.max(np.abs(w - w_sk))))
+    # another regularisation strength: same minimiser (the objectives differ by the factor C, so the trajectories do)
+    b = c1.blocks[1]
+    X = sps.csr_matrix((b.val.astype(np.float64), b.col_idx, b.row_ptr), shape=(b.l, b.n_local - 1))
+    clf = sk.LogisticRegression(penalty="l2", C=0.25, solver="liblinear", tol=1e-10, fit_intercept=True, intercept_scaling=1.0, max_iter=10000).fit(X, b.y)
+    w, _ = ol.OracleDataset.from_block(b).train(np.zeros(b.n_local), np.zeros(b.n_local), np.full(b.n_local, 0.25), 1e-10)
+    assert np.max(np.abs(w - np.concatenate([clf.coef_[0], clf.intercept_]))) <= 1e-7
