@@ -89,7 +89,6 @@ struct mlx_context {
     int step_threads = 256;
     int step_ch = 2048, step_max_nwg = 1;   // multi-workgroup CSR step: columns per workgroup, chunks of the widest CSR problem
     bool step_fused = false;                // phases A+B+C in one launch (k_step_fused)
-    int step_group = 0;                     // problems per A/B/C launch group (0 = all in one): see launch_step
     int cold_groups = 0;                    // > 0: row groups of the widest partition with cold column slices (k_rowcold launch)
     unsigned step_seq = 0;                  // its launch sequence number (the exchanges' flag value; never 0)
     int *d_stepctl = nullptr;               // [0] ticket counter [1] error flag
@@ -110,8 +109,6 @@ struct mlx_context {
     hipEvent_t ev_batch2[2] = {nullptr, nullptr}, ev_fork = nullptr, ev_join = nullptr;
     int *h_done2 = nullptr;
     int nstreams = 1;
-    bool anti_phase = false;                // MLX_STREAMS=3: the halves run half a tick apart, held there by cross-stream events
-    hipEvent_t ev_x[16] = {};
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
     std::vector<hipEvent_t> ev_pool;        // profiling: a chain of marks; the interval from mark i to mark i+1 belongs to ev_kind[i]
     std::vector<int> ev_kind;               // 0 dense X pass, 1 CSR row pass, 2 CSR column pass, 3 TRON/CG step, -1 not a launch
@@ -288,14 +285,10 @@ void launch_step(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
         return;
     }
 #endif
-    // Phases A, B, C run per GROUP of problems (A_g, B_g, C_g, then the next group), so that what one phase writes -- Hd, r', s --
-    // is still in the memory-side cache (256 MB Infinity Cache) when the next phase of the same group reads it; the phases of
-    // one problem depend only on that problem's partial sums. The commit stays one launch over all problems.
-    const int G = h->step_group > 0 ? h->step_group : std::max(nqc, 1);
-    for (int q0 = 0; q0 < nqc; q0 += G)
-        for (int which = 0; which < 3; which++)
-            mlxk_step_phase(h->stream, which, h->d_parts, h->d_probs, qcsr + q0, std::min(G, nqc - q0), h->step_ch, h->step_max_nwg, h->d_done, h->d_stepctl);
-    mlxk_step_phase(h->stream, 3, h->d_parts, h->d_probs, qcsr, nqc, h->step_ch, h->step_max_nwg, h->d_done, h->d_stepctl);
+    // (launching A, B, C per group of problems so that Hd / r' / s stay in the memory-side cache between phases was measured: every
+    // group size is slower than one launch per phase, profiles/r3_notes.md)
+    for (int which = 0; which < 4; which++)
+        mlxk_step_phase(h->stream, which, h->d_parts, h->d_probs, qcsr, nqc, h->step_ch, h->step_max_nwg, h->d_done, h->d_stepctl);
 }
 
 // Drive ticks until `count` problems starting at `first` are DONE.
@@ -334,7 +327,7 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
     // (dense lists too: the step of a dense tick is one workgroup per problem -- 21 us during which most of the chip idles; with
     // two halves it runs beside the other half's pass. Mixed dense + CSR handles stay on one stream.)
     const bool two_csr = h->nstreams == 2 && nqd == 0 && nqc >= 32 && !h->profiling;
-    const bool two_dense = h->nstreams == 2 && nqc == 0 && nqd >= 4 && !h->profiling && !h->anti_phase;
+    const bool two_dense = h->nstreams == 2 && nqc == 0 && nqd >= 4 && !h->profiling;
     const bool two = two_csr || two_dense;
     const int nq0 = two_csr ? (nqc / 2 + 7) / 8 * 8 : nqc;
     const int nd0 = two_dense ? (nqd + 1) / 2 : nqd;
@@ -344,28 +337,8 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
         HIPCHECK(h, hipEventRecord(h->ev_fork, sA));
         HIPCHECK(h, hipStreamWaitEvent(sB, h->ev_fork, 0));
     }
-    const bool anti = two && h->anti_phase;
-    int xk = 0;
-    auto xbar = [&]() {                                  // both streams wait for each other's work queued so far
-        hipEventRecord(h->ev_x[xk], sA); hipEventRecord(h->ev_x[xk + 1], sB);
-        hipStreamWaitEvent(sA, h->ev_x[xk + 1], 0); hipStreamWaitEvent(sB, h->ev_x[xk], 0);
-        xk = (xk + 2) % 16;
-    };
-    if (anti && (rc = launch_xpass(h, nullptr, 0, qcsr, nq0))) return rc;      // half 0 runs half a tick ahead
     for (;;) {
         for (int i = 0; i < batch; i++) {
-            if (anti) {
-                // phase 1: step of half 0 beside the passes of half 1; phase 2: passes of half 0 (next tick) beside the step of half 1
-                xbar();
-                launch_step(h, nullptr, 0, qcsr, nq0);
-                h->stream = sB; rc = launch_xpass(h, nullptr, 0, qcsr + nq0, nqc - nq0); h->stream = sA;
-                if (rc) return rc;
-                xbar();
-                if ((rc = launch_xpass(h, nullptr, 0, qcsr, nq0))) return rc;
-                h->stream = sB; launch_step(h, nullptr, 0, qcsr + nq0, nqc - nq0); h->stream = sA;
-                ticks++;
-                continue;
-            }
             if ((rc = launch_xpass(h, qdense, nd0, qcsr, nq0))) return rc;
             launch_step(h, qdense, nd0, qcsr, nq0);
             if (two) {
@@ -467,14 +440,13 @@ int mlx_create(int device_id, mlx_handle *out)
     h->own_stream = true;
     hipEventCreateWithFlags(&h->ev_batch[0], hipEventDisableTiming);
     hipEventCreateWithFlags(&h->ev_batch[1], hipEventDisableTiming);
-    // default: two tick streams (C3 5.1-5.2 k -> 5.4-5.5 k solves/s, 8 lambdas x 128 partitions 21.4 k -> 23.4 k; MLX_STREAMS=1: one).
-    // MLX_STREAMS=3 holds the halves half a tick apart with cross-stream events (passes of one beside the step of the other):
-    // measured SLOWER than one stream (4.88 k) -- the passes and the step do not complement each other, the gain of the free-running
-    // form is launch tails and gaps being filled (profiles/r3_notes.md).
+    // default: two tick streams (C3 5.1-5.2 k -> 5.4-5.5 k solves/s, 8 lambdas x 128 partitions 21.4 k -> 23.4 k, dense 64 problems
+    // 2.67 k -> 2.81 k; MLX_STREAMS=1: one). The halves run free: holding them half a tick apart with cross-stream events (the passes of
+    // one beside the step of the other) measured SLOWER than one stream -- the gain is launch tails and gaps being filled, and a dense
+    // half's one-workgroup-per-problem step running beside the other half's pass (profiles/r3_notes.md).
     h->nstreams = 2;
-    if (const char *se = getenv("MLX_STREAMS")) { h->nstreams = atoi(se) >= 2 ? 2 : 1; h->anti_phase = atoi(se) == 3; }
+    if (const char *se = getenv("MLX_STREAMS")) h->nstreams = atoi(se) >= 2 ? 2 : 1;
     if (h->nstreams == 2) {
-        for (auto &e : h->ev_x) hipEventCreateWithFlags(&e, hipEventDisableTiming);
         if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess) h->nstreams = 1;
         hipEventCreateWithFlags(&h->ev_batch2[0], hipEventDisableTiming);
         hipEventCreateWithFlags(&h->ev_batch2[1], hipEventDisableTiming);
@@ -500,7 +472,6 @@ int mlx_destroy(mlx_handle h)
     for (auto e : h->ev_pool) hipEventDestroy(e);
     for (auto e : h->ev_batch) if (e) hipEventDestroy(e);
     for (auto e : h->ev_batch2) if (e) hipEventDestroy(e);
-    for (auto e : h->ev_x) if (e) hipEventDestroy(e);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->stream2) hipStreamDestroy(h->stream2);
@@ -1287,7 +1258,6 @@ int mlx_finalize(mlx_handle h)
         h->step_ch = ch;
         h->step_max_nwg = (max_nlocal_csr + ch - 1) / ch;
         // MLX_STEP_FUSED=1 (opt-in, measured slower -- profiles/r2_notes.md): phases A+B+C in one launch with in-launch exchanges
-        if (const char *ge = getenv("MLX_STEP_GROUP")) h->step_group = std::max(0, atoi(ge));
         const char *fe = getenv("MLX_STEP_FUSED");
         h->step_fused = ch == 2048 && h->step_max_nwg <= 256 && fe && atoi(fe) == 1;
     }
