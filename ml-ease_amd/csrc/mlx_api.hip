@@ -105,9 +105,10 @@ struct mlx_context {
     hipEvent_t ev_batch[2] = {nullptr, nullptr};
     // second tick stream (MLX_STREAMS=2): the CSR problems are cut into two halves that tick independently, so that one half's
     // latency-bound passes overlap the other half's bandwidth-bound step launches (run_ticks)
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_batch2[2] = {nullptr, nullptr}, ev_fork = nullptr, ev_join = nullptr;
-    int *h_done2 = nullptr;
+    static constexpr int MAX_TS = 4;
+    hipStream_t xstream[MAX_TS] = {};       // tick streams 1..nstreams-1 (stream 0 is `stream`)
+    hipEvent_t ev_batchx[MAX_TS][2] = {}, ev_fork = nullptr, ev_join[MAX_TS] = {};
+    int *h_donex = nullptr;                 // [MAX_TS][2] pinned
     int nstreams = 1;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
     std::vector<hipEvent_t> ev_pool;        // profiling: a chain of marks; the interval from mark i to mark i+1 belongs to ev_kind[i]
@@ -322,29 +323,35 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
     int slot = 0;
     bool have_prev = false;
     int rc;
-    // two tick streams: the CSR list is cut in two (whole groups of 8 list positions, so the XCD placement of xcd_map is kept); the
-    // halves share nothing but the done counter
-    // (dense lists too: the step of a dense tick is one workgroup per problem -- 21 us during which most of the chip idles; with
-    // two halves it runs beside the other half's pass. Mixed dense + CSR handles stay on one stream.)
-    const bool two_csr = h->nstreams == 2 && nqd == 0 && nqc >= 32 && !h->profiling;
-    const bool two_dense = h->nstreams == 2 && nqc == 0 && nqd >= 4 && !h->profiling;
-    const bool two = two_csr || two_dense;
-    const int nq0 = two_csr ? (nqc / 2 + 7) / 8 * 8 : nqc;
-    const int nd0 = two_dense ? (nqd + 1) / 2 : nqd;
-    hipStream_t sA = h->stream, sB = h->stream2;
-    if (two) {
-        h->h_done2[0] = h->h_done2[1] = 0;
+    // Several tick streams: the problem list is cut into NS parts that tick independently (CSR: whole groups of 8 list positions, so
+    // the XCD placement of xcd_map is kept); the parts share nothing but the done counter. Launch tails and gaps of one part are
+    // filled by the others, and a dense part's TRON step (one workgroup per problem: 21 us during which most of the chip idles)
+    // runs beside another part's pass. Mixed dense + CSR handles, and runs with profiling events, stay on one stream.
+    int NS = 1;
+    if (h->nstreams > 1 && !h->profiling) {
+        if (nqd == 0 && nqc >= 32) NS = std::min(h->nstreams, nqc / 16);
+        else if (nqc == 0 && nqd >= 4) NS = std::min(h->nstreams, nqd / 2);
+    }
+    int c0[mlx_context::MAX_TS + 1], d0[mlx_context::MAX_TS + 1];      // part t = list positions [c0[t], c0[t+1]) / [d0[t], d0[t+1])
+    for (int t = 0; t <= NS; t++) {
+        c0[t] = (NS == 1 || t == NS) ? (t == 0 ? 0 : nqc) : (int)(((int64_t)nqc * t / NS + 7) / 8 * 8);
+        d0[t] = (int)((int64_t)nqd * t / NS);
+        if (t == 0) { c0[t] = 0; d0[t] = 0; }
+        c0[t] = std::min(c0[t], nqc);
+    }
+    hipStream_t sA = h->stream;
+    auto st_of = [&](int t) { return t == 0 ? sA : h->xstream[t]; };
+    if (NS > 1) {
+        for (int t = 1; t < NS; t++) h->h_donex[t * 2] = h->h_donex[t * 2 + 1] = 0;
         HIPCHECK(h, hipEventRecord(h->ev_fork, sA));
-        HIPCHECK(h, hipStreamWaitEvent(sB, h->ev_fork, 0));
+        for (int t = 1; t < NS; t++) HIPCHECK(h, hipStreamWaitEvent(st_of(t), h->ev_fork, 0));
     }
     for (;;) {
         for (int i = 0; i < batch; i++) {
-            if ((rc = launch_xpass(h, qdense, nd0, qcsr, nq0))) return rc;
-            launch_step(h, qdense, nd0, qcsr, nq0);
-            if (two) {
-                h->stream = sB;
-                rc = launch_xpass(h, qdense + nd0, nqd - nd0, qcsr + nq0, nqc - nq0);
-                if (!rc) launch_step(h, qdense + nd0, nqd - nd0, qcsr + nq0, nqc - nq0);
+            for (int t = 0; t < NS; t++) {
+                h->stream = st_of(t);
+                rc = launch_xpass(h, qdense + d0[t], d0[t + 1] - d0[t], qcsr + c0[t], c0[t + 1] - c0[t]);
+                if (!rc) launch_step(h, qdense + d0[t], d0[t + 1] - d0[t], qcsr + c0[t], c0[t + 1] - c0[t]);
                 h->stream = sA;
                 if (rc) return rc;
             }
@@ -353,14 +360,17 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
         mark(h, -1);
         HIPCHECK(h, hipMemcpyAsync(&h->h_done[slot], h->d_done, sizeof(int), hipMemcpyDeviceToHost, sA));
         HIPCHECK(h, hipEventRecord(h->ev_batch[slot], sA));
-        if (two) {
-            HIPCHECK(h, hipMemcpyAsync(&h->h_done2[slot], h->d_done, sizeof(int), hipMemcpyDeviceToHost, sB));
-            HIPCHECK(h, hipEventRecord(h->ev_batch2[slot], sB));
+        for (int t = 1; t < NS; t++) {
+            HIPCHECK(h, hipMemcpyAsync(&h->h_donex[t * 2 + slot], h->d_done, sizeof(int), hipMemcpyDeviceToHost, st_of(t)));
+            HIPCHECK(h, hipEventRecord(h->ev_batchx[t][slot], st_of(t)));
         }
         if (have_prev) {
             HIPCHECK(h, hipEventSynchronize(h->ev_batch[slot ^ 1]));
-            if (two) HIPCHECK(h, hipEventSynchronize(h->ev_batch2[slot ^ 1]));
-            const int done = two ? std::max(h->h_done[slot ^ 1], h->h_done2[slot ^ 1]) : h->h_done[slot ^ 1];
+            int done = h->h_done[slot ^ 1];
+            for (int t = 1; t < NS; t++) {
+                HIPCHECK(h, hipEventSynchronize(h->ev_batchx[t][slot ^ 1]));
+                done = std::max(done, h->h_donex[t * 2 + (slot ^ 1)]);        // snapshots of ONE monotone counter: the largest is the latest
+            }
             if (getenv("MLX_TRACE")) fprintf(stderr, "[mlx] ticks=%lld done=%d/%d\n", (long long)(ticks - batch), done, count);
             if (done >= count) break;      // the batch just queued runs as no-ops
         }
@@ -368,9 +378,9 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
         slot ^= 1;
         if (ticks > TICK_CAP) return fail(h, MLX_ERR_MODEL_FITTING, "Model fitting error! solve did not terminate within %lld ticks", (long long)TICK_CAP);
     }
-    if (two) {                                           // the first stream continues (outputs, means) after both halves
-        HIPCHECK(h, hipEventRecord(h->ev_join, sB));
-        HIPCHECK(h, hipStreamWaitEvent(sA, h->ev_join, 0));
+    for (int t = 1; t < NS; t++) {                        // the first stream continues (outputs, means) after all parts
+        HIPCHECK(h, hipEventRecord(h->ev_join[t], st_of(t)));
+        HIPCHECK(h, hipStreamWaitEvent(sA, h->ev_join[t], 0));
     }
     HIPCHECK(h, hipStreamSynchronize(h->stream));
     HIPCHECK(h, hipGetLastError());
@@ -445,14 +455,16 @@ int mlx_create(int device_id, mlx_handle *out)
     // one beside the step of the other) measured SLOWER than one stream -- the gain is launch tails and gaps being filled, and a dense
     // half's one-workgroup-per-problem step running beside the other half's pass (profiles/r3_notes.md).
     h->nstreams = 2;
-    if (const char *se = getenv("MLX_STREAMS")) h->nstreams = atoi(se) >= 2 ? 2 : 1;
-    if (h->nstreams == 2) {
-        if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess) h->nstreams = 1;
-        hipEventCreateWithFlags(&h->ev_batch2[0], hipEventDisableTiming);
-        hipEventCreateWithFlags(&h->ev_batch2[1], hipEventDisableTiming);
+    if (const char *se = getenv("MLX_STREAMS")) h->nstreams = std::max(1, std::min(atoi(se), (int)mlx_context::MAX_TS));
+    if (h->nstreams > 1) {
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
-        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
-        if (hipHostMalloc((void **)&h->h_done2, 2 * sizeof(int)) != hipSuccess) h->nstreams = 1;
+        if (hipHostMalloc((void **)&h->h_donex, mlx_context::MAX_TS * 2 * sizeof(int)) != hipSuccess) h->nstreams = 1;
+        for (int t = 1; t < h->nstreams; t++) {
+            if (hipStreamCreateWithFlags(&h->xstream[t], hipStreamNonBlocking) != hipSuccess) { h->nstreams = t; break; }
+            hipEventCreateWithFlags(&h->ev_batchx[t][0], hipEventDisableTiming);
+            hipEventCreateWithFlags(&h->ev_batchx[t][1], hipEventDisableTiming);
+            hipEventCreateWithFlags(&h->ev_join[t], hipEventDisableTiming);
+        }
     }
     hipEventCreate(&h->ev_t0);
     hipEventCreate(&h->ev_t1);
@@ -471,11 +483,13 @@ int mlx_destroy(mlx_handle h)
     if (h->h_diff) hipHostFree(h->h_diff);
     for (auto e : h->ev_pool) hipEventDestroy(e);
     for (auto e : h->ev_batch) if (e) hipEventDestroy(e);
-    for (auto e : h->ev_batch2) if (e) hipEventDestroy(e);
+    for (int t = 1; t < mlx_context::MAX_TS; t++) {
+        for (auto e : h->ev_batchx[t]) if (e) hipEventDestroy(e);
+        if (h->ev_join[t]) hipEventDestroy(h->ev_join[t]);
+        if (h->xstream[t]) hipStreamDestroy(h->xstream[t]);
+    }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
-    if (h->ev_join) hipEventDestroy(h->ev_join);
-    if (h->stream2) hipStreamDestroy(h->stream2);
-    if (h->h_done2) hipHostFree(h->h_done2);
+    if (h->h_donex) hipHostFree(h->h_donex);
     if (h->ev_t0) hipEventDestroy(h->ev_t0);
     if (h->ev_t1) hipEventDestroy(h->ev_t1);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
