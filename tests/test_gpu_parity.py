@@ -1139,3 +1139,36 @@ def test_hip_solve_follows_c_liblinear_through_scikit_learn(c1):
             assert int(clf.n_iter_[0]) == cnt[0] == cnt[1], (k, tol, clf.n_iter_, cnt)
             assert np.max(np.abs(w - w_sk)) <= 1e-9 * max(1.0, np.max(np.abs(w_sk))), (k, tol, float(np.max(np.abs(w - w_sk))))
     eng.close()
+
+
+@pytest.mark.parametrize("kind", ["onehot", "dense"])
+def test_kkt_at_exit_on_full_size_partitions(kind):
+    """Size-independent property at BASELINE's partition sizes (configs[2]: 39 063 one-hot rows x ~70 K local features; configs[1]:
+    15 625 x 1000 dense): whatever trajectory a solve took, it must EXIT where bw/Tron.java:108-110 says -- the gradient norm at the
+    returned point, evaluated independently by the oracle, at most epsilon * min(pos, neg) / l times the gradient norm at w = 0
+    (llf/LibLinear.java:272-276) -- and its objective must not exceed the oracle's own exit value by more than the tolerance implies."""
+    from fixtures import onehot_blocks, dense_blocks
+    if kind == "onehot":
+        pd = onehot_blocks(39063 * 2, 2)
+    else:
+        pd = dense_blocks(15625 * 2, 1000, 2)
+    eng = make_engine(pd, [1.0], [1.0])
+    b = pd.blocks[1]
+    n = b.n_local
+    z, one = np.zeros(n), np.ones(n)
+    rng = np.random.default_rng(5)
+    m = rng.normal(0, 0.05, n)                            # a non-trivial prior mean, as an ADMM iteration has it
+    od = ol.OracleDataset.from_block(b)
+    _, g0, _ = od.eval(z, m, one)
+    pos = int((b.y == 1).sum())
+    for eps in (1e-2, 1e-5):
+        w, cnt, (f, gn, gn1) = eng.solve_one(1, z, m, one, eps)
+        fo, g, _ = od.eval(w, m, one)
+        tol = eps * min(pos, b.l - pos) / b.l
+        assert abs(gn1 - np.linalg.norm(g0)) <= 1e-9 * np.linalg.norm(g0)
+        assert np.linalg.norm(g) <= tol * np.linalg.norm(g0) * (1 + 1e-6), (kind, eps, np.linalg.norm(g), tol * np.linalg.norm(g0))
+        assert abs(f - fo) <= 1e-9 * abs(fo)
+        wo, st = od.train(z, m, one, eps)
+        fo2, _, _ = od.eval(wo, m, one)
+        assert fo <= fo2 + 10 * tol * abs(fo2), (kind, eps, fo, fo2)
+    eng.close()
