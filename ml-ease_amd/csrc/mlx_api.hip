@@ -2111,9 +2111,22 @@ int mlx_posterior_variance(mlx_handle h, int32_t local_index, const double *w, c
         std::vector<int> blocks;
         for (int bi = 0; bi < nb; bi++) for (int bj = 0; bj <= bi; bj++) { blocks.push_back(bi); blocks.push_back(bj); }
         const int nblocks = (int)blocks.size() / 2;
-        const int wgs = 512;                                  // row splits in total: two per 8-wave workgroup, one workgroup per CU
-        int ksplit = std::max(1, std::min(wgs / nblocks, (l + 255) / 256));
-        ksplit = (ksplit + 1) / 2 * 2;                       // two row splits per 8-wave workgroup
+        // Row splits: two per 8-wave workgroup, one workgroup per CU at a time. The number of split PAIRS per block is the one that
+        // minimises (rounds of 256 workgroups) x (rows per split) -- 36 blocks: 7 pairs = 252 workgroups in one round; 136 blocks
+        // (n = 2001): 15 pairs = 2040 workgroups in 8 full rounds, where "about 512 / blocks" gave 272 = one full round and one of 16
+        // (0.38 of the MFMA peak) -- with at least 64 rows per split and at most 2 GB of partial blocks.
+        int ncu = 256;
+        { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, h->device) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
+        int best_ks = 1;
+        double best_cost = 0;
+        for (int ks = 1; ks <= 64; ks++) {
+            if (ks > 1 && (l / (2 * ks) < 64 || (double)ks * npad * npad * 8.0 > 2.0e9)) break;
+            const double rounds = std::ceil((double)nblocks * ks / ncu), rows = std::ceil((double)l / (2.0 * ks));
+            const double cost = rounds * rows * (1.0 + 0.002 * ks);       // (a slight preference for fewer partial blocks)
+            if (ks == 1 || cost < best_cost) { best_cost = cost; best_ks = ks; }
+        }
+        if (const char *e = getenv("MLX_GRAM_KS")) best_ks = std::max(1, std::min(64, atoi(e)));        // A/B switch
+        const int ksplit = 2 * best_ks;
         const int rows_per_split = ((l + ksplit - 1) / ksplit + 3) / 4 * 4;
         int *d_blocks;
         double *d_P, *d_H;
