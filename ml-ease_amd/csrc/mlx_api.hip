@@ -80,6 +80,7 @@ struct mlx_context {
     int64_t max_parts_len = 0;
     bool csr_hasval = false, any_absent = false, csr_sell = false, csr_small = false;
     int small_lds_doubles = 0;             // > 0: k_solve_small keeps every problem's work vectors in LDS (doubles needed by the largest)
+    int small_xl = 0, small_xl_bytes = 0;  // X in LDS too (1: uint8 ids, 2: uint16 ids), total dynamic LDS bytes
     int max_cunits = 0, max_rblk_rows = 0;
     int max_row_lds = 0;                    // sliced row pass: columns of the widest hot slice (LDS doubles, + zero slot)
     int row_ngc = 16;                       // row groups per row-pass workgroup (16, 32, 64 or 128)
@@ -98,6 +99,7 @@ struct mlx_context {
     double *d_cons = nullptr;              // [xbar | ubar], 2 * n_lambda * n_global, + 1 status slot summed with them (exchange())
     bool cons_external = false;
     double *d_weight_l = nullptr, *d_pinv_l = nullptr, *d_cmap = nullptr;
+    std::vector<double> pinv_admm_last;     // what d_pinv_l holds (mlx_admm_solve_local; the naive solve overwrites it and clears this)
     unsigned long long *d_diffbits = nullptr;
     int *d_done = nullptr;
     int *h_done = nullptr;                 // pinned [2]
@@ -302,7 +304,8 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
         // than SMALL_TICKS_PER_LAUNCH ticks
         int64_t ticks = 0;
         for (;;) {
-            mlxk_solve_small(h->stream, h->d_parts, h->d_probs, count, first, h->csr_hasval, SMALL_TICKS_PER_LAUNCH, h->d_done, h->small_lds_doubles, h->faithful);
+            mlxk_solve_small(h->stream, h->d_parts, h->d_probs, count, first, h->csr_hasval, SMALL_TICKS_PER_LAUNCH, h->d_done, h->small_lds_doubles, h->faithful,
+                             h->small_xl, h->small_xl_bytes);
             ticks += SMALL_TICKS_PER_LAUNCH;
             HIPCHECK(h, hipMemcpyAsync(&h->h_done[0], h->d_done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIPCHECK(h, hipStreamSynchronize(h->stream));
@@ -1229,6 +1232,21 @@ int mlx_finalize(mlx_handle h)
         for (auto &p : h->parts)
             if (!p.dense) need = std::max<int64_t>(need, 8LL * p.n_local + 3LL * p.l + p.n_items + 2LL * p.nblk);
         if (need > 0 && need <= 18 * 1024) h->small_lds_doubles = (int)need;      // 144 KiB of the 160 KiB LDS, next to 9 KiB static
+        // ... and the partition's own arrays when they fit as well (k_solve_small<.., XL>): narrow ids, see the kernel
+        if (h->small_lds_doubles > 0 && getenv("MLX_NO_SMALL_X") == nullptr) {
+            int maxdim = 0;
+            for (auto &p : h->parts) if (!p.dense) maxdim = std::max(maxdim, std::max(p.l, p.n_local));
+            const int idsz = maxdim <= 256 ? 1 : 2;
+            int64_t total = 0;
+            for (auto &p : h->parts) if (!p.dense) {
+                const int64_t vec = 8LL * (8LL * p.n_local + 3LL * p.l + p.n_items + 2LL * p.nblk);
+                const int64_t xb = 4LL * ((int64_t)p.l + 1 + 2LL * p.n_items + 1 + p.n_feat + 1) + (p.hasval ? 8LL * p.nnz : 0) + 2LL * idsz * p.nnz;
+                total = std::max(total, vec + xb + 16);
+            }
+            if (total > 0 && total <= 148 * 1024) {
+                h->small_xl = idsz; h->small_xl_bytes = (int)total;
+            }
+        }
     }
     // (if any CSR partition could not be sliced, all of them run the lane-group kernels; those accept any row chunking)
     bool first_csr = true;
@@ -1440,8 +1458,11 @@ int mlx_admm_solve_local(mlx_handle h, double liblinear_epsilon, float rho_adapt
         const double pv = 1.0 / rho;
         pinv[li] = 1.0 / pv;
     }
-    HIPCHECK(h, hipMemcpyAsync(h->d_pinv_l, pinv.data(), sizeof(double) * nl, hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(h, hipStreamSynchronize(h->stream));     // pinv is a stack vector
+    if (pinv != h->pinv_admm_last) {                  // (the same values every iteration unless rho adapts: one upload + sync less)
+        HIPCHECK(h, hipMemcpyAsync(h->d_pinv_l, pinv.data(), sizeof(double) * nl, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipStreamSynchronize(h->stream));     // pinv is a stack vector
+        h->pinv_admm_last = pinv;
+    }
     h->ev_used = 0; h->ev_kind.clear();
     HIPCHECK(h, hipEventRecord(h->ev_t0, h->stream));
     mlxk_setup(h->stream, h->d_parts, h->d_probs, h->nprob, nl, ng, h->max_nlocal, h->d_z32, h->d_u, h->d_pinv_l,
@@ -1638,6 +1659,7 @@ int mlx_naive_solve_local(mlx_handle h, double liblinear_epsilon, double prior_m
         for (int j = 0; j < ng; j++)
             if (!std::isnan(h->lambda_map[j])) ovr[j] = 1.0 / (1.0 / (double)h->lambda_map[j]);
     if (!h->penalize_intercept) ovr[ng - 1] = 1.0 / 100000.0;
+    h->pinv_admm_last.clear();
     HIPCHECK(h, hipMemcpyAsync(h->d_pinv_l, pinv.data(), sizeof(double) * nl, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(h, hipMemcpyAsync(h->d_pinv_ovr, ovr.data(), sizeof(double) * ng, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(h, hipStreamSynchronize(h->stream));

@@ -28,7 +28,7 @@ void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *p
 void mlxk_step_fused(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int max_nwg, unsigned seq, int *ctl);
 // whole solves of small CSR problems in one launch (one workgroup per problem runs the tick loop)
 void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int first, bool hasval,
-                      int max_ticks, int *done_counter, int lds_doubles, bool faithful);
+                      int max_ticks, int *done_counter, int lds_doubles, bool faithful, int xl, int lds_bytes_xl);
 void mlxk_collect_c0(hipStream_t st, const PartDev *parts, const ProbDev *probs, const int *qlist, int nq,
                      double *const *c0_ptrs);
 void mlxk_setup(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int n_lambda, int n_global,

@@ -122,6 +122,56 @@ __device__ __forceinline__ double norm_from_sumsq(double ss, const double *__res
     return block_norm(v, n, scratch);
 }
 
+// Who runs the TRON/CG step body: the whole workgroup (barriers, block reductions through LDS) or -- for the tiny problems of
+// k_solve_small<.., XL> -- its FIRST WAVE alone: at n ~ 200 a CG step is five reductions and a dozen barriers of 16 waves for a
+// few hundred flops, and one wave does the same elementwise work (column j on lane j % 64 in every loop, so values only cross
+// lanes inside the reductions) with shuffles and no barrier at all.
+struct BlockTeam {
+    static __device__ __forceinline__ int tid() { return threadIdx.x; }
+    static __device__ __forceinline__ int nt() { return blockDim.x; }
+    static __device__ __forceinline__ void sync() { __syncthreads(); }
+    template <int N> static __device__ __forceinline__ void allreduce(double (&v)[N], double *scratch) { block_allreduce_sum<N>(v, scratch); }
+    static __device__ __forceinline__ double allreduce_max(double x, double *scratch) { return block_allreduce_max(x, scratch); }
+};
+struct WaveTeam {
+    static __device__ __forceinline__ int tid() { return threadIdx.x & 63; }
+    static __device__ __forceinline__ int nt() { return 64; }
+    static __device__ __forceinline__ void sync() { __builtin_amdgcn_wave_barrier(); }      // (one wave: LDS operations complete in issue order)
+    template <int N> static __device__ __forceinline__ void allreduce(double (&v)[N], double *)
+    {
+#pragma unroll
+        for (int i = 0; i < N; i++) v[i] = wave_allreduce_sum(v[i]);
+    }
+    static __device__ __forceinline__ double allreduce_max(double x, double *) { return wave_allreduce_max(x); }
+};
+template <typename T>
+__device__ __forceinline__ double team_sum_array(const double *__restrict__ a, int cnt, double *scratch)
+{
+    double v[1] = {0.0};
+    for (int i = T::tid(); i < cnt; i += T::nt()) v[0] += a[i];
+    T::template allreduce<1>(v, scratch);
+    return v[0];
+}
+template <typename T>
+__device__ __forceinline__ double team_norm(const double *__restrict__ v, int n, double *scratch)      // block_norm for a team
+{
+    double mx = 0;
+    for (int j = T::tid(); j < n; j += T::nt()) mx = fmax(mx, fabs(v[j]));
+    mx = T::allreduce_max(mx, scratch);
+    if (!(mx > 0)) return (mx == 0) ? 0.0 : mx;
+    double a[1] = {0};
+    for (int j = T::tid(); j < n; j += T::nt()) { double t = fabs(v[j]) / mx; a[0] += t * t; }
+    T::template allreduce<1>(a, scratch);
+    return mx * sqrt(a[0]);
+}
+template <typename T>
+__device__ __forceinline__ double team_norm_from_sumsq(double ss, const double *__restrict__ v, int n, double *scratch)
+{
+    if (ss > 1e-280 && ss < 1e280) return sqrt(ss);
+    T::sync();
+    return team_norm<T>(v, n, scratch);
+}
+
 // ------------------------------------------------------------------------------------------------
 // row-wise scalar maps
 // ------------------------------------------------------------------------------------------------
@@ -1107,7 +1157,7 @@ __device__ __forceinline__ double seq_norm(const double *v, int n, double *scrat
     return seq_bcast(scale * sqrt(sum), scratch);
 }
 
-template <bool SEQ>
+template <bool SEQ, typename T = BlockTeam>
 __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, double *scratch, double *stage,
                                                int *__restrict__ done_counter)
 {
@@ -1115,7 +1165,8 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
     const int phase = pr.phase;
     if (phase == PH_DONE) return;
     const int n = pa.n_local;
-    const int tid = threadIdx.x, nt = blockDim.x;
+    static_assert(!SEQ || std::is_same<T, BlockTeam>::value, "the order-faithful mode runs on the whole workgroup");
+    const int tid = T::tid(), nt = T::nt();
     double *__restrict__ w = pr.w, *__restrict__ w_new = pr.w_new, *__restrict__ g = pr.g;
     double *__restrict__ s = pr.s, *__restrict__ r = pr.r, *__restrict__ d = pr.d, *__restrict__ Hd = pr.Hd;
     const double *__restrict__ m = pr.m;
@@ -1125,9 +1176,9 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
     const bool inl = !pa.dense;
     const int nf = pa.n_feat;
     double csum_icpt = 0.0;
-    if (inl) csum_icpt = SEQ ? seq_sum(pr.coef, pa.l, scratch, stage) : block_sum_array(pr.csump, pa.nblk, scratch);   // SEQ: XTv's row order
+    if (inl) csum_icpt = SEQ ? seq_sum(pr.coef, pa.l, scratch, stage) : team_sum_array<T>(pr.csump, pa.nblk, scratch);   // SEQ: XTv's row order
     else assemble_out(pa, pr, Hd, scratch, stage);
-    __syncthreads();
+    T::sync();
     const double *__restrict__ segsum = pr.parts;
     const int32_t *__restrict__ cptr = pa.col_ptr;
     // X'c for XB strided columns at once (j = jb + u*nt): all slot ranges are fetched first, then all first slots, then the
@@ -1179,7 +1230,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
                 }
             }
         }
-        block_allreduce_sum<1>(a1, scratch);
+        T::template allreduce<1>(a1, scratch);
         if (SEQ) a1[0] = seq_dot(d, Hd, n, scratch, stage);
         double alpha = rTr0 / a1[0];
         double ss1[1] = {0.0};
@@ -1188,8 +1239,8 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
             s[j] = sj;
             ss1[0] += sj * sj;
         }
-        block_allreduce_sum<1>(ss1, scratch);
-        const double snorm = SEQ ? seq_norm(s, n, scratch, stage) : norm_from_sumsq(ss1[0], s, n, scratch);
+        T::template allreduce<1>(ss1, scratch);
+        const double snorm = SEQ ? seq_norm(s, n, scratch, stage) : team_norm_from_sumsq<T>(ss1[0], s, n, scratch);
         bool end_cg = false;
         if (snorm > delta0) {
             // cg reaches trust region boundary (:150-168)
@@ -1202,7 +1253,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
                 a3[1] += sj * sj;
                 a3[2] += d[j] * d[j];
             }
-            block_allreduce_sum<3>(a3, scratch);
+            T::template allreduce<3>(a3, scratch);
             if (SEQ) { a3[0] = seq_dot(s, d, n, scratch, stage); a3[1] = seq_dot(s, s, n, scratch, stage); a3[2] = seq_dot(d, d, n, scratch, stage); }
             const double std_ = a3[0], sts = a3[1], dtd = a3[2];
             const double dsq = delta0 * delta0;
@@ -1223,7 +1274,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
                 r[j] = rj;
                 a2[0] += rj * rj;
             }
-            block_allreduce_sum<1>(a2, scratch);
+            T::template allreduce<1>(a2, scratch);
             if (SEQ) a2[0] = seq_dot(r, r, n, scratch, stage);
             const double rnew = a2[0];
             const double beta = rnew / rTr0;
@@ -1232,11 +1283,11 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
                 if (beta != 1.0) dj = dj * beta;                   // scale(beta, d)
                 d[j] = dj + 1.0 * r[j];                            // daxpy(one, r, d)
             }
-            const double rnorm = SEQ ? seq_norm(r, n, scratch, stage) : norm_from_sumsq(rnew, r, n, scratch);
+            const double rnorm = SEQ ? seq_norm(r, n, scratch, stage) : team_norm_from_sumsq<T>(rnew, r, n, scratch);
             if (tid == 0) pr.rTr = rnew;
             if (rnorm <= cgtol0) end_cg = true;                  // loop-top test of the next trip (:144)
         }
-        __syncthreads();
+        T::sync();
         if (tid == 0) { pr.cg_iter += 1; pr.ticks += 1; }
         if (end_cg) {
             // back in tron(): w_new = w + s, gs, prered (:69-73)
@@ -1246,7 +1297,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
                 a2[0] += g[j] * s[j];
                 a2[1] += s[j] * r[j];
             }
-            block_allreduce_sum<2>(a2, scratch);
+            T::template allreduce<2>(a2, scratch);
             if (SEQ) { a2[0] = seq_dot(g, s, n, scratch, stage); a2[1] = seq_dot(s, r, n, scratch, stage); }
             if (tid == 0) {
                 pr.gs = a2[0];
@@ -1275,8 +1326,8 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
             }
         }
     }
-    block_allreduce_sum<1>(a1, scratch);
-    const double loss = SEQ ? seq_sum(pr.rowtmp, pa.l, scratch, stage) : block_sum_array(pr.lossp, pa.nblk, scratch);
+    T::template allreduce<1>(a1, scratch);
+    const double loss = SEQ ? seq_sum(pr.rowtmp, pa.l, scratch, stage) : team_sum_array<T>(pr.lossp, pa.nblk, scratch);
     double fnew = 2.0 * loss;
     if (SEQ) {
         // fun :184-189 adds the prior terms to the running f one by one
@@ -1286,7 +1337,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
         fnew = fnew + a1[0];
     }
     fnew = fnew / 2.0;
-    __syncthreads();
+    T::sync();
     const double *__restrict__ c0 = SEQ ? pr.c0f : pa.c0;
 
     if (phase == PH_EVAL0) {
@@ -1295,9 +1346,9 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
             g[j] = Hd[j];
             s[j] = (0.0 - m[j]) * pinv_at(pr, j) + c0[j];           // grad(0) staged in s[]
         }
-        __syncthreads();
-        const double gnorm1 = SEQ ? seq_norm(s, n, scratch, stage) : block_norm(s, n, scratch);
-        const double gnorm = SEQ ? seq_norm(g, n, scratch, stage) : block_norm(g, n, scratch);
+        T::sync();
+        const double gnorm1 = SEQ ? seq_norm(s, n, scratch, stage) : team_norm<T>(s, n, scratch);
+        const double gnorm = SEQ ? seq_norm(g, n, scratch, stage) : team_norm<T>(g, n, scratch);
         if (tid == 0) {
             pr.f = fnew; pr.gnorm1 = gnorm1; pr.gnorm = gnorm; pr.delta = gnorm;
             pr.dsel ^= 1; pr.ticks += 1;
@@ -1312,7 +1363,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
         double f = pr.f, delta = delta0, gnorm = gnorm_cur;
         const double gs = pr.gs, prered = pr.prered;
         const double actred = f - fnew;
-        const double snorm = SEQ ? seq_norm(s, n, scratch, stage) : block_norm(s, n, scratch);
+        const double snorm = SEQ ? seq_norm(s, n, scratch, stage) : team_norm<T>(s, n, scratch);
         if (pr.iter == 1) delta = fmin(delta, snorm);
         double alpha;
         if (fnew - f - gs <= 0) alpha = sigma3;
@@ -1328,8 +1379,8 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
             iter++;
             _Pragma("unroll 8") for (int j = tid; j < n; j += nt) { w[j] = w_new[j]; g[j] = Hd[j]; }
             f = fnew;
-            __syncthreads();
-            gnorm = SEQ ? seq_norm(g, n, scratch, stage) : block_norm(g, n, scratch);
+            T::sync();
+            gnorm = SEQ ? seq_norm(g, n, scratch, stage) : team_norm<T>(g, n, scratch);
             if (gnorm <= eps0 * gnorm1_0) brk = true;
         }
         if (!brk) {
@@ -1337,7 +1388,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
             else if (fabs(actred) <= 0 && prered <= 0) brk = true;
             else if (fabs(actred) <= 1.0e-12 * fabs(f) && fabs(prered) <= 1.0e-12 * fabs(f)) brk = true;
         }
-        __syncthreads();
+        T::sync();
         if (tid == 0) {
             pr.f = f; pr.delta = delta; pr.gnorm = gnorm; pr.iter = iter; pr.ticks += 1;
             if (accept) { pr.accepted += 1; pr.dsel ^= 1; }
@@ -1356,7 +1407,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
             s[j] = 0.0; r[j] = rj; d[j] = rj;
             a2[0] += rj * rj;
         }
-        block_allreduce_sum<1>(a2, scratch);
+        T::template allreduce<1>(a2, scratch);
         if (SEQ) a2[0] = seq_dot(r, r, n, scratch, stage);
         const double gn = gnorm_cur;      // ||r|| = ||-g|| = ||g||
         if (tid == 0) {
@@ -1893,22 +1944,35 @@ k_step_commit(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
 // SEQ: the order-faithful verification mode (MLX_FAITHFUL=1): ONE lane per row / per (unsplit) column so that every row and
 // column sum runs in the reference's order, one thread for every n- or l-long reduction (tron_step_body<true>), grad(0)
 // from its own pass at w = 0 like bw/Tron.java:50-53, and the portable exp/log1p the oracle's verification twin uses too.
-template <bool HASVAL, bool LDSV, bool SEQ>
+// XL (1: uint8 ids, 2: uint16 ids; needs LDSV): the partition's index and value arrays live in LDS too -- CSR and CSC copies with
+// narrow ids, row / item pointers, item destinations and column pointers -- when everything fits beside the vectors (config #1:
+// 125 rows x 200 features x 12.5 K non-zeros = 125 KiB + 17 KiB of vectors). A tick then waits on LDS instead of ~7 dependent L2
+// round trips.
+template <bool HASVAL, bool LDSV, bool SEQ, int XL = 0>
 __global__ void __launch_bounds__(1024)
 k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int nprob, int max_ticks,
-              int *__restrict__ done_counter)
+              int *__restrict__ done_counter, int wave_step)
 {
 #pragma clang fp contract(off)
+    static_assert(XL == 0 || (LDSV && !SEQ), "X in LDS rides on the LDS-resident vectors");
     constexpr int G = SEQ ? 1 : 8, U = 8;   // lanes per row / per column item, loads in flight per lane
+    using IdT = typename std::conditional<XL == 1, uint8_t, typename std::conditional<XL == 2, uint16_t, int32_t>::type>::type;
     __shared__ double scratch[64];
     __shared__ double stage[1024];
     extern __shared__ double dyn[];
     __shared__ ProbDev prl;
+    __shared__ PartDev pal;
     const int q = blockIdx.x;
     if (q >= nprob) return;
     ProbDev &prg = probs[q];                 // the descriptor in global memory
-    const PartDev &pa = parts[prg.part];
-    const int tid = threadIdx.x, nt = 1024;
+    const PartDev &pag = parts[prg.part];
+    // (nt a CONSTANT: with nt = blockDim.x the same source compiled -- ROCm 7.2 -- to a kernel whose results sat 1e-6 off on
+    // the ill-conditioned binary case of tests/test_gpu_parity.py::test_sparse_absent_features_weights_offsets, deterministically and
+    // with every counter equal; 512 / 256 / 128 threads were slower on config #1 anyway: 14.0 / 18.3 / 26.8 ms against 11.7)
+    const int tid = threadIdx.x;
+    constexpr int nt = 1024;
+    if (XL != 0) { if (tid == 0) pal = pag; __syncthreads(); }
+    const PartDev &pa = XL != 0 ? pal : pag;
     if (LDSV) {
         const int n = pa.n_local, l0 = pa.l, ni = pa.n_items, nbk = pa.nblk;
         if (tid == 0) {
@@ -1934,17 +1998,46 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
     ProbDev &pr = LDSV ? prl : prg;          // the working descriptor
     const int gid = tid / G, gl = tid % G, ng = nt / G;
     const int l = pa.l, nitems = pa.n_items;
-    const int32_t *__restrict__ rp = pa.rp;
-    const int32_t *__restrict__ ci = pa.ci;
-    const float *__restrict__ val = pa.val;
-    const int32_t *__restrict__ item_ptr = pa.item_ptr;
-    const int32_t *__restrict__ cri = pa.cri;
-    const float *__restrict__ cval = pa.cval;
+    const int32_t *__restrict__ rp = pag.rp;
+    const IdT *__restrict__ ci = reinterpret_cast<const IdT *>(pag.ci);          // (XL == 0: IdT is int32_t, the global arrays)
+    const float *__restrict__ val = pag.val;
+    const int32_t *__restrict__ item_ptr = pag.item_ptr;
+    const IdT *__restrict__ cri = reinterpret_cast<const IdT *>(pag.cri);
+    const float *__restrict__ cval = pag.cval;
+    const int32_t *__restrict__ item_dst = pag.item_dst;
+    if (XL != 0) {
+        // carve the X region behind the vectors (same sizes the host summed: mlx_finalize) and copy, ids narrowed
+        const int n = pag.n_local, nz = (int)pag.nnz, nf1 = pag.n_feat + 1;
+        char *xb = reinterpret_cast<char *>(dyn + (8 * n + 3 * l + nitems + 2 * pag.nblk));
+        int32_t *s_rp = reinterpret_cast<int32_t *>(xb); xb += 4 * (size_t)(l + 1);
+        int32_t *s_ip = reinterpret_cast<int32_t *>(xb); xb += 4 * (size_t)(nitems + 1);
+        int32_t *s_id = reinterpret_cast<int32_t *>(xb); xb += 4 * (size_t)nitems;
+        int32_t *s_cp = reinterpret_cast<int32_t *>(xb); xb += 4 * (size_t)nf1;
+        float *s_v = reinterpret_cast<float *>(xb); xb += (HASVAL && pag.val) ? 4 * (size_t)nz : 0;
+        float *s_cv = reinterpret_cast<float *>(xb); xb += (HASVAL && pag.cval) ? 4 * (size_t)nz : 0;
+        IdT *s_ci = reinterpret_cast<IdT *>(xb); xb += sizeof(IdT) * (size_t)nz;
+        IdT *s_cr = reinterpret_cast<IdT *>(xb);
+        for (int i = tid; i <= l; i += nt) s_rp[i] = pag.rp[i];
+        for (int i = tid; i <= nitems; i += nt) s_ip[i] = pag.item_ptr[i];
+        for (int i = tid; i < nitems; i += nt) s_id[i] = pag.item_dst[i];
+        for (int i = tid; i < nf1; i += nt) s_cp[i] = pag.col_ptr[i];
+        for (int k = tid; k < nz; k += nt) {
+            s_ci[k] = (IdT)pag.ci[k];
+            s_cr[k] = (IdT)pag.cri[k];
+            if (HASVAL && pag.val) s_v[k] = pag.val[k];
+            if (HASVAL && pag.cval) s_cv[k] = pag.cval[k];
+        }
+        if (tid == 0) pal.col_ptr = s_cp;
+        rp = s_rp; item_ptr = s_ip; item_dst = s_id; ci = s_ci; cri = s_cr;
+        if (HASVAL && pag.val) val = s_v;
+        if (HASVAL && pag.cval) cval = s_cv;
+        __syncthreads();
+    }
     double *__restrict__ coef = pr.coef;
     double *__restrict__ segsum = pr.parts;
     for (int b = 1 + tid; b < pa.nblk; b += nt) { pr.lossp[b] = 0.0; pr.csump[b] = 0.0; }
     // lane-group sum of sparse dot products: lane gl takes entries k0+gl, k0+gl+G, ...; fixed xor tree inside the group
-    auto group_dot = [&](const int32_t *__restrict__ idxs, const float *__restrict__ vals, const double *__restrict__ vec,
+    auto group_dot = [&](const IdT *__restrict__ idxs, const float *__restrict__ vals, const double *__restrict__ vec,
                          int k0, int k1) -> double {
         double a = 0.0;
         for (int kb = k0 + gl; kb < k1; kb += G * U) {
@@ -1953,7 +2046,7 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int kk = min(kb + u * G, k1 - 1);
-                idx[u] = idxs[kk];
+                idx[u] = (int)idxs[kk];
                 if (HASVAL) xv[u] = vals ? vals[kk] : 1.0f;
             }
             double vv[U];
@@ -2016,7 +2109,7 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
             const int itc = min(it, nitems - 1);
             const int k0 = item_ptr[itc], k1 = valid ? item_ptr[itc + 1] : k0;
             const double a = group_dot(cri, cval, coef, k0, k1);
-            if (valid && gl == 0 && k1 > k0) segsum[pa.item_dst[itc]] = a;
+            if (valid && gl == 0 && k1 > k0) segsum[item_dst[itc]] = a;
         }
         __syncthreads();
         if (SEQ && tick < 0) {
@@ -2026,7 +2119,13 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
                 pr.c0f[j] = (j == pa.n_feat) ? ci : (pa.col_ptr[j + 1] > pa.col_ptr[j] ? segsum[pa.col_ptr[j]] : 0.0);
             continue;
         }
-        tron_step_body<SEQ>(pa, pr, scratch, stage, done_counter);
+        if constexpr (XL != 0) {
+            // the step on the first wave alone (WaveTeam); the others wait at the loop's barrier
+            if (wave_step) { if (tid < 64) tron_step_body<SEQ, WaveTeam>(pa, pr, scratch, stage, done_counter); }
+            else tron_step_body<SEQ>(pa, pr, scratch, stage, done_counter);
+        } else {
+            tron_step_body<SEQ>(pa, pr, scratch, stage, done_counter);
+        }
     }
     if (LDSV) {
         // write the state back (everything a relaunch, the outputs kernels or the host read)
@@ -2600,11 +2699,26 @@ void mlxk_step_fused(hipStream_t st, const PartDev *parts, ProbDev *probs, const
 #endif
 
 void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int first, bool hasval,
-                      int max_ticks, int *done_counter, int lds_doubles, bool faithful)
+                      int max_ticks, int *done_counter, int lds_doubles, bool faithful, int xl, int lds_bytes_xl)
 {
+    static const int wave_step = getenv("MLX_SMALL_WAVE_STEP") ? atoi(getenv("MLX_SMALL_WAVE_STEP")) : 1;     // A/B switch
+    if (xl != 0 && lds_doubles > 0 && !faithful) {
+        // vectors AND the partition's arrays in LDS (lds_bytes_xl = what the largest problem needs)
+        per_device_once(5, [&] {
+            set_max_lds(reinterpret_cast<const void *>(&k_solve_small<true, true, false, 1>), 150 * 1024);
+            set_max_lds(reinterpret_cast<const void *>(&k_solve_small<false, true, false, 1>), 150 * 1024);
+            set_max_lds(reinterpret_cast<const void *>(&k_solve_small<true, true, false, 2>), 150 * 1024);
+            set_max_lds(reinterpret_cast<const void *>(&k_solve_small<false, true, false, 2>), 150 * 1024);
+        });
+#define LSMALL(HV, X) hipLaunchKernelGGL((k_solve_small<HV, true, false, X>), dim3(nprob), dim3(1024), (size_t)lds_bytes_xl, st, parts, probs + first, nprob, max_ticks, done_counter, wave_step)
+        if (hasval) { if (xl == 1) LSMALL(true, 1); else LSMALL(true, 2); }
+        else { if (xl == 1) LSMALL(false, 1); else LSMALL(false, 2); }
+#undef LSMALL
+        return;
+    }
     if (faithful) {
-        if (hasval) hipLaunchKernelGGL((k_solve_small<true, false, true>), dim3(nprob), dim3(1024), 0, st, parts, probs + first, nprob, max_ticks, done_counter);
-        else hipLaunchKernelGGL((k_solve_small<false, false, true>), dim3(nprob), dim3(1024), 0, st, parts, probs + first, nprob, max_ticks, done_counter);
+        if (hasval) hipLaunchKernelGGL((k_solve_small<true, false, true>), dim3(nprob), dim3(1024), 0, st, parts, probs + first, nprob, max_ticks, done_counter, wave_step);
+        else hipLaunchKernelGGL((k_solve_small<false, false, true>), dim3(nprob), dim3(1024), 0, st, parts, probs + first, nprob, max_ticks, done_counter, wave_step);
         return;
     }
     // lds_doubles > 0: the work vectors of every problem fit in LDS (that many doubles for the largest) -> LDS-resident solve
@@ -2614,12 +2728,12 @@ void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, int 
             set_max_lds(reinterpret_cast<const void *>(&k_solve_small<false, true, false>), 150 * 1024);
         });
         const size_t bytes = (size_t)lds_doubles * sizeof(double);
-        if (hasval) hipLaunchKernelGGL((k_solve_small<true, true, false>), dim3(nprob), dim3(1024), bytes, st, parts, probs + first, nprob, max_ticks, done_counter);
-        else hipLaunchKernelGGL((k_solve_small<false, true, false>), dim3(nprob), dim3(1024), bytes, st, parts, probs + first, nprob, max_ticks, done_counter);
+        if (hasval) hipLaunchKernelGGL((k_solve_small<true, true, false>), dim3(nprob), dim3(1024), bytes, st, parts, probs + first, nprob, max_ticks, done_counter, wave_step);
+        else hipLaunchKernelGGL((k_solve_small<false, true, false>), dim3(nprob), dim3(1024), bytes, st, parts, probs + first, nprob, max_ticks, done_counter, wave_step);
         return;
     }
-    if (hasval) hipLaunchKernelGGL((k_solve_small<true, false, false>), dim3(nprob), dim3(1024), 0, st, parts, probs + first, nprob, max_ticks, done_counter);
-    else hipLaunchKernelGGL((k_solve_small<false, false, false>), dim3(nprob), dim3(1024), 0, st, parts, probs + first, nprob, max_ticks, done_counter);
+    if (hasval) hipLaunchKernelGGL((k_solve_small<true, false, false>), dim3(nprob), dim3(1024), 0, st, parts, probs + first, nprob, max_ticks, done_counter, wave_step);
+    else hipLaunchKernelGGL((k_solve_small<false, false, false>), dim3(nprob), dim3(1024), 0, st, parts, probs + first, nprob, max_ticks, done_counter, wave_step);
 }
 
 void mlxk_collect_c0(hipStream_t st, const PartDev *parts, const ProbDev *probs, const int *qlist, int nq,

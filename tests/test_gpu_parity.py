@@ -181,6 +181,30 @@ def test_sparse_absent_features_weights_offsets(binary, csr_path):
                 assert_coef_close(un, uno, "u")
 
 
+def test_one_launch_solvers_agree_with_the_tick_kernels_to_the_last_float32_bit_on_the_ill_conditioned_case(monkeypatch):
+    """GPU against GPU, so independent of the host's libm: on the binary case above -- the one that amplifies any difference --
+    k_solve_small (vectors in LDS / in global memory) and the lock-step tick kernels agree on the first iteration's float32 models
+    to one unit in the last place of the largest coefficient (measured: identical). Round 3: a k_solve_small build with
+    nt = blockDim.x instead of the constant 1024 sat 1e-6 off here with every TRON counter equal, deterministically -- a
+    code-generation difference that the 1e-5 parity bound against the oracle only caught on the near-zero coefficients."""
+    pd = synth_sparse(22, 3000, 2500, 6, 5, binary=True, weights=True, offsets=True)
+    lam, rho = [0.5, 200.0], [1.0, 10.0]
+    out = {}
+    for path, env in (("one_launch", {}), ("one_launch_global", {"MLX_NO_SMALL_LDS": "1"}), ("ticks", {"MLX_NO_SMALL": "1"})):
+        for k in ("MLX_NO_SMALL", "MLX_NO_SMALL_LDS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = make_engine(pd, lam, rho)
+        eng.iterate(0.01)
+        out[path] = ([np.asarray(eng.partition_model(k, li)[0], np.float64) for k in range(5) for li in range(2)], eng.solve_counters().copy())
+        eng.close()
+    for path in ("one_launch", "one_launch_global"):
+        assert np.array_equal(out[path][1], out["ticks"][1])
+        for a, b in zip(out[path][0], out["ticks"][0]):
+            assert np.max(np.abs(a - b)) <= 1.2e-7 * np.max(np.abs(b)), (path, float(np.max(np.abs(a - b))), float(np.max(np.abs(b))))
+
+
 def test_rho_adapt_rate_penalize_intercept_and_resume(c1):
     lam, rho = [1.0], [1.0]
     oc = ol.OracleAdmm(c1.blocks, c1.n_global, lam, rho, penalize_intercept=True)
