@@ -1240,7 +1240,7 @@ int mlx_finalize(mlx_handle h)
             int64_t total = 0;
             for (auto &p : h->parts) if (!p.dense) {
                 const int64_t vec = 8LL * (8LL * p.n_local + 3LL * p.l + p.n_items + 2LL * p.nblk);
-                const int64_t xb = 4LL * ((int64_t)p.l + 1 + 2LL * p.n_items + 1 + p.n_feat + 1) + (p.hasval ? 8LL * p.nnz : 0) + 2LL * idsz * p.nnz;
+                const int64_t xb = 4LL * ((int64_t)p.l + 1 + 2LL * p.n_items + 1 + p.n_feat + 1) + (p.hasval ? 8LL * p.nnz : 0) + 2LL * idsz * p.nnz + 9LL * p.l;
                 total = std::max(total, vec + xb + 16);
             }
             if (total > 0 && total <= 148 * 1024) {

@@ -22,6 +22,7 @@
 #include "mlx_kernels.h"
 #include "mlx_types.h"
 #include "portable_math.h"
+#include "mlx_wave.h"
 
 #define WAVE 64
 
@@ -43,26 +44,39 @@ extern "C" int mlx_debug_phase_times(double *out16)
 #define PT_MARK(k)
 #endif
 
+#ifdef MLX_SMALL_PROFILE
+// development build only (tools/small_profile.sh): shader-clock stamps of workgroup 0 around the phases of a k_solve_small tick
+__device__ unsigned long long g_small_prof[8], g_small_prof2[16];
+extern "C" void mlxk_small_prof_read(unsigned long long *out, int reset)
+{
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_small_prof), sizeof(unsigned long long) * 8);
+    hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(g_small_prof2), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_small_prof), z, sizeof(unsigned long long) * 8); hipMemcpyToSymbol(HIP_SYMBOL(g_small_prof2), z, sizeof(z)); }
+}
+__device__ unsigned long long g_small_prof_t;
+#define SPROF2(slot) do { if (blockIdx.x == 0 && T::tid() == 0 && threadIdx.x == 0) { const unsigned long long t_ = clock64(); g_small_prof2[slot] += t_ - g_small_prof_t; g_small_prof_t = t_; } } while (0)
+#define SPROF(slot) do { if (blockIdx.x == 0 && tid == 0) { const unsigned long long t_ = clock64(); g_small_prof[slot] += t_ - tprev; tprev = t_; } } while (0)
+#else
+#define SPROF(slot) do { } while (0)
+#define SPROF2(slot) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // wave / block reductions (deterministic trees; fp64)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_allreduce_sum(double x)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, WAVE);
-    return x;
-}
-__device__ __forceinline__ double wave_allreduce_max(double x)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) x = fmax(x, __shfl_xor(x, m, WAVE));
-    return x;
-}
+// (the butterflies themselves: mlx_wave.h -- v_permlane*_swap / DPP moves with the association of the __shfl_xor loops they replaced)
+__device__ __forceinline__ double wave_allreduce_sum(double x) { return mlx_wave_allreduce_sum(x); }      // partners i^32, i^16, ..., i^1
+__device__ __forceinline__ double wave_allreduce_max(double x) { return mlx_wave_allreduce_max(x); }
 template <int G>
-__device__ __forceinline__ double group_allreduce_sum(double x)
+__device__ __forceinline__ double group_allreduce_sum(double x)      // G aligned lanes: partners i ^ G/2, ..., i ^ 1
 {
-#pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1) x += __shfl_xor(x, m, WAVE);
+    double a, b;
+    if (G >= 64) { mlx_swap32(x, a, b); x = a + b; }
+    if (G >= 32) { mlx_swap16(x, a, b); x = a + b; }
+    if (G >= 16) x += mlx_xor8(x);
+    if (G >= 8) x += mlx_xor4(x);
+    if (G >= 4) x += mlx_xor2(x);
+    if (G >= 2) x += mlx_xor1(x);
     return x;
 }
 
@@ -144,16 +158,20 @@ struct WaveTeam {
     }
     static __device__ __forceinline__ double allreduce_max(double x, double *) { return wave_allreduce_max(x); }
 };
-template <typename T>
-__device__ __forceinline__ double team_sum_array(const double *__restrict__ a, int cnt, double *scratch)
+// Pointer type of the small solver's work vectors: generic, or -- when k_solve_small keeps them in LDS -- an LDS pointer, so that
+// every access is a ds_read / ds_write and not a flat instruction that finds the LDS aperture at run time (the descriptor holds
+// generic pointers; before this the one-workgroup solver issued ~800 flat loads and ~330 flat stores per tick-loop body).
+typedef __attribute__((address_space(3))) double *lds_dptr;
+template <typename T, typename P>
+__device__ __forceinline__ double team_sum_array(P a, int cnt, double *scratch)
 {
     double v[1] = {0.0};
     for (int i = T::tid(); i < cnt; i += T::nt()) v[0] += a[i];
     T::template allreduce<1>(v, scratch);
     return v[0];
 }
-template <typename T>
-__device__ __forceinline__ double team_norm(const double *__restrict__ v, int n, double *scratch)      // block_norm for a team
+template <typename T, typename P>
+__device__ __forceinline__ double team_norm(P v, int n, double *scratch)      // block_norm for a team
 {
     double mx = 0;
     for (int j = T::tid(); j < n; j += T::nt()) mx = fmax(mx, fabs(v[j]));
@@ -164,8 +182,8 @@ __device__ __forceinline__ double team_norm(const double *__restrict__ v, int n,
     T::template allreduce<1>(a, scratch);
     return mx * sqrt(a[0]);
 }
-template <typename T>
-__device__ __forceinline__ double team_norm_from_sumsq(double ss, const double *__restrict__ v, int n, double *scratch)
+template <typename T, typename P>
+__device__ __forceinline__ double team_norm_from_sumsq(double ss, P v, int n, double *scratch)
 {
     if (ss > 1e-280 && ss < 1e280) return sqrt(ss);
     T::sync();
@@ -1157,7 +1175,7 @@ __device__ __forceinline__ double seq_norm(const double *v, int n, double *scrat
     return seq_bcast(scale * sqrt(sum), scratch);
 }
 
-template <bool SEQ, typename T = BlockTeam>
+template <bool SEQ, typename T = BlockTeam, typename VP = double *>
 __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, double *scratch, double *stage,
                                                int *__restrict__ done_counter)
 {
@@ -1167,19 +1185,18 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
     const int n = pa.n_local;
     static_assert(!SEQ || std::is_same<T, BlockTeam>::value, "the order-faithful mode runs on the whole workgroup");
     const int tid = T::tid(), nt = T::nt();
-    double *__restrict__ w = pr.w, *__restrict__ w_new = pr.w_new, *__restrict__ g = pr.g;
-    double *__restrict__ s = pr.s, *__restrict__ r = pr.r, *__restrict__ d = pr.d, *__restrict__ Hd = pr.Hd;
-    const double *__restrict__ m = pr.m;
+    static_assert(!SEQ || std::is_same<VP, double *>::value, "the order-faithful mode keeps its vectors in global memory");
+    const VP w = (VP)pr.w, w_new = (VP)pr.w_new, g = (VP)pr.g, s = (VP)pr.s, r = (VP)pr.r, d = (VP)pr.d, Hd = (VP)pr.Hd, m = (VP)pr.m;
 
     // X'c of this tick: dense partitions assemble their per-block partial vectors into Hd[] first; CSR partitions read
     // their column-segment sums inline in the first update loop (one write + one read of Hd[] less per tick).
     const bool inl = !pa.dense;
     const int nf = pa.n_feat;
     double csum_icpt = 0.0;
-    if (inl) csum_icpt = SEQ ? seq_sum(pr.coef, pa.l, scratch, stage) : team_sum_array<T>(pr.csump, pa.nblk, scratch);   // SEQ: XTv's row order
-    else assemble_out(pa, pr, Hd, scratch, stage);
+    if (inl) csum_icpt = SEQ ? seq_sum(pr.coef, pa.l, scratch, stage) : team_sum_array<T>((VP)pr.csump, pa.nblk, scratch);   // SEQ: XTv's row order
+    else if constexpr (std::is_same<VP, double *>::value) assemble_out(pa, pr, Hd, scratch, stage);
     T::sync();
-    const double *__restrict__ segsum = pr.parts;
+    const VP segsum = (VP)pr.parts;
     const int32_t *__restrict__ cptr = pa.col_ptr;
     // X'c for XB strided columns at once (j = jb + u*nt): all slot ranges are fetched first, then all first slots, then the
     // (rare) further ones -- two dependent latencies per batch instead of per column.
@@ -1201,17 +1218,32 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
         double f0[XB];
 #pragma unroll
         for (int u = 0; u < XB; u++) f0[u] = i1[u] > i0[u] ? segsum[i0[u]] : 0.0;
+        int more = 0;
 #pragma unroll
         for (int u = 0; u < XB; u++) {
-            const int j = jb + u * nt;
-            double a = 0.0;                                    // slot order = (block, segment) order
-            if (i1[u] > i0[u]) { a += f0[u]; for (int it = i0[u] + 1; it < i1[u]; it++) a += segsum[it]; }
-            xa[u] = (j == nf) ? csum_icpt : a;
+            xa[u] = 0.0;                                       // slot order = (block, segment) order
+            if (i1[u] > i0[u]) xa[u] += f0[u];
+            more = max(more, i1[u] - i0[u]);
         }
+        for (int k = 1; k < more; k++) {                       // (columns with several slots: rare; ONE loop for the batch)
+#pragma unroll
+            for (int u = 0; u < XB; u++) if (i0[u] + k < i1[u]) xa[u] += segsum[i0[u] + k];
+        }
+#pragma unroll
+        for (int u = 0; u < XB; u++) if (jb + u * nt == nf) xa[u] = csum_icpt;
     };
+    // The elementwise loops below run in batches of SB strided elements: all loads of a batch first, then the arithmetic and the
+    // stores in element order -- the vectors may alias as far as the compiler knows, so a plain loop is one dependent
+    // load -> store chain per element (what a single wave of the small solver spends its step on). Same operations, same order.
+    constexpr int SB = 4;
+    const double *const pvec = pr.pinv_vec;
+    const double pscal = pr.pinv;
 
     const double rTr0 = pr.rTr, delta0 = pr.delta, cgtol0 = pr.cgtol, eps0 = pr.eps, gnorm1_0 = pr.gnorm1;
     double gnorm_cur = pr.gnorm;
+#ifdef MLX_SMALL_PROFILE
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_small_prof_t = clock64();
+#endif
     bool start_trcg = false, finished = false;
 
     if (phase == PH_CG) {
@@ -1220,27 +1252,46 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
         for (int jb = tid; jb < n; jb += XB * nt) {
             double xa[XB];
             xtc_batch(jb, xa);
+            double dv[XB], pv[XB];
+#pragma unroll
+            for (int u = 0; u < XB; u++) {
+                const int j = jb + u * nt;
+                dv[u] = j < n ? d[j] : 0.0;
+                pv[u] = j < n ? (pvec ? pvec[j] : pscal) : 0.0;
+            }
 #pragma unroll
             for (int u = 0; u < XB; u++) {
                 const int j = jb + u * nt;
                 if (j < n) {
-                    const double hd = d[j] * pinv_at(pr, j) + xa[u];     // Hs[i] = (s[i]*priorVar_inv[i] + Hs[i]) * 1
+                    const double hd = dv[u] * pv[u] + xa[u];             // Hs[i] = (s[i]*priorVar_inv[i] + Hs[i]) * 1
                     Hd[j] = hd;
-                    a1[0] += d[j] * hd;
+                    a1[0] += dv[u] * hd;
                 }
             }
         }
+        SPROF2(0);      // CG: Hd loop
         T::template allreduce<1>(a1, scratch);
-        if (SEQ) a1[0] = seq_dot(d, Hd, n, scratch, stage);
+        SPROF2(1);      // its reduction
+        if (SEQ) a1[0] = seq_dot(pr.d, pr.Hd, n, scratch, stage);
         double alpha = rTr0 / a1[0];
         double ss1[1] = {0.0};
-        _Pragma("unroll 8") for (int j = tid; j < n; j += nt) {
-            const double sj = s[j] + alpha * d[j];                  // daxpy(alpha, d, s)
-            s[j] = sj;
-            ss1[0] += sj * sj;
+        for (int jb = tid; jb < n; jb += SB * nt) {
+            double sv[SB], dv[SB];
+#pragma unroll
+            for (int u = 0; u < SB; u++) { const int j = jb + u * nt; sv[u] = j < n ? s[j] : 0.0; dv[u] = j < n ? d[j] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < SB; u++) {
+                const int j = jb + u * nt;
+                if (j < n) {
+                    const double sj = sv[u] + alpha * dv[u];        // daxpy(alpha, d, s)
+                    s[j] = sj;
+                    ss1[0] += sj * sj;
+                }
+            }
         }
         T::template allreduce<1>(ss1, scratch);
-        const double snorm = SEQ ? seq_norm(s, n, scratch, stage) : team_norm_from_sumsq<T>(ss1[0], s, n, scratch);
+        const double snorm = SEQ ? seq_norm(pr.s, n, scratch, stage) : team_norm_from_sumsq<T>(ss1[0], s, n, scratch);
+        SPROF2(2);      // s update + norm
         bool end_cg = false;
         if (snorm > delta0) {
             // cg reaches trust region boundary (:150-168)
@@ -1254,7 +1305,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
                 a3[2] += d[j] * d[j];
             }
             T::template allreduce<3>(a3, scratch);
-            if (SEQ) { a3[0] = seq_dot(s, d, n, scratch, stage); a3[1] = seq_dot(s, s, n, scratch, stage); a3[2] = seq_dot(d, d, n, scratch, stage); }
+            if (SEQ) { a3[0] = seq_dot(pr.s, pr.d, n, scratch, stage); a3[1] = seq_dot(pr.s, pr.s, n, scratch, stage); a3[2] = seq_dot(pr.d, pr.d, n, scratch, stage); }
             const double std_ = a3[0], sts = a3[1], dtd = a3[2];
             const double dsq = delta0 * delta0;
             const double rad = sqrt(std_ * std_ + dtd * (dsq - sts));
@@ -1269,36 +1320,67 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
         } else {
             alpha = -alpha;
             double a2[1] = {0.0};
-            _Pragma("unroll 8") for (int j = tid; j < n; j += nt) {
-                const double rj = r[j] + alpha * Hd[j];
-                r[j] = rj;
-                a2[0] += rj * rj;
+            for (int jb = tid; jb < n; jb += SB * nt) {
+                double rv[SB], hv[SB];
+#pragma unroll
+                for (int u = 0; u < SB; u++) { const int j = jb + u * nt; rv[u] = j < n ? r[j] : 0.0; hv[u] = j < n ? Hd[j] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < SB; u++) {
+                    const int j = jb + u * nt;
+                    if (j < n) {
+                        const double rj = rv[u] + alpha * hv[u];
+                        r[j] = rj;
+                        a2[0] += rj * rj;
+                    }
+                }
             }
             T::template allreduce<1>(a2, scratch);
-            if (SEQ) a2[0] = seq_dot(r, r, n, scratch, stage);
+            if (SEQ) a2[0] = seq_dot(pr.r, pr.r, n, scratch, stage);
             const double rnew = a2[0];
             const double beta = rnew / rTr0;
-            _Pragma("unroll 8") for (int j = tid; j < n; j += nt) {
-                double dj = d[j];
-                if (beta != 1.0) dj = dj * beta;                   // scale(beta, d)
-                d[j] = dj + 1.0 * r[j];                            // daxpy(one, r, d)
+            for (int jb = tid; jb < n; jb += SB * nt) {
+                double dv[SB], rv[SB];
+#pragma unroll
+                for (int u = 0; u < SB; u++) { const int j = jb + u * nt; dv[u] = j < n ? d[j] : 0.0; rv[u] = j < n ? r[j] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < SB; u++) {
+                    const int j = jb + u * nt;
+                    if (j < n) {
+                        double dj = dv[u];
+                        if (beta != 1.0) dj = dj * beta;           // scale(beta, d)
+                        d[j] = dj + 1.0 * rv[u];                   // daxpy(one, r, d)
+                    }
+                }
             }
-            const double rnorm = SEQ ? seq_norm(r, n, scratch, stage) : team_norm_from_sumsq<T>(rnew, r, n, scratch);
+            const double rnorm = SEQ ? seq_norm(pr.r, n, scratch, stage) : team_norm_from_sumsq<T>(rnew, r, n, scratch);
             if (tid == 0) pr.rTr = rnew;
             if (rnorm <= cgtol0) end_cg = true;                  // loop-top test of the next trip (:144)
         }
         T::sync();
+        SPROF2(3);      // r, d updates + norm
         if (tid == 0) { pr.cg_iter += 1; pr.ticks += 1; }
         if (end_cg) {
             // back in tron(): w_new = w + s, gs, prered (:69-73)
             double a2[2] = {0.0, 0.0};
-            _Pragma("unroll 8") for (int j = tid; j < n; j += nt) {
-                w_new[j] = w[j] + 1.0 * s[j];
-                a2[0] += g[j] * s[j];
-                a2[1] += s[j] * r[j];
+            for (int jb = tid; jb < n; jb += SB * nt) {
+                double wv[SB], sv[SB], gv[SB], rv[SB];
+#pragma unroll
+                for (int u = 0; u < SB; u++) {
+                    const int j = jb + u * nt;
+                    wv[u] = j < n ? w[j] : 0.0; sv[u] = j < n ? s[j] : 0.0; gv[u] = j < n ? g[j] : 0.0; rv[u] = j < n ? r[j] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < SB; u++) {
+                    const int j = jb + u * nt;
+                    if (j < n) {
+                        w_new[j] = wv[u] + 1.0 * sv[u];
+                        a2[0] += gv[u] * sv[u];
+                        a2[1] += sv[u] * rv[u];
+                    }
+                }
             }
             T::template allreduce<2>(a2, scratch);
-            if (SEQ) { a2[0] = seq_dot(g, s, n, scratch, stage); a2[1] = seq_dot(s, r, n, scratch, stage); }
+            if (SEQ) { a2[0] = seq_dot(pr.g, pr.s, n, scratch, stage); a2[1] = seq_dot(pr.s, pr.r, n, scratch, stage); }
             if (tid == 0) {
                 pr.gs = a2[0];
                 pr.prered = -0.5 * (a2[0] - a2[1]);
@@ -1307,6 +1389,10 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
                 pr.phase = PH_EVAL;
             }
         }
+        SPROF2(4);      // end of trcg
+#ifdef MLX_SMALL_PROFILE
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_small_prof2[14] += 1;
+#endif
         return;
     }
 
@@ -1315,19 +1401,26 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
     for (int jb = tid; jb < n; jb += XB * nt) {
         double xa[XB];
         xtc_batch(jb, xa);
+        double wv[XB], mv[XB], pv[XB];
+#pragma unroll
+        for (int u = 0; u < XB; u++) {
+            const int j = jb + u * nt;
+            wv[u] = j < n ? w_new[j] : 0.0; mv[u] = j < n ? m[j] : 0.0;
+            pv[u] = j < n ? (pvec ? pvec[j] : pscal) : 0.0;
+        }
 #pragma unroll
         for (int u = 0; u < XB; u++) {
             const int j = jb + u * nt;
             if (j < n) {
-                const double t = w_new[j] - m[j];
-                const double pj = pinv_at(pr, j);
+                const double t = wv[u] - mv[u];
+                const double pj = pv[u];
                 a1[0] += t * t * pj;                                        // fun :187-188
                 Hd[j] = t * pj + xa[u];                                     // grad :224 (multiplier 1)
             }
         }
     }
     T::template allreduce<1>(a1, scratch);
-    const double loss = SEQ ? seq_sum(pr.rowtmp, pa.l, scratch, stage) : team_sum_array<T>(pr.lossp, pa.nblk, scratch);
+    const double loss = SEQ ? seq_sum(pr.rowtmp, pa.l, scratch, stage) : team_sum_array<T>((VP)pr.lossp, pa.nblk, scratch);
     double fnew = 2.0 * loss;
     if (SEQ) {
         // fun :184-189 adds the prior terms to the running f one by one
@@ -1338,17 +1431,30 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
     }
     fnew = fnew / 2.0;
     T::sync();
+    SPROF2(5);          // EVAL: objective + gradient loop, reductions
     const double *__restrict__ c0 = SEQ ? pr.c0f : pa.c0;
 
     if (phase == PH_EVAL0) {
         // Tron prologue (:47-62): gnorm1 = ||grad(0)||, f, g, delta at the warm start
-        _Pragma("unroll 8") for (int j = tid; j < n; j += nt) {
-            g[j] = Hd[j];
-            s[j] = (0.0 - m[j]) * pinv_at(pr, j) + c0[j];           // grad(0) staged in s[]
+        for (int jb = tid; jb < n; jb += SB * nt) {
+            double hv[SB], mv[SB], pv[SB], cv[SB];
+#pragma unroll
+            for (int u = 0; u < SB; u++) {
+                const int j = jb + u * nt;
+                hv[u] = j < n ? Hd[j] : 0.0; mv[u] = j < n ? m[j] : 0.0; pv[u] = j < n ? (pvec ? pvec[j] : pscal) : 0.0; cv[u] = j < n ? c0[j] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < SB; u++) {
+                const int j = jb + u * nt;
+                if (j < n) {
+                    g[j] = hv[u];
+                    s[j] = (0.0 - mv[u]) * pv[u] + cv[u];           // grad(0) staged in s[]
+                }
+            }
         }
         T::sync();
-        const double gnorm1 = SEQ ? seq_norm(s, n, scratch, stage) : team_norm<T>(s, n, scratch);
-        const double gnorm = SEQ ? seq_norm(g, n, scratch, stage) : team_norm<T>(g, n, scratch);
+        const double gnorm1 = SEQ ? seq_norm(pr.s, n, scratch, stage) : team_norm<T>(s, n, scratch);
+        const double gnorm = SEQ ? seq_norm(pr.g, n, scratch, stage) : team_norm<T>(g, n, scratch);
         if (tid == 0) {
             pr.f = fnew; pr.gnorm1 = gnorm1; pr.gnorm = gnorm; pr.delta = gnorm;
             pr.dsel ^= 1; pr.ticks += 1;
@@ -1363,7 +1469,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
         double f = pr.f, delta = delta0, gnorm = gnorm_cur;
         const double gs = pr.gs, prered = pr.prered;
         const double actred = f - fnew;
-        const double snorm = SEQ ? seq_norm(s, n, scratch, stage) : team_norm<T>(s, n, scratch);
+        const double snorm = SEQ ? seq_norm(pr.s, n, scratch, stage) : team_norm<T>(s, n, scratch);
         if (pr.iter == 1) delta = fmin(delta, snorm);
         double alpha;
         if (fnew - f - gs <= 0) alpha = sigma3;
@@ -1377,10 +1483,16 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
         const bool accept = actred > eta0 * prered;
         if (accept) {
             iter++;
-            _Pragma("unroll 8") for (int j = tid; j < n; j += nt) { w[j] = w_new[j]; g[j] = Hd[j]; }
+            for (int jb = tid; jb < n; jb += SB * nt) {
+                double wv[SB], hv[SB];
+#pragma unroll
+                for (int u = 0; u < SB; u++) { const int j = jb + u * nt; wv[u] = j < n ? w_new[j] : 0.0; hv[u] = j < n ? Hd[j] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < SB; u++) { const int j = jb + u * nt; if (j < n) { w[j] = wv[u]; g[j] = hv[u]; } }
+            }
             f = fnew;
             T::sync();
-            gnorm = SEQ ? seq_norm(g, n, scratch, stage) : team_norm<T>(g, n, scratch);
+            gnorm = SEQ ? seq_norm(pr.g, n, scratch, stage) : team_norm<T>(g, n, scratch);
             if (gnorm <= eps0 * gnorm1_0) brk = true;
         }
         if (!brk) {
@@ -1402,13 +1514,22 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
     if (start_trcg) {
         // trcg prologue (:133-141): s = 0, r = -g, d = r, cgtol = 0.1||g||, rTr = r.r
         double a2[1] = {0.0};
-        _Pragma("unroll 8") for (int j = tid; j < n; j += nt) {
-            const double rj = -g[j];
-            s[j] = 0.0; r[j] = rj; d[j] = rj;
-            a2[0] += rj * rj;
+        for (int jb = tid; jb < n; jb += SB * nt) {
+            double gv[SB];
+#pragma unroll
+            for (int u = 0; u < SB; u++) { const int j = jb + u * nt; gv[u] = j < n ? g[j] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < SB; u++) {
+                const int j = jb + u * nt;
+                if (j < n) {
+                    const double rj = -gv[u];
+                    s[j] = 0.0; r[j] = rj; d[j] = rj;
+                    a2[0] += rj * rj;
+                }
+            }
         }
         T::template allreduce<1>(a2, scratch);
-        if (SEQ) a2[0] = seq_dot(r, r, n, scratch, stage);
+        if (SEQ) a2[0] = seq_dot(pr.r, pr.r, n, scratch, stage);
         const double gn = gnorm_cur;      // ||r|| = ||-g|| = ||g||
         if (tid == 0) {
             pr.rTr = a2[0];
@@ -1427,6 +1548,10 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
         pr.phase = PH_DONE;
         atomicAdd(done_counter, 1);
     }
+    SPROF2(6);          // EVAL: the rest (norms, trust region update, trcg prologue)
+#ifdef MLX_SMALL_PROFILE
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_small_prof2[15] += 1;
+#endif
 }
 
 __global__ void __launch_bounds__(1024)
@@ -2005,6 +2130,8 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
     const IdT *__restrict__ cri = reinterpret_cast<const IdT *>(pag.cri);
     const float *__restrict__ cval = pag.cval;
     const int32_t *__restrict__ item_dst = pag.item_dst;
+    const float *__restrict__ row_wt = pag.wt, *__restrict__ row_off = pag.off;
+    const int8_t *__restrict__ row_y = pag.y;
     if (XL != 0) {
         // carve the X region behind the vectors (same sizes the host summed: mlx_finalize) and copy, ids narrowed
         const int n = pag.n_local, nz = (int)pag.nnz, nf1 = pag.n_feat + 1;
@@ -2015,8 +2142,12 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
         int32_t *s_cp = reinterpret_cast<int32_t *>(xb); xb += 4 * (size_t)nf1;
         float *s_v = reinterpret_cast<float *>(xb); xb += (HASVAL && pag.val) ? 4 * (size_t)nz : 0;
         float *s_cv = reinterpret_cast<float *>(xb); xb += (HASVAL && pag.cval) ? 4 * (size_t)nz : 0;
+        float *s_wt = reinterpret_cast<float *>(xb); xb += 4 * (size_t)l;
+        float *s_off = reinterpret_cast<float *>(xb); xb += 4 * (size_t)l;
         IdT *s_ci = reinterpret_cast<IdT *>(xb); xb += sizeof(IdT) * (size_t)nz;
-        IdT *s_cr = reinterpret_cast<IdT *>(xb);
+        IdT *s_cr = reinterpret_cast<IdT *>(xb); xb += sizeof(IdT) * (size_t)nz;
+        int8_t *s_y = reinterpret_cast<int8_t *>(xb);
+        for (int i = tid; i < l; i += nt) { s_wt[i] = pag.wt[i]; s_off[i] = pag.off[i]; s_y[i] = pag.y[i]; }
         for (int i = tid; i <= l; i += nt) s_rp[i] = pag.rp[i];
         for (int i = tid; i <= nitems; i += nt) s_ip[i] = pag.item_ptr[i];
         for (int i = tid; i < nitems; i += nt) s_id[i] = pag.item_dst[i];
@@ -2028,17 +2159,17 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
             if (HASVAL && pag.cval) s_cv[k] = pag.cval[k];
         }
         if (tid == 0) pal.col_ptr = s_cp;
+        row_wt = s_wt; row_off = s_off; row_y = s_y;
         rp = s_rp; item_ptr = s_ip; item_dst = s_id; ci = s_ci; cri = s_cr;
         if (HASVAL && pag.val) val = s_v;
         if (HASVAL && pag.cval) cval = s_cv;
         __syncthreads();
     }
-    double *__restrict__ coef = pr.coef;
-    double *__restrict__ segsum = pr.parts;
+    using VP = typename std::conditional<LDSV, lds_dptr, double *>::type;      // see lds_dptr
+    const VP coef = (VP)pr.coef, segsum = (VP)pr.parts;
     for (int b = 1 + tid; b < pa.nblk; b += nt) { pr.lossp[b] = 0.0; pr.csump[b] = 0.0; }
     // lane-group sum of sparse dot products: lane gl takes entries k0+gl, k0+gl+G, ...; fixed xor tree inside the group
-    auto group_dot = [&](const IdT *__restrict__ idxs, const float *__restrict__ vals, const double *__restrict__ vec,
-                         int k0, int k1) -> double {
+    auto group_dot = [&](const IdT *__restrict__ idxs, const float *__restrict__ vals, const VP vec, int k0, int k1) -> double {
         double a = 0.0;
         for (int kb = k0 + gl; kb < k1; kb += G * U) {
             int idx[U];
@@ -2058,9 +2189,7 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
                 if (kb + u * G < k1) a = a + term;
             }
         }
-#pragma unroll
-        for (int m = G / 2; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
-        return a;
+        return group_allreduce_sum<G>(a);
     };
     // SEQ: tick -1 is the reference's fun(0) + grad(0) (bw/Tron.java:50-53): an EVAL pass at w = 0 (d is free before the
     // first trcg) whose X'c is kept in c0f
@@ -2068,14 +2197,20 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
     if (c0_tick) {
         for (int j = tid; j < pa.n_local; j += nt) pr.d[j] = 0.0;
     }
+#ifdef MLX_SMALL_PROFILE
+    unsigned long long tprev = clock64();
+#endif
     for (int tick = c0_tick ? -1 : 0; tick < max_ticks; tick++) {
         __syncthreads();
+        SPROF(4);                            // (waiting for the step's wave at the loop barrier)
         const int phase = pr.phase;
         if (phase == PH_DONE) break;
+#ifdef MLX_SMALL_PROFILE
+        if (blockIdx.x == 0 && tid == 0) g_small_prof[5] += 1;
+#endif
         const bool cg = (phase == PH_CG) && tick >= 0;
-        const double *__restrict__ v = tick < 0 ? pr.d : (cg ? pr.d : pr.w_new);
-        const double *__restrict__ wdcur = pr.wd[pr.dsel];
-        double *__restrict__ wdnew = pr.wd[pr.dsel ^ 1];
+        const VP v = (VP)(tick < 0 ? pr.d : (cg ? pr.d : pr.w_new));
+        const VP wdcur = (VP)pr.wd[pr.dsel], wdnew = (VP)pr.wd[pr.dsel ^ 1];
         const double vb = v[pa.n_feat];
         double red[2] = {0.0, 0.0};
         for (int rowb = 0; rowb < l; rowb += ng) {
@@ -2091,7 +2226,7 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
                     cf = wdcur[row] * t;
                 } else {
                     double loss, wdv;
-                    row_eval<SEQ>(t + (double)pa.off[row], (int)pa.y[row], (double)pa.wt[row], loss, wdv, cf);
+                    row_eval<SEQ>(t + (double)row_off[row], (int)row_y[row], (double)row_wt[row], loss, wdv, cf);
                     wdnew[row] = wdv;
                     red[0] += loss;
                     if (SEQ) pr.rowtmp[row] = loss;
@@ -2100,9 +2235,20 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
                 red[1] += cf;
             }
         }
-        block_allreduce_sum<2>(red, scratch);
-        if (tid == 0) { pr.lossp[0] = red[0]; pr.csump[0] = red[1]; }
+        SPROF(0);                            // row pass
+        // loss and coefficient sums over the block: wave tree, then the 16 wave sums in wave order (block_allreduce_sum's order).
+        // When the step runs on the first wave alone, that wave also adds the wave sums (after the column pass): one barrier
+        // here instead of three, and 15 waves spared the 32 LDS reads.
+        const bool wave_red = XL != 0 && wave_step != 0;
+        if (wave_red) {
+            red[0] = wave_allreduce_sum(red[0]); red[1] = wave_allreduce_sum(red[1]);
+            if ((tid & 63) == 0) { scratch[tid >> 6] = red[0]; scratch[16 + (tid >> 6)] = red[1]; }
+        } else {
+            block_allreduce_sum<2>(red, scratch);
+            if (tid == 0) { pr.lossp[0] = red[0]; pr.csump[0] = red[1]; }
+        }
         __syncthreads();
+        SPROF(1);                            // its block reduction
         for (int itb = 0; itb < nitems; itb += ng) {
             const int it = itb + gid;
             const bool valid = it < nitems;
@@ -2114,18 +2260,28 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
         __syncthreads();
         if (SEQ && tick < 0) {
             // c0f = X' t(0): unsplit columns, so a column's slot IS its sum; the intercept's is the row-ordered sum of coef
-            const double ci = seq_sum(coef, l, scratch, stage);
+            const double ci = seq_sum(pr.coef, l, scratch, stage);
             for (int j = tid; j < pa.n_local; j += nt)
                 pr.c0f[j] = (j == pa.n_feat) ? ci : (pa.col_ptr[j + 1] > pa.col_ptr[j] ? segsum[pa.col_ptr[j]] : 0.0);
             continue;
         }
+        SPROF(2);                            // column pass + barrier
         if constexpr (XL != 0) {
             // the step on the first wave alone (WaveTeam); the others wait at the loop's barrier
-            if (wave_step) { if (tid < 64) tron_step_body<SEQ, WaveTeam>(pa, pr, scratch, stage, done_counter); }
-            else tron_step_body<SEQ>(pa, pr, scratch, stage, done_counter);
+            if (wave_step) {
+                if (tid < 64) {
+                    double a0 = 0, a1 = 0;
+                    for (int w = 0; w < nt / 64; w++) { a0 += scratch[w]; a1 += scratch[16 + w]; }
+                    if (tid == 0) { pr.lossp[0] = a0; pr.csump[0] = a1; }
+                    __builtin_amdgcn_wave_barrier();
+                    tron_step_body<SEQ, WaveTeam, VP>(pa, pr, scratch, stage, done_counter);
+                }
+            }
+            else tron_step_body<SEQ, BlockTeam, VP>(pa, pr, scratch, stage, done_counter);
         } else {
-            tron_step_body<SEQ>(pa, pr, scratch, stage, done_counter);
+            tron_step_body<SEQ, BlockTeam, VP>(pa, pr, scratch, stage, done_counter);
         }
+        SPROF(3);                            // step
     }
     if (LDSV) {
         // write the state back (everything a relaunch, the outputs kernels or the host read)

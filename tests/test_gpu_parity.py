@@ -5,6 +5,8 @@ check is |gpu - oracle| <= 1e-5 * max(|oracle|, COEF_FLOOR) per coefficient with
 vector's max magnitude (a coefficient 10 000x smaller than the largest is compared on an absolute 1e-9
 scale), plus a count of bit-identical float32 values. Trajectories (TRON / CG counters) must be EQUAL.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -16,6 +18,7 @@ from fixtures import load_c1, load_c1_golden, synth_sparse
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-5
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def assert_coef_close(got, want, what="", floor=1e-4):
@@ -203,6 +206,17 @@ def test_one_launch_solvers_agree_with_the_tick_kernels_to_the_last_float32_bit_
         assert np.array_equal(out[path][1], out["ticks"][1])
         for a, b in zip(out[path][0], out["ticks"][0]):
             assert np.max(np.abs(a - b)) <= 1.2e-7 * np.max(np.abs(b)), (path, float(np.max(np.abs(a - b))), float(np.max(np.abs(b))))
+
+
+def test_valu_wave_butterflies_equal_the_shuffle_forms_bit_for_bit():
+    """csrc/mlx_wave.h (v_permlane*_swap / DPP moves) against the __shfl_xor loops it replaced: wave sum, wave max, 8-lane group sum
+    and every single step, on random doubles incl. zeros, denormals, huge values and NaNs. tools/wave_selftest is built by csrc/Makefile."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "wave_selftest")
+    assert os.path.exists(exe), "run `make -C ml-ease_amd/csrc` (or __graft_entry__.build())"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("bit-identical") == 9, r.stdout
 
 
 def test_rho_adapt_rate_penalize_intercept_and_resume(c1):
