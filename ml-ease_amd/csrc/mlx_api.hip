@@ -74,6 +74,7 @@ struct mlx_context {
     PartDev *d_parts = nullptr;
     ProbDev *d_probs = nullptr;            // nprob + 1 (scratch problem for mlx_solve_one)
     std::vector<ProbDev> h_probs;
+    bool h_probs_pinned = false;
     int *d_qdense = nullptr, *d_qcsr = nullptr, *d_qscratch = nullptr;
     int nq_dense = 0, nq_csr = 0;
     int maxblk_dense = 0, maxblk_csr = 0, max_nfeat_dense = 0, max_items = 0, max_short = 0, max_long = 0, rowgroup = 64, max_nlocal = 0, max_l = 0;
@@ -112,6 +113,7 @@ struct mlx_context {
     hipEvent_t ev_batchx[MAX_TS][2] = {}, ev_fork = nullptr, ev_join[MAX_TS] = {};
     int *h_donex = nullptr;                 // [MAX_TS][2] pinned
     int nstreams = 1;
+    int small_ticks = SMALL_TICKS_PER_LAUNCH;   // ticks one k_solve_small launch may run (MLX_SMALL_TICKS: the tests shrink it to walk the relaunch path)
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
     std::vector<hipEvent_t> ev_pool;        // profiling: a chain of marks; the interval from mark i to mark i+1 belongs to ev_kind[i]
     std::vector<int> ev_kind;               // 0 dense X pass, 1 CSR row pass, 2 CSR column pass, 3 TRON/CG step, -1 not a launch
@@ -294,32 +296,49 @@ void launch_step(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
         mlxk_step_phase(h->stream, which, h->d_parts, h->d_probs, qcsr, nqc, h->step_ch, h->step_max_nwg, h->d_done, h->d_stepctl);
 }
 
+// One-launch solves of small CSR problems (k_solve_small): launch, wait, relaunch while a problem needs more than
+// SMALL_TICKS_PER_LAUNCH ticks (d_done keeps counting across the launches; finished problems leave at once).
+static int run_ticks_small_more(mlx_handle h, int first, int count, int64_t *ticks_out)
+{
+    int64_t ticks = 0;
+    for (;;) {
+        mlxk_solve_small(h->stream, h->d_parts, h->d_probs, count, first, h->csr_hasval, h->small_ticks, h->d_done, h->small_lds_doubles, h->faithful,
+                         h->small_xl, h->small_xl_bytes);
+        ticks += h->small_ticks;
+        HIPCHECK(h, hipMemcpyAsync(&h->h_done[0], h->d_done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(h, hipStreamSynchronize(h->stream));
+        HIPCHECK(h, hipGetLastError());
+        if (h->h_done[0] >= count) break;
+        if (ticks > TICK_CAP) return fail(h, MLX_ERR_MODEL_FITTING, "Model fitting error! solve did not terminate within %lld ticks", (long long)TICK_CAP);
+    }
+    if (ticks_out) {                  // report the longest problem's tick count
+        HIPCHECK(h, hipMemcpy(h->h_probs.data() + first, h->d_probs + first, sizeof(ProbDev) * count, hipMemcpyDeviceToHost));
+        int mx = 0;
+        for (int q = first; q < first + count; q++) mx = std::max(mx, h->h_probs[(size_t)q].ticks);
+        *ticks_out = mx;
+    }
+    return MLX_OK;
+}
+
 // Drive ticks until `count` problems starting at `first` are DONE.
-int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, const int *qcsr, int nqc, int64_t *ticks_out)
+// `deferred` (optional): the one-launch path of small CSR problems may enqueue its launch and return WITHOUT waiting (*deferred =
+// true, *ticks_out untouched); the caller enqueues its tail behind it and collect_solve_stats() -- one synchronisation for the
+// whole iteration -- finds out whether every problem finished (it returns MLX_MORE_TICKS if not; then run_ticks_small_more()).
+constexpr int MLX_MORE_TICKS = 1;      // internal, never crosses the C-ABI
+int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, const int *qcsr, int nqc, int64_t *ticks_out, bool *deferred = nullptr)
 {
     HIPCHECK(h, hipMemsetAsync(h->d_done, 0, sizeof(int), h->stream));
     h->h_done[0] = h->h_done[1] = 0;
     if (h->csr_small && nqd == 0 && nqc == count && (!h->profiling || h->faithful)) {
         // small CSR problems: the whole solve in one launch (k_solve_small), relaunched only if a problem needs more
         // than SMALL_TICKS_PER_LAUNCH ticks
-        int64_t ticks = 0;
-        for (;;) {
-            mlxk_solve_small(h->stream, h->d_parts, h->d_probs, count, first, h->csr_hasval, SMALL_TICKS_PER_LAUNCH, h->d_done, h->small_lds_doubles, h->faithful,
+        if (deferred) {
+            mlxk_solve_small(h->stream, h->d_parts, h->d_probs, count, first, h->csr_hasval, h->small_ticks, h->d_done, h->small_lds_doubles, h->faithful,
                              h->small_xl, h->small_xl_bytes);
-            ticks += SMALL_TICKS_PER_LAUNCH;
-            HIPCHECK(h, hipMemcpyAsync(&h->h_done[0], h->d_done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-            HIPCHECK(h, hipStreamSynchronize(h->stream));
-            HIPCHECK(h, hipGetLastError());
-            if (h->h_done[0] >= count) break;
-            if (ticks > TICK_CAP) return fail(h, MLX_ERR_MODEL_FITTING, "Model fitting error! solve did not terminate within %lld ticks", (long long)TICK_CAP);
+            *deferred = true;
+            return MLX_OK;
         }
-        if (ticks_out) {                  // report the longest problem's tick count
-            HIPCHECK(h, hipMemcpy(h->h_probs.data() + first, h->d_probs + first, sizeof(ProbDev) * count, hipMemcpyDeviceToHost));
-            int mx = 0;
-            for (int q = first; q < first + count; q++) mx = std::max(mx, h->h_probs[(size_t)q].ticks);
-            *ticks_out = mx;
-        }
-        return MLX_OK;
+        return run_ticks_small_more(h, first, count, ticks_out);
     }
     const int batch = 4;
     int64_t ticks = 0;
@@ -458,6 +477,7 @@ int mlx_create(int device_id, mlx_handle *out)
     // one beside the step of the other) measured SLOWER than one stream -- the gain is launch tails and gaps being filled, and a dense
     // half's one-workgroup-per-problem step running beside the other half's pass (profiles/r3_notes.md).
     h->nstreams = 2;
+    if (const char *te = getenv("MLX_SMALL_TICKS")) h->small_ticks = std::max(1, atoi(te));
     if (const char *se = getenv("MLX_STREAMS")) h->nstreams = std::max(1, std::min(atoi(se), (int)mlx_context::MAX_TS));
     if (h->nstreams > 1) {
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
@@ -482,6 +502,7 @@ int mlx_destroy(mlx_handle h)
     hipDeviceSynchronize();
     if (h->comm) ncclCommDestroy(h->comm);
     for (void *p : h->allocs) hipFree(p);
+    if (h->h_probs_pinned) hipHostUnregister(h->h_probs.data());
     if (h->h_done) hipHostFree(h->h_done);
     if (h->h_diff) hipHostFree(h->h_diff);
     for (auto e : h->ev_pool) hipEventDestroy(e);
@@ -1295,7 +1316,11 @@ int mlx_finalize(mlx_handle h)
     }
 
     // problems (+1 scratch for mlx_solve_one)
+    if (h->h_probs_pinned) { hipHostUnregister(h->h_probs.data()); h->h_probs_pinned = false; }
     h->h_probs.assign(h->nprob + 1, ProbDev{});
+    // (page-locked: the per-iteration read-back of the descriptors is then a true asynchronous copy)
+    if (hipHostRegister(h->h_probs.data(), h->h_probs.size() * sizeof(ProbDev), hipHostRegisterDefault) == hipSuccess) h->h_probs_pinned = true;
+    else (void)hipGetLastError();
     // All work vectors of all problems are carved out of ONE allocation (256-byte aligned pieces): thousands of problems
     // (configs #4/#5: 1024 partitions x 8 lambdas) must not become 10^5 hipMalloc calls of a few hundred KB each.
     auto carve_size = [](size_t count) { return (count * sizeof(double) + 255) / 256 * 256; };
@@ -1443,7 +1468,7 @@ int mlx_set_state(mlx_handle h, const double *z, const float *u)
     return MLX_OK;
 }
 
-static int collect_solve_stats(mlx_handle h, int64_t ticks, mlx_stats *stats);
+static int collect_solve_stats(mlx_handle h, int64_t ticks, mlx_stats *stats, bool deferred = false);
 
 int mlx_admm_solve_local(mlx_handle h, double liblinear_epsilon, float rho_adapt_rate, mlx_stats *stats)
 {
@@ -1468,21 +1493,40 @@ int mlx_admm_solve_local(mlx_handle h, double liblinear_epsilon, float rho_adapt
     mlxk_setup(h->stream, h->d_parts, h->d_probs, h->nprob, nl, ng, h->max_nlocal, h->d_z32, h->d_u, h->d_pinv_l,
                liblinear_epsilon, DEFAULT_MAX_ITER);
     int64_t ticks = 0;
-    int rc = run_ticks(h, 0, h->nprob, h->d_qdense, h->nq_dense, h->d_qcsr, h->nq_csr, &ticks);
+    bool deferred = false;
+    int rc = run_ticks(h, 0, h->nprob, h->d_qdense, h->nq_dense, h->d_qcsr, h->nq_csr, &ticks, &deferred);
     if (rc) return rc;
-    mlxk_outputs(h->stream, h->d_parts, h->d_probs, h->nprob, nl, ng, h->max_nlocal, h->any_absent, h->d_z32, h->d_u,
-                 h->d_B, h->d_UPX);
-    mlxk_partial_means(h->stream, np, nl, ng, 1.0 / h->num_blocks, h->d_B, h->d_u, h->d_cons, h->d_cons + (size_t)nl * ng);
-    return collect_solve_stats(h, ticks, stats);
+    for (;;) {
+        mlxk_outputs(h->stream, h->d_parts, h->d_probs, h->nprob, nl, ng, h->max_nlocal, h->any_absent, h->d_z32, h->d_u,
+                     h->d_B, h->d_UPX);
+        mlxk_partial_means(h->stream, np, nl, ng, 1.0 / h->num_blocks, h->d_B, h->d_u, h->d_cons, h->d_cons + (size_t)nl * ng);
+        rc = collect_solve_stats(h, ticks, stats, deferred);
+        if (rc != MLX_MORE_TICKS) return rc;
+        // (a problem of the one-launch path needs more than SMALL_TICKS_PER_LAUNCH ticks: finish it, then redo the outputs --
+        // both output kernels are pure functions of the problems' state)
+        deferred = false;
+        if ((rc = run_ticks_small_more(h, 0, h->nprob, &ticks))) return rc;
+    }
 }
 
 // Common tail of the batched solves: wait for the stream, check every problem, fill the counters.
-static int collect_solve_stats(mlx_handle h, int64_t ticks, mlx_stats *stats)
+// deferred: the solves were enqueued without waiting (run_ticks); a problem still short of DONE then means "relaunch"
+// (MLX_MORE_TICKS), not an error, and the tick count is read off the descriptors.
+static int collect_solve_stats(mlx_handle h, int64_t ticks, mlx_stats *stats, bool deferred)
 {
     HIPCHECK(h, hipEventRecord(h->ev_t1, h->stream));
     HIPCHECK(h, hipMemcpyAsync(h->h_probs.data(), h->d_probs, sizeof(ProbDev) * h->nprob, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
     HIPCHECK(h, hipGetLastError());
+    if (deferred) {
+        int mx = 0;
+        for (int q = 0; q < h->nprob; q++) {
+            const ProbDev &pr = h->h_probs[q];
+            if (pr.status == ST_OK && pr.phase != PH_DONE) return MLX_MORE_TICKS;
+            mx = std::max(mx, pr.ticks);
+        }
+        ticks = mx;
+    }
 
     mlx_stats s{};
     s.solves = h->nprob;

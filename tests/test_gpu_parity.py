@@ -208,6 +208,32 @@ def test_one_launch_solvers_agree_with_the_tick_kernels_to_the_last_float32_bit_
             assert np.max(np.abs(a - b)) <= 1.2e-7 * np.max(np.abs(b)), (path, float(np.max(np.abs(a - b))), float(np.max(np.abs(b))))
 
 
+def test_one_launch_solver_relaunches_until_every_problem_is_done(c1, monkeypatch):
+    """mlx_admm_solve_local enqueues the one-launch solves, the output kernels and the read-back behind each other and waits once;
+    a problem that needs more ticks than one launch may run (16384; MLX_SMALL_TICKS shrinks it here) sends it round again:
+    relaunch, outputs redone. Same models and counters as the one-launch run, bit for bit, for 3, 7 and 40 ticks per launch."""
+    lam, rho = [1.0, 30.0], [1.0, 1.0]
+    ref = None
+    for ticks in (None, 3, 7, 40):
+        if ticks is None:
+            monkeypatch.delenv("MLX_SMALL_TICKS", raising=False)
+        else:
+            monkeypatch.setenv("MLX_SMALL_TICKS", str(ticks))
+        eng = make_engine(c1, lam, rho)
+        out = []
+        for it in range(3):
+            st = eng.iterate(0.01)
+            out.append((eng.z()[0].copy(), eng.solve_counters().copy(), st.ticks, [eng.partition_model(k, 1)[0].copy() for k in (0, 7)]))
+        eng.close()
+        if ref is None:
+            ref = out
+            assert max(o[2] for o in out) > 40          # so that every shrunken budget really relaunches
+            continue
+        for a, b in zip(out, ref):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+            assert all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
+
+
 def test_valu_wave_butterflies_equal_the_shuffle_forms_bit_for_bit():
     """csrc/mlx_wave.h (v_permlane*_swap / DPP moves) against the __shfl_xor loops it replaced: wave sum, wave max, 8-lane group sum
     and every single step, on random doubles incl. zeros, denormals, huge values and NaNs. tools/wave_selftest is built by csrc/Makefile."""
