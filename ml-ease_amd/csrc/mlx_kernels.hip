@@ -24,6 +24,20 @@
 #include "portable_math.h"
 #include "mlx_wave.h"
 
+// Global-memory accesses said to be global. The kernels take their pointers out of PartDev / ProbDev records in memory, so to the
+// compiler they are generic and every access became a FLAT instruction: 64-bit per-lane addresses, and -- what costs -- a FLAT load
+// counts on vmcnt AND lgkmcnt, so in the kernels that gather from LDS a wait for LDS data also waited for every index pack in flight.
+// gld / gst cast at the access (the variables stay plain pointers); -DMLX_NO_GLOBAL_AS: A/B build with the flat accesses.
+#ifdef MLX_NO_GLOBAL_AS
+#define MLX_GAS
+#else
+#define MLX_GAS __attribute__((address_space(1)))
+#endif
+template <typename T> __device__ __forceinline__ T gld(const T *p) { return *(const MLX_GAS T *)p; }
+template <typename T> __device__ __forceinline__ T gld_nt(const T *p) { return __builtin_nontemporal_load((const MLX_GAS T *)p); }
+template <typename T> __device__ __forceinline__ void gst(T *p, T v) { *(MLX_GAS T *)p = v; }
+template <typename T> __device__ __forceinline__ void gst_nt(T *p, T v) { __builtin_nontemporal_store(v, (MLX_GAS T *)p); }
+
 #define WAVE 64
 
 // Timing experiments only (tools/ablate_build.sh -DMLX_PHASE_TIMING): thread 0 of every workgroup of the sparse passes adds
@@ -243,9 +257,9 @@ k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     for (int c = 0; c < NV; c++) {
         const int col0 = (c * 64 + lane) * 4;
 #pragma unroll
-        for (int e = 0; e < 4; e++) vr[c][e] = (col0 + e < nf) ? v[col0 + e] : 0.0;
+        for (int e = 0; e < 4; e++) vr[c][e] = (col0 + e < nf) ? gld(v + col0 + e) : 0.0;
     }
-    const double vb = v[nf];
+    const double vb = gld(v + nf);
     double acc[NV][4];
 #pragma unroll
     for (int c = 0; c < NV; c++)
@@ -268,13 +282,11 @@ k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
 #pragma unroll
             for (int c = 0; c < NV; c++) {
                 const int col0 = min((c * 64 + lane) * 4, (int)ld - 4);
-                if (NT) {       // single lambda: the tile is read once per tick and must not displace the vectors in L2/MALL
-                    typedef float f4v __attribute__((ext_vector_type(4)));
-                    const f4v t4 = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(xr + col0));
-                    x[u][c] = make_float4(t4.x, t4.y, t4.z, t4.w);
-                } else {        // several lambdas per partition run side by side and share the tile through the caches
-                    x[u][c] = *reinterpret_cast<const float4 *>(xr + col0);
-                }
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                // NT (single lambda): the tile is read once per tick and must not displace the vectors in L2/MALL; with several
+                // lambdas per partition the problems run side by side and share the tile through the caches
+                const f4v t4 = NT ? gld_nt(reinterpret_cast<const f4v *>(xr + col0)) : gld(reinterpret_cast<const f4v *>(xr + col0));
+                x[u][c] = make_float4(t4.x, t4.y, t4.z, t4.w);
             }
         }
         double t[U];
@@ -307,17 +319,17 @@ k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
         double coef_m = 0.0;
         if (lane < U && myrow < r1) {
             if (cg) {
-                coef_m = wdcur[myrow] * tm;                          // wa[i] = weight*D * (X s)[i], :243
+                coef_m = gld(wdcur + myrow) * tm;                    // wa[i] = weight*D * (X s)[i], :243
             } else {
                 double loss, wdv;
-                row_eval(tm + (double)pa.off[myrow], (int)pa.y[myrow], (double)pa.wt[myrow], loss, wdv, coef_m);
-                wdnew[myrow] = wdv;
+                row_eval(tm + (double)gld(pa.off + myrow), (int)gld(pa.y + myrow), (double)gld(pa.wt + myrow), loss, wdv, coef_m);
+                gst(wdnew + myrow, wdv);
                 lossacc += loss;
             }
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const double cf = __shfl(coef_m, u, WAVE);
+            const double cf = mlx_wave_bcast(coef_m, u);             // (lane u's value in scalar registers: v_readlane, no LDS crossbar)
             accb += cf;
 #pragma unroll
             for (int c = 0; c < NV; c++) {
@@ -344,7 +356,7 @@ k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     __syncthreads();
     double *__restrict__ outp = pr.parts + (int64_t)b * n;
     for (int j = threadIdx.x; j < nf; j += 256)
-        outp[j] = ((red[j] + red[NC + j]) + red[2 * NC + j]) + red[3 * NC + j];
+        gst(outp + j, ((red[j] + red[NC + j]) + red[2 * NC + j]) + red[3 * NC + j]);
     if (threadIdx.x == 0) {
         outp[nf] = ((redb[0] + redb[1]) + redb[2]) + redb[3];
         pr.lossp[b] = ((redb[4] + redb[5]) + redb[6]) + redb[7];
@@ -546,7 +558,7 @@ __device__ __forceinline__ u2v_t pack_load(const uint16_t *__restrict__ idx, int
     u2v_t q; q.x = (unsigned)((lane * 37 + kk * 101 + base) & 0x3FFF) * 0x10001u; q.y = q.x + 0x00010001u; return q;
 #else
     const u2v_t *__restrict__ ip = reinterpret_cast<const u2v_t *>(idx + base) + kk * 64 + lane;
-    return NT ? __builtin_nontemporal_load(ip) : *ip;
+    return NT ? gld_nt(ip) : gld(ip);
 #endif
 }
 template <bool NT>
@@ -554,7 +566,7 @@ __device__ __forceinline__ f4v_t pack_load_val(const float *__restrict__ val, in
 {
     if (val == nullptr) return (f4v_t){1.0f, 1.0f, 1.0f, 1.0f};     // a binary partition in a valued handle: x * 1.0 == x
     const f4v_t *__restrict__ vp = reinterpret_cast<const f4v_t *>(val + base) + kk * 64 + lane;
-    return NT ? __builtin_nontemporal_load(vp) : *vp;
+    return NT ? gld_nt(vp) : gld(vp);
 }
 
 // Packs kb .. L4-1 of ONE work item (a row's entries in one column slice / a column item), LSU packs in flight: the deep
@@ -618,12 +630,14 @@ __device__ __forceinline__ void sell_lds_first(double (&a)[NI], const uint16_t *
 struct StageRegs { double2 r[STAGE_MAX2]; };
 __device__ __forceinline__ void stage_fetch(StageRegs &R, const double *__restrict__ src, int cnt, int tid)
 {
-    const double2 *__restrict__ s2 = reinterpret_cast<const double2 *>(src);
+    typedef double d2v_t __attribute__((ext_vector_type(2)));
+    const d2v_t *__restrict__ s2 = reinterpret_cast<const d2v_t *>(src);
     const int np2 = cnt >> 1;
 #pragma unroll
     for (int u = 0; u < STAGE_MAX2; u++) {
         const int i = tid + u * 1024;
-        R.r[u] = s2[min(i, max(np2 - 1, 0))];
+        const d2v_t t = gld(s2 + min(i, max(np2 - 1, 0)));
+        R.r[u].x = t.x; R.r[u].y = t.y;
     }
 }
 __device__ __forceinline__ void stage_store(const StageRegs &R, double *__restrict__ lds, const double *__restrict__ src, int cnt, int tid)
@@ -660,7 +674,7 @@ __device__ __forceinline__ void sell_gather_round(double *a, const uint16_t *__r
         const unsigned id[4] = {q[i].x & 0xFFFFu, q[i].x >> 16, q[i].y & 0xFFFFu, q[i].y >> 16};
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            const double g = src[id[e] == 0xFFFFu ? 0u : id[e]];        // unconditional load, clamped address
+            const double g = gld(src + (id[e] == 0xFFFFu ? 0u : id[e]));        // unconditional load, clamped address
             c[i][e] = id[e] == 0xFFFFu ? 0.0 : g;
         }
     }
@@ -722,7 +736,7 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     int kmax;
     auto offsets = [&](int sl) {
         const int32_t *__restrict__ ptr = pa.rs_ptr + (int64_t)sl * ngr + g0;
-        const int pv = ptr[min(wg0 + min(lane, GPW), gcount)];
+        const int pv = gld(ptr + min(wg0 + min(lane, GPW), gcount));
         kmax = 0;
 #pragma unroll
         for (int i = 0; i < GPW; i++) {
@@ -791,11 +805,11 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
             const int row = (g0 + wg0 + i0 + i) * 64 + lane;
             ok[i] = (wg0 + i0 + i < gcount) && row < l;
             rowi[i] = min(row, l - 1);
-            wdv0[i] = cg ? __builtin_nontemporal_load(wdcur + rowi[i]) : 0.0;      // (read once per tick)
-            zc[i] = add_cold ? coef[rowi[i]] : 0.0;
-            offv[i] = cg ? 0.f : pa.off[rowi[i]];
-            wtv[i] = cg ? 0.f : pa.wt[rowi[i]];
-            yv[i] = cg ? 0 : (int)pa.y[rowi[i]];
+            wdv0[i] = cg ? gld_nt(wdcur + rowi[i]) : 0.0;      // (read once per tick)
+            zc[i] = add_cold ? gld(coef + rowi[i]) : 0.0;
+            offv[i] = cg ? 0.f : gld(pa.off + rowi[i]);
+            wtv[i] = cg ? 0.f : gld(pa.wt + rowi[i]);
+            yv[i] = cg ? 0 : (int)gld(pa.y + rowi[i]);
         }
 #pragma unroll
         for (int i = 0; i < EH; i++) {
@@ -807,10 +821,10 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
                 } else {
                     double loss, wdv;
                     row_eval(t + (double)offv[i], yv[i], (double)wtv[i], loss, wdv, cf);
-                    wdnew[rowi[i]] = wdv;
+                    gst(wdnew + rowi[i], wdv);
                     red[0] += loss;
                 }
-                coef[rowi[i]] = cf;
+                gst(coef + rowi[i], cf);
                 red[1] += cf;
             }
         }
@@ -922,10 +936,10 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
         for (int u = 0; u < COL_B; u++) {
             const int sl = sb + 16 * u;
             const int sc = min(sl, s1 - 1);
-            base[u] = __builtin_amdgcn_readfirstlane(cs_ptr[sc]);
-            const int nx = __builtin_amdgcn_readfirstlane(cs_ptr[sc + 1]);
+            base[u] = __builtin_amdgcn_readfirstlane(gld(cs_ptr + sc));
+            const int nx = __builtin_amdgcn_readfirstlane(gld(cs_ptr + sc + 1));
             L4[u] = (sl < s1) ? (nx - base[u]) >> 8 : 0;
-            const int dl = __builtin_nontemporal_load(item_dst + sc * 64 + lane);   // unconditional, clamped; read once per tick
+            const int dl = gld_nt(item_dst + sc * 64 + lane);   // unconditional, clamped; read once per tick
             dst[u] = (sl < s1) ? dl : -1;
             a[u] = 0.0;
         }
@@ -935,7 +949,7 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
 #pragma unroll
         for (int u = 0; u < COL_B; u++) {
             if (L4[u] > KP) a[u] = sell_lds_sum<HASVAL, NT>(a[u], cs_idx, cs_val, base[u], KP, L4[u], lane, cf, zs);
-            if (dst[u] >= 0) out[dst[u]] = a[u];          // (plain store: phase A reads the slots from L2 right after; a streaming store cost the pass 13 %)
+            if (dst[u] >= 0) gst(out + dst[u], a[u]);          // (plain store: phase A reads the slots from L2 right after; a streaming store cost the pass 13 %)
         }
         PT_MARK(11);
     }
@@ -1589,11 +1603,11 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, cons
 // tick, 5.06 k -> 5.29 k solves/s). NOT for what the next launch reads from L2: the column pass's slot stores and phase A's slot /
 // pointer loads as streaming accesses cost 13 % of the column pass and 10 % of phase A. -DMLX_STEP_NO_NT: A/B build.
 #ifdef MLX_STEP_NO_NT
-#define SLD(p) (*(p))
-#define SST(p, v) (*(p) = (v))
+#define SLD(p) gld(p)
+#define SST(p, v) gst((p), (v))
 #else
-#define SLD(p) __builtin_nontemporal_load(p)
-#define SST(p, v) __builtin_nontemporal_store((v), (p))
+#define SLD(p) gld_nt(p)
+#define SST(p, v) gst_nt((p), (v))
 #endif
 #ifndef STEP_XB
 #define STEP_XB 4      // columns per thread and round (independent loads in flight)
@@ -1689,21 +1703,21 @@ k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
             const int jc = min(j, G.j1 - 1);
             const bool col = j < nf;
             const int jf = min(jc, max(nf - 1, 0));
-            i0[u] = (col && nf > 0) ? cptr[jf] : 0; i1[u] = (col && nf > 0) ? cptr[jf + 1] : 0;
+            i0[u] = (col && nf > 0) ? gld(cptr + jf) : 0; i1[u] = (col && nf > 0) ? gld(cptr + jf + 1) : 0;
             vv[u] = SLD(v + jc);
-            pj[u] = pvec ? pvec[jc] : pscal;
-            mm[u] = cg ? 0.0 : m[jc];
-            cc[u] = (phase == PH_EVAL0) ? c0[jc] : 0.0;
+            pj[u] = pvec ? gld(pvec + jc) : pscal;
+            mm[u] = cg ? 0.0 : gld(m + jc);
+            cc[u] = (phase == PH_EVAL0) ? gld(c0 + jc) : 0.0;
         }
         double f0[STEP_XB];
 #pragma unroll
-        for (int u = 0; u < STEP_XB; u++) f0[u] = i1[u] > i0[u] ? segsum[i0[u]] : 0.0;
+        for (int u = 0; u < STEP_XB; u++) f0[u] = i1[u] > i0[u] ? gld(segsum + i0[u]) : 0.0;
 #pragma unroll
         for (int u = 0; u < STEP_XB; u++) {
             const int j = jb + u * STEP_T;
             if (j >= G.j1) continue;
             double xa = 0.0;                                   // slot order = (row block, segment) order
-            if (i1[u] > i0[u]) { xa += f0[u]; for (int it = i0[u] + 1; it < i1[u]; it++) xa += segsum[it]; }
+            if (i1[u] > i0[u]) { xa += f0[u]; for (int it = i0[u] + 1; it < i1[u]; it++) xa += gld(segsum + it); }
             if (j == nf) xa = csum_icpt;
             if (cg) {
                 const double hd = vv[u] * pj[u] + xa;          // Hs[i] = (s[i]*priorVar_inv[i] + Hs[i]) * 1
@@ -1713,7 +1727,7 @@ k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
                 const double t = vv[u] - mm[u];
                 acc[0] += t * t * pj[u];                       // fun :187-188
                 const double hd = t * pj[u] + xa;              // grad :224 (multiplier 1)
-                Hd[j] = hd;
+                gst(Hd + j, hd);
                 acc[1] += hd * hd;
                 if (phase == PH_EVAL0) {
                     const double g0 = (0.0 - mm[u]) * pj[u] + cc[u];      // grad(0)
@@ -1896,24 +1910,24 @@ k_step_b(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
 #pragma unroll
         for (int u = 0; u < STEP_XB; u++) {
             const int jc = min(jb + u * STEP_T, G.j1 - 1);
-            hv[u] = Hd[jc];
-            gv[u] = D.copy_g ? 0.0 : g[jc];
-            wn[u] = (D.copy_w || D.nullstep) ? w_new[jc] : 0.0;
-            wv[u] = (D.nullstep && !D.copy_w) ? w[jc] : 0.0;
+            hv[u] = gld(Hd + jc);
+            gv[u] = D.copy_g ? 0.0 : gld(g + jc);
+            wn[u] = (D.copy_w || D.nullstep) ? gld(w_new + jc) : 0.0;
+            wv[u] = (D.nullstep && !D.copy_w) ? gld(w + jc) : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < STEP_XB; u++) {
             const int j = jb + u * STEP_T;
             if (j >= G.j1) continue;
-            if (D.copy_w) w[j] = wn[u];
-            if (D.copy_g) g[j] = hv[u];
+            if (D.copy_w) gst(w + j, wn[u]);
+            if (D.copy_g) gst(g + j, hv[u]);
             if (D.start) {
                 // trcg prologue (:133-141): s = 0, r = -g, d = r
                 const double gj = D.copy_g ? hv[u] : gv[u];
                 const double rj = -gj;
-                s[j] = 0.0; r0[j] = rj; d[j] = rj;
+                gst(s + j, 0.0); gst(r0 + j, rj); gst(d + j, rj);
                 // the CG loop exits at once with s = 0: the (null) step is evaluated like any other
-                if (D.nullstep) w_new[j] = (D.copy_w ? wn[u] : wv[u]) + 1.0 * 0.0;
+                if (D.nullstep) gst(w_new + j, (D.copy_w ? wn[u] : wv[u]) + 1.0 * 0.0);
             }
         }
     }
@@ -1966,17 +1980,17 @@ k_step_c(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
             if (boundary) {
                 const double sb = sv[u] + nalpha * dv[u];              // daxpy(-alpha, d, s)
                 sf = sb + alpha2 * dv[u];                              // daxpy(alpha', d, s)
-                s[j] = sf;
+                gst(s + j, sf);
                 rf = rv[u] + nalpha2 * hv[u];                          // daxpy(-alpha', Hd, r)
-                rn[j] = rf;
+                gst(rn + j, rf);
             } else {
                 double dj = dv[u];
                 if (beta != 1.0) dj = dj * beta;                       // scale(beta, d)
-                d[j] = dj + 1.0 * r1[u];                               // daxpy(one, r, d)
+                gst(d + j, dj + 1.0 * r1[u]);                               // daxpy(one, r, d)
             }
             if (end_cg) {
                 // back in tron(): w_new = w + s, gs, prered (:69-73)
-                w_new[j] = wv[u] + 1.0 * sf;
+                gst(w_new + j, wv[u] + 1.0 * sf);
                 acc[0] += gv[u] * sf;
                 acc[1] += sf * rf;
                 acc[2] += sf * sf;

@@ -49,6 +49,12 @@ __device__ __forceinline__ double mlx_xor4(double x)                            
 __device__ __forceinline__ double mlx_xor2(double x) { return mlx_dpp64<0x4E>(x, x); }             // quad_perm [2,3,0,1]
 __device__ __forceinline__ double mlx_xor1(double x) { return mlx_dpp64<0xB1>(x, x); }             // quad_perm [1,0,3,2]
 
+// lane `src` (wave-uniform) of x to every lane
+__device__ __forceinline__ double mlx_wave_bcast(double x, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src), hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double mlx_wave_allreduce_sum(double x)
 {
     double a, b;
