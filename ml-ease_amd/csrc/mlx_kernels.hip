@@ -1214,7 +1214,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
     const int32_t *__restrict__ cptr = pa.col_ptr;
     // X'c for XB strided columns at once (j = jb + u*nt): all slot ranges are fetched first, then all first slots, then the
     // (rare) further ones -- two dependent latencies per batch instead of per column.
-    constexpr int XB = 8;
+    constexpr int XB = std::is_same<T, WaveTeam>::value ? 4 : 8;      // (one wave: n <= 256 is one batch of 4 without idle slots)
     auto xtc_batch = [&](int jb, double (&xa)[XB]) {
         if (!inl) {
 #pragma unroll

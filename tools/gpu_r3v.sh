@@ -1,2 +1,3 @@
 #!/bin/bash
-timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -k "relaunch or c1_admm or butterflies" 2>&1 | grep -E "passed|failed|^E  " | head -5
+python tools/c1_latency.py 7
+timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -k "c1 or relaunch or solve_one or mean_model" 2>&1 | grep -E "passed|failed" | tail -1
