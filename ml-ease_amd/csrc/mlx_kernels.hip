@@ -2227,6 +2227,10 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
         const VP wdcur = (VP)pr.wd[pr.dsel], wdnew = (VP)pr.wd[pr.dsel ^ 1];
         const double vb = v[pa.n_feat];
         double red[2] = {0.0, 0.0};
+        // EVAL ticks of short partitions evaluate the row maps in a second, compact sweep (one row per lane): in the sweep below only
+        // lane 0 of every 8-lane group holds a row, so the ~400 fp64 instructions of exp + log1p would issue on all 16 waves for 8 rows
+        // each. The sums are then collected by the same lanes in the same order as before (bit-identical).
+        const bool compact = LDSV && !SEQ && !cg && l <= 1024;
         for (int rowb = 0; rowb < l; rowb += ng) {
             const int row = rowb + gid;
             const bool valid = row < l;
@@ -2235,6 +2239,7 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
             const double a = group_dot(ci, val, v, k0, k1);
             if (valid && gl == 0) {
                 const double t = a + vb;
+                if (compact) { coef[row] = t; continue; }          // parked for the compact sweep
                 double cf;
                 if (cg) {
                     cf = wdcur[row] * t;
@@ -2247,6 +2252,21 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
                 }
                 coef[row] = cf;
                 red[1] += cf;
+            }
+        }
+        if (compact) {
+            __syncthreads();
+            if (tid < l) {
+                double loss, wdv, cf;
+                row_eval<false>(coef[tid] + (double)row_off[tid], (int)row_y[tid], (double)row_wt[tid], loss, wdv, cf);
+                wdnew[tid] = wdv;
+                coef[tid] = cf;
+                stage[tid] = loss;
+            }
+            __syncthreads();
+            for (int rowb = 0; rowb < l; rowb += ng) {
+                const int row = rowb + gid;
+                if (row < l && gl == 0) { red[0] += stage[row]; red[1] += coef[row]; }
             }
         }
         SPROF(0);                            // row pass

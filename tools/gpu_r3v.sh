@@ -1,12 +1,3 @@
 #!/bin/bash
-mkdir -p gpurun_out
-for v in v7 v8; do MLX_LIB_PATH=$PWD/tools/libmlease_hip_$v.so python tools/dbg_probs.py $v 2>&1 | tail -2; done
-python - <<'PY'
-import numpy as np
-a=np.load("gpurun_out/probs_v7.npz", allow_pickle=True); b=np.load("gpurun_out/probs_v8.npz", allow_pickle=True)
-names=["f","delta","gnorm","gnorm1","eps","rTr","cgtol","prered","gs"]
-print("ints equal:", np.array_equal(a["ints"], b["ints"]))
-print(a["ints"][:, [2,4,7,8,9,10]])
-for q in range(10):
-    print(q, " ".join("%s %.3e" % (n, abs(a["dbl"][q,i]-b["dbl"][q,i])/max(abs(b["dbl"][q,i]),1e-300)) for i,n in enumerate(names)))
-PY
+python tools/c1_latency.py 7
+timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -k "c1 or relaunch or solve_one or mean_model or sparse_absent or ill_conditioned or ragged or degenerate" 2>&1 | grep -E "passed|failed" | tail -1
