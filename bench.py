@@ -26,6 +26,7 @@ Extra top-level keys of the same JSON line:
                 partitions, binary.feature, with per-kernel rooflines (row pass, column pass, TRON/CG step), its own
                 cpu_baseline (same timed iterations, from the GPU's state) and parity_check (order-faithful mode vs the
                 oracle twin; product path vs oracle beside the oracle's own row-permutation spread)
+  config1_latency  BASELINE configs[0], the reference's sample data: wall time of its 20 ADMM iterations (latency, N = 1 only)
   lambda_sweep  BASELINE configs[4], per-GPU shape: 128 partitions x 9 765 rows x 8 lambdas (rho = 10 above lambda = 100)
 """
 import argparse
@@ -113,6 +114,7 @@ def main():
     ap.add_argument("--sparse-warmup", type=int, default=1)
     ap.add_argument("--sparse-rows", type=int, default=SP_ROWS)
     ap.add_argument("--sparse-partitions", type=int, default=0, help="0 = 256 at one GPU, 1024 sharded otherwise")
+    ap.add_argument("--no-config1", action="store_true", help="skip the configs[0] latency leg (the reference's sample data, 20 ADMM iterations)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the configs[4] lambda-sweep leg")
     ap.add_argument("--sweep-only", action="store_true", help="run only the lambda-sweep leg (development / profiling)")
     ap.add_argument("--sweep-partitions", type=int, default=128, help="partitions per GPU of the lambda-sweep leg")
@@ -215,6 +217,8 @@ def main():
                 out = sw
             else:
                 out["lambda_sweep"] = sw
+    if world == 1 and not (args.sparse_only or args.sweep_only or args.no_config1):
+        out["config1_latency"] = run_config1(ctx)
     if rank == 0:
         if share:
             out["test_mode"] = "MLX_BENCH_SHARE_GPU=1: all ranks on ONE device, collectives over gloo -- control-flow check, not a measurement"
@@ -222,6 +226,62 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# ======================================================================================================================
+def run_config1(C):
+    """BASELINE configs[0] -- the reference's own sample data (tests/golden: 8 partitions of 125 rows x 200 features, lambda = 1):
+    wall time of the 20 ADMM iterations of the driver loop (jobs/RegressionAdmmTrain.java:338-346 epsilon schedule) through the
+    split API, the float32 consensus against the committed golden run, and the C oracle on the host beside it. A latency figure
+    (8 workgroups on 256 CUs), not a throughput one: it is reported, never the headline."""
+    try:
+        import numpy as np
+        tests = os.path.join(ROOT, "tests")
+        if tests not in sys.path:
+            sys.path.insert(0, tests)
+        from fixtures import load_c1, load_c1_golden
+        admm, HipAdmmEngine = C["admm"], C["HipAdmmEngine"]
+        c1, gold = load_c1(), load_c1_golden()
+        best, ident = None, None
+        for rep in range(5):
+            eng = HipAdmmEngine(c1.n_global, [1.0], [1.0], 8)
+            for b in c1.blocks:
+                eng.add_partition(b)
+            eng.finalize()
+            e, mind, ts, tf = np.float32(0.01), 99999999.0, 0.0, 0.0
+            t0 = time.perf_counter()
+            for it in range(1, 21):
+                if it > 1 and mind < 0.001:
+                    e = np.float32(e / np.float32(10))
+                a = time.perf_counter()
+                eng.solve_local(admm.float_string_roundtrip(e), 1.0)
+                b = time.perf_counter()
+                mind = eng.consensus_finish().mindiff
+                ts += b - a
+                tf += time.perf_counter() - b
+            tot = time.perf_counter() - t0
+            if rep == 0:
+                ident = bool(np.array_equal(eng.z()[1], np.asarray(gold["Z"][-1], np.float32)))
+            if best is None or tot < best[0]:
+                best = (tot, ts, tf)
+            eng.close()
+        out = {"workload": "configs[0]: sample data, 8 partitions x 125 rows x 200 features, lambda 1, 20 ADMM iterations from zero",
+               "ms_20_iterations": round(best[0] * 1e3, 3), "solve_local_ms": round(best[1] * 1e3, 3), "consensus_finish_ms": round(best[2] * 1e3, 3),
+               "best_of": 5, "z32_bit_identical_to_golden_run": ident}
+        try:
+            import oracle_lib as ol
+            cpu = {}
+            for th in (1, 8):
+                oc = ol.OracleAdmm(c1.blocks, c1.n_global, [1.0], [1.0])
+                t0 = time.perf_counter()
+                oc.run(20, nthreads=th)
+                cpu["%d_threads" % th] = round((time.perf_counter() - t0) * 1e3, 3)
+            out["cpu_oracle_ms_20_iterations"] = cpu
+        except Exception as ex:                                   # the checker is optional here
+            out["cpu_oracle_ms_20_iterations"] = {"error": str(ex)[:200]}
+        return out
+    except Exception as ex:
+        return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
 
 
 # ======================================================================================================================
