@@ -413,3 +413,17 @@ def test_regression_test_job_flow(tmp_path):
             assert abs(np.float32(o["pred"]) - want) <= 2e-7 * max(1.0, abs(want))
     # empty input.paths: nothing is done (:109-111)
     assert admm.regression_test(dict(props, **{"input.paths": ""}), OracleScorer()) == []
+
+
+def test_bench_config1_leg_reports_an_error_instead_of_raising_without_a_gpu():
+    """bench.py's configs[0] latency leg is an extra: a missing GPU / fixture must become an {"error": ...} entry of the JSON line,
+    never an exception that would cost the headline figure."""
+    import importlib
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    out = bench.run_config1({"admm": admm, "HipAdmmEngine": hip_engine.HipAdmmEngine})
+    assert isinstance(out, dict) and "error" in out and "ms_20_iterations" not in out
