@@ -239,6 +239,8 @@ def test_valu_wave_butterflies_equal_the_shuffle_forms_bit_for_bit():
     and every single step, on random doubles incl. zeros, denormals, huge values and NaNs. tools/wave_selftest is built by csrc/Makefile."""
     import subprocess
     exe = os.path.join(ROOT, "tools", "wave_selftest")
+    if not os.path.exists(exe):          # (normally built by __graft_entry__.build(); hipcc is on the GPU box too)
+        subprocess.run(["make", "-C", os.path.join(ROOT, "ml-ease_amd", "csrc"), "-s", "../../tools/wave_selftest"], check=False, timeout=300)
     assert os.path.exists(exe), "run `make -C ml-ease_amd/csrc` (or __graft_entry__.build())"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
