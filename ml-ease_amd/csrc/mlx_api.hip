@@ -41,8 +41,6 @@ constexpr int SMALL_MAX_DIM = 16384;
 struct PartHost {
     int pid = 0, l = 0, n_local = 0, n_feat = 0;
     bool dense = false, hasval = false, all_present = false;
-    int multi_R = 0;                       // lambda sweep: row blocks sized for R = 2, 4 or 8 lambdas side by side in LDS (0 = not)
-    bool row_multi_ok = false;             // the shared row pass can hold this partition's packs in registers
     int64_t nnz = 0, ld = 0;
     int n_short = 0, n_long = 0;
     bool sell = false;
@@ -85,15 +83,9 @@ struct mlx_context {
     int max_cunits = 0, max_rblk_rows = 0;
     int max_row_lds = 0;                    // sliced row pass: columns of the widest hot slice (LDS doubles, + zero slot)
     int row_ngc = 16;                       // row groups per row-pass workgroup (16, 32, 64 or 128)
-    int multi_R = 0;                        // > 0: lambda sweep on the shared-X passes (k_rowpass_multi / k_colpass_multi)
-    bool row_multi = false;                 // ... including the row pass (binary partitions whose packs fit in registers)
-    int *d_plist = nullptr; int np_csr = 0; // first problem of every CSR partition
     int step_threads = 256;
     int step_ch = 2048, step_max_nwg = 1;   // multi-workgroup CSR step: columns per workgroup, chunks of the widest CSR problem
-    bool step_fused = false;                // phases A+B+C in one launch (k_step_fused)
     int cold_groups = 0;                    // > 0: row groups of the widest partition with cold column slices (k_rowcold launch)
-    unsigned step_seq = 0;                  // its launch sequence number (the exchanges' flag value; never 0)
-    int *d_stepctl = nullptr;               // [0] ticket counter [1] error flag
 
     double *d_Z = nullptr;
     float *d_z32 = nullptr, *d_u = nullptr, *d_B = nullptr, *d_UPX = nullptr;
@@ -117,7 +109,16 @@ struct mlx_context {
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
     std::vector<hipEvent_t> ev_pool;        // profiling: a chain of marks; the interval from mark i to mark i+1 belongs to ev_kind[i]
     std::vector<int> ev_kind;               // 0 dense X pass, 1 CSR row pass, 2 CSR column pass, 3 TRON/CG step, -1 not a launch
+    std::vector<int> ev_sidx;               // the tick stream a mark was recorded on: an interval runs between consecutive marks of ONE stream
     size_t ev_used = 0;
+    int mark_sidx = 0;                      // index of the stream h->stream currently points at (run_ticks)
+    bool prof_one_stream = false;           // MLX_PROFILE_ONE_STREAM=1: with events on, all ticks on one stream (a launch's duration is then its own)
+    // Dense tick pipeline (default for dense-only lists of >= 4 problems): the X passes of the parts run back to back on the
+    // handle's stream, every part's TRON step on a second stream beside the NEXT part's pass (run_ticks)
+    bool dense_pipe = true;
+    int dense_parts = 2;
+    static constexpr int EV_RING = 4;
+    hipEvent_t ev_pass[MAX_TS][EV_RING] = {}, ev_step[MAX_TS][EV_RING] = {};
     // scratch vectors of the solve_one problem
     double *sc_vec[8] = {nullptr}, *sc_pinv = nullptr;
     // mean-model warm start: per-problem prior precision [nprob][max_nlocal], global overrides [n_global]
@@ -246,6 +247,7 @@ void mark(mlx_handle h, int kind)
         h->ev_pool.push_back(e);
     }
     h->ev_kind.push_back(kind);
+    h->ev_sidx.push_back(h->mark_sidx);
     hipEventRecord(h->ev_pool[h->ev_used++], h->stream);
 }
 
@@ -258,20 +260,9 @@ int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
     };
     if (nqd > 0 && bracket(0, [&] { return mlxk_xpass_dense(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->maxblk_dense, h->max_nfeat_dense, h->n_lambda == 1); }))
         return fail(h, MLX_ERR_INVALID, "dense tile wider than 2048 features is not supported; use the CSR form");
-    // lambda sweeps: the whole-handle list runs on the shared-X passes (one workgroup per partition piece carries all lambdas)
-    const bool multi = h->multi_R > 0 && qcsr == h->d_qcsr && nqc == h->nq_csr;
     if (nqc > 0)
         for (int which = 1; which <= 2; which++)
             bracket(which, [&] {
-#ifdef MLX_EXPERIMENTAL
-                if (multi && (which == 2 || h->row_multi)) {
-                    mlxk_xpass_multi(h->stream, h->d_parts, h->d_probs, h->d_plist, h->np_csr, h->n_lambda, h->multi_R, h->maxblk_csr, h->csr_hasval,
-                                     h->max_cunits, h->max_rblk_rows, h->max_row_lds, h->row_ngc, h->row_multi, which);
-                    return 0;
-                }
-#else
-                (void)multi;
-#endif
                 return mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_short, h->max_long, h->rowgroup, h->csr_hasval, h->csr_sell, h->max_cunits, h->max_rblk_rows, h->max_row_lds, h->row_ngc, h->n_lambda == 1, which, h->cold_groups);
             });
     return MLX_OK;
@@ -282,18 +273,10 @@ void launch_step(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
 {
     mark(h, 3);
     mlxk_tron_step(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->step_threads, h->d_done);
-#ifdef MLX_EXPERIMENTAL
-    if (h->step_fused) {
-        if (++h->step_seq == 0) h->step_seq = 1;
-        mlxk_step_fused(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->step_max_nwg, h->step_seq, h->d_stepctl);
-        mlxk_step_phase(h->stream, 3, h->d_parts, h->d_probs, qcsr, nqc, h->step_ch, h->step_max_nwg, h->d_done, h->d_stepctl);
-        return;
-    }
-#endif
     // (launching A, B, C per group of problems so that Hd / r' / s stay in the memory-side cache between phases was measured: every
     // group size is slower than one launch per phase, profiles/r3_notes.md)
     for (int which = 0; which < 4; which++)
-        mlxk_step_phase(h->stream, which, h->d_parts, h->d_probs, qcsr, nqc, h->step_ch, h->step_max_nwg, h->d_done, h->d_stepctl);
+        mlxk_step_phase(h->stream, which, h->d_parts, h->d_probs, qcsr, nqc, h->step_ch, h->step_max_nwg, h->d_done);
 }
 
 // One-launch solves of small CSR problems (k_solve_small): launch, wait, relaunch while a problem needs more than
@@ -335,6 +318,7 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
         if (deferred) {
             mlxk_solve_small(h->stream, h->d_parts, h->d_probs, count, first, h->csr_hasval, h->small_ticks, h->d_done, h->small_lds_doubles, h->faithful,
                              h->small_xl, h->small_xl_bytes);
+            HIPCHECK(h, hipGetLastError());          // a launch that failed (LDS budget, ...) must not read as "needs more ticks" later
             *deferred = true;
             return MLX_OK;
         }
@@ -345,15 +329,23 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
     int slot = 0;
     bool have_prev = false;
     int rc;
-    // Several tick streams: the problem list is cut into NS parts that tick independently (CSR: whole groups of 8 list positions, so
-    // the XCD placement of xcd_map is kept); the parts share nothing but the done counter. Launch tails and gaps of one part are
-    // filled by the others, and a dense part's TRON step (one workgroup per problem: 21 us during which most of the chip idles)
-    // runs beside another part's pass. Mixed dense + CSR handles, and runs with profiling events, stay on one stream.
+    // Several tick streams. CSR lists of >= 32 problems are cut into NS parts that tick independently on NS streams (whole groups of 8
+    // list positions, so the XCD placement of xcd_map is kept); the parts share nothing but the done counter, and launch tails and
+    // gaps of one part are filled by the others. Dense lists of >= 4 problems run as a two-stage PIPELINE instead: the X passes of
+    // the parts back to back on the handle's stream (a pass never shares the memory system with another pass, so a launch's
+    // duration is its own), every part's TRON step (one workgroup per problem: 21 us during which most of the chip would idle) on
+    // the second stream, beside the next part's pass. MLX_DENSE_PIPE=0: the parts tick free on NS streams like the CSR ones (round 3).
+    // Mixed dense + CSR handles stay on one stream.
     int NS = 1;
-    if (h->nstreams > 1 && !h->profiling) {
+    bool pipe = false;
+    if (h->nstreams > 1 && !(h->profiling && h->prof_one_stream)) {
         if (nqd == 0 && nqc >= 32) NS = std::min(h->nstreams, nqc / 16);
-        else if (nqc == 0 && nqd >= 4) NS = std::min(h->nstreams, nqd / 2);
+        else if (nqc == 0 && nqd >= 4) {
+            pipe = h->dense_pipe;
+            NS = pipe ? std::min(std::min(h->dense_parts, (int)mlx_context::MAX_TS), nqd / 2) : std::min(h->nstreams, nqd / 2);
+        }
     }
+    if (NS <= 1) pipe = false;
     int c0[mlx_context::MAX_TS + 1], d0[mlx_context::MAX_TS + 1];      // part t = list positions [c0[t], c0[t+1]) / [d0[t], d0[t+1])
     for (int t = 0; t <= NS; t++) {
         c0[t] = (NS == 1 || t == NS) ? (t == 0 ? 0 : nqc) : (int)(((int64_t)nqc * t / NS + 7) / 8 * 8);
@@ -363,33 +355,78 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
     }
     hipStream_t sA = h->stream;
     auto st_of = [&](int t) { return t == 0 ? sA : h->xstream[t]; };
-    if (NS > 1) {
-        for (int t = 1; t < NS; t++) h->h_donex[t * 2] = h->h_donex[t * 2 + 1] = 0;
+    const int nextra = pipe ? 2 : NS;                    // streams in use: sA + xstream[1 .. nextra-1]
+    // Whatever way this function is left, the handle's stream is restored and made to wait for everything queued on the other tick
+    // streams: a later call on the handle (set_state, the next solve's memset of d_done) must not overtake in-flight ticks of a
+    // solve that failed.
+    struct Join {
+        mlx_handle h; hipStream_t sA; int n;
+        ~Join()
+        {
+            h->stream = sA; h->mark_sidx = 0;
+            for (int t = 1; t < n; t++)
+                if (hipEventRecord(h->ev_join[t], h->xstream[t]) == hipSuccess) hipStreamWaitEvent(sA, h->ev_join[t], 0);
+        }
+    } join{h, sA, nextra};
+    auto on = [&](int t) { h->stream = st_of(t); h->mark_sidx = t; };
+    if (nextra > 1) {
+        for (int t = 1; t < nextra; t++) h->h_donex[t * 2] = h->h_donex[t * 2 + 1] = 0;
         HIPCHECK(h, hipEventRecord(h->ev_fork, sA));
-        for (int t = 1; t < NS; t++) HIPCHECK(h, hipStreamWaitEvent(st_of(t), h->ev_fork, 0));
+        for (int t = 1; t < nextra; t++) HIPCHECK(h, hipStreamWaitEvent(st_of(t), h->ev_fork, 0));
     }
+    if (pipe)
+        for (int t = 0; t < NS; t++)
+            for (int k = 0; k < mlx_context::EV_RING; k++) {
+                if (!h->ev_pass[t][k]) HIPCHECK(h, hipEventCreateWithFlags(&h->ev_pass[t][k], hipEventDisableTiming));
+                if (!h->ev_step[t][k]) HIPCHECK(h, hipEventCreateWithFlags(&h->ev_step[t][k], hipEventDisableTiming));
+            }
     for (;;) {
         for (int i = 0; i < batch; i++) {
+            const int k = (int)(ticks % mlx_context::EV_RING), kp = (int)((ticks + mlx_context::EV_RING - 1) % mlx_context::EV_RING);
             for (int t = 0; t < NS; t++) {
-                h->stream = st_of(t);
+                if (pipe) {
+                    // pass of part t on the pass stream, behind this part's previous step; its step on the step stream
+                    on(0);
+                    if (ticks > 0) HIPCHECK(h, hipStreamWaitEvent(sA, h->ev_step[t][kp], 0));
+                    rc = launch_xpass(h, qdense + d0[t], d0[t + 1] - d0[t], nullptr, 0);
+                    if (rc) return rc;
+                    mark(h, -1);
+                    HIPCHECK(h, hipEventRecord(h->ev_pass[t][k], sA));
+                    on(1);
+                    HIPCHECK(h, hipStreamWaitEvent(h->stream, h->ev_pass[t][k], 0));
+                    launch_step(h, qdense + d0[t], d0[t + 1] - d0[t], nullptr, 0);
+                    mark(h, -1);
+                    HIPCHECK(h, hipEventRecord(h->ev_step[t][k], h->stream));
+                    on(0);
+                    continue;
+                }
+                on(t);
                 rc = launch_xpass(h, qdense + d0[t], d0[t + 1] - d0[t], qcsr + c0[t], c0[t + 1] - c0[t]);
                 if (!rc) launch_step(h, qdense + d0[t], d0[t + 1] - d0[t], qcsr + c0[t], c0[t + 1] - c0[t]);
-                h->stream = sA;
+                on(0);
                 if (rc) return rc;
             }
             ticks++;
         }
-        mark(h, -1);
-        HIPCHECK(h, hipMemcpyAsync(&h->h_done[slot], h->d_done, sizeof(int), hipMemcpyDeviceToHost, sA));
-        HIPCHECK(h, hipEventRecord(h->ev_batch[slot], sA));
-        for (int t = 1; t < NS; t++) {
-            HIPCHECK(h, hipMemcpyAsync(&h->h_donex[t * 2 + slot], h->d_done, sizeof(int), hipMemcpyDeviceToHost, st_of(t)));
-            HIPCHECK(h, hipEventRecord(h->ev_batchx[t][slot], st_of(t)));
+        if (pipe) {
+            on(1);
+            HIPCHECK(h, hipMemcpyAsync(&h->h_done[slot], h->d_done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHECK(h, hipEventRecord(h->ev_batch[slot], h->stream));
+            on(0);
+        } else {
+            for (int t = 0; t < NS; t++) { on(t); mark(h, -1); }
+            on(0);
+            HIPCHECK(h, hipMemcpyAsync(&h->h_done[slot], h->d_done, sizeof(int), hipMemcpyDeviceToHost, sA));
+            HIPCHECK(h, hipEventRecord(h->ev_batch[slot], sA));
+            for (int t = 1; t < NS; t++) {
+                HIPCHECK(h, hipMemcpyAsync(&h->h_donex[t * 2 + slot], h->d_done, sizeof(int), hipMemcpyDeviceToHost, st_of(t)));
+                HIPCHECK(h, hipEventRecord(h->ev_batchx[t][slot], st_of(t)));
+            }
         }
         if (have_prev) {
             HIPCHECK(h, hipEventSynchronize(h->ev_batch[slot ^ 1]));
             int done = h->h_done[slot ^ 1];
-            for (int t = 1; t < NS; t++) {
+            for (int t = 1; t < NS && !pipe; t++) {
                 HIPCHECK(h, hipEventSynchronize(h->ev_batchx[t][slot ^ 1]));
                 done = std::max(done, h->h_donex[t * 2 + (slot ^ 1)]);        // snapshots of ONE monotone counter: the largest is the latest
             }
@@ -400,20 +437,13 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
         slot ^= 1;
         if (ticks > TICK_CAP) return fail(h, MLX_ERR_MODEL_FITTING, "Model fitting error! solve did not terminate within %lld ticks", (long long)TICK_CAP);
     }
-    for (int t = 1; t < NS; t++) {                        // the first stream continues (outputs, means) after all parts
+    // the first stream continues (outputs, means) after all parts
+    for (int t = 1; t < nextra; t++) {
         HIPCHECK(h, hipEventRecord(h->ev_join[t], st_of(t)));
         HIPCHECK(h, hipStreamWaitEvent(sA, h->ev_join[t], 0));
     }
-    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    HIPCHECK(h, hipStreamSynchronize(sA));
     HIPCHECK(h, hipGetLastError());
-    if (h->step_fused && nqc > 0) {
-        int ctl[2] = {0, 0};
-        HIPCHECK(h, hipMemcpy(ctl, h->d_stepctl, sizeof ctl, hipMemcpyDeviceToHost));
-        if (ctl[1] != 0) {
-            hipMemset(h->d_stepctl, 0, 2 * sizeof(int));
-            return fail(h, MLX_ERR_HIP, "fused TRON step: an in-launch exchange timed out (unset MLX_STEP_FUSED to run the three-launch step)");
-        }
-    }
     if (ticks_out) *ticks_out = ticks;
     return MLX_OK;
 }
@@ -446,9 +476,9 @@ int finish_part(mlx_handle h, PartHost &ph)
 extern "C" {
 
 #ifdef MLX_EXPERIMENTAL
-const char *mlx_version(void) { return "mlease_hip gfx950 r3 +experimental (" __DATE__ ")"; }
+const char *mlx_version(void) { return "mlease_hip gfx950 r4 +experimental (" __DATE__ ")"; }
 #else
-const char *mlx_version(void) { return "mlease_hip gfx950 r3 (" __DATE__ ")"; }
+const char *mlx_version(void) { return "mlease_hip gfx950 r4 (" __DATE__ ")"; }
 #endif
 
 const char *mlx_last_error(mlx_handle h) { return h ? h->err.c_str() : g_err_nohandle.c_str(); }
@@ -479,6 +509,9 @@ int mlx_create(int device_id, mlx_handle *out)
     h->nstreams = 2;
     if (const char *te = getenv("MLX_SMALL_TICKS")) h->small_ticks = std::max(1, atoi(te));
     if (const char *se = getenv("MLX_STREAMS")) h->nstreams = std::max(1, std::min(atoi(se), (int)mlx_context::MAX_TS));
+    if (const char *pe = getenv("MLX_PROFILE_ONE_STREAM")) h->prof_one_stream = atoi(pe) != 0;
+    if (const char *pe = getenv("MLX_DENSE_PIPE")) h->dense_pipe = atoi(pe) != 0;
+    if (const char *pe = getenv("MLX_DENSE_PARTS")) h->dense_parts = std::max(2, std::min(atoi(pe), (int)mlx_context::MAX_TS));
     if (h->nstreams > 1) {
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
         if (hipHostMalloc((void **)&h->h_donex, mlx_context::MAX_TS * 2 * sizeof(int)) != hipSuccess) h->nstreams = 1;
@@ -507,6 +540,10 @@ int mlx_destroy(mlx_handle h)
     if (h->h_diff) hipHostFree(h->h_diff);
     for (auto e : h->ev_pool) hipEventDestroy(e);
     for (auto e : h->ev_batch) if (e) hipEventDestroy(e);
+    for (int t = 0; t < mlx_context::MAX_TS; t++) {
+        for (auto e : h->ev_pass[t]) if (e) hipEventDestroy(e);
+        for (auto e : h->ev_step[t]) if (e) hipEventDestroy(e);
+    }
     for (int t = 1; t < mlx_context::MAX_TS; t++) {
         for (auto e : h->ev_batchx[t]) if (e) hipEventDestroy(e);
         if (h->ev_join[t]) hipEventDestroy(h->ev_join[t]);
@@ -658,6 +695,11 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
                     for (int64_t k = row_ptr[i]; k < row_ptr[i + 1]; k++)
                         if (is_cold[(size_t)col_idx[k]]) crow[(size_t)fillp[(size_t)col_idx[k]]++] = i;
                 std::vector<char> seen((size_t)l, 0);
+                // A column with many rows is expanded ONCE (its unseen rows pushed by the first row that reaches it); re-pushing them
+                // from every later row would cost sum k^2 over the cold columns in time and stack memory -- nothing on the one-hot
+                // configs (k = 1..4, where the re-push keeps a column's rows next to each other), hours on wide valued data whose
+                // cold columns hold thousands of entries. With the cap the walk is O(16 nnz).
+                std::vector<char> expanded((size_t)nf, 0);
                 std::vector<int32_t> stack;
                 rowperm.reserve((size_t)l);
                 int nvis = 0;
@@ -673,6 +715,10 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
                         for (int64_t k = row_ptr[r + 1] - 1; k >= row_ptr[r]; k--) {     // (reverse: the row's first cold column is walked first)
                             const int32_t c = col_idx[k];
                             if (!is_cold[(size_t)c]) continue;
+                            if (cstart[(size_t)c + 1] - cstart[(size_t)c] > 16) {
+                                if (expanded[(size_t)c]) continue;
+                                expanded[(size_t)c] = 1;
+                            }
                             for (int32_t q = cstart[(size_t)c + 1] - 1; q >= cstart[(size_t)c]; q--)
                                 if (!seen[(size_t)crow[(size_t)q]]) stack.push_back(crow[(size_t)q]);
                         }
@@ -742,13 +788,6 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
     // (verification mode: one row block, unsplit columns -- a column's sum then runs over its rows in ascending order, XTv's order)
     const int seg = faithful ? std::numeric_limits<int32_t>::max() : (getenv("MLX_SEG") ? atoi(getenv("MLX_SEG")) : CSC_SEG);
     int rbmax = faithful ? std::numeric_limits<int32_t>::max() - 64 : (getenv("MLX_RBMAX") ? std::min(RBLK_MAX_ROWS, std::max(64, atoi(getenv("MLX_RBMAX")))) : RBLK_MAX_ROWS);
-    // lambda sweeps of 2..8 lambdas: the shared column pass keeps the block's coefficients of R = 2 / 4 / 8 lambdas in LDS at once
-    // (opt-in, MLX_MULTI=1: measured SLOWER than the per-problem passes sharing the streams through L2 -- the passes are not
-    // bound by the index stream, and R times shorter row blocks multiply the column items; profiles/r2_notes.md)
-    if (!faithful && n_lambda >= 2 && n_lambda <= 8 && getenv("MLX_MULTI") != nullptr && atoi(getenv("MLX_MULTI")) != 0) {
-        ph.multi_R = n_lambda <= 2 ? 2 : (n_lambda <= 4 ? 4 : 8);
-        rbmax = std::min(rbmax, (RBLK_MAX_ROWS + 1) / ph.multi_R / 64 * 64 - 64);
-    }
     const int nb = std::max(1, (l + rbmax - 1) / rbmax);
     const int RB = std::max(64, ((l + nb - 1) / nb + 63) / 64 * 64);
     ph.n_rblk = nb; ph.rblk_rows = RB;
@@ -866,15 +905,6 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
         ph.sell = nnz > 0 && (double)padded <= 2.0 * (double)nnz + 4096.0 && padded < (int64_t)std::numeric_limits<int32_t>::max() &&
                   (int64_t)nnz + 64LL * ph.n_items < (int64_t)std::numeric_limits<int32_t>::max() / 2 && getenv("MLX_NO_SELL") == nullptr &&
                   !faithful;
-        if (ph.sell && ph.multi_R && ncs_r <= 2 && n_hs == 1) {
-            // the shared row pass keeps a row group's packs in registers: <= 6 hot and <= 3 cold packs per group
-            int mxh = 0, mxc = 0;
-            for (int g = 0; g < ngr; g++) {
-                mxh = std::max(mxh, (rs_ptr[(size_t)g + 1] - rs_ptr[(size_t)g]) >> 8);
-                if (ncs_r == 2) mxc = std::max(mxc, (rs_ptr[(size_t)ngr + g + 1] - rs_ptr[(size_t)ngr + g]) >> 8);
-            }
-            ph.row_multi_ok = mxh <= 6 && mxc <= 3;
-        }
         if (ph.sell) {
             // (+256 entries of padding behind the last block: a wave whose trailing groups do not exist issues its unconditional,
             // clamped pack load at the END offset -- one 512-byte pack that must still be inside the allocation)
@@ -1167,27 +1197,17 @@ int mlx_finalize(mlx_handle h)
     // Sliced CSR partitions: the row chunk of one row-pass workgroup (a range of 64-row groups; the sliced layout does not
     // depend on it). Every workgroup stages the whole gathered vector once, slice by slice, so chunks are as long as the
     // handle's total work allows: about three workgroups per CU over all problems, 16..128 groups (1 024..8 192 rows).
-#ifndef MLX_EXPERIMENTAL
     for (const char *sw : {"MLX_MULTI", "MLX_STEP_FUSED"})
         if (getenv(sw) && atoi(getenv(sw)) != 0)
-            return fail(h, MLX_ERR_INVALID, "%s needs the experimental build (libmlease_hip_exp.so); the product library does not contain that code", sw);
-#endif
+            return fail(h, MLX_ERR_INVALID, "%s: that code was measured slower and left the library in round 4 (attic/csrc, profiles/r2_notes.md)", sw);
     h->csr_sell = true;
     for (auto &p : h->parts) if (!p.dense) h->csr_sell = h->csr_sell && p.sell;
-    if (h->csr_sell && nl >= 2) {
-        int R = -1;
-        bool rm = true, hv = false;
-        for (auto &p : h->parts) if (!p.dense) { R = (R == -1 || R == p.multi_R) ? p.multi_R : 0; rm = rm && p.row_multi_ok; hv = hv || p.hasval; }
-        h->multi_R = R > 0 ? R : 0;
-        h->row_multi = h->multi_R > 0 && rm && !hv;
-    }
     if (h->csr_sell) {
         int64_t total_groups = 0;
         for (auto &p : h->parts) if (!p.dense) total_groups += (int64_t)nl * p.n_rgroups;
         int ngc = 16;                                    // 16 * {1, 2, 4, 8}: the row pass is compiled for these group counts per wave
         while (ngc < 128 && total_groups / ngc > 768) ngc *= 2;
         if (const char *e = getenv("MLX_ROW_NG")) { ngc = 16; while (ngc < 128 && ngc < atoi(e)) ngc *= 2; }
-        if (h->row_multi) ngc = 16;                      // the shared row pass: one row group per wave
         h->row_ngc = ngc;
         for (auto &p : h->parts) if (!p.dense) {
             p.dev.rgroups_per_chunk = ngc;
@@ -1201,7 +1221,7 @@ int mlx_finalize(mlx_handle h)
         // saves (configs[3] per-GPU shape 51.5 vs 49 us). MLX_COLD_SEP=1 / 0 forces it on / off.
         const char *ce = getenv("MLX_COLD_SEP");
         h->cold_groups = 0;
-        if ((ce ? atoi(ce) != 0 : ngc >= 128) && !h->row_multi)
+        if (ce ? atoi(ce) != 0 : ngc >= 128)
             for (auto &p : h->parts) if (!p.dense && p.n_cs > p.n_hs) h->cold_groups = std::max(h->cold_groups, p.n_rgroups);
     }
     // Dense tiles: 512-row chunks are the optimum when the handle's problems make >= ~1000 of them (profiles/r1_notes.md);
@@ -1291,12 +1311,6 @@ int mlx_finalize(mlx_handle h)
         qc.clear();
         for (int q : ordered) if (q >= 0) qc.push_back(q);
     }
-    if (h->multi_R) {
-        std::vector<int> pl;
-        for (int k = 0; k < np; k++) if (!h->parts[k].dense) pl.push_back(k * nl);
-        h->np_csr = (int)pl.size();
-        if ((rc = dev_upload(h, &h->d_plist, pl.data(), pl.size()))) return rc;
-    }
     h->nq_dense = (int)qd.size(); h->nq_csr = (int)qc.size();
     if ((rc = dev_upload(h, &h->d_qdense, qd.data(), qd.size()))) return rc;
     if ((rc = dev_upload(h, &h->d_qcsr, qc.data(), qc.size()))) return rc;
@@ -1310,9 +1324,6 @@ int mlx_finalize(mlx_handle h)
         while ((max_nlocal_csr + ch - 1) / ch > 256) ch *= 2;
         h->step_ch = ch;
         h->step_max_nwg = (max_nlocal_csr + ch - 1) / ch;
-        // MLX_STEP_FUSED=1 (opt-in, measured slower -- profiles/r2_notes.md): phases A+B+C in one launch with in-launch exchanges
-        const char *fe = getenv("MLX_STEP_FUSED");
-        h->step_fused = ch == 2048 && h->step_max_nwg <= 256 && fe && atoi(fe) == 1;
     }
 
     // problems (+1 scratch for mlx_solve_one)
@@ -1327,7 +1338,7 @@ int mlx_finalize(mlx_handle h)
     auto step_nwg = [&](int n_local) { return (size_t)((n_local + h->step_ch - 1) / h->step_ch); };
     auto vec_bytes = [&](int n_local, int l, int64_t plen, int nblk, bool dense) {
         return 8 * carve_size((size_t)n_local) + (dense ? 2 : 3) * carve_size((size_t)l) + carve_size((size_t)plen) + 2 * carve_size((size_t)nblk) +
-               (dense ? 0 : carve_size((size_t)n_local) + 3 * carve_size(step_nwg(n_local) * STEP_NP) + carve_size(16)) +
+               (dense ? 0 : carve_size((size_t)n_local) + 3 * carve_size(step_nwg(n_local) * STEP_NP)) +
                (h->faithful ? carve_size((size_t)l) + carve_size((size_t)n_local) : 0);
     };
     const int scratch_blk = std::max(h->maxblk_dense, h->maxblk_csr);
@@ -1350,7 +1361,6 @@ int mlx_finalize(mlx_handle h)
             pr.coef = carve((size_t)l);
             pr.rb[0] = pr.r; pr.rb[1] = carve((size_t)n_local);
             pr.pA = carve(step_nwg(n_local) * STEP_NP); pr.pB = carve(step_nwg(n_local) * STEP_NP); pr.pC = carve(step_nwg(n_local) * STEP_NP);
-            pr.xs = carve(16);
         }
         if (h->faithful) { pr.rowtmp = carve((size_t)l); pr.c0f = carve((size_t)n_local); }
         pr.parts = carve((size_t)plen);
@@ -1377,8 +1387,6 @@ int mlx_finalize(mlx_handle h)
 
     if ((rc = dev_alloc(h, &h->d_done, 1))) return rc;
     HIPCHECK(h, hipMemset(h->d_done, 0, sizeof(int)));
-    if ((rc = dev_alloc(h, &h->d_stepctl, 2))) return rc;
-    HIPCHECK(h, hipMemset(h->d_stepctl, 0, 2 * sizeof(int)));
 
     // c0 = X' t0: one EVAL pass at w = 0 on the first problem of every partition
     std::vector<int> qfirst_d, qfirst_c, qfirst_all;
@@ -1488,7 +1496,7 @@ int mlx_admm_solve_local(mlx_handle h, double liblinear_epsilon, float rho_adapt
         HIPCHECK(h, hipStreamSynchronize(h->stream));     // pinv is a stack vector
         h->pinv_admm_last = pinv;
     }
-    h->ev_used = 0; h->ev_kind.clear();
+    h->ev_used = 0; h->ev_kind.clear(); h->ev_sidx.clear();
     HIPCHECK(h, hipEventRecord(h->ev_t0, h->stream));
     mlxk_setup(h->stream, h->d_parts, h->d_probs, h->nprob, nl, ng, h->max_nlocal, h->d_z32, h->d_u, h->d_pinv_l,
                liblinear_epsilon, DEFAULT_MAX_ITER);
@@ -1548,10 +1556,17 @@ static int collect_solve_stats(mlx_handle h, int64_t ticks, mlx_stats *stats, bo
     if (h->profiling) {
         double acc[4] = {0, 0, 0, 0};
         int64_t cnt[4] = {0, 0, 0, 0};
-        for (size_t i = 0; i + 1 < h->ev_used; i++) {
-            float m2 = 0;
-            const int kind = h->ev_kind[i];
-            if (kind >= 0 && hipEventElapsedTime(&m2, h->ev_pool[i], h->ev_pool[i + 1]) == hipSuccess) { acc[kind] += m2; cnt[kind]++; }
+        // an interval runs from a mark to the NEXT mark recorded on the same tick stream
+        int prev[mlx_context::MAX_TS];
+        for (int &p : prev) p = -1;
+        for (size_t i = 0; i < h->ev_used; i++) {
+            const int sx = h->ev_sidx[i];
+            if (prev[sx] >= 0) {
+                float m2 = 0;
+                const int kind = h->ev_kind[(size_t)prev[sx]];
+                if (kind >= 0 && hipEventElapsedTime(&m2, h->ev_pool[(size_t)prev[sx]], h->ev_pool[i]) == hipSuccess) { acc[kind] += m2; cnt[kind]++; }
+            }
+            prev[sx] = (int)i;
         }
         s.xpass_ms = acc[0] + acc[1] + acc[2];
         s.rowpass_ms = acc[1]; s.colpass_ms = acc[2]; s.step_ms = acc[3];
@@ -1707,7 +1722,7 @@ int mlx_naive_solve_local(mlx_handle h, double liblinear_epsilon, double prior_m
     HIPCHECK(h, hipMemcpyAsync(h->d_pinv_l, pinv.data(), sizeof(double) * nl, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(h, hipMemcpyAsync(h->d_pinv_ovr, ovr.data(), sizeof(double) * ng, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
-    h->ev_used = 0; h->ev_kind.clear();
+    h->ev_used = 0; h->ev_kind.clear(); h->ev_sidx.clear();
     HIPCHECK(h, hipEventRecord(h->ev_t0, h->stream));
     mlxk_setup_naive(h->stream, h->d_parts, h->d_probs, h->nprob, h->max_nlocal, h->d_pinv_l, h->d_pinv_ovr,
                      h->d_naive_pinv, prior_mean, liblinear_epsilon, DEFAULT_MAX_ITER);

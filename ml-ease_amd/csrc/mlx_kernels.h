@@ -13,19 +13,13 @@ int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const i
                    int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cunits, int max_rblk_rows, int row_slw, int row_ngc, bool stream_once,
                    int which /* 1 = row pass, 2 = column pass, 3 = both */,
                    int cold_groups /* > 0: the row pass's cold slices run as their own launch (k_rowcold) over that many row groups */);
-// Shared-X passes of a lambda sweep (n_lambda <= 8): one workgroup per (partition, piece) carries all lambdas; plist = first
-// problem of every CSR partition. row_multi false = only the column pass has a shared form for these partitions.
-void mlxk_xpass_multi(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *plist, int np, int nl, int R, int maxblk,
-                      bool hasval, int max_cunits, int max_rblk_rows, int row_slw, int row_ngc, bool row_multi, int which);
 // TRON/CG control flow for the problems in qlist: one workgroup per problem (dense tiles)
 void mlxk_tron_step(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int threads,
                     int *done_counter);
 // the same for CSR problems, split over column chunks of `ch` columns (max_nwg chunks for the widest problem):
 // four launches per tick, which = 0 (A), 1 (B), 2 (C), 3 (commit)
 void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int ch,
-                     int max_nwg, int *done_counter, int *ctl);
-// phases A+B+C in one launch with in-launch exchanges (ch == 2048, max_nwg <= 256); ctl: [0] ticket counter, [1] error flag
-void mlxk_step_fused(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int max_nwg, unsigned seq, int *ctl);
+                     int max_nwg, int *done_counter);
 // whole solves of small CSR problems in one launch (one workgroup per problem runs the tick loop)
 void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int first, bool hasval,
                       int max_ticks, int *done_counter, int lds_doubles, bool faithful, int xl, int lds_bytes_xl);

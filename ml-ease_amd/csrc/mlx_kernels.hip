@@ -955,10 +955,6 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     }
 }
 
-#ifdef MLX_EXPERIMENTAL
-#include "mlx_experimental_passes.inc"   // shared-X passes of lambda sweeps (MLX_MULTI=1): measured slower, kept out of the product
-#endif
-
 // ------------------------------------------------------------------------------------------------
 // per-iteration problem setup: warm start z~, prior mean z~ - u_k on the partition's local index set
 // (jobs/RegressionAdmmTrain.java:692-698 ; llf/LibLinear.java:236-245 initSetup)
@@ -1615,20 +1611,7 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, cons
 
 // chunk-ordered totals of the previous launch's partial sums px[nwg][STEP_NP] -> tot[NP] (LDS); the loads run in
 // parallel (one partial per thread), the additions sequentially per column
-// agent-scope (cross-XCD coherent) relaxed accesses: served at the memory side, no cache maintenance -- the only accesses the
-// fused step's exchanges use for data another workgroup of the SAME launch wrote
-__device__ __forceinline__ void st_coh(double *p, double v)
-{
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double ld_coh(const double *p)
-{
-    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
-                                                            __HIP_MEMORY_SCOPE_AGENT));
-}
-
-template <int NP, bool COH = false>
+template <int NP>
 __device__ __forceinline__ void step_gather(const double *__restrict__ px, int nwg, double *tot /* LDS [NP] */,
                                             double *stage /* LDS [STEP_T] */)
 {
@@ -1639,7 +1622,7 @@ __device__ __forceinline__ void step_gather(const double *__restrict__ px, int n
     for (int w0 = 0; w0 < nwg; w0 += WPR) {
         const int w = w0 + tid / STEP_NP, k = tid % STEP_NP;
         __syncthreads();
-        stage[tid] = (w < nwg && k < NP) ? (COH ? ld_coh(px + w * STEP_NP + k) : px[w * STEP_NP + k]) : 0.0;
+        stage[tid] = (w < nwg && k < NP) ? px[w * STEP_NP + k] : 0.0;
         __syncthreads();
         if (tid < NP) {
             const int cnt = min(WPR, nwg - w0);
@@ -2005,27 +1988,17 @@ k_step_c(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
     }
 }
 
-#ifdef MLX_EXPERIMENTAL
-#include "mlx_experimental_step.inc"     // the three step phases in one launch (MLX_STEP_FUSED=1): measured slower
-#endif
-
 // ---- commit: one workgroup per problem writes the scalars of the tick ---------------------------------------------
 __global__ void __launch_bounds__(STEP_T)
 k_step_commit(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int ch,
-              int *__restrict__ done_counter, int *__restrict__ ctl)
+              int *__restrict__ done_counter)
 {
 #pragma clang fp contract(off)
     __shared__ double stage[STEP_T];
     __shared__ double totA[4], totB[5], totC[3];
     ProbDev &pr = probs[qlist[blockIdx.x]];
     const int phase = pr.phase;
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctl[0] = 0;             // the fused step's ticket counter, for the next tick
     if (phase == PH_DONE) return;
-    if (ctl[1] != 0) {
-        // an exchange of the fused step timed out: nothing of this tick can be trusted -- stop every problem, the host reports it
-        if (threadIdx.x == 0) { pr.status = ST_NAN; pr.phase = PH_DONE; atomicAdd(done_counter, 1); }
-        return;
-    }
     const PartDev &pa = parts[pr.part];
     const int nwg = (pa.n_local + ch - 1) / ch;
     step_gather<4>(pr.pA, nwg, totA, stage);
@@ -2101,6 +2074,10 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
     extern __shared__ double dyn[];
     __shared__ ProbDev prl;
     __shared__ PartDev pal;
+    // static LDS of this kernel beside the <= 150 KiB of dynamic LDS the launcher may ask for (mlxk_solve_small): a descriptor that
+    // grows past the budget must fail the build, not the launch
+    static_assert(sizeof(ProbDev) + sizeof(PartDev) + (64 + 1024) * sizeof(double) + 256 <= (160 - 150) * 1024,
+                  "k_solve_small: static LDS + 150 KiB dynamic LDS exceed the 160 KiB of a CU");
     const int q = blockIdx.x;
     if (q >= nprob) return;
     ProbDev &prg = probs[q];                 // the descriptor in global memory
@@ -2833,35 +2810,6 @@ int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const i
     return 0;
 }
 
-#ifdef MLX_EXPERIMENTAL
-// Shared-X passes of a lambda sweep: plist = first problem of every CSR partition (its n_lambda problems are consecutive)
-void mlxk_xpass_multi(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *plist, int np, int nl, int R, int maxblk,
-                      bool hasval, int max_cunits, int max_rblk_rows, int row_slw, int row_ngc, bool row_multi, int which)
-{
-    if (np <= 0) return;
-    const size_t lds_col = (size_t)R * ((size_t)max_rblk_rows + 1) * sizeof(double), lds_row = ((size_t)row_slw + 1) * sizeof(double);
-    per_device_once(2, [&] {
-#define SETM(HV)                                                                                                                              \
-        set_max_lds(reinterpret_cast<const void *>(&k_colpass_multi<HV, false, 2>), 160 * 1024 - 64); \
-        set_max_lds(reinterpret_cast<const void *>(&k_colpass_multi<HV, false, 4>), 160 * 1024 - 64); \
-        set_max_lds(reinterpret_cast<const void *>(&k_colpass_multi<HV, false, 8>), 160 * 1024 - 64)
-        SETM(true); SETM(false);
-#undef SETM
-        set_max_lds(reinterpret_cast<const void *>(&k_rowpass_multi<false, false, 1>), 160 * 1024 - 512);
-        });
-    // (the shared row pass exists for binary.feature partitions, one row group per wave: its packs stay in registers across
-    // the lambda loop, and a float4 of values per pack or a second group does not fit beside them)
-    if ((which & 1) && row_multi && !hasval && row_ngc == 16)
-        hipLaunchKernelGGL((k_rowpass_multi<false, false, 1>), dim3(XGRID(np, maxblk)), dim3(1024), lds_row, st, parts, probs, plist, np, maxblk, nl);
-    if ((which & 2) && max_cunits > 0) {
-#define LCOL(HV, RR) hipLaunchKernelGGL((k_colpass_multi<HV, false, RR>), dim3(XGRID(np, max_cunits)), dim3(1024), lds_col, st, parts, probs, plist, np, max_cunits, nl)
-        if (hasval) { if (R == 2) LCOL(true, 2); else if (R == 4) LCOL(true, 4); else LCOL(true, 8); }
-        else { if (R == 2) LCOL(false, 2); else if (R == 4) LCOL(false, 4); else LCOL(false, 8); }
-#undef LCOL
-    }
-}
-#endif
-
 void mlxk_tron_step(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int threads,
                     int *done_counter)
 {
@@ -2869,24 +2817,15 @@ void mlxk_tron_step(hipStream_t st, const PartDev *parts, ProbDev *probs, const 
 }
 
 void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int ch,
-                     int max_nwg, int *done_counter, int *ctl)
+                     int max_nwg, int *done_counter)
 {
     if (nq <= 0) return;
     const dim3 grid((unsigned)max_nwg, (unsigned)nq);
     if (which == 0) hipLaunchKernelGGL(k_step_a, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
     else if (which == 1) hipLaunchKernelGGL(k_step_b, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
     else if (which == 2) hipLaunchKernelGGL(k_step_c, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
-    else hipLaunchKernelGGL(k_step_commit, dim3((unsigned)nq), dim3(STEP_T), 0, st, parts, probs, qlist, ch, done_counter, ctl);
+    else hipLaunchKernelGGL(k_step_commit, dim3((unsigned)nq), dim3(STEP_T), 0, st, parts, probs, qlist, ch, done_counter);
 }
-
-#ifdef MLX_EXPERIMENTAL
-// phases A, B and C in one launch (ch must be FUSE_CH = 2048 and max_nwg <= 256); the commit launch follows as before
-void mlxk_step_fused(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int max_nwg, unsigned seq, int *ctl)
-{
-    if (nq <= 0) return;
-    hipLaunchKernelGGL(k_step_fused, dim3((unsigned)max_nwg * (unsigned)nq), dim3(STEP_T), 0, st, parts, probs, qlist, max_nwg, seq, ctl);
-}
-#endif
 
 void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int first, bool hasval,
                       int max_ticks, int *done_counter, int lds_doubles, bool faithful, int xl, int lds_bytes_xl)

@@ -90,7 +90,6 @@ struct ProbDev {
     double *rb[2];
     int32_t rsel;
     double *pA, *pB, *pC;  // [n_step_wg][STEP_NP] each
-    double *xs;            // [16] exchange state of the fused step (k_step_fused): arrival counters, flags, totals
     double gsq;            // sum g_j^2 at the last accepted point (= rTr of the next trcg call)
     double snorm;          // ||s|| at the end of the last trcg call
     double *wd[2];         // [l] wt_i * D_i at the accepted / trial point

@@ -849,14 +849,13 @@ def _counters(oc):
 
 
 @pytest.mark.parametrize("binary,nlam", [(True, 8), (True, 3), (False, 5), (False, 2)])
-def test_lambda_sweep_shared_x_passes(binary, nlam, monkeypatch):
-    """BASELINE configs[4] in the small: a lambda sweep on the tick kernels runs the shared-X passes (k_rowpass_multi for
-    binary partitions, k_colpass_multi with R = 2 / 4 / 8 lambdas side by side in LDS; the reference replicates every row per
-    lambda instead, jobs/RegressionAdmmTrain.java:553-568). Per problem the result must be the per-problem kernels' result:
-    TRON/CG counters equal to the oracle's, coefficients within 1e-5, lambdas finishing at different ticks included."""
+def test_lambda_sweep_on_the_tick_kernels(binary, nlam, monkeypatch):
+    """BASELINE configs[4] in the small: a lambda sweep on the tick kernels. A partition's rows are uploaded once and its
+    n_lambda problems run side by side on one XCD, sharing the index streams through that L2 (the reference replicates every row
+    per lambda instead, jobs/RegressionAdmmTrain.java:553-568). Per problem: TRON/CG counters equal to the oracle's, coefficients
+    within 1e-5, lambdas finishing at different ticks included. (The one-workgroup-per-partition passes that read the index
+    streams once were measured slower in round 2 and left the library in round 4: attic/csrc, profiles/r2_notes.md.)"""
     monkeypatch.setenv("MLX_NO_SMALL", "1")
-    monkeypatch.setenv("MLX_EXPERIMENTAL", "1")             # libmlease_hip_exp.so: the product library does not contain these passes
-    monkeypatch.setenv("MLX_MULTI", "1")                    # opt-in: measured slower than the per-problem passes (DESIGN 4)
     pd = synth_sparse(23, 9000, 400, 14, 3, binary=binary, weights=not binary, offsets=not binary)
     lam = [0.05, 0.3, 1.0, 3.0, 10.0, 30.0, 100.0, 300.0][:nlam]
     rho = [1.0 if v <= 100 else 10.0 for v in lam]
@@ -869,14 +868,6 @@ def test_lambda_sweep_shared_x_passes(binary, nlam, monkeypatch):
         for li in range(nlam):
             assert_coef_close(eng.z()[1][li], oc.z()[1][li], "lambda %g iteration %d" % (lam[li], it + 1), floor=1e-2)
     eng.close()
-    # the same sweep on the (default) per-problem passes: same trajectories
-    monkeypatch.delenv("MLX_MULTI")
-    monkeypatch.delenv("MLX_EXPERIMENTAL")                  # ... of the product library
-    eng2 = make_engine(pd, lam, rho)
-    for it in range(4):
-        eng2.iterate(0.01)
-    assert np.array_equal(eng2.solve_counters(), _counters(oc))
-    eng2.close()
 
 
 @pytest.mark.parametrize("binary", [True, False])
@@ -951,41 +942,6 @@ def test_two_cold_slices_on_wide_partitions(monkeypatch):
             assert np.max(err) <= 1e-4, "MLX_COLD_SEP=%s iteration %d: %.3e" % (sep, it + 1, np.max(err))
     for eng in engs:
         eng.close()
-
-
-@pytest.mark.parametrize("kind", ["onehot", "valued-multilambda", "wide"])
-def test_fused_step_is_bit_identical_to_the_three_launch_step(kind, monkeypatch):
-    """The CSR tick path's TRON/CG step in ONE launch (MLX_STEP_FUSED=1, opt-in because it measured slower: k_step_fused keeps
-    d, Hd and r' in registers between the phases, the two reductions are in-launch exchanges over agent-scope atomics)
-    against the three phase launches of the default path: same arithmetic, same order, same partial sums -> every counter
-    equal and every output bit-identical, on problems of 1 chunk, a few chunks and ~35 chunks per problem, with lambdas
-    finishing at different ticks."""
-    from fixtures import onehot_blocks
-    monkeypatch.setenv("MLX_NO_SMALL", "1")
-    monkeypatch.setenv("MLX_EXPERIMENTAL", "1")             # k_step_fused lives in libmlease_hip_exp.so only
-    if kind == "onehot":
-        pd, lam, rho, iters = onehot_blocks(160000, 4), [1.0], [1.0], 5
-    elif kind == "wide":
-        pd, lam, rho, iters = synth_sparse(31, 3000, 9000, 25, 3, binary=True), [0.3, 30.0], [1.0, 1.0], 4
-    else:
-        pd, lam, rho, iters = synth_sparse(11, 6000, 300, 12, 3, weights=True, offsets=True), [0.05, 1.0, 100.0], [1.0, 1.0, 1.0], 4
-    outs = []
-    for fused in ("1", "0"):
-        monkeypatch.setenv("MLX_STEP_FUSED", fused)
-        eng = make_engine(pd, lam, rho)
-        rec = []
-        for it in range(iters):
-            eng.iterate(0.01 if it < 2 else 0.001)
-            rec.append((eng.solve_counters().copy(), eng.z()[0].copy(),
-                        [eng.partition_model(k, li)[0].copy() for k in range(len(pd.blocks)) for li in range(len(lam))]))
-        outs.append(rec)
-        eng.close()
-    for it, (a, b) in enumerate(zip(*outs)):
-        assert np.array_equal(a[0], b[0]), "iteration %d: counters differ" % (it + 1)
-        assert np.array_equal(a[1], b[1]), "iteration %d: z differs" % (it + 1)
-        for x, y in zip(a[2], b[2]):
-            assert np.array_equal(x, y), "iteration %d: a partition model differs" % (it + 1)
-    assert outs[0][-1][0][:, 2].sum() > 0
 
 
 def test_tight_epsilon_differences_are_summation_order_only(monkeypatch):
