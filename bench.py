@@ -1,5 +1,10 @@
 #!/usr/bin/env python3
-"""bench.py -- benchmark of the MI355X-native ADMM L2-logistic hot path (one JSON line on stdout).
+"""bench.py -- benchmark of the MI355X-native ADMM L2-logistic hot path.
+
+stdout carries ONE compact JSON line (< 4 KB: the contract's keys, `roofline` and `cpu_baseline` of the headline leg, one-line
+summaries of the parity checks and of the sparse / lambda-sweep legs); the FULL record goes to `bench_full.json` beside this file
+(and to gpurun_out/ when that directory exists) and to stderr. Round 3 printed the full record as the one line: 29 KB, which the
+driver could not parse.
 
 Headline (BASELINE.json metric, configs[1]): partition Newton-solves/sec on synthetic dense 1M x 1K, 64 partitions
 (row % 64), single lambda. One "step" = one ADMM iteration = one batched TRON solve of every (partition, lambda)
@@ -13,19 +18,22 @@ N > 1: one process per GPU. Default is STRONG scaling, the metric's "1Mx1K at 1/
 partition k -> rank k mod N (64/N per GPU), the consensus means [xbar | ubar] all-reduced over RCCL (torch.distributed
 backend "nccl"). --scaling weak keeps 64 partitions per GPU (num.blocks = 64 N).
 
-Extra top-level keys of the same JSON line:
-  roofline      dominant kernel of the headline (k_xpass_dense): algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak. The
-                timed iterations run as a production job does (no per-launch events; two tick streams); the events live in a
-                replay of exactly those iterations from the same state (`measured_in`, `reproduced_timed_run`)
+Keys of the full record beside the contract's:
+  roofline      dominant kernel of the headline (k_xpass_dense): algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak,
+                measured IN the timed region at one GPU (the library pipelines the dense ticks: passes back to back on one
+                stream, TRON steps on a second one, so a pass launch's event interval is the kernel's own duration);
+                N > 1: timed without events, events in a replay of the same iterations
+  whole_step    algorithmic bytes of the timed iterations / their wall time
   cpu_baseline  the C oracle on the host cores, ALL 64 partitions, the SAME ADMM iterations as the first timed ones
                 (it starts from the GPU's state after the warm-up iterations), one thread per partition solve
   parity_check  the GPU re-run of exactly those iterations against the oracle's result
   time_to_ref_loglik  metric (ii): full run from z = 0, test log-likelihood per iteration against the ORACLE's
                 committed 20-iteration value (tests/golden/c2_ref_loglik.json, tests/golden/make_ref_loglik.py)
+  all_launches  every k_xpass_dense launch of the process with its event-timed average: what rocprofv3 --kernel-trace shows
   sparse        BASELINE configs[2] (N = 1) / configs[3] (N > 1): one-hot 10M x 100K, 20 nnz/row, 256 / 1024
                 partitions, binary.feature, with per-kernel rooflines (row pass, column pass, TRON/CG step), its own
                 cpu_baseline (same timed iterations, from the GPU's state) and parity_check (order-faithful mode vs the
-                oracle twin; product path vs oracle beside the oracle's own row-permutation spread)
+                oracle twin; product path vs oracle beside the oracle's own row-permutation envelope)
   config1_latency  BASELINE configs[0], the reference's sample data: wall time of its 20 ADMM iterations (latency, N = 1 only)
   lambda_sweep  BASELINE configs[4], per-GPU shape: 128 partitions x 9 765 rows x 8 lambdas (rho = 10 above lambda = 100)
 """
@@ -121,6 +129,7 @@ def main():
     ap.add_argument("--sweep-steps", type=int, default=3)
     ap.add_argument("--sweep-warmup", type=int, default=1)
     ap.add_argument("--sweep-cpu-sample", type=int, default=8, help="partitions (x 8 lambdas) of the lambda-sweep CPU / parity sample (0 = skip)")
+    ap.add_argument("--full-json", default="", help="where the full record goes (default: bench_full.json beside bench.py, + gpurun_out/)")
     ap.add_argument("--sparse-cpu-sample", type=int, default=256, help="partitions of the sparse CPU-baseline / parity sample (0 = skip)")
     args = ap.parse_args()
 
@@ -222,10 +231,146 @@ def main():
     if rank == 0:
         if share:
             out["test_mode"] = "MLX_BENCH_SHARE_GPU=1: all ranks on ONE device, collectives over gloo -- control-flow check, not a measurement"
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        emit(out, json_fd, args)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+
+# ======================================================================================================================
+COMPACT_LIMIT = 4000            # bytes: the driver keeps the tail of stdout and parses its LAST line (round 3's 29 KB line was cut)
+
+
+def _finite(x):
+    """JSON has no NaN / Infinity: non-finite floats become null (recursively)."""
+    if isinstance(x, float):
+        return x if np.isfinite(x) else None
+    if isinstance(x, (np.floating,)):
+        return float(x) if np.isfinite(x) else None
+    if isinstance(x, (np.integer,)):
+        return int(x)
+    if isinstance(x, (np.bool_,)):
+        return bool(x)
+    if isinstance(x, dict):
+        return {str(k): _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _r(x, nd=4):
+    return None if x is None else (round(float(x), nd) if isinstance(x, (float, np.floating)) else x)
+
+
+def compact_record(full):
+    """The headline line: the contract's keys + roofline + cpu_baseline of the headline leg, one-line summaries of the parity
+    checks and of the sparse / lambda-sweep legs. Everything else lives in bench_full.json (and on stderr)."""
+    full = _finite(full)
+    c = _pick(full, ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                     "dtype", "data"])
+    cfg = full.get("config") or {}
+    c["config"] = _pick(cfg, ["workload", "rows", "features", "partitions", "partitions_per_gpu", "admm_iterations_timed"])
+    if len(c["config"].get("workload", "")) > 200:
+        c["config"]["workload"] = c["config"]["workload"][:200]
+    roof = full.get("roofline")
+    if roof:
+        c["roofline"] = _pick(roof, ["kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "alg_bytes_per_launch", "avg_launch_ms",
+                                     "launches", "kernel_ms_per_step"])
+        for k in ("traffic", "alg_bytes_per_launch"):
+            if isinstance(c["roofline"].get(k), float):
+                c["roofline"][k] = round(c["roofline"][k])
+        c["roofline"]["avg_launch_ms"] = _r(c["roofline"].get("avg_launch_ms"), 5)
+        c["roofline"]["measured_in"] = roof.get("measured_in_short", "timed region")
+    c["whole_step_frac"] = (full.get("whole_step") or {}).get("frac_of_hbm_peak")
+    cb = full.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = _pick(cb, ["value", "unit", "cores", "kind"])
+        c["cpu_baseline"]["sample"] = cb.get("sample_short", cb.get("sample", ""))[:160]
+        c["gpu_over_cpu"] = (full.get("gpu_over_cpu") or {}).get("solves_per_s")
+    par = {}
+    c1 = full.get("config1_latency") or {}
+    if c1:
+        par["config1"] = {"z32_bit_identical_to_golden_20_iterations": c1.get("z32_bit_identical_to_golden_run"),
+                          "gpu_ms": c1.get("ms_20_iterations"), "cpu_ms": c1.get("cpu_oracle_ms_20_iterations")}
+    pc = full.get("parity_check") or {}
+    vo = ((full.get("time_to_ref_loglik") or {}).get("vs_oracle_run")) or {}
+    if pc or vo:
+        par["config2"] = {"tolerance": 1e-5, "max_rel_err_z": _r(pc.get("max_rel_err_z"), 9), "tron_counters_equal": pc.get("tron_counters_equal"),
+                          "bit_identical_f32": pc.get("bit_identical_float32_fraction"),
+                          "run20_max_rel_err_through_eps_1e-6": _r(vo.get("max_rel_err_z32_through_epsilon_1e-6"), 9),
+                          "run20_max_rel_err": _r(vo.get("max_rel_err_z32_over_iterations"), 9),
+                          "run20_oracle_rowperm_max_rel_err": _r(vo.get("oracle_rowperm_max_rel_err_z32_over_iterations"), 9),
+                          "run20_iterations_all_counters_equal": vo.get("iterations_with_all_counters_equal")}
+    sp = full.get("sparse") or {}
+    spc = sp.get("parity_check") or {}
+    if spc:
+        par["config3"] = spc.get("summary") or {}
+    if par:
+        c["parity"] = par
+
+    def leg(d):
+        o = _pick(d, ["value", "unit", "steps", "warmup", "ms_per_step"])
+        o["whole_step_frac"] = (d.get("whole_step") or {}).get("frac_of_hbm_peak")
+        ks = ((d.get("roofline") or {}).get("kernels")) or []
+        for name, k in zip(("rowpass", "colpass", "step"), ks):
+            if name != "step":                      # (the step has no algorithmic bytes)
+                o[name + "_frac"] = k.get("frac")
+            o[name + "_us_per_tick"] = k.get("us_per_tick")
+        if d.get("cpu_baseline"):
+            o["cpu_baseline"] = _pick(d["cpu_baseline"], ["value", "cores", "kind"])
+            o["gpu_over_cpu"] = (d.get("gpu_over_cpu") or {}).get("solves_per_s")
+        return o
+
+    if sp:
+        c["sparse"] = leg(sp)
+        c["sparse"]["workload"] = "configs[%d] one-hot 10Mx100K, %s partitions" % (2 if full.get("n_gpus", 1) == 1 else 3, sp.get("partitions", "?"))
+    sw = full.get("lambda_sweep") or {}
+    if sw:
+        c["lambda_sweep"] = leg(sw)
+        c["lambda_sweep"]["workload"] = "configs[4] per-GPU shape: %s problems" % sw.get("problems_per_gpu", "?")
+    ll = full.get("time_to_ref_loglik") or {}
+    if ll:
+        c["time_to_ref_loglik"] = _pick(ll, ["seconds_to_ref_loglik", "reached_at_iteration", "seconds_all_iterations", "iterations"])
+    if full.get("gram"):
+        c["gram"] = _pick(full["gram"], ["achieved", "peak", "unit", "frac"])
+    al = full.get("all_launches") or {}
+    if al:
+        c["all_xpass_launches"] = _pick(al, ["timed_by_events", "avg_us", "alg_bytes_timed_by_events"])
+    if full.get("test_mode"):
+        c["test_mode"] = "MLX_BENCH_SHARE_GPU=1 (control-flow check, not a measurement)"
+    c["full_record"] = "bench_full.json (also on stderr)"
+    c = _finite(c)
+    # never exceed the limit: drop the optional blocks, least important first
+    for k in ("gram", "all_xpass_launches", "time_to_ref_loglik", "lambda_sweep", "sparse", "parity", "gpu_over_cpu"):
+        if len(json.dumps(c, allow_nan=False)) <= COMPACT_LIMIT:
+            break
+        c.pop(k, None)
+    return c
+
+
+def emit(out, json_fd, args):
+    """Full record -> bench_full.json beside this file (+ gpurun_out/ when that exists) and stderr; stdout gets ONE compact line."""
+    full = _finite(out)
+    text = json.dumps(full, allow_nan=False)
+    paths = [args.full_json] if args.full_json else [os.path.join(d, "bench_full.json") for d in (ROOT, os.path.join(ROOT, "gpurun_out")) if os.path.isdir(d)]
+    for path in paths:
+        try:
+            with open(path, "w") as fh:
+                fh.write(text + "\n")
+        except OSError as ex:
+            sys.stderr.write("[bench] could not write %s: %s\n" % (path, ex))
+    sys.stderr.write("[bench] full record: " + text + "\n")
+    sys.stderr.flush()
+    if "metric" in full:
+        line = json.dumps(compact_record(full), allow_nan=False)
+    else:                       # --sparse-only / --sweep-only development runs: the leg's own record
+        line = text
+    os.write(json_fd, (line + "\n").encode())
 
 
 # ======================================================================================================================
@@ -313,7 +458,24 @@ def run_dense(args, C):
     eps_used = []
     acc = dict(solves=0, newton=0, cg=0, passes_ref=0, passes_dev=0, ticks=0, alg_bytes=0.0, xpass_ms=0.0,
                total_ms=0.0, launches=0)
-    allrun = dict(alg_bytes=P * (4.0 * rows * nf + 8.0 * rows + 8.0 * (nf + 1)), launches=1)   # + the c0 pass of finalize
+    # every k_xpass_dense launch of this leg that ran with events on: what a rocprofv3 --kernel-trace of this command must agree with
+    # (it also sees finalize's one c0 launch, which runs without events)
+    allrun = dict(alg_bytes=0.0, launches=0, xpass_ms=0.0, untimed_launches=1, untimed_alg_bytes=P * (4.0 * rows * nf + 8.0 * rows + 8.0 * (nf + 1)))
+    C["allrun_dense"] = allrun
+    # At one GPU the HIP events that time k_xpass_dense are ON in the timed region itself (and in every other solve of this leg):
+    # the library runs the dense ticks as a pipeline -- the passes of the two halves back to back on one stream, each half's TRON
+    # step on a second stream beside the other half's pass -- so a pass launch never shares the memory system with another pass and
+    # the interval between the marks around it is the kernel's own duration. N > 1 (the driver's scaling runs) times without events
+    # and replays the iterations with events afterwards.
+    prof_timed = (not args.no_profile) and world == 1
+    eng.set_profiling(prof_timed)
+
+    def account(st):
+        if st.xpass_ms > 0:
+            allrun["alg_bytes"] += st.alg_bytes_dev; allrun["launches"] += st.xpass_launches; allrun["xpass_ms"] += st.xpass_ms
+        else:
+            allrun["untimed_alg_bytes"] += st.alg_bytes_dev; allrun["untimed_launches"] += st.xpass_launches
+    C["account_dense"] = account
 
     def step(timed):
         eps = sched.next()
@@ -322,8 +484,7 @@ def run_dense(args, C):
         C["all_reduce"](eng.consensus_tensor())
         fin = eng.consensus_finish()
         sched.mindiff = fin.mindiff
-        allrun["alg_bytes"] += st.alg_bytes_dev
-        allrun["launches"] += st.ticks
+        account(st)
         if timed:
             acc["solves"] += st.solves; acc["newton"] += st.newton_iters; acc["cg"] += st.cg_iters
             acc["passes_ref"] += st.x_passes_ref; acc["passes_dev"] += st.x_passes_dev; acc["ticks"] += st.ticks
@@ -345,16 +506,17 @@ def run_dense(args, C):
         step_times.append((time.perf_counter() - ts, st.solves, st.x_passes_ref))
     C["barrier"]()
     dt = C["reduce_max"](time.perf_counter() - t0)
-    tot_solves, tot_pref, tot_pdev, tot_cg, tot_newton = C["reduce_sum"](
-        [acc["solves"], acc["passes_ref"], acc["passes_dev"], acc["cg"], acc["newton"]])
+    tot_solves, tot_pref, tot_pdev, tot_cg, tot_newton, tot_alg = C["reduce_sum"](
+        [acc["solves"], acc["passes_ref"], acc["passes_dev"], acc["cg"], acc["newton"], acc["alg_bytes"]])
     z32_end = eng.z()[1].copy()            # the consensus as the final-model file would hold it (identical on every rank)
-    # ---- roofline of the dominant kernel: the timed iterations ran as a production job does (no per-launch events; the library then
-    # ticks two halves of the problems on two streams, so that one half's TRON step -- one workgroup per problem -- runs beside the
-    # other half's pass). The HIP events that time k_xpass_dense live in a REPLAY of exactly those iterations from the same state
-    # (bit-reproducible; `reproduced_timed_run`), where events keep every launch on one stream so that a duration is the kernel's own.
+    # ---- roofline of the dominant kernel
     prof = None
-    if not args.no_profile:
-        prof = dict(alg_bytes=0.0, xpass_ms=0.0, launches=0, ticks=0, wall=0.0)
+    if prof_timed:
+        prof = dict(alg_bytes=acc["alg_bytes"], xpass_ms=acc["xpass_ms"], launches=acc["launches"], ticks=acc["ticks"], wall=dt,
+                    where="timed", reproduced=None)
+    elif not args.no_profile:
+        # N > 1: a REPLAY of exactly the timed iterations from the same state (bit-reproducible) with events on
+        prof = dict(alg_bytes=0.0, xpass_ms=0.0, launches=0, ticks=0, wall=0.0, where="replay")
         eng.set_state(snap[0], snap[1])
         eng.set_profiling(True)
         C["barrier"]()
@@ -365,8 +527,7 @@ def run_dense(args, C):
             C["all_reduce"](eng.consensus_tensor())
             f2 = eng.consensus_finish()
             prof["alg_bytes"] += st2.alg_bytes_dev; prof["xpass_ms"] += st2.xpass_ms; prof["launches"] += st2.xpass_launches; prof["ticks"] += st2.ticks
-            allrun["alg_bytes"] += st2.alg_bytes_dev
-            allrun["launches"] += st2.ticks
+            account(st2)
         C["barrier"]()
         prof["wall"] = C["reduce_max"](time.perf_counter() - tp)
         eng.set_profiling(False)
@@ -394,16 +555,25 @@ def run_dense(args, C):
                 tsrc = "profiles/traffic.json: (2 x FETCH_SIZE + WRITE_SIZE) / algorithmic bytes = %.4f from the committed rocprofv3 " \
                        "--pmc passes of `%s`, times this run's algorithmic bytes per launch (not a counter read in this run)" % (
                            tj["hbm_bytes_per_alg_byte"], tj.get("command", "bench.py"))
+            timed = prof["where"] == "timed"
             roof = {"bound": "hbm", "kernel": "k_xpass_dense<4,4>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                     "alg_bytes_per_launch": prof["alg_bytes"] / max(1, prof["launches"]),
-                    "avg_launch_ms": prof["xpass_ms"] / max(1, prof["launches"]), "launches": prof["launches"],
-                    "xpass_share_of_replay": round(prof["xpass_ms"] / (prof["wall"] * 1e3), 4),
-                    "replay_ms_per_step": round(prof["wall"] * 1e3 / args.steps, 3), "timed_ms_per_step": round(dt * 1e3 / args.steps, 3),
-                    "reproduced_timed_run": prof["reproduced"],
-                    "measured_in": "a replay of the %d timed iterations (same state, same epsilons; reproduced_timed_run = %s) with the library's per-launch "
-                                   "HIP events on its own stream and ONE tick stream: %.3f ms per iteration there against %.3f ms in the timed run "
-                                   "(no events, two tick streams)" % (args.steps, prof["reproduced"], prof["wall"] * 1e3 / args.steps, dt * 1e3 / args.steps)}
+                    "avg_launch_ms": round(prof["xpass_ms"] / max(1, prof["launches"]), 5), "launches": prof["launches"],
+                    "kernel_ms_per_step": round(prof["xpass_ms"] / args.steps, 3),
+                    "xpass_share_of_wall": round(prof["xpass_ms"] / (prof["wall"] * 1e3), 4),
+                    "timed_ms_per_step": round(dt * 1e3 / args.steps, 3),
+                    "measured_in_short": "timed region (HIP events on the pass stream)" if timed else "replay of the timed iterations with events (N>1)",
+                    "measured_in": ("the TIMED region itself: HIP events on the stream the passes are launched on, one mark in front of and one behind every "
+                                    "k_xpass_dense launch; the library pipelines the dense ticks (passes of the two halves back to back on that stream, "
+                                    "each half's TRON step on a second stream beside the other half's pass), so passes never overlap each other and "
+                                    "kernel_ms_per_step <= ms_per_step" if timed else
+                                    "a replay of the %d timed iterations (same state, same epsilons; reproduced = %s) with events on: %.3f ms per "
+                                    "iteration there against %.3f ms in the timed run (no events)" % (
+                                        args.steps, prof["reproduced"], prof["wall"] * 1e3 / args.steps, dt * 1e3 / args.steps))}
+            if not timed:
+                roof["replay_ms_per_step"] = round(prof["wall"] * 1e3 / args.steps, 3)
+                roof["reproduced_timed_run"] = prof["reproduced"]
         out = {"metric": "partition Newton-solves/sec (ADMM L2-LR, dense 1Mx1K, 64 partitions)",
                "value": round(value, 3), "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": args.scaling,
@@ -421,12 +591,21 @@ def run_dense(args, C):
                         "last_maxdiff": fin.maxdiff,
                         "z32_sha1_after_timed_steps": __import__("hashlib").sha1(z32_end.tobytes()).hexdigest()},
                "roofline": roof,
-               "time_to_ref_loglik": loglik,
-               "all_launches": {"xpass_launches_incl_c0_and_warmup": allrun["launches"], "alg_bytes": allrun["alg_bytes"]}}
+               "whole_step": {"alg_bytes_per_s_GB": round(tot_alg / dt / 1e9, 1), "frac_of_hbm_peak": round(tot_alg / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
+                              "definition": "sum over solves of device passes x B_pass (SURVEY 8d: 4 l n + 8 l + 8 n per pass) / wall time of the timed iterations"},
+               "time_to_ref_loglik": loglik}
         if not args.no_gram:
             out["gram"] = gram_leg(eng, rows, nf)
         if want_cpu:
             cpu_leg(args, C, eng, out, sample, snap, eps_used, step_times, nf, N)
+        # every k_xpass_dense launch of the process: the numbers a `rocprofv3 --kernel-trace --stats` of this command must show
+        out["all_launches"] = {"timed_by_events": allrun["launches"], "avg_us": round(1e3 * allrun["xpass_ms"] / max(1, allrun["launches"]), 3),
+                               "alg_bytes_timed_by_events": allrun["alg_bytes"], "without_events": allrun["untimed_launches"],
+                               "alg_bytes_without_events": allrun["untimed_alg_bytes"],
+                               "alg_bytes": allrun["alg_bytes"] + allrun["untimed_alg_bytes"],
+                               "launches": allrun["launches"] + allrun["untimed_launches"],
+                               "note": "k_xpass_dense launches of the whole dense leg (warm-up, timed, log-likelihood run, CPU-parity re-run): "
+                                       "rocprofv3 counts the same launches (+ the Gram leg's none)"}
     eng.close()
     return out
 
@@ -485,7 +664,7 @@ def loglik_run(args, C, eng, P, nf, N, rows_total):
     tl0 = time.perf_counter()
     for it in range(args.loglik_iters):
         eps = sched.next()
-        eng.solve_local(eps, 1.0)
+        C["account_dense"](eng.solve_local(eps, 1.0))
         C["all_reduce"](eng.consensus_tensor())
         sched.mindiff = eng.consensus_finish().mindiff
         if rank == 0:
@@ -601,7 +780,7 @@ def cpu_leg(args, C, eng, out, sample, snap, eps_used, step_times, nf, N):
     per_it = []
     only_last_accept = True        # every mismatch = same TRON iterations and CG steps, `accepted` (and with it the passes) off by one
     for i, e in enumerate(eps):
-        eng.solve_local(e, 1.0)
+        C["account_dense"](eng.solve_local(e, 1.0))
         eng.consensus_finish()
         gc = eng.solve_counters()
         eq = np.all(gc == cnts[i], axis=1)
@@ -649,8 +828,11 @@ def cpu_leg(args, C, eng, out, sample, snap, eps_used, step_times, nf, N):
 def sparse_timed_run(args, C, eng, blocks, lam, warmup, steps, snapshot):
     """warmup + steps ADMM iterations of a one-hot job with the driver's epsilon schedule. The TIMED iterations run as a production
     job does: no per-launch events, two tick streams. The per-class rooflines come from a REPLAY of exactly those iterations (from
-    the state the first of them started from; runs are bit-reproducible) with the library's per-launch-class HIP events on, which
-    also puts all ticks on one stream so that a class's duration is its own."""
+    the state the first of them started from; runs are bit-reproducible) with the library's per-launch-class HIP events on, in the
+    SAME stream configuration (every tick stream carries its own chain of marks). The two halves of the problems run concurrently
+    there as in the timed run, so a class's summed durations overlap the other half's launches: the per-class fractions are those
+    of the kernels as they run in production (what a rocprofv3 kernel trace of this command shows), not of a kernel alone on the
+    chip (MLX_PROFILE_ONE_STREAM=1 gives that: tools/bench_sparse.py)."""
     sched = EpsSchedule(C["admm"])
     nl, P = len(lam), len(blocks)
     acc = dict(solves=0, cg=0, newton=0, pref=0, pdev=0, ticks=0, alg=0.0)
@@ -719,8 +901,10 @@ def sparse_rooflines(prof, n_mean, row_kernel, col_kernel):
                 "us_per_tick": round(1e3 * ms / max(1, prof["ticks"]), 1), "alg_bytes": alg_bytes, "note": note}
 
     step_model = 13.0 * 8.0 * n_mean * (prof["pdev"] / 2.0)        # 13 n-vector streams per problem and tick
-    return {"measured_in": "a replay of the timed iterations (same state, same epsilons; reproduced_timed_run = %s) with per-launch-class HIP events "
-                           "and ONE tick stream, %.1f ms wall against %s" % (prof["reproduced_timed_run"], wall_ms, "the timed run"),
+    return {"measured_in": "a replay of the timed iterations (same state, same epsilons, same two tick streams; reproduced_timed_run = %s) with "
+                           "per-launch-class HIP events on every tick stream, %.1f ms wall; the halves run concurrently, so class durations "
+                           "overlap the other half's launches (production conditions, as in a rocprofv3 trace of this command)" % (
+                               prof["reproduced_timed_run"], wall_ms),
             "kernels": [roof(row_kernel, prof["rms"], half, "B_pass = nnz*4 + 8l + 8n per active problem; the cold column slices run as their own launch in front of the row kernel"),
                         roof(col_kernel, prof["cms"], half, "B_pass = nnz*4 + 8l + 8n per active problem"),
                         roof("k_step_a+b+c+commit", prof["sms"], 0.0,
@@ -758,6 +942,7 @@ def run_sparse(args, C):
                            "%d partitions%s, lambda=1, rho=1" % (2 if world == 1 else 3, rows * Ptot, ng - 1, Ptot,
                                                                  " sharded k -> rank k mod %d" % world if world > 1 else ""),
                "value": round(tot_solves / dt, 2), "unit": "solves/s", "n_gpus": world, "steps": args.sparse_steps, "warmup": args.sparse_warmup,
+               "partitions": Ptot,
                "ms_per_step": round(dt * 1e3 / args.sparse_steps, 3), "liblinear_epsilon_by_iteration": eps_all,
                "nnz": int(nnz), "rows_per_partition": rows, "n_local_mean": n_mean, "gen_s": round(tgen, 1), "upload_s": round(tup, 1),
                "x_passes_ref_per_s": round(tot_pref / dt, 1), "x_passes_dev_per_s": round(tot_pdev / dt, 1),

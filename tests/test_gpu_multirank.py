@@ -34,13 +34,23 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _bench(cmd, env):
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+def _bench(cmd, env, tmp_path, tag):
+    """Runs bench.py; returns its FULL record (--full-json) after checking what the driver sees: exactly one stdout line, compact
+    (< 4 KB), strict JSON, carrying the same headline as the full record."""
+    full_path = str(tmp_path / ("bench_full_%s.json" % tag))
+    r = subprocess.run(cmd + ["--full-json", full_path], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stderr[-3000:], r.stdout[-500:])
-    return json.loads(r.stdout.strip().splitlines()[-1])
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1 and len(lines[0].encode()) < 4096, (len(lines), len(lines[-1]))
+    line = json.loads(lines[0])
+    full = json.loads(open(full_path).read())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype"):
+        assert line[k] == full[k], k
+    assert line["roofline"]["frac"] == full["roofline"]["frac"] and line["sparse"]["value"] == full["sparse"]["value"]
+    return full
 
 
-def test_bench_two_ranks_on_one_gpu_reproduce_the_one_rank_consensus():
+def test_bench_two_ranks_on_one_gpu_reproduce_the_one_rank_consensus(tmp_path):
     flags = ["--steps", "3", "--warmup", "1", "--rows", "65536", "--partitions", "8", "--no-cpu-baseline", "--no-gram", "--loglik-iters", "3",
              "--test-rows", "4096", "--sparse-rows", "160000", "--sparse-partitions", "8", "--sparse-steps", "2", "--sparse-warmup", "1",
              "--sparse-cpu-sample", "0", "--sweep-partitions", "2", "--sweep-steps", "1", "--sweep-warmup", "1", "--sweep-cpu-sample", "0"]
@@ -48,10 +58,10 @@ def test_bench_two_ranks_on_one_gpu_reproduce_the_one_rank_consensus():
     # ranks with 4 each add the same partial sums in the same order
     env = dict(os.environ, MLX_DENSE_RPB="256")
     env.pop("MLX_BENCH_SHARE_GPU", None)
-    one = _bench([sys.executable, "bench.py"] + flags, env)
+    one = _bench([sys.executable, "bench.py"] + flags, env, tmp_path, "one")
     env2 = dict(env, MLX_BENCH_SHARE_GPU="1")
     two = _bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                  "--master-port", str(_free_port()), "bench.py", "--gpus", "2"] + flags, env2)
+                  "--master-port", str(_free_port()), "bench.py", "--gpus", "2"] + flags, env2, tmp_path, "two")
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and "test_mode" in two
     assert two["config"]["partitions"] == 8 and two["config"]["partitions_per_gpu"] == 4 and two["scaling"] == "strong"
     assert two["work"]["solves"] == one["work"]["solves"] == 24

@@ -429,3 +429,36 @@ def test_bench_config1_leg_reports_an_error_instead_of_raising_without_a_gpu():
     bench = importlib.import_module("bench")
     out = bench.run_config1({"admm": admm, "HipAdmmEngine": hip_engine.HipAdmmEngine})
     assert isinstance(out, dict) and "error" in out and "ms_20_iterations" not in out
+
+
+def test_bench_headline_line_is_compact_strict_json():
+    """Round 3's bench.py printed its whole 29 KB record as the one stdout line and the driver could not parse it (BENCH_r03:
+    parsed = null). The line is now a compact summary: under 4 KB whatever the legs produce, strict JSON (no NaN / Infinity),
+    with the contract's keys, `roofline` and `cpu_baseline`; the full record goes to bench_full.json."""
+    import json
+    import bench
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r3_bench_driver.json")).read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 20000                       # the record that broke the driver
+    # hostile content: non-finite floats, numpy scalars, long strings, a huge per-iteration list
+    full["roofline"]["traffic"] = float("nan")
+    full["cpu_baseline"]["value"] = np.float64(19.84)
+    full["work"]["last_maxdiff"] = float("inf")
+    full["config"]["workload"] = full["config"]["workload"] + " x" * 3000
+    full["sparse"]["parity_check"]["summary"] = {"faithful_solves_bit_identical": "40/40", "gpu_equal_counters": [149, 32], "perm_envelope": [[100, 160]] * 6}
+    full["whole_step"] = {"frac_of_hbm_peak": 0.8}
+    line = json.dumps(bench.compact_record(full), allow_nan=False)
+    assert len(line.encode()) < 4096, len(line)
+    rec = json.loads(line, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in rec, key
+    assert rec["config"]["workload"].startswith("BASELINE configs[1]") and "model" not in rec["config"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(rec["roofline"]) and rec["roofline"]["traffic"] is None
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(rec["cpu_baseline"])
+    assert rec["sparse"]["value"] > 0 and rec["lambda_sweep"]["value"] > 0 and rec["parity"]["config3"]
+    # a record far beyond anything real still yields a parsable line: optional blocks are dropped, the contract's keys stay
+    full["sparse"]["parity_check"]["summary"] = {"x": "y" * 20000}
+    line = json.dumps(bench.compact_record(full), allow_nan=False)
+    assert len(line.encode()) < 4096 and "roofline" in json.loads(line) and "cpu_baseline" in json.loads(line)
+    # the full record is sanitised the same way
+    json.dumps(bench._finite(full), allow_nan=False)
