@@ -12,6 +12,8 @@ import scipy.optimize as so
 
 import admm_numpy as an
 import oracle_lib as ol
+import mlease_amd  # noqa: F401
+from mlease_amd import dataset
 from fixtures import load_c1, load_c1_golden, synth_sparse
 
 
@@ -453,3 +455,122 @@ def test_oracle_tron_follows_c_liblinear_through_scikit_learn():
     clf = sk.LogisticRegression(penalty="l2", C=0.25, solver="liblinear", tol=1e-10, fit_intercept=True, intercept_scaling=1.0, max_iter=10000).fit(X, b.y)
     w, _ = ol.OracleDataset.from_block(b).train(np.zeros(b.n_local), np.zeros(b.n_local), np.full(b.n_local, 0.25), 1e-10)
     assert np.max(np.abs(w - np.concatenate([clf.coef_[0], clf.intercept_]))) <= 1e-7
+
+
+def _closed_form(b, w, pm, pv, s=None):
+    """F, grad F, (hess F) s of the local objective (Appendix A5 of SURVEY.md) as three lines of scipy.sparse algebra -- shares no
+    loop, no order of operations and no code with oracle/admm_oracle.c or oracle/admm_numpy.py."""
+    import scipy.sparse as sps
+    from scipy.special import expit, log1p
+    nf = b.n_local - 1
+    vals = np.ones(len(b.col_idx)) if b.val is None else b.val.astype(np.float64)
+    X = sps.hstack([sps.csr_matrix((vals, b.col_idx, b.row_ptr), shape=(b.l, nf)), sps.csr_matrix(np.ones((b.l, 1)))]).tocsr()
+    y, wt = b.y.astype(np.float64), b.weight.astype(np.float64)
+    yz = y * (X @ w + b.offset.astype(np.float64))
+    f = float(np.sum(wt * (np.maximum(-yz, 0) + log1p(np.exp(-np.abs(yz))))) + 0.5 * np.sum((w - pm) ** 2 / pv))
+    p = expit(yz)
+    g = X.T @ (wt * (p - 1) * y) + (w - pm) / pv
+    Hs = None if s is None else X.T @ (wt * p * (1 - p) * (X @ s)) + s / pv
+    return f, g, Hs
+
+
+def test_linkedin_additions_against_closed_forms_and_scipy_trust_ncg():
+    """Pins what the scikit-learn pin cannot reach -- LinkedIn's additions to liblinear's L2-LR: prior MEAN, per-coordinate prior
+    VARIANCE, per-row weights, OFFSETS, a warm start != 0, gnorm1 taken at w = 0 with the prior term (llf/LogisticRegressionL2.java
+    :156-248, llf/LibLinear.java:221-312, bw/Tron.java:47-62) -- against (a) the objective, gradient and Hessian action written as
+    closed-form sparse algebra, (b) scipy's own trust-region Newton-CG (`trust-ncg`, a third-party optimiser) run on those closed
+    forms, and (c) the exit rule evaluated by the closed forms at every tolerance of the driver's schedule."""
+    from fixtures import load_c1, onehot_blocks
+    c1 = load_c1()
+    rng = np.random.default_rng(11)
+    cases = [c1.blocks[4], onehot_blocks(4000, 1, levels=60).blocks[0]]
+    for ci, b0 in enumerate(cases):
+        wt = rng.uniform(0.25, 3.0, b0.l).astype(np.float32)
+        off = rng.normal(0, 0.5, b0.l).astype(np.float32)
+        b = dataset.PartitionBlock(b0.partition_id, b0.l, b0.n_local, b0.row_ptr, b0.col_idx, b0.val, b0.y, wt, off, b0.local_to_global)
+        n = b.n_local
+        pm = rng.normal(0, 0.3, n)
+        pv = rng.uniform(0.2, 5.0, n)
+        w0 = rng.normal(0, 0.2, n)
+        s = rng.normal(0, 1, n)
+        d = ol.OracleDataset.from_block(b)
+        # (a) closed forms
+        f, g, Hs = d.eval(w0, pm, pv, s)
+        fc, gc, Hc = _closed_form(b, w0, pm, pv, s)
+        assert abs(f - fc) <= 1e-12 * abs(fc)
+        assert np.max(np.abs(g - gc)) <= 1e-11 * np.max(np.abs(gc))
+        assert np.max(np.abs(Hs - Hc)) <= 1e-11 * np.max(np.abs(Hc))
+        # (b) a third-party trust-region Newton-CG on the closed forms finds the minimiser TRON finds from the warm start
+        res = so.minimize(lambda v: _closed_form(b, v, pm, pv)[0], w0, jac=lambda v: _closed_form(b, v, pm, pv)[1],
+                          hessp=lambda v, q: _closed_form(b, v, pm, pv, q)[2], method="trust-ncg", options={"gtol": 1e-9, "maxiter": 500})
+        # (at the optimum scipy may stop on "failure to predict improvement", i.e. rounding noise; the bound below uses the gradient it reached)
+        w, st = d.train(w0, pm, pv, 1e-12)
+        # F is strongly convex with modulus 1 / max(priorVar): ||a - b|| <= max(pv) (||grad F(a)|| + ||grad F(b)||) for any two points
+        bound = float(np.max(pv)) * (np.linalg.norm(_closed_form(b, res.x, pm, pv)[1]) + np.linalg.norm(_closed_form(b, w, pm, pv)[1]))
+        assert bound <= 1e-4 and np.linalg.norm(w - res.x) <= bound * (1 + 1e-6) + 1e-13, (ci, float(np.linalg.norm(w - res.x)), bound)
+        # (c) exit rule at every tolerance: ||grad F(w)|| <= eps_tron ||grad F(0)|| (gnorm1 WITH the prior term, at w = 0),
+        # eps_tron = epsilon min(pos, neg) / l; and one accepted step fewer would not have satisfied it
+        pos = int(np.sum(b.y == 1))
+        g0 = np.linalg.norm(_closed_form(b, np.zeros(n), pm, pv)[1])
+        last = None
+        for eps in (1e-2, 1e-3, 1e-4, 1e-6, 1e-8):
+            w, st = d.train(w0, pm, pv, eps)
+            eps_tron = eps * min(pos, b.l - pos) / b.l
+            assert np.linalg.norm(_closed_form(b, w, pm, pv)[1]) <= eps_tron * g0 * (1 + 1e-9), (ci, eps)
+            assert abs(st.gnorm1 - g0) <= 1e-12 * g0
+            assert last is None or st.newton_iters >= last          # a tighter tolerance never needs fewer Newton iterations
+            last = st.newton_iters
+
+
+def test_prior_mean_is_a_shift_of_offsets_and_start():
+    """TRON on F(w) with prior mean m, from w0, is TRON on G(v) = F(m + v): prior mean 0, offsets + X m, from w0 - m -- the same
+    iterates shifted by m, provided the stopping threshold is the same number (LinkedIn's gnorm1 is taken at w = 0, :50-53, which is
+    v = -m for G: epsilon is rescaled by the ratio of the two gnorm1). Ties the prior-mean code path to the offset / warm-start path:
+    equal Newton, CG and pass counts, coefficients equal to ~1e-8. X m must survive the float32 offset column: binary rows and a
+    dyadic m make it exact."""
+    from fixtures import onehot_blocks
+    b = onehot_blocks(6000, 1, levels=6).blocks[0]          # (few levels: every feature is frequent, the problem well conditioned)
+    n = b.n_local
+    rng = np.random.default_rng(5)
+    m = rng.integers(-64, 64, n) / 256.0
+    pv = np.full(n, 0.5)
+    w0 = rng.integers(-32, 32, n) / 128.0
+    import scipy.sparse as sps
+    X = sps.hstack([sps.csr_matrix((np.ones(len(b.col_idx)), b.col_idx, b.row_ptr), shape=(b.l, n - 1)), sps.csr_matrix(np.ones((b.l, 1)))]).tocsr()
+    xm = X @ m
+    assert np.array_equal(xm.astype(np.float32).astype(np.float64), xm)
+    bs = dataset.PartitionBlock(b.partition_id, b.l, n, b.row_ptr, b.col_idx, b.val, b.y, b.weight, xm.astype(np.float32), b.local_to_global)
+    d, ds = ol.OracleDataset.from_block(b), ol.OracleDataset.from_block(bs)
+    g1_f = np.linalg.norm(d.eval(np.zeros(n), m, pv)[1])
+    g1_g = np.linalg.norm(ds.eval(np.zeros(n), np.zeros(n), pv)[1])
+    for eps in (1e-2, 1e-4, 1e-7):
+        w, st = d.train(w0, m, pv, eps)
+        v, sv = ds.train(w0 - m, np.zeros(n), pv, eps * g1_f / g1_g)
+        assert (st.newton_iters, st.accepted, st.cg_iters, st.x_passes) == (sv.newton_iters, sv.accepted, sv.cg_iters, sv.x_passes), eps
+        assert np.max(np.abs(w - (v + m))) <= 1e-6 * max(1.0, np.max(np.abs(w))), eps      # (measured 1e-8: two roundings of the same iterates)
+
+
+def test_driver_block_against_its_closed_form(c1):
+    """One pass of the driver block (jobs/RegressionAdmmTrain.java:362-405, 736-765) recomputed from the reducers' float32 outputs
+    in three numpy lines: xbar / ubar with the fixed divisor num.blocks, z = c xbar + c ubar with the FLOAT weight c and the
+    intercept rule, u_k = f32(f32(u_k + beta_k) - z)."""
+    lam, rho, N = 3.0, 1.0, len(c1.blocks)
+    oc = ol.OracleAdmm(c1.blocks, c1.n_global, [lam], [rho])
+    for it in range(3):
+        u_prev = np.stack([oc.partition_model(k, 0)[2] for k in range(N)]) if it else np.zeros((N, c1.n_global), np.float32)
+        oc.solve_local(0.01, 1.0, nthreads=2)
+        oc.finish()
+        B = np.stack([oc.partition_model(k, 0)[0] for k in range(N)]).astype(np.float64)
+        UPX = np.stack([oc.partition_model(k, 0)[1] for k in range(N)])
+        xbar = np.zeros(c1.n_global)
+        ubar = np.zeros(c1.n_global)
+        for k in range(N):                      # sequential, file order; weight 1/N (utils/LinearModelUtils.java:77-84)
+            xbar += (1.0 / N) * B[k]
+            ubar += (1.0 / N) * u_prev[k].astype(np.float64)
+        c = float(np.float32(N * np.float32(rho) / (np.float32(lam) + N * np.float32(rho))))
+        z = c * xbar + c * ubar
+        z[-1] = xbar[-1] + ubar[-1]             # the intercept is not shrunk (penalize.intercept = false)
+        Z = oc.z()[0][0]
+        assert np.array_equal(Z, z), float(np.max(np.abs(Z - z)))
+        u_next = np.stack([oc.partition_model(k, 0)[2] for k in range(N)])
+        assert np.array_equal(u_next, (UPX.astype(np.float64) - z).astype(np.float32))
