@@ -280,7 +280,7 @@ def compact_record(full):
     roof = full.get("roofline")
     if roof:
         c["roofline"] = _pick(roof, ["kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "alg_bytes_per_launch", "avg_launch_ms",
-                                     "launches", "kernel_ms_per_step"])
+                                     "launches", "kernel_ms_per_step", "launches_in_flight", "frac_by_launch_durations"])
         for k in ("traffic", "alg_bytes_per_launch"):
             if isinstance(c["roofline"].get(k), float):
                 c["roofline"][k] = round(c["roofline"][k])
@@ -456,23 +456,26 @@ def run_dense(args, C):
 
     sched = EpsSchedule(admm)
     eps_used = []
-    acc = dict(solves=0, newton=0, cg=0, passes_ref=0, passes_dev=0, ticks=0, alg_bytes=0.0, xpass_ms=0.0,
+    acc = dict(solves=0, newton=0, cg=0, passes_ref=0, passes_dev=0, ticks=0, alg_bytes=0.0, xpass_ms=0.0, busy_ms=0.0,
                total_ms=0.0, launches=0)
     # every k_xpass_dense launch of this leg that ran with events on: what a rocprofv3 --kernel-trace of this command must agree with
     # (it also sees finalize's one c0 launch, which runs without events)
-    allrun = dict(alg_bytes=0.0, launches=0, xpass_ms=0.0, untimed_launches=1, untimed_alg_bytes=P * (4.0 * rows * nf + 8.0 * rows + 8.0 * (nf + 1)))
+    allrun = dict(alg_bytes=0.0, launches=0, xpass_ms=0.0, busy_ms=0.0, untimed_launches=1, untimed_alg_bytes=P * (4.0 * rows * nf + 8.0 * rows + 8.0 * (nf + 1)))
     C["allrun_dense"] = allrun
-    # At one GPU the HIP events that time k_xpass_dense are ON in the timed region itself (and in every other solve of this leg):
-    # the library runs the dense ticks as a pipeline -- the passes of the two halves back to back on one stream, each half's TRON
-    # step on a second stream beside the other half's pass -- so a pass launch never shares the memory system with another pass and
-    # the interval between the marks around it is the kernel's own duration. N > 1 (the driver's scaling runs) times without events
-    # and replays the iterations with events afterwards.
+    # At one GPU the HIP events that time k_xpass_dense are ON in the timed region itself (and in every other solve of this leg), on
+    # the streams the kernel is launched on. The library ticks the two halves of the problems on two streams (production default:
+    # +10 % over one stream), so two k_xpass_dense launches usually run side by side: a launch's own duration (what a kernel trace
+    # lists: avg_launch_ms) then spans time it shared the memory system with the other half's launch. The roofline figure divides the
+    # algorithmic bytes by the time during which AT LEAST ONE k_xpass_dense launch was running (union of the event intervals on the
+    # device clock, xpass_busy_ms) -- the bandwidth the kernel achieved while it ran, <= the wall time by construction.
+    # N > 1 (the driver's scaling runs) times without events and replays the iterations with events afterwards.
     prof_timed = (not args.no_profile) and world == 1
     eng.set_profiling(prof_timed)
 
     def account(st):
         if st.xpass_ms > 0:
             allrun["alg_bytes"] += st.alg_bytes_dev; allrun["launches"] += st.xpass_launches; allrun["xpass_ms"] += st.xpass_ms
+            allrun["busy_ms"] += st.xpass_busy_ms
         else:
             allrun["untimed_alg_bytes"] += st.alg_bytes_dev; allrun["untimed_launches"] += st.xpass_launches
     C["account_dense"] = account
@@ -489,6 +492,7 @@ def run_dense(args, C):
             acc["solves"] += st.solves; acc["newton"] += st.newton_iters; acc["cg"] += st.cg_iters
             acc["passes_ref"] += st.x_passes_ref; acc["passes_dev"] += st.x_passes_dev; acc["ticks"] += st.ticks
             acc["alg_bytes"] += st.alg_bytes_dev; acc["xpass_ms"] += st.xpass_ms; acc["total_ms"] += st.total_ms
+            acc["busy_ms"] += st.xpass_busy_ms
             acc["launches"] += st.xpass_launches
         return st, fin
 
@@ -512,11 +516,11 @@ def run_dense(args, C):
     # ---- roofline of the dominant kernel
     prof = None
     if prof_timed:
-        prof = dict(alg_bytes=acc["alg_bytes"], xpass_ms=acc["xpass_ms"], launches=acc["launches"], ticks=acc["ticks"], wall=dt,
+        prof = dict(alg_bytes=acc["alg_bytes"], xpass_ms=acc["xpass_ms"], busy_ms=acc["busy_ms"], launches=acc["launches"], ticks=acc["ticks"], wall=dt,
                     where="timed", reproduced=None)
     elif not args.no_profile:
         # N > 1: a REPLAY of exactly the timed iterations from the same state (bit-reproducible) with events on
-        prof = dict(alg_bytes=0.0, xpass_ms=0.0, launches=0, ticks=0, wall=0.0, where="replay")
+        prof = dict(alg_bytes=0.0, xpass_ms=0.0, busy_ms=0.0, launches=0, ticks=0, wall=0.0, where="replay")
         eng.set_state(snap[0], snap[1])
         eng.set_profiling(True)
         C["barrier"]()
@@ -527,6 +531,7 @@ def run_dense(args, C):
             C["all_reduce"](eng.consensus_tensor())
             f2 = eng.consensus_finish()
             prof["alg_bytes"] += st2.alg_bytes_dev; prof["xpass_ms"] += st2.xpass_ms; prof["launches"] += st2.xpass_launches; prof["ticks"] += st2.ticks
+            prof["busy_ms"] += st2.xpass_busy_ms
             account(st2)
         C["barrier"]()
         prof["wall"] = C["reduce_max"](time.perf_counter() - tp)
@@ -544,8 +549,8 @@ def run_dense(args, C):
     if rank == 0:
         value = tot_solves / dt
         roof = None
-        if prof is not None and prof["xpass_ms"] > 0:
-            achieved = prof["alg_bytes"] / (prof["xpass_ms"] * 1e-3) / 1e9
+        if prof is not None and prof["busy_ms"] > 0:
+            achieved = prof["alg_bytes"] / (prof["busy_ms"] * 1e-3) / 1e9
             traffic, tsrc = None, None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
@@ -560,14 +565,19 @@ def run_dense(args, C):
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                     "alg_bytes_per_launch": prof["alg_bytes"] / max(1, prof["launches"]),
                     "avg_launch_ms": round(prof["xpass_ms"] / max(1, prof["launches"]), 5), "launches": prof["launches"],
-                    "kernel_ms_per_step": round(prof["xpass_ms"] / args.steps, 3),
-                    "xpass_share_of_wall": round(prof["xpass_ms"] / (prof["wall"] * 1e3), 4),
+                    "kernel_ms_per_step": round(prof["busy_ms"] / args.steps, 3),
+                    "launches_in_flight": round(prof["xpass_ms"] / prof["busy_ms"], 3),
+                    "frac_by_launch_durations": round(prof["alg_bytes"] / (prof["xpass_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "xpass_share_of_wall": round(prof["busy_ms"] / (prof["wall"] * 1e3), 4),
                     "timed_ms_per_step": round(dt * 1e3 / args.steps, 3),
-                    "measured_in_short": "timed region (HIP events on the pass stream)" if timed else "replay of the timed iterations with events (N>1)",
-                    "measured_in": ("the TIMED region itself: HIP events on the stream the passes are launched on, one mark in front of and one behind every "
-                                    "k_xpass_dense launch; the library pipelines the dense ticks (passes of the two halves back to back on that stream, "
-                                    "each half's TRON step on a second stream beside the other half's pass), so passes never overlap each other and "
-                                    "kernel_ms_per_step <= ms_per_step" if timed else
+                    "measured_in_short": "timed region: HIP events on both tick streams, bytes / time with >= 1 launch running" if timed
+                                         else "replay of the timed iterations with events (N>1)",
+                    "measured_in": ("the TIMED region itself: HIP events on the streams the kernel is launched on, one mark in front of every k_xpass_dense "
+                                    "launch and one behind it (the mark of the step launch). The two halves of the problems tick on two streams, so "
+                                    "launches_in_flight k_xpass_dense launches run side by side on average: `achieved` = algorithmic bytes / "
+                                    "kernel_ms_per_step, the time during which at least one launch was running (union of the event intervals, <= "
+                                    "ms_per_step); avg_launch_ms is a launch's own duration as a kernel trace lists it (it spans time shared with "
+                                    "the other half's launch: frac_by_launch_durations)" if timed else
                                     "a replay of the %d timed iterations (same state, same epsilons; reproduced = %s) with events on: %.3f ms per "
                                     "iteration there against %.3f ms in the timed run (no events)" % (
                                         args.steps, prof["reproduced"], prof["wall"] * 1e3 / args.steps, dt * 1e3 / args.steps))}
@@ -600,6 +610,7 @@ def run_dense(args, C):
             cpu_leg(args, C, eng, out, sample, snap, eps_used, step_times, nf, N)
         # every k_xpass_dense launch of the process: the numbers a `rocprofv3 --kernel-trace --stats` of this command must show
         out["all_launches"] = {"timed_by_events": allrun["launches"], "avg_us": round(1e3 * allrun["xpass_ms"] / max(1, allrun["launches"]), 3),
+                               "busy_ms": round(allrun["busy_ms"], 3), "sum_of_durations_ms": round(allrun["xpass_ms"], 3),
                                "alg_bytes_timed_by_events": allrun["alg_bytes"], "without_events": allrun["untimed_launches"],
                                "alg_bytes_without_events": allrun["untimed_alg_bytes"],
                                "alg_bytes": allrun["alg_bytes"] + allrun["untimed_alg_bytes"],
@@ -867,7 +878,7 @@ def sparse_timed_run(args, C, eng, blocks, lam, warmup, steps, snapshot):
     C["barrier"]()
     dt = C["reduce_max"](time.perf_counter() - tstart)
     # the replay with events
-    prof = dict(ticks=0, alg=0.0, pdev=0, rms=0.0, cms=0.0, sms=0.0, tms=0.0, wall=0.0, maxdiff=None)
+    prof = dict(ticks=0, alg=0.0, pdev=0, rms=0.0, cms=0.0, sms=0.0, rbusy=0.0, cbusy=0.0, sbusy=0.0, tms=0.0, wall=0.0, maxdiff=None)
     eng.set_profiling(True)
     eng.set_state(*snap)
     C["barrier"]()
@@ -878,6 +889,7 @@ def sparse_timed_run(args, C, eng, blocks, lam, warmup, steps, snapshot):
         f2 = eng.consensus_finish()
         prof["ticks"] += st.ticks; prof["alg"] += st.alg_bytes_dev; prof["pdev"] += st.x_passes_dev; prof["tms"] += st.total_ms
         prof["rms"] += st.rowpass_ms; prof["cms"] += st.colpass_ms; prof["sms"] += st.step_ms
+        prof["rbusy"] += st.rowpass_busy_ms; prof["cbusy"] += st.colpass_busy_ms; prof["sbusy"] += st.step_busy_ms
         prof["maxdiff"] = f2.maxdiff
     C["barrier"]()
     prof["wall"] = C["reduce_max"](time.perf_counter() - t0)
@@ -894,75 +906,24 @@ def sparse_rooflines(prof, n_mean, row_kernel, col_kernel):
     half = prof["alg"] / 2.0
     wall_ms = prof["wall"] * 1e3
 
-    def roof(kernel, ms, alg_bytes, note):
-        a = alg_bytes / max(1e-9, ms * 1e-3) / 1e9
+    def roof(kernel, busy, ms, alg_bytes, note):
+        a = alg_bytes / max(1e-9, busy * 1e-3) / 1e9
         return {"kernel": kernel, "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(a / HBM_PEAK_GBS, 4), "ms": round(ms, 3), "share_of_replay": round(ms / wall_ms, 4),
-                "us_per_tick": round(1e3 * ms / max(1, prof["ticks"]), 1), "alg_bytes": alg_bytes, "note": note}
+                "frac": round(a / HBM_PEAK_GBS, 4), "busy_ms": round(busy, 3), "sum_of_launch_durations_ms": round(ms, 3),
+                "share_of_replay": round(busy / wall_ms, 4),
+                "us_per_tick": round(1e3 * busy / max(1, prof["ticks"]), 1), "alg_bytes": alg_bytes, "note": note}
 
     step_model = 13.0 * 8.0 * n_mean * (prof["pdev"] / 2.0)        # 13 n-vector streams per problem and tick
     return {"measured_in": "a replay of the timed iterations (same state, same epsilons, same two tick streams; reproduced_timed_run = %s) with "
-                           "per-launch-class HIP events on every tick stream, %.1f ms wall; the halves run concurrently, so class durations "
-                           "overlap the other half's launches (production conditions, as in a rocprofv3 trace of this command)" % (
-                               prof["reproduced_timed_run"], wall_ms),
-            "kernels": [roof(row_kernel, prof["rms"], half, "B_pass = nnz*4 + 8l + 8n per active problem; the cold column slices run as their own launch in front of the row kernel"),
-                        roof(col_kernel, prof["cms"], half, "B_pass = nnz*4 + 8l + 8n per active problem"),
-                        roof("k_step_a+b+c+commit", prof["sms"], 0.0,
+                           "per-launch-class HIP events on every tick stream, %.1f ms wall. The halves run concurrently: a class's time is the time "
+                           "during which at least one of its launches was running (busy_ms, union of the event intervals); it still shares the "
+                           "memory system with the OTHER classes of the other half, so the per-class fractions are lower bounds of a kernel alone "
+                           "on the chip (MLX_PROFILE_ONE_STREAM=1)" % (prof["reproduced_timed_run"], wall_ms),
+            "kernels": [roof(row_kernel, prof["rbusy"], prof["rms"], half, "B_pass = nnz*4 + 8l + 8n per active problem; the cold column slices run as their own launch in front of the row kernel"),
+                        roof(col_kernel, prof["cbusy"], prof["cms"], half, "B_pass = nnz*4 + 8l + 8n per active problem"),
+                        roof("k_step_a+b+c+commit", prof["sbusy"], prof["sms"], 0.0,
                              "no algorithmic X bytes (SURVEY 8d counts the n-vector work as zero); streams ~13 x 8n bytes per problem and "
-                             "tick = %.1f GB/s" % (step_model / max(1e-9, prof["sms"] * 1e-3) / 1e9))]}
-
-
-def run_sparse(args, C):
-    """BASELINE configs[2] at one GPU (256 partitions), configs[3] sharded (1024 partitions, k -> rank k mod N)."""
-    world, rank, sd = C["world"], C["rank"], C["sd"]
-    from mlease_amd.dataset import PartitionBlock
-    Ptot = args.sparse_partitions or (SP_PARTS_1GPU if world == 1 else SP_PARTS_MULTI)
-    rows = args.sparse_rows // Ptot
-    mine = [k for k in range(Ptot) if k % world == rank]
-    t0 = time.time()
-    blocks, ng = [], None
-    for k in mine:
-        rp, ci, y, l2g, ng = sd.onehot_partition(k, rows)
-        blocks.append(PartitionBlock(k, rows, len(l2g), rp, ci, None, y, np.ones(rows, np.float32), np.zeros(rows, np.float32), l2g))
-    tgen = time.time() - t0
-    eng = C["HipAdmmEngine"](ng, [1.0], [1.0], Ptot, device=C["local_rank"], stream=C["stream"])
-    t0 = time.time()
-    eng.add_partitions(blocks)
-    eng.finalize()
-    tup = time.time() - t0
-    nnz = sum(b.nnz for b in blocks)
-    nloc = np.array([b.n_local for b in blocks])
-    want_checks = world == 1 and args.sparse_cpu_sample > 0
-    acc, allrun, dt, fin, snap, eps_all, step_s, prof = sparse_timed_run(args, C, eng, blocks, [1.0], args.sparse_warmup, args.sparse_steps, want_checks)
-    tot_solves, tot_pref, tot_pdev, tot_alg = C["reduce_sum"]([acc["solves"], acc["pref"], acc["pdev"], acc["alg"]])
-    res = None
-    if rank == 0:
-        n_mean = float(nloc.mean())
-        res = {"workload": "BASELINE configs[%d]: synthetic one-hot %d rows x %d binary features (20 fields x 5000 Zipf(1.1) levels, 20 nnz/row), "
-                           "%d partitions%s, lambda=1, rho=1" % (2 if world == 1 else 3, rows * Ptot, ng - 1, Ptot,
-                                                                 " sharded k -> rank k mod %d" % world if world > 1 else ""),
-               "value": round(tot_solves / dt, 2), "unit": "solves/s", "n_gpus": world, "steps": args.sparse_steps, "warmup": args.sparse_warmup,
-               "partitions": Ptot,
-               "ms_per_step": round(dt * 1e3 / args.sparse_steps, 3), "liblinear_epsilon_by_iteration": eps_all,
-               "nnz": int(nnz), "rows_per_partition": rows, "n_local_mean": n_mean, "gen_s": round(tgen, 1), "upload_s": round(tup, 1),
-               "x_passes_ref_per_s": round(tot_pref / dt, 1), "x_passes_dev_per_s": round(tot_pdev / dt, 1),
-               "ticks_per_step": acc["ticks"] / args.sparse_steps, "cg_per_solve": round(acc["cg"] / max(1, acc["solves"]), 2),
-               "whole_step": {"alg_bytes_per_s_GB": round(tot_alg / dt / 1e9, 1), "frac_of_hbm_peak": round(tot_alg / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
-                              "definition": "sum over solves of device passes x B_pass (SURVEY 8d) / wall time of the timed iterations"},
-               "roofline": sparse_rooflines(prof, n_mean, "k_rowcold + k_rowpass_lds<binary>", "k_colpass_lds<binary>"),
-               "timed_run": "no per-launch events, two tick streams (library default)",
-               "last_maxdiff": fin.maxdiff,
-               "all_launches": {"ticks_incl_c0_and_warmup": allrun["ticks"], "alg_bytes_row_plus_column": allrun["alg"]}}
-        tpath = os.path.join(ROOT, "profiles", "traffic_sparse.json")
-        if os.path.exists(tpath):
-            with open(tpath) as fh:
-                tj = json.load(fh)
-            res["traffic"] = {"source": "profiles/traffic_sparse.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `%s` (committed; not a counter read in this run)" % tj.get("command", ""),
-                              "hbm_bytes_per_alg_byte": tj.get("hbm_bytes_per_alg_byte"), "per_kernel": tj.get("per_kernel")}
-        if want_checks:
-            sparse_checks(args, C, eng, blocks, ng, Ptot, snap, eps_all, step_s, res)
-    eng.close()
-    return res
+                             "tick = %.1f GB/s" % (step_model / max(1e-9, prof["sbusy"] * 1e-3) / 1e9))]}
 
 
 LS_LAMBDAS = [0.1, 0.3, 1.0, 3.0, 10.0, 30.0, 100.0, 300.0]       # SURVEY 8d C5

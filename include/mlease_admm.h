@@ -77,6 +77,11 @@ typedef struct mlx_stats {
     double rowpass_ms;       /* CSR path, profiling on: device time of the row-pass launches           */
     double colpass_ms;       /*   ... of the column-pass launches (xpass_ms = dense + row + column)    */
     double step_ms;          /*   ... of the TRON/CG step launches                                     */
+    /* With several tick streams the launches of a class overlap each other: the *_ms fields above sum the launches' own       */
+    /* durations (what a kernel trace lists); the *_busy_ms fields are the time during which AT LEAST ONE launch of the class  */
+    /* was running (union of the intervals on the device clock). One tick stream: busy == ms.                                  */
+    double xpass_busy_ms;    /* all X-pass classes together                                            */
+    double rowpass_busy_ms, colpass_busy_ms, step_busy_ms;
 } mlx_stats;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */

@@ -32,6 +32,7 @@ public final class MleaseHip implements AutoCloseable
     public double algBytesDev, xpassMs, totalMs;
     public long xpassLaunches;
     public double rowpassMs, colpassMs, stepMs;
+    public double xpassBusyMs, rowpassBusyMs, colpassBusyMs, stepBusyMs;
   }
 
   private long handle;                    // mlx_handle

@@ -128,6 +128,8 @@ static jobject stats_to_java(JNIEnv *env, const mlx_stats *s)
     SETD("algBytesDev", s->alg_bytes_dev); SETD("xpassMs", s->xpass_ms); SETD("totalMs", s->total_ms);
     SETJ("xpassLaunches", s->xpass_launches);
     SETD("rowpassMs", s->rowpass_ms); SETD("colpassMs", s->colpass_ms); SETD("stepMs", s->step_ms);
+    SETD("xpassBusyMs", s->xpass_busy_ms); SETD("rowpassBusyMs", s->rowpass_busy_ms); SETD("colpassBusyMs", s->colpass_busy_ms);
+    SETD("stepBusyMs", s->step_busy_ms);
 #undef SETD
 #undef SETJ
     return o;

@@ -113,12 +113,6 @@ struct mlx_context {
     size_t ev_used = 0;
     int mark_sidx = 0;                      // index of the stream h->stream currently points at (run_ticks)
     bool prof_one_stream = false;           // MLX_PROFILE_ONE_STREAM=1: with events on, all ticks on one stream (a launch's duration is then its own)
-    // Dense tick pipeline (default for dense-only lists of >= 4 problems): the X passes of the parts run back to back on the
-    // handle's stream, every part's TRON step on a second stream beside the NEXT part's pass (run_ticks)
-    bool dense_pipe = true;
-    int dense_parts = 2;
-    static constexpr int EV_RING = 4;
-    hipEvent_t ev_pass[MAX_TS][EV_RING] = {}, ev_step[MAX_TS][EV_RING] = {};
     // scratch vectors of the solve_one problem
     double *sc_vec[8] = {nullptr}, *sc_pinv = nullptr;
     // mean-model warm start: per-problem prior precision [nprob][max_nlocal], global overrides [n_global]
@@ -329,23 +323,19 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
     int slot = 0;
     bool have_prev = false;
     int rc;
-    // Several tick streams. CSR lists of >= 32 problems are cut into NS parts that tick independently on NS streams (whole groups of 8
-    // list positions, so the XCD placement of xcd_map is kept); the parts share nothing but the done counter, and launch tails and
-    // gaps of one part are filled by the others. Dense lists of >= 4 problems run as a two-stage PIPELINE instead: the X passes of
-    // the parts back to back on the handle's stream (a pass never shares the memory system with another pass, so a launch's
-    // duration is its own), every part's TRON step (one workgroup per problem: 21 us during which most of the chip would idle) on
-    // the second stream, beside the next part's pass. MLX_DENSE_PIPE=0: the parts tick free on NS streams like the CSR ones (round 3).
-    // Mixed dense + CSR handles stay on one stream.
+    // Several tick streams: the problem list is cut into NS parts that tick independently (CSR: whole groups of 8 list positions, so
+    // the XCD placement of xcd_map is kept); the parts share nothing but the done counter. Launch tails and gaps of one part are
+    // filled by the others, and a dense part's TRON step (one workgroup per problem: 21 us during which most of the chip idles)
+    // runs beside another part's pass. Mixed dense + CSR handles stay on one stream. With profiling on every stream carries its own
+    // chain of marks (MLX_PROFILE_ONE_STREAM=1: all ticks on one stream, a launch's duration is then the kernel's alone).
+    // (Round 4 measured the alternative for dense lists -- passes of the parts back to back on one stream, steps on a second one,
+    // ordered by cross-stream events so that passes never overlap: every event wait costs ~20 us of idle stream; 2 600 against
+    // 2 966 solves/s at 64 problems, 1 693 against 2 558 at 8. Not kept; profiles/r4_notes.md.)
     int NS = 1;
-    bool pipe = false;
     if (h->nstreams > 1 && !(h->profiling && h->prof_one_stream)) {
         if (nqd == 0 && nqc >= 32) NS = std::min(h->nstreams, nqc / 16);
-        else if (nqc == 0 && nqd >= 4) {
-            pipe = h->dense_pipe;
-            NS = pipe ? std::min(std::min(h->dense_parts, (int)mlx_context::MAX_TS), nqd / 2) : std::min(h->nstreams, nqd / 2);
-        }
+        else if (nqc == 0 && nqd >= 4) NS = std::min(h->nstreams, nqd / 2);
     }
-    if (NS <= 1) pipe = false;
     int c0[mlx_context::MAX_TS + 1], d0[mlx_context::MAX_TS + 1];      // part t = list positions [c0[t], c0[t+1]) / [d0[t], d0[t+1])
     for (int t = 0; t <= NS; t++) {
         c0[t] = (NS == 1 || t == NS) ? (t == 0 ? 0 : nqc) : (int)(((int64_t)nqc * t / NS + 7) / 8 * 8);
@@ -355,7 +345,6 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
     }
     hipStream_t sA = h->stream;
     auto st_of = [&](int t) { return t == 0 ? sA : h->xstream[t]; };
-    const int nextra = pipe ? 2 : NS;                    // streams in use: sA + xstream[1 .. nextra-1]
     // Whatever way this function is left, the handle's stream is restored and made to wait for everything queued on the other tick
     // streams: a later call on the handle (set_state, the next solve's memset of d_done) must not overtake in-flight ticks of a
     // solve that failed.
@@ -367,39 +356,16 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
             for (int t = 1; t < n; t++)
                 if (hipEventRecord(h->ev_join[t], h->xstream[t]) == hipSuccess) hipStreamWaitEvent(sA, h->ev_join[t], 0);
         }
-    } join{h, sA, nextra};
+    } join{h, sA, NS};
     auto on = [&](int t) { h->stream = st_of(t); h->mark_sidx = t; };
-    if (nextra > 1) {
-        for (int t = 1; t < nextra; t++) h->h_donex[t * 2] = h->h_donex[t * 2 + 1] = 0;
+    if (NS > 1) {
+        for (int t = 1; t < NS; t++) h->h_donex[t * 2] = h->h_donex[t * 2 + 1] = 0;
         HIPCHECK(h, hipEventRecord(h->ev_fork, sA));
-        for (int t = 1; t < nextra; t++) HIPCHECK(h, hipStreamWaitEvent(st_of(t), h->ev_fork, 0));
+        for (int t = 1; t < NS; t++) HIPCHECK(h, hipStreamWaitEvent(st_of(t), h->ev_fork, 0));
     }
-    if (pipe)
-        for (int t = 0; t < NS; t++)
-            for (int k = 0; k < mlx_context::EV_RING; k++) {
-                if (!h->ev_pass[t][k]) HIPCHECK(h, hipEventCreateWithFlags(&h->ev_pass[t][k], hipEventDisableTiming));
-                if (!h->ev_step[t][k]) HIPCHECK(h, hipEventCreateWithFlags(&h->ev_step[t][k], hipEventDisableTiming));
-            }
     for (;;) {
         for (int i = 0; i < batch; i++) {
-            const int k = (int)(ticks % mlx_context::EV_RING), kp = (int)((ticks + mlx_context::EV_RING - 1) % mlx_context::EV_RING);
             for (int t = 0; t < NS; t++) {
-                if (pipe) {
-                    // pass of part t on the pass stream, behind this part's previous step; its step on the step stream
-                    on(0);
-                    if (ticks > 0) HIPCHECK(h, hipStreamWaitEvent(sA, h->ev_step[t][kp], 0));
-                    rc = launch_xpass(h, qdense + d0[t], d0[t + 1] - d0[t], nullptr, 0);
-                    if (rc) return rc;
-                    mark(h, -1);
-                    HIPCHECK(h, hipEventRecord(h->ev_pass[t][k], sA));
-                    on(1);
-                    HIPCHECK(h, hipStreamWaitEvent(h->stream, h->ev_pass[t][k], 0));
-                    launch_step(h, qdense + d0[t], d0[t + 1] - d0[t], nullptr, 0);
-                    mark(h, -1);
-                    HIPCHECK(h, hipEventRecord(h->ev_step[t][k], h->stream));
-                    on(0);
-                    continue;
-                }
                 on(t);
                 rc = launch_xpass(h, qdense + d0[t], d0[t + 1] - d0[t], qcsr + c0[t], c0[t + 1] - c0[t]);
                 if (!rc) launch_step(h, qdense + d0[t], d0[t + 1] - d0[t], qcsr + c0[t], c0[t + 1] - c0[t]);
@@ -408,25 +374,18 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
             }
             ticks++;
         }
-        if (pipe) {
-            on(1);
-            HIPCHECK(h, hipMemcpyAsync(&h->h_done[slot], h->d_done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-            HIPCHECK(h, hipEventRecord(h->ev_batch[slot], h->stream));
-            on(0);
-        } else {
-            for (int t = 0; t < NS; t++) { on(t); mark(h, -1); }
-            on(0);
-            HIPCHECK(h, hipMemcpyAsync(&h->h_done[slot], h->d_done, sizeof(int), hipMemcpyDeviceToHost, sA));
-            HIPCHECK(h, hipEventRecord(h->ev_batch[slot], sA));
-            for (int t = 1; t < NS; t++) {
-                HIPCHECK(h, hipMemcpyAsync(&h->h_donex[t * 2 + slot], h->d_done, sizeof(int), hipMemcpyDeviceToHost, st_of(t)));
-                HIPCHECK(h, hipEventRecord(h->ev_batchx[t][slot], st_of(t)));
-            }
+        for (int t = 0; t < NS; t++) { on(t); mark(h, -1); }
+        on(0);
+        HIPCHECK(h, hipMemcpyAsync(&h->h_done[slot], h->d_done, sizeof(int), hipMemcpyDeviceToHost, sA));
+        HIPCHECK(h, hipEventRecord(h->ev_batch[slot], sA));
+        for (int t = 1; t < NS; t++) {
+            HIPCHECK(h, hipMemcpyAsync(&h->h_donex[t * 2 + slot], h->d_done, sizeof(int), hipMemcpyDeviceToHost, st_of(t)));
+            HIPCHECK(h, hipEventRecord(h->ev_batchx[t][slot], st_of(t)));
         }
         if (have_prev) {
             HIPCHECK(h, hipEventSynchronize(h->ev_batch[slot ^ 1]));
             int done = h->h_done[slot ^ 1];
-            for (int t = 1; t < NS && !pipe; t++) {
+            for (int t = 1; t < NS; t++) {
                 HIPCHECK(h, hipEventSynchronize(h->ev_batchx[t][slot ^ 1]));
                 done = std::max(done, h->h_donex[t * 2 + (slot ^ 1)]);        // snapshots of ONE monotone counter: the largest is the latest
             }
@@ -438,7 +397,7 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
         if (ticks > TICK_CAP) return fail(h, MLX_ERR_MODEL_FITTING, "Model fitting error! solve did not terminate within %lld ticks", (long long)TICK_CAP);
     }
     // the first stream continues (outputs, means) after all parts
-    for (int t = 1; t < nextra; t++) {
+    for (int t = 1; t < NS; t++) {
         HIPCHECK(h, hipEventRecord(h->ev_join[t], st_of(t)));
         HIPCHECK(h, hipStreamWaitEvent(sA, h->ev_join[t], 0));
     }
@@ -510,8 +469,6 @@ int mlx_create(int device_id, mlx_handle *out)
     if (const char *te = getenv("MLX_SMALL_TICKS")) h->small_ticks = std::max(1, atoi(te));
     if (const char *se = getenv("MLX_STREAMS")) h->nstreams = std::max(1, std::min(atoi(se), (int)mlx_context::MAX_TS));
     if (const char *pe = getenv("MLX_PROFILE_ONE_STREAM")) h->prof_one_stream = atoi(pe) != 0;
-    if (const char *pe = getenv("MLX_DENSE_PIPE")) h->dense_pipe = atoi(pe) != 0;
-    if (const char *pe = getenv("MLX_DENSE_PARTS")) h->dense_parts = std::max(2, std::min(atoi(pe), (int)mlx_context::MAX_TS));
     if (h->nstreams > 1) {
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
         if (hipHostMalloc((void **)&h->h_donex, mlx_context::MAX_TS * 2 * sizeof(int)) != hipSuccess) h->nstreams = 1;
@@ -540,10 +497,6 @@ int mlx_destroy(mlx_handle h)
     if (h->h_diff) hipHostFree(h->h_diff);
     for (auto e : h->ev_pool) hipEventDestroy(e);
     for (auto e : h->ev_batch) if (e) hipEventDestroy(e);
-    for (int t = 0; t < mlx_context::MAX_TS; t++) {
-        for (auto e : h->ev_pass[t]) if (e) hipEventDestroy(e);
-        for (auto e : h->ev_step[t]) if (e) hipEventDestroy(e);
-    }
     for (int t = 1; t < mlx_context::MAX_TS; t++) {
         for (auto e : h->ev_batchx[t]) if (e) hipEventDestroy(e);
         if (h->ev_join[t]) hipEventDestroy(h->ev_join[t]);
@@ -1556,18 +1509,41 @@ static int collect_solve_stats(mlx_handle h, int64_t ticks, mlx_stats *stats, bo
     if (h->profiling) {
         double acc[4] = {0, 0, 0, 0};
         int64_t cnt[4] = {0, 0, 0, 0};
-        // an interval runs from a mark to the NEXT mark recorded on the same tick stream
+        // An interval runs from a mark to the NEXT mark recorded on the same tick stream. With several tick streams the intervals of
+        // a class overlap those of the other streams: acc[] sums the durations as they are (what a kernel trace shows per launch),
+        // busy[] is the measure of the UNION of a class's intervals on the device's clock (the time during which at least one launch
+        // of the class was running): bytes / busy time = the bandwidth the class achieved while it ran.
         int prev[mlx_context::MAX_TS];
         for (int &p : prev) p = -1;
+        std::vector<std::pair<float, float>> iv[5];      // per class + [4] = all X-pass classes together
         for (size_t i = 0; i < h->ev_used; i++) {
             const int sx = h->ev_sidx[i];
             if (prev[sx] >= 0) {
-                float m2 = 0;
+                float m2 = 0, t_a = 0;
                 const int kind = h->ev_kind[(size_t)prev[sx]];
-                if (kind >= 0 && hipEventElapsedTime(&m2, h->ev_pool[(size_t)prev[sx]], h->ev_pool[i]) == hipSuccess) { acc[kind] += m2; cnt[kind]++; }
+                if (kind >= 0 && hipEventElapsedTime(&m2, h->ev_pool[(size_t)prev[sx]], h->ev_pool[i]) == hipSuccess) {
+                    acc[kind] += m2; cnt[kind]++;
+                    if (hipEventElapsedTime(&t_a, h->ev_t0, h->ev_pool[(size_t)prev[sx]]) == hipSuccess) {
+                        iv[kind].emplace_back(t_a, t_a + m2);
+                        if (kind <= 2) iv[4].emplace_back(t_a, t_a + m2);
+                    }
+                }
             }
             prev[sx] = (int)i;
         }
+        auto union_ms = [](std::vector<std::pair<float, float>> &v) {
+            std::sort(v.begin(), v.end());
+            double tot = 0;
+            float lo = 0, hi = -1;
+            for (auto &p : v) {
+                if (hi < lo || p.first > hi) { if (hi >= lo) tot += hi - lo; lo = p.first; hi = p.second; }
+                else hi = std::max(hi, p.second);
+            }
+            if (hi >= lo) tot += hi - lo;
+            return tot;
+        };
+        s.xpass_busy_ms = union_ms(iv[4]);
+        s.rowpass_busy_ms = union_ms(iv[1]); s.colpass_busy_ms = union_ms(iv[2]); s.step_busy_ms = union_ms(iv[3]);
         s.xpass_ms = acc[0] + acc[1] + acc[2];
         s.rowpass_ms = acc[1]; s.colpass_ms = acc[2]; s.step_ms = acc[3];
         s.xpass_launches = std::max(cnt[0], cnt[1]);

@@ -33,7 +33,8 @@ class MlxStats(C.Structure):
                 ("x_passes_ref", C.c_int64), ("x_passes_dev", C.c_int64), ("ticks", C.c_int64),
                 ("alg_bytes_dev", C.c_double), ("xpass_ms", C.c_double), ("total_ms", C.c_double),
                 ("xpass_launches", C.c_int64), ("rowpass_ms", C.c_double), ("colpass_ms", C.c_double),
-                ("step_ms", C.c_double)]
+                ("step_ms", C.c_double), ("xpass_busy_ms", C.c_double), ("rowpass_busy_ms", C.c_double),
+                ("colpass_busy_ms", C.c_double), ("step_busy_ms", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

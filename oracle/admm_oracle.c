@@ -154,7 +154,12 @@ void orc_dataset_destroy(orc_dataset *d)
  * Used by tools/sum_order_experiment.py and tests/test_oracle.py to measure how far a summation order (or an exact sum) moves
  * the reference's TRON trajectory on one-hot data; never by a parity check. */
 static int g_sum_mode = 0;
+/* per call site of Tron.dot (0: r.r at the start of trcg, 1: d.Hd, 2: r.r in the loop, 3: the three boundary dots, 4: g.s, 5: s.r):
+ * dot-related bits (1, 32, 64, 128, 256) that replace those of the global mode at that site; -1 = use the global mode */
+static int g_site_mode[6] = {-1, -1, -1, -1, -1, -1};
+static _Thread_local int t_site = 0;
 void orc_set_sum_mode(int m) { g_sum_mode = m; }
+void orc_set_dot_site_mode(int site, int m) { if (site >= 0 && site < 6) g_site_mode[site] = m; }
 int orc_get_sum_mode(void) { return g_sum_mode; }
 static inline void acc2(double *hi, double *lo, double x)
 {
@@ -314,6 +319,8 @@ static void daxpy(int n, double c, const double *v1, double *v2)     /* :190-197
 }
 static double dot(int n, const double *a, const double *b)           /* :204-213 */
 {
+    const int g_sum_mode_global = g_sum_mode;
+    const int g_sum_mode = g_site_mode[t_site] >= 0 ? g_site_mode[t_site] : g_sum_mode_global;     /* (experiments only; shadows the global) */
     if (g_sum_mode & 1) {            /* experiment: compensated */
         double hi = 0, lo = 0;
         for (int i = 0; i < n; i++) acc2(&hi, &lo, a[i] * b[i]);
@@ -409,16 +416,18 @@ static int trcg(orc_func *fo, int n, double delta, const double *g, double *s, d
     for (int i = 0; i < n; i++) { s[i] = 0; r[i] = -g[i]; d[i] = r[i]; }
     cgtol = 0.1 * euclideanNorm(n, g);
     int cg_iter = 0;
-    rTr = dot(n, r, r);
+    t_site = 0; rTr = dot(n, r, r);
     while (1) {
         if (euclideanNorm(n, r) <= cgtol) break;
         cg_iter++;
         Hv(fo, d, Hd);
+        t_site = 1;
         double alpha = rTr / dot(n, d, Hd);
         daxpy(n, alpha, d, s);
         if (euclideanNorm(n, s) > delta) {
             alpha = -alpha;
             daxpy(n, alpha, d, s);
+            t_site = 3;
             double std = dot(n, s, d), sts = dot(n, s, s), dtd = dot(n, d, d);
             double dsq = delta * delta;
             double rad = sqrt(std * std + dtd * (dsq - sts));
@@ -431,7 +440,7 @@ static int trcg(orc_func *fo, int n, double delta, const double *g, double *s, d
         }
         alpha = -alpha;
         daxpy(n, alpha, Hd, r);
-        rnewTrnew = dot(n, r, r);
+        t_site = 2; rnewTrnew = dot(n, r, r);
         double beta = rnewTrnew / rTr;
         scale_(n, beta, d);
         daxpy(n, one, r, d);
@@ -471,8 +480,8 @@ static void tron(orc_func *fo, int n, double eps, int max_iter, double *w, orc_t
         if (st) { st->newton_iters++; st->cg_iters += cg_iter; }
         memcpy(w_new, w, sizeof(double) * (size_t)n);
         daxpy(n, one, s, w_new);
-        gs = dot(n, g, s);
-        prered = -0.5 * (gs - dot(n, s, r));
+        t_site = 4; gs = dot(n, g, s);
+        t_site = 5; prered = -0.5 * (gs - dot(n, s, r));
         fnew = fun(fo, w_new, 1);
         actred = f - fnew;
         snorm = euclideanNorm(n, s);

@@ -76,6 +76,22 @@ def main():
     variants["all"] = (15, ol.OracleAdmm(blocks, ng, [1.0], [1.0]))
     variants["all+perm"] = (15, ol.OracleAdmm([permute_rows(b, 5000 + j, relabel=True) for j, b in enumerate(blocks)], ng, [1.0], [1.0]))
     variants["scalars+perm"] = (13, ol.OracleAdmm([permute_rows(b, 5000 + j, relabel=True) for j, b in enumerate(blocks)], ng, [1.0], [1.0]))
+    def freq_order(b):
+        """columns renumbered most-frequent-first (the library's own order of the n-vectors), rows as they are"""
+        nf = b.n_local - 1
+        cnt = np.bincount(b.col_idx, minlength=nf)
+        order = np.argsort(-cnt, kind="stable")
+        newid = np.empty(nf, np.int64)
+        newid[order] = np.arange(nf)
+        cols = newid[b.col_idx]
+        rowid = np.repeat(np.arange(b.l, dtype=np.int64), np.diff(b.row_ptr))
+        srt = np.lexsort((cols, rowid))
+        l2g = np.concatenate([b.local_to_global[:nf][order], b.local_to_global[nf:]]).astype(np.int32)
+        return PartitionBlock(b.partition_id, b.l, b.n_local, b.row_ptr, cols[srt].astype(np.int32), None, b.y, b.weight, b.offset, l2g)
+    fb = [freq_order(b) for b in blocks]
+    for name, mode in (("freq_order", 0), ("freq_order+grid2048", 128), ("freq_order+grid2048+passes", 130), ("freq_order+tree+passes", 66)):
+        variants[name] = (mode, ol.OracleAdmm(fb, ng, [1.0], [1.0]))
+    variants["perm+grid2048+passes"] = (130, ol.OracleAdmm([permute_rows(b, 5000 + j, relabel=True) for j, b in enumerate(blocks)], ng, [1.0], [1.0]))
     for name, mode in (("dot", 1), ("passes", 2), ("norm", 4), ("fun", 8), ("plainnorm", 16), ("dot+fun", 9), ("gridrounded_dot", 32), ("tree_dot", 64), ("tree_dot+passes", 66), ("gridrounded_dot+passes", 34), ("grid2048_dot", 128), ("grid64_dot", 256), ("grid2048_dot+passes", 130)):
         variants["only_" + name] = (mode, ol.OracleAdmm(blocks, ng, [1.0], [1.0]))
 
