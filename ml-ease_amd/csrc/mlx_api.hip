@@ -47,6 +47,7 @@ struct PartHost {
     std::vector<int32_t> new2old;          // CSR partitions: library local id -> caller's local id (features only)
     std::vector<int32_t> col_ptr_h;        // CSR partitions: host copy of col_ptr (slots of each column)
     int n_cs = 1, n_hs = 1, slw = 64, n_rgroups = 0, n_cslices = 0, n_rblk = 1, rblk_rows = 0, n_cunits = 0;
+    int upw = 1;                           // dense: row units per pass workgroup
     int nblk = 0, rows_per_blk = 0, n_items = 0, n_slots = 0, rowgroup = 64, pos = 0, neg = 0;
     PartDev dev{};
     double *c0 = nullptr;
@@ -86,6 +87,9 @@ struct mlx_context {
     int step_threads = 256;
     int step_ch = 2048, step_max_nwg = 1;   // multi-workgroup CSR step: columns per workgroup, chunks of the widest CSR problem
     int cold_groups = 0;                    // > 0: row groups of the widest partition with cold column slices (k_rowcold launch)
+    bool seq_dots = true;                   // CSR step: d.Hd and r.r as grid-rounded sums (lookback_grid in mlx_kernels.hip); MLX_SEQ_DOTS=0: plain trees
+    unsigned step_seq = 0;                  // launch sequence number of the step phases (the look-back's tag; never 0)
+    int *d_stepctl = nullptr;               // [0] != 0: a look-back timed out
 
     double *d_Z = nullptr;
     float *d_z32 = nullptr, *d_u = nullptr, *d_B = nullptr, *d_UPX = nullptr;
@@ -269,8 +273,9 @@ void launch_step(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
     mlxk_tron_step(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->step_threads, h->d_done);
     // (launching A, B, C per group of problems so that Hd / r' / s stay in the memory-side cache between phases was measured: every
     // group size is slower than one launch per phase, profiles/r3_notes.md)
+    if (++h->step_seq >= (1u << 30)) h->step_seq = 1;
     for (int which = 0; which < 4; which++)
-        mlxk_step_phase(h->stream, which, h->d_parts, h->d_probs, qcsr, nqc, h->step_ch, h->step_max_nwg, h->d_done);
+        mlxk_step_phase(h->stream, which, h->d_parts, h->d_probs, qcsr, nqc, h->step_ch, h->step_max_nwg, h->d_done, h->seq_dots, h->step_seq, h->d_stepctl);
 }
 
 // One-launch solves of small CSR problems (k_solve_small): launch, wait, relaunch while a problem needs more than
@@ -403,6 +408,14 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
     }
     HIPCHECK(h, hipStreamSynchronize(sA));
     HIPCHECK(h, hipGetLastError());
+    if (h->seq_dots && nqc > 0) {
+        int ctl = 0;
+        HIPCHECK(h, hipMemcpy(&ctl, h->d_stepctl, sizeof ctl, hipMemcpyDeviceToHost));
+        if (ctl != 0) {
+            hipMemset(h->d_stepctl, 0, sizeof(int));
+            return fail(h, MLX_ERR_HIP, "TRON step: a look-back over a problem's column chunks timed out (MLX_SEQ_DOTS=0 runs the step without it)");
+        }
+    }
     if (ticks_out) *ticks_out = ticks;
     return MLX_OK;
 }
@@ -420,7 +433,7 @@ double alg_bytes_per_tick(const PartHost &p)
 int finish_part(mlx_handle h, PartHost &ph)
 {
     ph.dev.l = ph.l; ph.dev.n_local = ph.n_local; ph.dev.n_feat = ph.n_feat; ph.dev.dense = ph.dense ? 1 : 0;
-    ph.dev.nblk = ph.nblk; ph.dev.rows_per_blk = ph.rows_per_blk; ph.dev.pos = ph.pos; ph.dev.neg = ph.neg;
+    ph.dev.nblk = ph.nblk; ph.dev.n_rowparts = ph.nblk; ph.dev.rows_per_blk = ph.rows_per_blk; ph.dev.units_per_wg = ph.upw; ph.dev.pos = ph.pos; ph.dev.neg = ph.neg;
     ph.dev.ld = ph.ld; ph.dev.nnz = ph.nnz; ph.dev.n_items = ph.n_items; ph.dev.n_rblk = ph.n_rblk; ph.dev.rblk_rows = ph.rblk_rows; ph.dev.rowgroup = ph.rowgroup;
     int rc = dev_alloc(h, &ph.c0, (size_t)ph.n_local);
     if (rc) return rc;
@@ -469,6 +482,7 @@ int mlx_create(int device_id, mlx_handle *out)
     if (const char *te = getenv("MLX_SMALL_TICKS")) h->small_ticks = std::max(1, atoi(te));
     if (const char *se = getenv("MLX_STREAMS")) h->nstreams = std::max(1, std::min(atoi(se), (int)mlx_context::MAX_TS));
     if (const char *pe = getenv("MLX_PROFILE_ONE_STREAM")) h->prof_one_stream = atoi(pe) != 0;
+    if (const char *pe = getenv("MLX_SEQ_DOTS")) h->seq_dots = atoi(pe) != 0;
     if (h->nstreams > 1) {
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
         if (hipHostMalloc((void **)&h->h_donex, mlx_context::MAX_TS * 2 * sizeof(int)) != hipSuccess) h->nstreams = 1;
@@ -1127,13 +1141,16 @@ int mlx_add_partition_dense(mlx_handle h, int32_t partition_id, int32_t l, int32
     int32_t *d_l2g;
     if ((rc = dev_upload(h, &d_l2g, local_to_global, (size_t)n_local))) return rc;
     ph.dev.X = dX; ph.dev.l2g = d_l2g;
-    // Row chunk per workgroup. Measured on 64 x (15625 x 1000) (profiles/r1_notes.md): 512 rows/chunk is the
-    // optimum (5.9 TB/s); finer chunks pay per-block prologue/epilogue, coarser ones leave CUs idle in the tail.
-    int rpb = l >= 4096 ? 512 : std::max(16, ((l + 7) / 8 + 15) / 16 * 16);
-    if ((l + rpb - 1) / rpb > 1024) rpb = ((l + 1023) / 1024 + 15) / 16 * 16;
-    if (const char *e = getenv("MLX_DENSE_RPB")) rpb = std::max(16, atoi(e) / 16 * 16);   // A/B knob (profiles/r1_notes.md)
+    // Row UNITS: one partial X'c per unit, a function of the partition alone (256 rows from 4096 rows on), so that the sums
+    // associate the same way whatever else the handle holds. How many units a workgroup of the pass takes is decided at
+    // mlx_finalize from the handle's work: 2 (= 512-row chunks, the optimum on 64 x (15625 x 1000): finer chunks pay per-block
+    // prologues, coarser ones leave CUs idle in the tail; profiles/r1_notes.md) or 1 when the handle holds few problems.
+    int rpb = l >= 4096 ? 256 : std::max(16, ((l + 7) / 8 + 15) / 16 * 16);
+    if ((l + rpb - 1) / rpb > 2048) rpb = ((l + 2047) / 2048 + 15) / 16 * 16;
+    if (const char *e = getenv("MLX_DENSE_RPB")) rpb = std::max(16, atoi(e) / 16 * 16);   // A/B knob: rows per unit
     ph.rows_per_blk = rpb;
     ph.nblk = (l + rpb - 1) / rpb;
+    ph.upw = l >= 4096 ? 2 : 1;
     if ((rc = upload_row_meta(h, ph, l, y, weight, offset, x_on_device != 0))) return rc;
     return finish_part(h, ph);
 }
@@ -1177,26 +1194,18 @@ int mlx_finalize(mlx_handle h)
         if (ce ? atoi(ce) != 0 : ngc >= 128)
             for (auto &p : h->parts) if (!p.dense && p.n_cs > p.n_hs) h->cold_groups = std::max(h->cold_groups, p.n_rgroups);
     }
-    // Dense tiles: 512-row chunks are the optimum when the handle's problems make >= ~1000 of them (profiles/r1_notes.md);
-    // with FEW problems (the 64-partition job strong-scaled over 8 GPUs leaves 8 per GPU = 248 chunks for 256 CUs, one
-    // wave per SIMD where the pass needs two) the chunks shrink until about 512 workgroups exist (1774 solves/s at that shape
-    // against 1617 with 512-row chunks; 1024 workgroups: 1670, the step's assembly of the partials then costs more), down to 64 rows.
-    if (getenv("MLX_DENSE_RPB") == nullptr) {
+    // Dense tiles: a workgroup of the pass takes two 256-row units (512-row chunks: the optimum when the handle's problems make
+    // >= ~1000 of them, profiles/r1_notes.md); with FEW problems (the 64-partition job strong-scaled over 8 GPUs leaves 8 per GPU =
+    // 248 such chunks for 256 CUs, one wave per SIMD where the pass needs two) it takes one (1774 solves/s at that shape against 1617
+    // with 512-row chunks, round 2). The partial sums are per unit either way: the choice changes no result. MLX_DENSE_UPW forces it.
+    {
         int64_t dense_rows = 0;
-        for (auto &p : h->parts) if (p.dense) dense_rows += (int64_t)nl * p.l;
+        for (auto &p : h->parts) if (p.dense && p.l >= 4096) dense_rows += (int64_t)nl * p.l;
         const int64_t want = getenv("MLX_DENSE_WGS") ? std::max(64, atoi(getenv("MLX_DENSE_WGS"))) : 512;
-        if (dense_rows > 0 && dense_rows / 512 < want) {
-            int rpb = (int)std::max<int64_t>(64, std::min<int64_t>(512, (dense_rows / want + 15) / 16 * 16));
-            for (auto &p : h->parts) if (p.dense && p.l >= 4096) {
-                p.rows_per_blk = rpb;
-                p.nblk = (p.l + rpb - 1) / rpb;
-                p.dev.rows_per_blk = p.rows_per_blk; p.dev.nblk = p.nblk;
-            }
-        }
+        int upw = dense_rows / 512 < want ? 1 : 2;
+        if (const char *e = getenv("MLX_DENSE_UPW")) upw = std::max(1, std::min(8, atoi(e)));
+        for (auto &p : h->parts) if (p.dense && p.l >= 4096) { p.upw = upw; p.dev.units_per_wg = upw; }
     }
-    std::vector<PartDev> pd(np);
-    for (int k = 0; k < np; k++) pd[k] = h->parts[k].dev;
-    if ((rc = dev_upload(h, &h->d_parts, pd.data(), pd.size()))) return rc;
 
     // geometry maxima
     std::vector<int> qd, qc;
@@ -1207,7 +1216,7 @@ int mlx_finalize(mlx_handle h)
         if (!p.all_present) h->any_absent = true;
         const int64_t plen = p.dense ? (int64_t)p.nblk * p.n_local : (int64_t)p.n_items;
         h->max_parts_len = std::max(h->max_parts_len, plen);
-        if (p.dense) { h->maxblk_dense = std::max(h->maxblk_dense, p.nblk); h->max_nfeat_dense = std::max(h->max_nfeat_dense, p.n_feat); }
+        if (p.dense) { h->maxblk_dense = std::max(h->maxblk_dense, (p.nblk + p.upw - 1) / p.upw); h->max_nfeat_dense = std::max(h->max_nfeat_dense, p.n_feat); }
         else {
             h->maxblk_csr = std::max(h->maxblk_csr, p.nblk); h->max_items = std::max(h->max_items, p.n_items);
             h->max_short = std::max(h->max_short, p.n_short); h->max_long = std::max(h->max_long, p.n_long);
@@ -1242,6 +1251,15 @@ int mlx_finalize(mlx_handle h)
             }
         }
     }
+    // Loss / coefficient-sum partials of a pass (lossp / csump): the sliced row pass of the tick kernels leaves one per 64-row group
+    // (a function of the partition alone), every other kernel one per row chunk / unit
+    for (auto &p : h->parts) {
+        p.dev.nblk = p.nblk;
+        p.dev.n_rowparts = (!p.dense && h->csr_sell && !h->csr_small) ? p.n_rgroups : p.nblk;
+    }
+    std::vector<PartDev> pd(np);
+    for (int k = 0; k < np; k++) pd[k] = h->parts[k].dev;
+    if ((rc = dev_upload(h, &h->d_parts, pd.data(), pd.size()))) return rc;
     // (if any CSR partition could not be sliced, all of them run the lane-group kernels; those accept any row chunking)
     bool first_csr = true;
     for (auto &p : h->parts) if (!p.dense) {
@@ -1291,14 +1309,15 @@ int mlx_finalize(mlx_handle h)
     auto step_nwg = [&](int n_local) { return (size_t)((n_local + h->step_ch - 1) / h->step_ch); };
     auto vec_bytes = [&](int n_local, int l, int64_t plen, int nblk, bool dense) {
         return 8 * carve_size((size_t)n_local) + (dense ? 2 : 3) * carve_size((size_t)l) + carve_size((size_t)plen) + 2 * carve_size((size_t)nblk) +
-               (dense ? 0 : carve_size((size_t)n_local) + 3 * carve_size(step_nwg(n_local) * STEP_NP)) +
+               (dense ? 0 : carve_size((size_t)n_local) + 3 * carve_size(step_nwg(n_local) * STEP_NP) + carve_size(2 * step_nwg(n_local))) +
                (h->faithful ? carve_size((size_t)l) + carve_size((size_t)n_local) : 0);
     };
-    const int scratch_blk = std::max(h->maxblk_dense, h->maxblk_csr);
+    int scratch_blk = h->maxblk_csr;                       // partial sums of the widest partition (dense: units, not workgroups)
+    for (auto &p : h->parts) scratch_blk = std::max(scratch_blk, std::max(p.nblk, p.dev.n_rowparts));
     size_t slab_bytes = vec_bytes(h->max_nlocal, h->max_l, h->max_parts_len, scratch_blk, false) + carve_size((size_t)h->max_nlocal);
     for (int k = 0; k < np; k++) {
         const PartHost &p = h->parts[k];
-        slab_bytes += (size_t)nl * vec_bytes(p.n_local, p.l, p.dense ? (int64_t)p.nblk * p.n_local : (int64_t)p.n_items, p.nblk, p.dense);
+        slab_bytes += (size_t)nl * vec_bytes(p.n_local, p.l, p.dense ? (int64_t)p.nblk * p.n_local : (int64_t)p.n_items, std::max(p.nblk, p.dev.n_rowparts), p.dense);
     }
     uint8_t *slab = nullptr;
     if ((rc = dev_alloc(h, &slab, slab_bytes))) return rc;
@@ -1314,6 +1333,7 @@ int mlx_finalize(mlx_handle h)
             pr.coef = carve((size_t)l);
             pr.rb[0] = pr.r; pr.rb[1] = carve((size_t)n_local);
             pr.pA = carve(step_nwg(n_local) * STEP_NP); pr.pB = carve(step_nwg(n_local) * STEP_NP); pr.pC = carve(step_nwg(n_local) * STEP_NP);
+            pr.lb = reinterpret_cast<unsigned long long *>(carve(2 * step_nwg(n_local)));
         }
         if (h->faithful) { pr.rowtmp = carve((size_t)l); pr.c0f = carve((size_t)n_local); }
         pr.parts = carve((size_t)plen);
@@ -1325,7 +1345,7 @@ int mlx_finalize(mlx_handle h)
         for (int li = 0; li < nl; li++) {
             ProbDev &pr = h->h_probs[k * nl + li];
             pr.part = k; pr.lambda_idx = li; pr.phase = PH_DONE;
-            alloc_vecs(pr, p.n_local, p.l, p.dense ? (int64_t)p.nblk * p.n_local : (int64_t)p.n_items, p.nblk, p.dense);
+            alloc_vecs(pr, p.n_local, p.l, p.dense ? (int64_t)p.nblk * p.n_local : (int64_t)p.n_items, std::max(p.nblk, p.dev.n_rowparts), p.dense);
         }
     }
     {
@@ -1340,6 +1360,8 @@ int mlx_finalize(mlx_handle h)
 
     if ((rc = dev_alloc(h, &h->d_done, 1))) return rc;
     HIPCHECK(h, hipMemset(h->d_done, 0, sizeof(int)));
+    if ((rc = dev_alloc(h, &h->d_stepctl, 1))) return rc;
+    HIPCHECK(h, hipMemset(h->d_stepctl, 0, sizeof(int)));
 
     // c0 = X' t0: one EVAL pass at w = 0 on the first problem of every partition
     std::vector<int> qfirst_d, qfirst_c, qfirst_all;

@@ -228,8 +228,12 @@ __device__ __forceinline__ void row_eval(double z, int y, double wt, double &los
 // (c < NV), i.e. 16*NV bytes per lane per row, loaded as 1 KiB-per-instruction coalesced reads.
 // Per row: partial dot -> wave all-reduce -> row coefficient -> rank-1 accumulate into the lane's
 // 4*NV fp64 column accumulators. U rows are in flight per wave for ILP.
-// The rows of a partition are cut into fixed chunks of rows_per_blk rows (512: finer chunks cost one no-op-ish
-// prologue each, coarser ones leave CUs idle in the tail; profiles/r1_notes.md).
+// The rows of a partition are cut into UNITS of rows_per_blk rows (256 for partitions of >= 4096 rows: a property of the partition
+// alone); a workgroup owns units_per_wg consecutive units (2 = 512 rows when the handle holds many problems -- finer chunks cost one
+// prologue each, coarser ones leave CUs idle in the tail, profiles/r1_notes.md -- 1 when it holds few) and writes ONE partial X'c,
+// loss and intercept sum PER UNIT. The step adds the units' partials in unit order, so the sums associate the same way however many
+// units a workgroup takes: a partition gives bit-identical results whether it shares its GPU with 7 others or with 63 (1/2/4/8-GPU
+// runs of one job).
 template <int NV, int U, bool NT>
 __global__ void __launch_bounds__(256)
 k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist)
@@ -241,8 +245,8 @@ k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     if (phase == PH_DONE) return;
     const PartDev &pa = parts[pr.part];
     const int b = blockIdx.x;
-    const int rpb = pa.rows_per_blk;
-    if (b >= pa.nblk) return;
+    const int rpb = pa.rows_per_blk, upw = pa.units_per_wg;
+    if (b * upw >= pa.nblk) return;
     const int nf = pa.n_feat, n = nf + 1;
     const int64_t ld = pa.ld;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -260,6 +264,10 @@ k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
         for (int e = 0; e < 4; e++) vr[c][e] = (col0 + e < nf) ? gld(v + col0 + e) : 0.0;
     }
     const double vb = gld(v + nf);
+    const int NC = NV * 256;                 // padded columns per wave slice
+    double *red = smem;                      // [4][NC]
+    double *redb = smem + 4 * NC;            // [4] intercept, [4] loss
+    for (int ub = b * upw; ub < min((b + 1) * upw, pa.nblk); ub++) {
     double acc[NV][4];
 #pragma unroll
     for (int c = 0; c < NV; c++)
@@ -267,7 +275,7 @@ k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
         for (int e = 0; e < 4; e++) acc[c][e] = 0.0;
     double accb = 0.0, lossacc = 0.0;
 
-    const int r0 = b * rpb;
+    const int r0 = ub * rpb;
     const int r1 = min(pa.l, r0 + rpb);
     for (int rb = r0 + wave * U; rb < r1; rb += 4 * U) {
         float4 x[U][NV];
@@ -342,9 +350,6 @@ k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     }
 
     // cross-wave reduction in LDS, fixed wave order -> deterministic partials
-    const int NC = NV * 256;                 // padded columns per wave slice
-    double *red = smem;                      // [4][NC]
-    double *redb = smem + 4 * NC;            // [4] intercept, [4] loss
 #pragma unroll
     for (int c = 0; c < NV; c++) {
         const int col0 = (c * 64 + lane) * 4;
@@ -354,12 +359,14 @@ k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     lossacc = wave_allreduce_sum(lossacc);
     if (lane == 0) { redb[wave] = accb; redb[4 + wave] = lossacc; }
     __syncthreads();
-    double *__restrict__ outp = pr.parts + (int64_t)b * n;
+    double *__restrict__ outp = pr.parts + (int64_t)ub * n;
     for (int j = threadIdx.x; j < nf; j += 256)
         gst(outp + j, ((red[j] + red[NC + j]) + red[2 * NC + j]) + red[3 * NC + j]);
     if (threadIdx.x == 0) {
         outp[nf] = ((redb[0] + redb[1]) + redb[2]) + redb[3];
-        pr.lossp[b] = ((redb[4] + redb[5]) + redb[6]) + redb[7];
+        pr.lossp[ub] = ((redb[4] + redb[5]) + redb[6]) + redb[7];
+    }
+    __syncthreads();                         // the next unit overwrites red[]
     }
 }
 
@@ -705,7 +712,6 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
 {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) double vs[];      // [slw + 1]: the staged hot slice, then the zero slot
-    __shared__ double scratch[48];
     PT_INIT;
     int pi_, bx_;
     if (!xcd_map(nq, gx, pi_, bx_)) return;
@@ -790,8 +796,10 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
         }
     }
     // row maps: the loads of (up to) four of the wave's rows are issued before the first is used (clamped, unconditional)
+    // The loss and the coefficient sum (the intercept's column of X'c) leave the kernel as ONE partial per 64-row GROUP -- a wave
+    // all-reduce over the group's rows -- not per workgroup: the step adds the groups' partials in group order, so the sums do not
+    // depend on how many groups a workgroup owns (chosen at mlx_finalize from the handle's total work).
     const double vb = v[nf];
-    double red[2] = {0.0, 0.0};          // loss, sum of coef
     constexpr int EH = GPW < 4 ? GPW : 4;
 #pragma unroll
     for (int i0 = 0; i0 < GPW; i0 += EH) {
@@ -813,25 +821,26 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
         }
 #pragma unroll
         for (int i = 0; i < EH; i++) {
+            double lossv = 0.0, cfv = 0.0;
             if (ok[i]) {
                 const double t = (add_cold ? acc[i0 + i] + zc[i] : acc[i0 + i]) + vb;
-                double cf;
                 if (cg) {
-                    cf = wdv0[i] * t;
+                    cfv = wdv0[i] * t;
                 } else {
-                    double loss, wdv;
-                    row_eval(t + (double)offv[i], yv[i], (double)wtv[i], loss, wdv, cf);
+                    double wdv;
+                    row_eval(t + (double)offv[i], yv[i], (double)wtv[i], lossv, wdv, cfv);
                     gst(wdnew + rowi[i], wdv);
-                    red[0] += loss;
                 }
-                gst(coef + rowi[i], cf);
-                red[1] += cf;
+                gst(coef + rowi[i], cfv);
+            }
+            if (wg0 + i0 + i < gcount) {                       // (wave-uniform)
+                const double cs = wave_allreduce_sum(cfv);
+                const double ls = cg ? 0.0 : wave_allreduce_sum(lossv);
+                if (lane == 0) { pr.csump[g0 + wg0 + i0 + i] = cs; if (!cg) pr.lossp[g0 + wg0 + i0 + i] = ls; }
             }
         }
     }
     PT_MARK(6);
-    block_allreduce_sum<2>(red, scratch);
-    if (tid == 0) { pr.lossp[c] = red[0]; pr.csump[c] = red[1]; }
     PT_MARK(5);
 }
 
@@ -1105,7 +1114,7 @@ __device__ __forceinline__ void assemble_out(const PartDev &pa, const ProbDev &p
             for (int it = i0; it < i1; it++) a += parts[it];
             out[j] = a;
         }
-        const double cs = block_sum_array(pr.csump, pa.nblk, scratch);
+        const double cs = block_sum_array(pr.csump, pa.n_rowparts, scratch);
         if (tid == 0) out[nf] = cs;
     }
 }
@@ -1203,7 +1212,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
     const bool inl = !pa.dense;
     const int nf = pa.n_feat;
     double csum_icpt = 0.0;
-    if (inl) csum_icpt = SEQ ? seq_sum(pr.coef, pa.l, scratch, stage) : team_sum_array<T>((VP)pr.csump, pa.nblk, scratch);   // SEQ: XTv's row order
+    if (inl) csum_icpt = SEQ ? seq_sum(pr.coef, pa.l, scratch, stage) : team_sum_array<T>((VP)pr.csump, pa.n_rowparts, scratch);   // SEQ: XTv's row order
     else if constexpr (std::is_same<VP, double *>::value) assemble_out(pa, pr, Hd, scratch, stage);
     T::sync();
     const VP segsum = (VP)pr.parts;
@@ -1430,7 +1439,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
         }
     }
     T::template allreduce<1>(a1, scratch);
-    const double loss = SEQ ? seq_sum(pr.rowtmp, pa.l, scratch, stage) : team_sum_array<T>((VP)pr.lossp, pa.nblk, scratch);
+    const double loss = SEQ ? seq_sum(pr.rowtmp, pa.l, scratch, stage) : team_sum_array<T>((VP)pr.lossp, pa.n_rowparts, scratch);
     double fnew = 2.0 * loss;
     if (SEQ) {
         // fun :184-189 adds the prior terms to the running f one by one
@@ -1633,6 +1642,70 @@ __device__ __forceinline__ void step_gather(const double *__restrict__ px, int n
     __syncthreads();
 }
 
+
+// ---- grid-rounded dots: what Tron.dot's SEQUENTIAL loop does to the small terms, without its dependency chain -------------------
+// `for (i) p += a[i]*b[i]` (bw/Tron.java:204-213) adds every term to a running sum that is already large after the first few hundred
+// (hot) columns: the term's bits below the running sum's ulp are rounded away on the spot. That rounding is a property of (term,
+// binade of the running sum), hardly of the order of the terms, so every row / feature order the reference may see reproduces almost
+// the same sum -- while a tree (or an exact sum) keeps those bits and lands 50-100 ulp away, enough to leave the reference's own
+// family of trajectories on one-hot data (measured: tools/sum_order_experiment.py, profiles/r4_notes.md; counters equal to the
+// oracle's in 58-65 of 96 full-size solves with tree dots, 67-77 for the oracle on permuted rows, 74-82 with this).
+// Here: the chunk's terms stay in registers; its raw sum is published as an 8-byte {tag, float} granule (relaxed agent-scope store:
+// write-through, no fence); the workgroup reads the granules of the chunks BEFORE it in the same problem (decoupled look-back: they
+// were dispatched earlier, so this cannot deadlock), takes the binade of that prefix, rounds its terms to that binade's ulp -- the
+// magic-constant trick (x + 1.5 * 2^52 u) - 1.5 * 2^52 u, exactly what the FPU does to x when it is added to a sum of that size --
+// and sums the rounded terms (all multiples of u: the tree is exact). The first chunk of a problem is not rounded (the running sum
+// starts at 0). The next launch adds the chunks' sums in chunk order as before. Results are deterministic (fixed trees, fixed
+// values); the tag is the handle's launch sequence number, so a granule of an earlier launch never matches.
+#define LB_SPIN_LIMIT (1 << 22)
+__device__ __forceinline__ double lookback_grid(unsigned long long *__restrict__ lb, int wg, int nwg, unsigned tag, double agg,
+                                                double *stage /* LDS [STEP_T] */, int *__restrict__ ctl)
+{
+    typedef unsigned long long u64;
+    const int tid = threadIdx.x;
+    if (tid == 0 && wg + 1 < nwg)
+        __hip_atomic_store(lb + wg, ((u64)tag << 32) | (u64)__float_as_uint((float)agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wg == 0) return 0.0;
+    double pre = 0.0;
+    for (int c0 = 0; c0 < wg; c0 += STEP_T) {
+        const int c = c0 + tid;
+        double v = 0.0;
+        if (c < wg) {
+            u64 g = 0;
+            int spins = 0;
+            for (;;) {
+                g = __hip_atomic_load(lb + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(g >> 32) == tag || ++spins >= LB_SPIN_LIMIT) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if ((unsigned)(g >> 32) == tag) v = (double)__uint_as_float((unsigned)g);
+            else ctl[0] = 1;                                  // the host fails the solve: a predecessor never published
+        }
+        __syncthreads();
+        stage[tid] = v;
+        __syncthreads();
+        if (tid == 0) { const int cnt = min(STEP_T, wg - c0); for (int i = 0; i < cnt; i++) pre += stage[i]; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double u = 0.0;
+        const double ap = fabs(pre);
+        if (ap > 0.0 && ap < 1e300) { int e; (void)frexp(ap, &e); u = ldexp(1.0, e - 53); }      // ap in [2^(e-1), 2^e): ulp = 2^(e-53)
+        stage[0] = u;
+    }
+    __syncthreads();
+    const double u = stage[0];
+    __syncthreads();
+    return u;
+}
+// x as the FPU leaves it when it is added to a running sum whose ulp is u (round to nearest multiple of u, ties to even)
+__device__ __forceinline__ double round_to_grid(double x, double u)
+{
+#pragma clang fp contract(off)
+    const double magic = 6755399441055744.0 * u;              // 1.5 * 2^52 * u
+    return (fabs(x) < 1125899906842624.0 * u) ? (x + magic) - magic : x;      // (|x| >= 2^50 u: x is a multiple of u/4 at most bits away: leave it)
+}
+
 // sqrt of a sum of squares gathered in an update loop; a sum that overflowed (or is NaN) is reported as NaN so that the
 // caller stops the solve with ST_NAN instead of comparing against inf
 __device__ __forceinline__ double norm_of_sumsq(double ss) { return (ss < 1e300) ? sqrt(ss) : (0.0 / 0.0); }
@@ -1651,11 +1724,13 @@ __device__ __forceinline__ bool step_geom(const PartDev &pa, int ch, StepGeom &g
 }
 
 // ---- phase A ------------------------------------------------------------------------------------
+template <bool EMU>
 __global__ void __launch_bounds__(STEP_T)
-k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int ch)
+k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int ch, unsigned seq, int *__restrict__ ctl)
 {
 #pragma clang fp contract(off)
     __shared__ double scratch[64];
+    __shared__ double lbstage[EMU ? STEP_T : 1];
     ProbDev &pr = probs[qlist[blockIdx.y]];
     const int phase = pr.phase;
     if (phase == PH_DONE) return;
@@ -1666,8 +1741,8 @@ k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
     const bool cg = (phase == PH_CG);
     // the intercept's column sum (the chunk that holds column nf) and the loss (chunk 0) come from the row pass's partials
     double csum_icpt = 0.0, loss = 0.0;
-    if (G.j1 == n) csum_icpt = block_sum_array(pr.csump, pa.nblk, scratch);
-    if (G.wg == 0 && !cg) loss = block_sum_array(pr.lossp, pa.nblk, scratch);
+    if (G.j1 == n) csum_icpt = block_sum_array(pr.csump, pa.n_rowparts, scratch);
+    if (G.wg == 0 && !cg) loss = block_sum_array(pr.lossp, pa.n_rowparts, scratch);
     const double *__restrict__ segsum = pr.parts;
     const int32_t *__restrict__ cptr = pa.col_ptr;
     const double *__restrict__ v = cg ? pr.d : pr.w_new;
@@ -1677,7 +1752,16 @@ k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
     const double pscal = pr.pinv;
     double *__restrict__ Hd = pr.Hd;
     double acc[3] = {0.0, 0.0, 0.0};
-    for (int jb = G.j0 + tid; jb < G.j1; jb += STEP_XB * STEP_T) {
+    // EMU (ch == 2 * STEP_XB * STEP_T): the terms of the dot the reference computes sequentially -- d.Hd on a CG tick, g.g (= the
+    // r.r a trcg call starts from) on an EVAL tick -- stay in registers for lookback_grid's second pass
+    constexpr int NR = EMU ? 2 : 1;
+    double xt[NR * STEP_XB];
+#pragma unroll
+    for (int k = 0; k < NR * STEP_XB; k++) xt[k] = 0.0;
+#pragma unroll
+    for (int rnd = 0; rnd < (EMU ? 2 : 1 << 30); rnd++) {
+        const int jb = G.j0 + tid + rnd * (STEP_XB * STEP_T);
+        if (jb >= G.j1) break;
         int i0[STEP_XB], i1[STEP_XB];
         double vv[STEP_XB], mm[STEP_XB], pj[STEP_XB], cc[STEP_XB];
 #pragma unroll
@@ -1705,13 +1789,17 @@ k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
             if (cg) {
                 const double hd = vv[u] * pj[u] + xa;          // Hs[i] = (s[i]*priorVar_inv[i] + Hs[i]) * 1
                 SST(Hd + j, hd);
-                acc[0] += vv[u] * hd;
+                const double term = vv[u] * hd;
+                acc[0] += term;
+                if (EMU) xt[(EMU ? rnd : 0) * STEP_XB + u] = term;
             } else {
                 const double t = vv[u] - mm[u];
                 acc[0] += t * t * pj[u];                       // fun :187-188
                 const double hd = t * pj[u] + xa;              // grad :224 (multiplier 1)
                 gst(Hd + j, hd);
-                acc[1] += hd * hd;
+                const double term = hd * hd;
+                acc[1] += term;
+                if (EMU) xt[(EMU ? rnd : 0) * STEP_XB + u] = term;
                 if (phase == PH_EVAL0) {
                     const double g0 = (0.0 - mm[u]) * pj[u] + cc[u];      // grad(0)
                     acc[2] += g0 * g0;
@@ -1720,6 +1808,17 @@ k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
         }
     }
     block_allreduce_sum<3>(acc, scratch);
+    if (EMU && G.nwg > 1) {
+        const int k = cg ? 0 : 1;
+        const double u = lookback_grid(pr.lb, G.wg, G.nwg, (seq << 2) | 1u, acc[k], lbstage, ctl);
+        if (u > 0.0) {
+            double rs[1] = {0.0};
+#pragma unroll
+            for (int q = 0; q < NR * STEP_XB; q++) rs[0] += round_to_grid(xt[q], u);
+            block_allreduce_sum<1>(rs, scratch);
+            acc[k] = rs[0];
+        }
+    }
     if (tid == 0) {
         double *__restrict__ px = pr.pA + G.wg * STEP_NP;
         px[0] = acc[0]; px[1] = acc[1]; px[2] = acc[2];
@@ -1829,8 +1928,9 @@ __device__ __forceinline__ CgDecision cg_decide(const ProbDev &pr, const double 
 }
 
 // ---- phase B ------------------------------------------------------------------------------------
+template <bool EMU>
 __global__ void __launch_bounds__(STEP_T)
-k_step_b(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int ch)
+k_step_b(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int ch, unsigned seq, int *__restrict__ ctl)
 {
 #pragma clang fp contract(off)
     __shared__ double scratch[96];
@@ -1852,7 +1952,14 @@ k_step_b(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
         const double *__restrict__ rc = pr.rb[pr.rsel];
         double *__restrict__ rn = pr.rb[pr.rsel ^ 1];
         double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-        for (int jb = G.j0 + tid; jb < G.j1; jb += STEP_XB * STEP_T) {
+        constexpr int NR = EMU ? 2 : 1;
+        double xt[NR * STEP_XB];                               // EMU: the terms of r'.r' (lookback_grid)
+#pragma unroll
+        for (int k = 0; k < NR * STEP_XB; k++) xt[k] = 0.0;
+#pragma unroll
+        for (int rnd = 0; rnd < (EMU ? 2 : 1 << 30); rnd++) {
+            const int jb = G.j0 + tid + rnd * (STEP_XB * STEP_T);
+            if (jb >= G.j1) break;
             double dv[STEP_XB], sv[STEP_XB], rv[STEP_XB], hv[STEP_XB];
 #pragma unroll
             for (int u = 0; u < STEP_XB; u++) {
@@ -1872,10 +1979,22 @@ k_step_b(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
                 acc[3] += dv[u] * dv[u];
                 const double r1 = rv[u] + nalpha * hv[u];              // daxpy(-alpha, Hd, r)
                 SST(rn + j, r1);
-                acc[4] += r1 * r1;
+                const double term = r1 * r1;
+                acc[4] += term;
+                if (EMU) xt[(EMU ? rnd : 0) * STEP_XB + u] = term;
             }
         }
         block_allreduce_sum<5>(acc, scratch);
+        if (EMU && G.nwg > 1) {
+            const double u = lookback_grid(pr.lb + G.nwg, G.wg, G.nwg, (seq << 2) | 2u, acc[4], stage, ctl);
+            if (u > 0.0) {
+                double rs[1] = {0.0};
+#pragma unroll
+                for (int q = 0; q < NR * STEP_XB; q++) rs[0] += round_to_grid(xt[q], u);
+                block_allreduce_sum<1>(rs, scratch);
+                acc[4] = rs[0];
+            }
+        }
         if (tid == 0) {
             double *__restrict__ px = pr.pB + G.wg * STEP_NP;
 #pragma unroll
@@ -2817,12 +2936,18 @@ void mlxk_tron_step(hipStream_t st, const PartDev *parts, ProbDev *probs, const 
 }
 
 void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int ch,
-                     int max_nwg, int *done_counter)
+                     int max_nwg, int *done_counter, bool emu, unsigned seq, int *ctl)
 {
     if (nq <= 0) return;
     const dim3 grid((unsigned)max_nwg, (unsigned)nq);
-    if (which == 0) hipLaunchKernelGGL(k_step_a, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
-    else if (which == 1) hipLaunchKernelGGL(k_step_b, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
+    emu = emu && ch == 2 * STEP_XB * STEP_T;                   // the terms of a chunk must fit the kernels' register arrays
+    if (which == 0) {
+        if (emu) hipLaunchKernelGGL(k_step_a<true>, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch, seq, ctl);
+        else hipLaunchKernelGGL(k_step_a<false>, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch, seq, ctl);
+    } else if (which == 1) {
+        if (emu) hipLaunchKernelGGL(k_step_b<true>, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch, seq, ctl);
+        else hipLaunchKernelGGL(k_step_b<false>, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch, seq, ctl);
+    }
     else if (which == 2) hipLaunchKernelGGL(k_step_c, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
     else hipLaunchKernelGGL(k_step_commit, dim3((unsigned)nq), dim3(STEP_T), 0, st, parts, probs, qlist, ch, done_counter);
 }

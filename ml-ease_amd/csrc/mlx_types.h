@@ -15,8 +15,12 @@ struct PartDev {
     int32_t n_local;       // features incl. intercept (intercept = local index n_local-1, implicit column of 1.0)
     int32_t n_feat;        // n_local - 1
     int32_t dense;         // 1: X dense tile, 0: CSR+CSC
-    int32_t nblk;          // workgroups (row chunks) per X pass over this partition; sizes the partial buffers
-    int32_t rows_per_blk;  // rows per chunk
+    int32_t nblk;          // partial sums per X pass over this partition (sizes the partial buffers): dense = row units, CSR = row chunks
+    int32_t rows_per_blk;  // rows per unit / chunk
+    int32_t n_rowparts;    // loss / coefficient-sum partials a pass leaves in lossp / csump: dense = nblk (per unit), sliced CSR on the
+                           // tick kernels = n_rgroups (per 64-row group), otherwise nblk (per chunk of the fallback / one-launch kernels)
+    int32_t units_per_wg;  // dense: consecutive units one workgroup of the pass owns (set at finalize from the handle's work; the
+                           // partials stay per unit, so the result does not depend on it)
     int32_t pos, neg;      // #y==+1, #y==-1 (llf/LibLinear.java:272-276)
     int64_t ld;            // dense row stride in floats (multiple of 4, zero padded)
     int64_t nnz;
@@ -90,6 +94,7 @@ struct ProbDev {
     double *rb[2];
     int32_t rsel;
     double *pA, *pB, *pC;  // [n_step_wg][STEP_NP] each
+    unsigned long long *lb;  // [2][n_step_wg] look-back granules {tag, float raw sum} of phases A and B (grid-rounded dots)
     double gsq;            // sum g_j^2 at the last accepted point (= rTr of the next trcg call)
     double snorm;          // ||s|| at the end of the last trcg call
     double *wd[2];         // [l] wt_i * D_i at the accepted / trial point

@@ -54,10 +54,11 @@ def test_bench_two_ranks_on_one_gpu_reproduce_the_one_rank_consensus(tmp_path):
     flags = ["--steps", "3", "--warmup", "1", "--rows", "65536", "--partitions", "8", "--no-cpu-baseline", "--no-gram", "--loglik-iters", "3",
              "--test-rows", "4096", "--sparse-rows", "160000", "--sparse-partitions", "8", "--sparse-steps", "2", "--sparse-warmup", "1",
              "--sparse-cpu-sample", "0", "--sweep-partitions", "2", "--sweep-steps", "1", "--sweep-warmup", "1", "--sweep-cpu-sample", "0"]
-    # the dense chunking adapts to the work a handle holds; pinned here so that one rank with 8 partitions and two
-    # ranks with 4 each add the same partial sums in the same order
-    env = dict(os.environ, MLX_DENSE_RPB="256")
+    # (no chunking pinned: the work of a pass workgroup adapts to what a handle holds, but the partial sums are per 256-row unit /
+    # 64-row group and added in unit order, so one rank with 8 partitions and two ranks with 4 each produce the same bits -- DESIGN 8)
+    env = dict(os.environ)
     env.pop("MLX_BENCH_SHARE_GPU", None)
+    env.pop("MLX_DENSE_RPB", None)
     one = _bench([sys.executable, "bench.py"] + flags, env, tmp_path, "one")
     env2 = dict(env, MLX_BENCH_SHARE_GPU="1")
     two = _bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

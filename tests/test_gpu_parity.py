@@ -1194,3 +1194,40 @@ def test_kkt_at_exit_on_full_size_partitions(kind):
         fo2, _, _ = od.eval(wo, m, one)
         assert fo <= fo2 + 10 * tol * abs(fo2), (kind, eps, fo, fo2)
     eng.close()
+
+
+@pytest.mark.parametrize("kind", ["dense", "onehot", "valued"])
+def test_results_do_not_depend_on_the_chunking_the_handle_picks(kind, monkeypatch):
+    """mlx_finalize sizes the work of a pass workgroup from what the whole HANDLE holds (dense: 1 or 2 row units of 256 rows; sliced
+    CSR: 16 ... 128 row groups), so a partition shares a workgroup layout with 7 others on one GPU of 8 and with 63 others on a single
+    GPU. Round 3 that changed how its partial sums associate, and 1/2/4/8-GPU runs of one job agreed bit for bit only with the
+    chunking pinned by hand. Now the partial sums are per UNIT / per 64-row GROUP -- functions of the partition alone -- and added
+    in unit order: every chunking gives the same bits (consumers/MeanLinearModelConsumer.java:44-70 sees the same float32 models
+    from every reducer layout). Forced here through the A/B switches; z (double), every float32 model and every TRON counter equal."""
+    from fixtures import dense_blocks, onehot_blocks
+    monkeypatch.setenv("MLX_NO_SMALL", "1")
+    if kind == "dense":
+        pd, lam, rho, sw, vals = dense_blocks(4 * 5000, 300, 4), [1.0], [1.0], "MLX_DENSE_UPW", ("1", "2", "4")
+    elif kind == "onehot":
+        pd, lam, rho, sw, vals = onehot_blocks(4 * 20000, 4), [1.0], [1.0], "MLX_ROW_NG", ("16", "32", "128")
+    else:
+        pd, lam, rho, sw, vals = synth_sparse(17, 30000, 500, 12, 3, weights=True, offsets=True), [0.3, 30.0], [1.0, 1.0], "MLX_ROW_NG", ("16", "64")
+    outs = []
+    for v in vals:
+        monkeypatch.setenv(sw, v)
+        eng = make_engine(pd, lam, rho)
+        rec = []
+        for it in range(4):
+            eng.iterate(0.01 if it < 2 else 0.001)
+            rec.append((eng.solve_counters().copy(), eng.z()[0].copy(),
+                        [eng.partition_model(k, li)[0].copy() for k in range(len(pd.blocks)) for li in range(len(lam))]))
+        outs.append(rec)
+        eng.close()
+    monkeypatch.delenv(sw)
+    for other in outs[1:]:
+        for it, (a, b) in enumerate(zip(outs[0], other)):
+            assert np.array_equal(a[0], b[0]), "iteration %d: counters differ" % (it + 1)
+            assert np.array_equal(a[1], b[1]), "iteration %d: z differs" % (it + 1)
+            for x, y in zip(a[2], b[2]):
+                assert np.array_equal(x, y), "iteration %d: a partition model differs" % (it + 1)
+    assert outs[0][-1][0][:, 2].sum() > 0

@@ -101,6 +101,14 @@ def main():
         eng = HipAdmmEngine(ng, [1.0], [1.0], P)
         eng.add_partitions(blocks)
         eng.finalize()
+    # per-call-site mixes on the frequency-ordered partitions (the library's column order): which dots must be grid-rounded?
+    L.orc_set_dot_site_mode.argtypes = [__import__("ctypes").c_int, __import__("ctypes").c_int]
+    site_mixes = {"fo:sites012=grid,345=tree,+passes": ({0: 128, 1: 128, 2: 128, 3: 64, 4: 64, 5: 64}, 2),
+                  "fo:sites12=grid,0345=tree,+passes": ({0: 64, 1: 128, 2: 128, 3: 64, 4: 64, 5: 64}, 2),
+                  "fo:sites01245=grid,3=tree,+passes": ({0: 128, 1: 128, 2: 128, 3: 64, 4: 128, 5: 128}, 2),
+                  "fo:all sites grid,+passes": ({}, 130)}
+    for name in site_mixes:
+        variants[name] = (("mix", name), ol.OracleAdmm(fb, ng, [1.0], [1.0]))
     e, mind = np.float32(0.01), 99999999.0
     out = []
     t0 = time.time()
@@ -116,12 +124,21 @@ def main():
         cb, bb = counters(base), betas(base, P)
         rec = {"iteration": it, "epsilon": eps, "cg_per_solve": float(cb[:, 2].mean()), "newton_per_solve": float(cb[:, 0].mean())}
         for name, (mode, o) in variants.items():
+            for st_ in range(6):
+                L.orc_set_dot_site_mode(st_, -1)
+            if isinstance(mode, tuple):
+                sites, gm = site_mixes[mode[1]]
+                for st_, m_ in sites.items():
+                    L.orc_set_dot_site_mode(st_, m_)
+                mode = gm
             L.orc_set_sum_mode(mode)
             o.set_state(Z, U)
             o.solve_local(eps, 1.0, nthreads=a.threads)
             er = rel_err(betas(o, P), bb)
             rec[name] = {"equal": int(np.all(counters(o) == cb, axis=1).sum()), "median": float(np.median(er)), "max": float(er.max())}
         L.orc_set_sum_mode(0)
+        for st_ in range(6):
+            L.orc_set_dot_site_mode(st_, -1)
         if eng is not None:
             eng.set_state(Z, U)
             eng.solve_local(eps, 1.0)
