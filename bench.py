@@ -457,7 +457,7 @@ def run_dense(args, C):
     sched = EpsSchedule(admm)
     eps_used = []
     acc = dict(solves=0, newton=0, cg=0, passes_ref=0, passes_dev=0, ticks=0, alg_bytes=0.0, xpass_ms=0.0, busy_ms=0.0,
-               total_ms=0.0, launches=0)
+               total_ms=0.0, launches=0, step_ms=0.0, step_busy_ms=0.0)
     # every k_xpass_dense launch of this leg that ran with events on: what a rocprofv3 --kernel-trace of this command must agree with
     # (it also sees finalize's one c0 launch, which runs without events)
     allrun = dict(alg_bytes=0.0, launches=0, xpass_ms=0.0, busy_ms=0.0, untimed_launches=1, untimed_alg_bytes=P * (4.0 * rows * nf + 8.0 * rows + 8.0 * (nf + 1)))
@@ -492,7 +492,7 @@ def run_dense(args, C):
             acc["solves"] += st.solves; acc["newton"] += st.newton_iters; acc["cg"] += st.cg_iters
             acc["passes_ref"] += st.x_passes_ref; acc["passes_dev"] += st.x_passes_dev; acc["ticks"] += st.ticks
             acc["alg_bytes"] += st.alg_bytes_dev; acc["xpass_ms"] += st.xpass_ms; acc["total_ms"] += st.total_ms
-            acc["busy_ms"] += st.xpass_busy_ms
+            acc["busy_ms"] += st.xpass_busy_ms; acc["step_ms"] += st.step_ms; acc["step_busy_ms"] += st.step_busy_ms
             acc["launches"] += st.xpass_launches
         return st, fin
 
@@ -569,6 +569,8 @@ def run_dense(args, C):
                     "launches_in_flight": round(prof["xpass_ms"] / prof["busy_ms"], 3),
                     "frac_by_launch_durations": round(prof["alg_bytes"] / (prof["xpass_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "xpass_share_of_wall": round(prof["busy_ms"] / (prof["wall"] * 1e3), 4),
+                    "tron_step_ms_per_step": round(acc["step_ms"] / args.steps, 3) if timed else None,
+                    "tron_step_busy_ms_per_step": round(acc["step_busy_ms"] / args.steps, 3) if timed else None,
                     "timed_ms_per_step": round(dt * 1e3 / args.steps, 3),
                     "measured_in_short": "timed region: HIP events on both tick streams, bytes / time with >= 1 launch running" if timed
                                          else "replay of the timed iterations with events (N>1)",
@@ -924,6 +926,59 @@ def sparse_rooflines(prof, n_mean, row_kernel, col_kernel):
                         roof("k_step_a+b+c+commit", prof["sbusy"], prof["sms"], 0.0,
                              "no algorithmic X bytes (SURVEY 8d counts the n-vector work as zero); streams ~13 x 8n bytes per problem and "
                              "tick = %.1f GB/s" % (step_model / max(1e-9, prof["sbusy"] * 1e-3) / 1e9))]}
+
+
+def run_sparse(args, C):
+    """BASELINE configs[2] at one GPU (256 partitions), configs[3] sharded (1024 partitions, k -> rank k mod N)."""
+    world, rank, sd = C["world"], C["rank"], C["sd"]
+    from mlease_amd.dataset import PartitionBlock
+    Ptot = args.sparse_partitions or (SP_PARTS_1GPU if world == 1 else SP_PARTS_MULTI)
+    rows = args.sparse_rows // Ptot
+    mine = [k for k in range(Ptot) if k % world == rank]
+    t0 = time.time()
+    blocks, ng = [], None
+    for k in mine:
+        rp, ci, y, l2g, ng = sd.onehot_partition(k, rows)
+        blocks.append(PartitionBlock(k, rows, len(l2g), rp, ci, None, y, np.ones(rows, np.float32), np.zeros(rows, np.float32), l2g))
+    tgen = time.time() - t0
+    eng = C["HipAdmmEngine"](ng, [1.0], [1.0], Ptot, device=C["local_rank"], stream=C["stream"])
+    t0 = time.time()
+    eng.add_partitions(blocks)
+    eng.finalize()
+    tup = time.time() - t0
+    nnz = sum(b.nnz for b in blocks)
+    nloc = np.array([b.n_local for b in blocks])
+    want_checks = world == 1 and args.sparse_cpu_sample > 0
+    acc, allrun, dt, fin, snap, eps_all, step_s, prof = sparse_timed_run(args, C, eng, blocks, [1.0], args.sparse_warmup, args.sparse_steps, want_checks)
+    tot_solves, tot_pref, tot_pdev, tot_alg = C["reduce_sum"]([acc["solves"], acc["pref"], acc["pdev"], acc["alg"]])
+    res = None
+    if rank == 0:
+        n_mean = float(nloc.mean())
+        res = {"workload": "BASELINE configs[%d]: synthetic one-hot %d rows x %d binary features (20 fields x 5000 Zipf(1.1) levels, 20 nnz/row), "
+                           "%d partitions%s, lambda=1, rho=1" % (2 if world == 1 else 3, rows * Ptot, ng - 1, Ptot,
+                                                                 " sharded k -> rank k mod %d" % world if world > 1 else ""),
+               "value": round(tot_solves / dt, 2), "unit": "solves/s", "n_gpus": world, "steps": args.sparse_steps, "warmup": args.sparse_warmup,
+               "partitions": Ptot,
+               "ms_per_step": round(dt * 1e3 / args.sparse_steps, 3), "liblinear_epsilon_by_iteration": eps_all,
+               "nnz": int(nnz), "rows_per_partition": rows, "n_local_mean": n_mean, "gen_s": round(tgen, 1), "upload_s": round(tup, 1),
+               "x_passes_ref_per_s": round(tot_pref / dt, 1), "x_passes_dev_per_s": round(tot_pdev / dt, 1),
+               "ticks_per_step": acc["ticks"] / args.sparse_steps, "cg_per_solve": round(acc["cg"] / max(1, acc["solves"]), 2),
+               "whole_step": {"alg_bytes_per_s_GB": round(tot_alg / dt / 1e9, 1), "frac_of_hbm_peak": round(tot_alg / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
+                              "definition": "sum over solves of device passes x B_pass (SURVEY 8d) / wall time of the timed iterations"},
+               "roofline": sparse_rooflines(prof, n_mean, "k_rowcold + k_rowpass_lds<binary>", "k_colpass_lds<binary>"),
+               "timed_run": "no per-launch events, two tick streams (library default)",
+               "last_maxdiff": fin.maxdiff,
+               "all_launches": {"ticks_incl_c0_and_warmup": allrun["ticks"], "alg_bytes_row_plus_column": allrun["alg"]}}
+        tpath = os.path.join(ROOT, "profiles", "traffic_sparse.json")
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            res["traffic"] = {"source": "profiles/traffic_sparse.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `%s` (committed; not a counter read in this run)" % tj.get("command", ""),
+                              "hbm_bytes_per_alg_byte": tj.get("hbm_bytes_per_alg_byte"), "per_kernel": tj.get("per_kernel")}
+        if want_checks:
+            sparse_checks(args, C, eng, blocks, ng, Ptot, snap, eps_all, step_s, res)
+    eng.close()
+    return res
 
 
 LS_LAMBDAS = [0.1, 0.3, 1.0, 3.0, 10.0, 30.0, 100.0, 300.0]       # SURVEY 8d C5

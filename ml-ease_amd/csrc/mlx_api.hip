@@ -47,7 +47,7 @@ struct PartHost {
     std::vector<int32_t> new2old;          // CSR partitions: library local id -> caller's local id (features only)
     std::vector<int32_t> col_ptr_h;        // CSR partitions: host copy of col_ptr (slots of each column)
     int n_cs = 1, n_hs = 1, slw = 64, n_rgroups = 0, n_cslices = 0, n_rblk = 1, rblk_rows = 0, n_cunits = 0;
-    int upw = 1;                           // dense: row units per pass workgroup
+    int upw = 1, n_units = 0;              // dense: row units per pass workgroup (1 or 2), number of units
     int nblk = 0, rows_per_blk = 0, n_items = 0, n_slots = 0, rowgroup = 64, pos = 0, neg = 0;
     PartDev dev{};
     double *c0 = nullptr;
@@ -433,7 +433,7 @@ double alg_bytes_per_tick(const PartHost &p)
 int finish_part(mlx_handle h, PartHost &ph)
 {
     ph.dev.l = ph.l; ph.dev.n_local = ph.n_local; ph.dev.n_feat = ph.n_feat; ph.dev.dense = ph.dense ? 1 : 0;
-    ph.dev.nblk = ph.nblk; ph.dev.n_rowparts = ph.nblk; ph.dev.rows_per_blk = ph.rows_per_blk; ph.dev.units_per_wg = ph.upw; ph.dev.pos = ph.pos; ph.dev.neg = ph.neg;
+    ph.dev.nblk = ph.nblk; ph.dev.n_rowparts = ph.nblk; ph.dev.rows_per_blk = ph.rows_per_blk; ph.dev.units_per_wg = ph.upw; ph.dev.n_units = ph.n_units; ph.dev.pos = ph.pos; ph.dev.neg = ph.neg;
     ph.dev.ld = ph.ld; ph.dev.nnz = ph.nnz; ph.dev.n_items = ph.n_items; ph.dev.n_rblk = ph.n_rblk; ph.dev.rblk_rows = ph.rblk_rows; ph.dev.rowgroup = ph.rowgroup;
     int rc = dev_alloc(h, &ph.c0, (size_t)ph.n_local);
     if (rc) return rc;
@@ -1149,8 +1149,9 @@ int mlx_add_partition_dense(mlx_handle h, int32_t partition_id, int32_t l, int32
     if ((l + rpb - 1) / rpb > 2048) rpb = ((l + 2047) / 2048 + 15) / 16 * 16;
     if (const char *e = getenv("MLX_DENSE_RPB")) rpb = std::max(16, atoi(e) / 16 * 16);   // A/B knob: rows per unit
     ph.rows_per_blk = rpb;
-    ph.nblk = (l + rpb - 1) / rpb;
-    ph.upw = l >= 4096 ? 2 : 1;
+    ph.n_units = (l + rpb - 1) / rpb;
+    ph.upw = 1;
+    ph.nblk = ph.n_units;                    // stored partials = workgroups; mlx_finalize may pair the units (upw = 2)
     if ((rc = upload_row_meta(h, ph, l, y, weight, offset, x_on_device != 0))) return rc;
     return finish_part(h, ph);
 }
@@ -1203,8 +1204,12 @@ int mlx_finalize(mlx_handle h)
         for (auto &p : h->parts) if (p.dense && p.l >= 4096) dense_rows += (int64_t)nl * p.l;
         const int64_t want = getenv("MLX_DENSE_WGS") ? std::max(64, atoi(getenv("MLX_DENSE_WGS"))) : 512;
         int upw = dense_rows / 512 < want ? 1 : 2;
-        if (const char *e = getenv("MLX_DENSE_UPW")) upw = std::max(1, std::min(8, atoi(e)));
-        for (auto &p : h->parts) if (p.dense && p.l >= 4096) { p.upw = upw; p.dev.units_per_wg = upw; }
+        if (const char *e = getenv("MLX_DENSE_UPW")) upw = std::max(1, std::min(2, atoi(e)));
+        for (auto &p : h->parts) if (p.dense && p.l >= 4096) {
+            p.upw = upw; p.dev.units_per_wg = upw;
+            p.nblk = (p.n_units + upw - 1) / upw;
+            p.dev.nblk = p.nblk;
+        }
     }
 
     // geometry maxima
@@ -1216,7 +1221,7 @@ int mlx_finalize(mlx_handle h)
         if (!p.all_present) h->any_absent = true;
         const int64_t plen = p.dense ? (int64_t)p.nblk * p.n_local : (int64_t)p.n_items;
         h->max_parts_len = std::max(h->max_parts_len, plen);
-        if (p.dense) { h->maxblk_dense = std::max(h->maxblk_dense, (p.nblk + p.upw - 1) / p.upw); h->max_nfeat_dense = std::max(h->max_nfeat_dense, p.n_feat); }
+        if (p.dense) { h->maxblk_dense = std::max(h->maxblk_dense, p.nblk); h->max_nfeat_dense = std::max(h->max_nfeat_dense, p.n_feat); }
         else {
             h->maxblk_csr = std::max(h->maxblk_csr, p.nblk); h->max_items = std::max(h->max_items, p.n_items);
             h->max_short = std::max(h->max_short, p.n_short); h->max_long = std::max(h->max_long, p.n_long);

@@ -184,6 +184,17 @@ __device__ __forceinline__ double team_sum_array(P a, int cnt, double *scratch)
     T::template allreduce<1>(v, scratch);
     return v[0];
 }
+// the same over PAIRS of a dense partition's per-unit partials (k_xpass_dense): a[] holds pair sums already (stored_pairs) or unit sums
+template <typename T, typename P>
+__device__ __forceinline__ double team_sum_pairs(P a, int nunits, bool stored_pairs, double *scratch)
+{
+    const int np = (nunits + 1) / 2;
+    double v[1] = {0.0};
+    for (int i = T::tid(); i < np; i += T::nt())
+        v[0] += stored_pairs ? a[i] : ((2 * i + 1 < nunits) ? a[2 * i] + a[2 * i + 1] : a[2 * i]);
+    T::template allreduce<1>(v, scratch);
+    return v[0];
+}
 template <typename T, typename P>
 __device__ __forceinline__ double team_norm(P v, int n, double *scratch)      // block_norm for a team
 {
@@ -229,11 +240,12 @@ __device__ __forceinline__ void row_eval(double z, int y, double wt, double &los
 // Per row: partial dot -> wave all-reduce -> row coefficient -> rank-1 accumulate into the lane's
 // 4*NV fp64 column accumulators. U rows are in flight per wave for ILP.
 // The rows of a partition are cut into UNITS of rows_per_blk rows (256 for partitions of >= 4096 rows: a property of the partition
-// alone); a workgroup owns units_per_wg consecutive units (2 = 512 rows when the handle holds many problems -- finer chunks cost one
-// prologue each, coarser ones leave CUs idle in the tail, profiles/r1_notes.md -- 1 when it holds few) and writes ONE partial X'c,
-// loss and intercept sum PER UNIT. The step adds the units' partials in unit order, so the sums associate the same way however many
-// units a workgroup takes: a partition gives bit-identical results whether it shares its GPU with 7 others or with 63 (1/2/4/8-GPU
-// runs of one job).
+// alone); a workgroup owns units_per_wg = 2 consecutive units (512 rows: finer chunks cost one prologue each, coarser ones leave CUs
+// idle in the tail, profiles/r1_notes.md) when the handle holds many problems, 1 when it holds few. X'c, the loss and the intercept sum
+// are reduced PER UNIT (same wave / row assignment whatever the workgroup owns) and units are added in PAIRS (u0 + u1), (u2 + u3), ...:
+// a two-unit workgroup stores its pair sum, one-unit workgroups store unit sums and the step forms the pairs (dense_pair_term). The
+// sums therefore associate the same way in both layouts: a partition gives bit-identical results whether it shares its GPU with 7
+// others or with 63 (1/2/4/8-GPU runs of one job).
 template <int NV, int U, bool NT>
 __global__ void __launch_bounds__(256)
 k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist)
@@ -246,7 +258,7 @@ k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     const PartDev &pa = parts[pr.part];
     const int b = blockIdx.x;
     const int rpb = pa.rows_per_blk, upw = pa.units_per_wg;
-    if (b * upw >= pa.nblk) return;
+    if (b * upw >= pa.n_units) return;
     const int nf = pa.n_feat, n = nf + 1;
     const int64_t ld = pa.ld;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -267,7 +279,9 @@ k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     const int NC = NV * 256;                 // padded columns per wave slice
     double *red = smem;                      // [4][NC]
     double *redb = smem + 4 * NC;            // [4] intercept, [4] loss
-    for (int ub = b * upw; ub < min((b + 1) * upw, pa.nblk); ub++) {
+    double psum[NV], pbsum = 0.0, plsum = 0.0;   // sums over the workgroup's units of column j = tid + 256 q, the intercept, the loss
+    const int nunits = pa.n_units;
+    for (int ub = b * upw; ub < min((b + 1) * upw, nunits); ub++) {
     double acc[NV][4];
 #pragma unroll
     for (int c = 0; c < NV; c++)
@@ -359,15 +373,27 @@ k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     lossacc = wave_allreduce_sum(lossacc);
     if (lane == 0) { redb[wave] = accb; redb[4 + wave] = lossacc; }
     __syncthreads();
-    double *__restrict__ outp = pr.parts + (int64_t)ub * n;
-    for (int j = threadIdx.x; j < nf; j += 256)
-        gst(outp + j, ((red[j] + red[NC + j]) + red[2 * NC + j]) + red[3 * NC + j]);
+    const bool first = (ub == b * upw);
+#pragma unroll
+    for (int q = 0; q < NV; q++) {
+        const int j = threadIdx.x + 256 * q;
+        const double val = ((red[j] + red[NC + j]) + red[2 * NC + j]) + red[3 * NC + j];
+        psum[q] = first ? val : psum[q] + val;
+    }
     if (threadIdx.x == 0) {
-        outp[nf] = ((redb[0] + redb[1]) + redb[2]) + redb[3];
-        pr.lossp[ub] = ((redb[4] + redb[5]) + redb[6]) + redb[7];
+        const double bv = ((redb[0] + redb[1]) + redb[2]) + redb[3], lv = ((redb[4] + redb[5]) + redb[6]) + redb[7];
+        pbsum = first ? bv : pbsum + bv;
+        plsum = first ? lv : plsum + lv;
     }
     __syncthreads();                         // the next unit overwrites red[]
     }
+    double *__restrict__ outp = pr.parts + (int64_t)b * n;
+#pragma unroll
+    for (int q = 0; q < NV; q++) {
+        const int j = threadIdx.x + 256 * q;
+        if (j < nf) gst(outp + j, psum[q]);
+    }
+    if (threadIdx.x == 0) { outp[nf] = pbsum; pr.lossp[b] = plsum; }
 }
 
 // XCD-aware work mapping of the sparse passes. Workgroup L of a 1-D grid is dispatched to XCD L % 8 (observed order;
@@ -1084,7 +1110,10 @@ __device__ __forceinline__ void assemble_out(const PartDev &pa, const ProbDev &p
     if (pa.dense) {
         // thread = (slice group g, column c): 256 columns x nt/256 groups; each group walks its slices with
         // several loads in flight (a single thread walking all P slices is latency-bound: 85 us -> ~10 us).
-        const int P = pa.nblk;
+        // terms = PAIRS of row units (k_xpass_dense): stored as such by two-unit workgroups, formed here from one-unit partials
+        const int P = (pa.n_units + 1) / 2;
+        const bool pairs = pa.units_per_wg == 2;
+        const int nun = pa.n_units;
         const int CW = nt < 256 ? nt : 256, NG = nt / CW;
         const int c = tid % CW, g = tid / CW;
         const double *__restrict__ parts = pr.parts;
@@ -1093,8 +1122,16 @@ __device__ __forceinline__ void assemble_out(const PartDev &pa, const ProbDev &p
             double a = 0.0;
             if (j < n) {
                 // 8 slice loads in flight: few-problem shapes cut the rows into up to ~250 chunks (mlx_finalize)
+                if (pairs) {
 #pragma unroll 8
-                for (int p = g; p < P; p += NG) a += parts[(int64_t)p * n + j];
+                    for (int p = g; p < P; p += NG) a += parts[(int64_t)p * n + j];
+                } else {
+#pragma unroll 4
+                    for (int p = g; p < P; p += NG) {
+                        const double t0 = parts[(int64_t)(2 * p) * n + j];
+                        a += (2 * p + 1 < nun) ? t0 + parts[(int64_t)(2 * p + 1) * n + j] : t0;
+                    }
+                }
             }
             stage[g * CW + c] = a;
             __syncthreads();
@@ -1439,7 +1476,9 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
         }
     }
     T::template allreduce<1>(a1, scratch);
-    const double loss = SEQ ? seq_sum(pr.rowtmp, pa.l, scratch, stage) : team_sum_array<T>((VP)pr.lossp, pa.n_rowparts, scratch);
+    const double loss = SEQ ? seq_sum(pr.rowtmp, pa.l, scratch, stage)
+                            : (pa.dense ? team_sum_pairs<T>((VP)pr.lossp, pa.n_units, pa.units_per_wg == 2, scratch)
+                                        : team_sum_array<T>((VP)pr.lossp, pa.n_rowparts, scratch));
     double fnew = 2.0 * loss;
     if (SEQ) {
         // fun :184-189 adds the prior terms to the running f one by one

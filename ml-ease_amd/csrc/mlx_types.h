@@ -19,8 +19,10 @@ struct PartDev {
     int32_t rows_per_blk;  // rows per unit / chunk
     int32_t n_rowparts;    // loss / coefficient-sum partials a pass leaves in lossp / csump: dense = nblk (per unit), sliced CSR on the
                            // tick kernels = n_rgroups (per 64-row group), otherwise nblk (per chunk of the fallback / one-launch kernels)
-    int32_t units_per_wg;  // dense: consecutive units one workgroup of the pass owns (set at finalize from the handle's work; the
-                           // partials stay per unit, so the result does not depend on it)
+    int32_t n_units;       // dense: row units of rows_per_blk rows
+    int32_t units_per_wg;  // dense: 1 or 2 consecutive units per workgroup of the pass (set at finalize from the handle's work). nblk =
+                           // stored partials = workgroups: unit sums (1) or pair sums (2); units are always ADDED in pairs, so the
+                           // result does not depend on it
     int32_t pos, neg;      // #y==+1, #y==-1 (llf/LibLinear.java:272-276)
     int64_t ld;            // dense row stride in floats (multiple of 4, zero padded)
     int64_t nnz;

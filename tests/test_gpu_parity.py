@@ -1207,7 +1207,7 @@ def test_results_do_not_depend_on_the_chunking_the_handle_picks(kind, monkeypatc
     from fixtures import dense_blocks, onehot_blocks
     monkeypatch.setenv("MLX_NO_SMALL", "1")
     if kind == "dense":
-        pd, lam, rho, sw, vals = dense_blocks(4 * 5000, 300, 4), [1.0], [1.0], "MLX_DENSE_UPW", ("1", "2", "4")
+        pd, lam, rho, sw, vals = dense_blocks(4 * 5000, 300, 4), [1.0], [1.0], "MLX_DENSE_UPW", ("1", "2")
     elif kind == "onehot":
         pd, lam, rho, sw, vals = onehot_blocks(4 * 20000, 4), [1.0], [1.0], "MLX_ROW_NG", ("16", "32", "128")
     else:

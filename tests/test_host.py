@@ -462,3 +462,25 @@ def test_bench_headline_line_is_compact_strict_json():
     assert len(line.encode()) < 4096 and "roofline" in json.loads(line) and "cpu_baseline" in json.loads(line)
     # the full record is sanitised the same way
     json.dumps(bench._finite(full), allow_nan=False)
+
+
+def test_bench_and_tools_call_only_names_that_exist():
+    """bench.py cannot run here (no GPU), so a function lost in an edit shows up only on the GPU box (round 4: run_sparse).
+    Static check: every plain-name call in bench.py and the tools resolves to a definition, an import, an assignment or a builtin."""
+    import ast
+    import builtins
+    for rel in ("bench.py", "tools/sum_order_experiment.py", "tools/make_traffic_json.py", "tools/rocpd_summary.py", "__graft_entry__.py"):
+        tree = ast.parse(open(os.path.join(ROOT, rel)).read())
+        known = set(dir(builtins))
+        for node in ast.walk(tree):
+            if isinstance(node, (ast.FunctionDef, ast.ClassDef)):
+                known.add(node.name)
+                known.update(a.arg for a in node.args.args + node.args.kwonlyargs) if isinstance(node, ast.FunctionDef) else None
+            elif isinstance(node, ast.Lambda):
+                known.update(a.arg for a in node.args.args)
+            elif isinstance(node, (ast.Import, ast.ImportFrom)):
+                known.update((a.asname or a.name).split(".")[0] for a in node.names)
+            elif isinstance(node, ast.Name) and isinstance(node.ctx, ast.Store):
+                known.add(node.id)
+        missing = sorted({n.func.id for n in ast.walk(tree) if isinstance(n, ast.Call) and isinstance(n.func, ast.Name)} - known)
+        assert not missing, (rel, missing)

@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
-"""Copies the summaries of tools/profile_round3.sh from gpurun_out/prof_<tag>/ into profiles/<tag>_* and derives the
-HBM-traffic ratios bench.py quotes:
+"""Copies the summaries of tools/profile_round4.sh from gpurun_out/prof_<tag>/ into profiles/<tag>_* and derives the HBM-traffic ratios
+bench.py quotes:
 
-    profiles/traffic.json          dense leg: (2 x FETCH_SIZE + WRITE_SIZE) of k_xpass_dense / its algorithmic bytes
-    profiles/traffic_sparse.json   sparse leg: the same per kernel (row pass, column pass, step phases) and for the whole tick
+    profiles/traffic.json          dense leg: (2 x FETCH_SIZE + WRITE_SIZE) of k_xpass_dense / the algorithmic bytes of THE SAME launches
+    profiles/traffic_sparse.json   sparse leg: the same per kernel class (row pass, column pass, step phases) and for the whole tick
 
-FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for gfx950: the counter tallies
-128-byte requests at 64 bytes for wide coalesced reads. That calibration was made on 16-byte-per-lane streaming reads
-(the dense kernel); the sparse kernels read 8 bytes per lane (packs) and 16 (staging) -- uncalibrated widths, so both the
-raw and the doubled figure are recorded there.
+Numerator and denominator come from ONE invocation: profile_round4.sh runs `rocprofv3 --pmc <counter> -- python bench.py ...
+--full-json X`, and X's all_launches.alg_bytes / launches are that very process's launches (round 3 divided the counters of a
+`--no-profile` run by the algorithmic bytes of another run that also replayed its iterations: 0.568 bytes per algorithmic byte,
+impossible for a 4 GB stream; the judge's finding). The launch counts of the two sources must agree and the dense ratio must lie in
+[0.95, 1.5], or this script stops.
 
-    python tools/make_traffic_json.py r2
+FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for gfx950: the counter tallies 128-byte
+requests at 64 bytes for wide coalesced reads. That calibration was made on 16-byte-per-lane streaming reads (the dense kernel); the
+sparse kernels read 8 bytes per lane (packs) and 16 (staging) -- uncalibrated widths, so both the raw and the doubled figure are
+recorded there. FETCH_SIZE / WRITE_SIZE are reported in KB by this rocprofv3.
+
+    python tools/make_traffic_json.py r4
 """
 import json
 import os
@@ -31,50 +37,66 @@ def pmc_sums(path, counter):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
     for f in sorted(os.listdir(src)):
-        shutil.copy(os.path.join(src, f), os.path.join(dst, "%s_%s" % (tag, f)))
-    last = lambda p: json.loads(open(os.path.join(src, p)).read().strip().splitlines()[-1])
+        if os.path.isfile(os.path.join(src, f)):
+            shutil.copy(os.path.join(src, f), os.path.join(dst, "%s_%s" % (tag, f)))
+    full = lambda p: json.load(open(os.path.join(src, p)))
     # ---- dense
-    bd = last("bench_dense_short.json")
     fe, wr = pmc_sums(os.path.join(src, "dense_pmc_fetch.txt"), "FETCH_SIZE"), pmc_sums(os.path.join(src, "dense_pmc_write.txt"), "WRITE_SIZE")
     kd = next(k for k in fe if "k_xpass_dense" in k)
-    hbm = 2.0 * fe[kd][1] + wr[kd][1]
-    alg = bd["all_launches"]["alg_bytes"]
-    json.dump({"kernel": "k_xpass_dense<4,4>", "command": "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --loglik-iters 0 --no-sparse --no-sweep --no-profile",
-               "launches": fe[kd][0], "FETCH_SIZE_bytes": fe[kd][1], "WRITE_SIZE_bytes": wr[kd][1],
+    kw = next(k for k in wr if "k_xpass_dense" in k)
+    bf, bw = full("dense_pmc_fetch_full.json"), full("dense_pmc_write_full.json")
+    for b, (n, _), what in ((bf, fe[kd], "FETCH_SIZE"), (bw, wr[kw], "WRITE_SIZE")):
+        assert b["all_launches"]["launches"] == n, "%s pass: rocprofv3 saw %d k_xpass_dense dispatches, bench.py counted %d launches" % (
+            what, n, b["all_launches"]["launches"])
+    assert bf["all_launches"]["alg_bytes"] == bw["all_launches"]["alg_bytes"], "the two PMC passes did not run the same launches"
+    alg = bf["all_launches"]["alg_bytes"]
+    hbm = 2.0 * fe[kd][1] + wr[kw][1]
+    ratio = hbm / alg
+    assert 0.95 <= ratio <= 1.5, "dense HBM bytes per algorithmic byte = %.4f: outside [0.95, 1.5] -- mismatched inputs?" % ratio
+    json.dump({"kernel": "k_xpass_dense<4,4>",
+               "command": "rocprofv3 --pmc {FETCH_SIZE | WRITE_SIZE} --kernel-trace -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline "
+                          "--loglik-iters 0 --no-sparse --no-sweep --no-config1 --no-gram --full-json <same run>",
+               "launches": fe[kd][0], "FETCH_SIZE_bytes": fe[kd][1], "WRITE_SIZE_bytes": wr[kw][1],
                "fetch_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests at 64 B for wide coalesced reads; MI355X_MICROARCH.md, HBM section)",
-               "hbm_bytes": hbm, "alg_bytes_same_launches": alg, "hbm_bytes_per_alg_byte": round(hbm / alg, 4),
-               "source": ["profiles/%s_dense_pmc_fetch.txt" % tag, "profiles/%s_dense_pmc_write.txt" % tag]},
+               "hbm_bytes": hbm, "alg_bytes_same_launches": alg, "hbm_bytes_per_alg_byte": round(ratio, 4),
+               "raw_fetch_plus_write_per_alg_byte": round((fe[kd][1] + wr[kw][1]) / alg, 4),
+               "source": ["profiles/%s_dense_pmc_fetch.txt" % tag, "profiles/%s_dense_pmc_write.txt" % tag,
+                          "profiles/%s_dense_pmc_fetch_full.json" % tag, "profiles/%s_dense_pmc_write_full.json" % tag]},
               open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     # ---- sparse
-    bs = last("bench_sparse_only.json")
     fe, wr = pmc_sums(os.path.join(src, "sparse_pmc_fetch.txt"), "FETCH_SIZE"), pmc_sums(os.path.join(src, "sparse_pmc_write.txt"), "WRITE_SIZE")
+    bs, bs2 = full("sparse_pmc_fetch_full.json"), full("sparse_pmc_write_full.json")
     alg = bs["all_launches"]["alg_bytes_row_plus_column"]
+    assert alg == bs2["all_launches"]["alg_bytes_row_plus_column"], "the two sparse PMC passes did not run the same launches"
     per, tot_raw, tot_x2 = {}, 0.0, 0.0
     for keys, label in ((("k_rowpass_lds", "k_rowcold"), "row pass"), (("k_colpass_lds",), "column pass"), (("k_step_a",), "step A"),
                         (("k_step_b",), "step B"), (("k_step_c(",), "step C"), (("k_step_commit",), "step commit")):
         kf = [k for k in fe if any(key in k for key in keys)]
-        kw = [k for k in wr if any(key in k for key in keys)]
+        kw_ = [k for k in wr if any(key in k for key in keys)]
         f = sum(fe[k][1] for k in kf)
-        w = sum(wr[k][1] for k in kw)
+        w = sum(wr[k][1] for k in kw_)
         n = sum(fe[k][0] for k in kf if keys[0] in k)        # (the cold-slice launch in front of the row kernel is part of the row pass)
         per[label] = {"launches": n, "FETCH_SIZE_bytes": f, "WRITE_SIZE_bytes": w, "hbm_bytes_raw": f + w, "hbm_bytes_fetch_x2": 2 * f + w}
         tot_raw += f + w
         tot_x2 += 2 * f + w
+    # launch count: with two tick streams every tick launches each class twice (once per half)
     half = alg / 2.0
     for label in ("row pass", "column pass"):
         per[label]["alg_bytes"] = half
         per[label]["raw_per_alg_byte"] = round(per[label]["hbm_bytes_raw"] / half, 4)
         per[label]["fetch_x2_per_alg_byte"] = round(per[label]["hbm_bytes_fetch_x2"] / half, 4)
-    json.dump({"command": "python bench.py --sparse-only --sparse-cpu-sample 0", "workload": bs["workload"],
-               "alg_bytes_row_plus_column_all_launches": alg,
+    assert 0.3 <= tot_raw / alg <= 4.0, "sparse HBM bytes per algorithmic byte = %.3f: mismatched inputs?" % (tot_raw / alg)
+    json.dump({"command": "rocprofv3 --pmc {FETCH_SIZE | WRITE_SIZE} --kernel-trace -- python bench.py --sparse-only --sparse-cpu-sample 0 --full-json <same run>",
+               "workload": bs["workload"], "alg_bytes_row_plus_column_all_launches": alg,
                "note": "algorithmic bytes = SURVEY 8(d) B_pass = nnz*4 + 8l + 8n per pass and active problem (int32 ids); the kernels read "
                        "uint16 ids, so the passes can move fewer bytes than that; the step's n-vector streams count as zero algorithmic bytes",
                "hbm_bytes_per_alg_byte": {"raw": round(tot_raw / alg, 4), "fetch_x2": round(tot_x2 / alg, 4)},
-               "per_kernel": per, "source": ["profiles/%s_sparse_pmc_fetch.txt" % tag, "profiles/%s_sparse_pmc_write.txt" % tag]},
+               "per_kernel": per, "source": ["profiles/%s_sparse_pmc_fetch.txt" % tag, "profiles/%s_sparse_pmc_write.txt" % tag,
+                                             "profiles/%s_sparse_pmc_fetch_full.json" % tag]},
               open(os.path.join(dst, "traffic_sparse.json"), "w"), indent=1)
     print(open(os.path.join(dst, "traffic.json")).read())
     print(open(os.path.join(dst, "traffic_sparse.json")).read())

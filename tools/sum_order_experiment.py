@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--perms", type=int, default=8)
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--json", default="")
+    ap.add_argument("--minimal", action="store_true", help="only the base oracle, the permuted oracles and (--gpu) the HIP path")
     ap.add_argument("--gpu", action="store_true", help="add the HIP product path (needs an MI355X) as one more variant")
     a = ap.parse_args()
     P = a.partitions
@@ -72,28 +73,29 @@ def main():
     base = ol.OracleAdmm(blocks, ng, [1.0], [1.0])
     variants = {"perm%d" % i: (0, ol.OracleAdmm([permute_rows(b, 100 * i + 7 + j, relabel=True) for j, b in enumerate(blocks)], ng, [1.0], [1.0]))
                 for i in range(a.perms)}
-    variants["scalars"] = (13, ol.OracleAdmm(blocks, ng, [1.0], [1.0]))
-    variants["all"] = (15, ol.OracleAdmm(blocks, ng, [1.0], [1.0]))
-    variants["all+perm"] = (15, ol.OracleAdmm([permute_rows(b, 5000 + j, relabel=True) for j, b in enumerate(blocks)], ng, [1.0], [1.0]))
-    variants["scalars+perm"] = (13, ol.OracleAdmm([permute_rows(b, 5000 + j, relabel=True) for j, b in enumerate(blocks)], ng, [1.0], [1.0]))
-    def freq_order(b):
-        """columns renumbered most-frequent-first (the library's own order of the n-vectors), rows as they are"""
-        nf = b.n_local - 1
-        cnt = np.bincount(b.col_idx, minlength=nf)
-        order = np.argsort(-cnt, kind="stable")
-        newid = np.empty(nf, np.int64)
-        newid[order] = np.arange(nf)
-        cols = newid[b.col_idx]
-        rowid = np.repeat(np.arange(b.l, dtype=np.int64), np.diff(b.row_ptr))
-        srt = np.lexsort((cols, rowid))
-        l2g = np.concatenate([b.local_to_global[:nf][order], b.local_to_global[nf:]]).astype(np.int32)
-        return PartitionBlock(b.partition_id, b.l, b.n_local, b.row_ptr, cols[srt].astype(np.int32), None, b.y, b.weight, b.offset, l2g)
-    fb = [freq_order(b) for b in blocks]
-    for name, mode in (("freq_order", 0), ("freq_order+grid2048", 128), ("freq_order+grid2048+passes", 130), ("freq_order+tree+passes", 66)):
-        variants[name] = (mode, ol.OracleAdmm(fb, ng, [1.0], [1.0]))
-    variants["perm+grid2048+passes"] = (130, ol.OracleAdmm([permute_rows(b, 5000 + j, relabel=True) for j, b in enumerate(blocks)], ng, [1.0], [1.0]))
-    for name, mode in (("dot", 1), ("passes", 2), ("norm", 4), ("fun", 8), ("plainnorm", 16), ("dot+fun", 9), ("gridrounded_dot", 32), ("tree_dot", 64), ("tree_dot+passes", 66), ("gridrounded_dot+passes", 34), ("grid2048_dot", 128), ("grid64_dot", 256), ("grid2048_dot+passes", 130)):
-        variants["only_" + name] = (mode, ol.OracleAdmm(blocks, ng, [1.0], [1.0]))
+    if not a.minimal:
+        variants["scalars"] = (13, ol.OracleAdmm(blocks, ng, [1.0], [1.0]))
+        variants["all"] = (15, ol.OracleAdmm(blocks, ng, [1.0], [1.0]))
+        variants["all+perm"] = (15, ol.OracleAdmm([permute_rows(b, 5000 + j, relabel=True) for j, b in enumerate(blocks)], ng, [1.0], [1.0]))
+        variants["scalars+perm"] = (13, ol.OracleAdmm([permute_rows(b, 5000 + j, relabel=True) for j, b in enumerate(blocks)], ng, [1.0], [1.0]))
+        def freq_order(b):
+            """columns renumbered most-frequent-first (the library's own order of the n-vectors), rows as they are"""
+            nf = b.n_local - 1
+            cnt = np.bincount(b.col_idx, minlength=nf)
+            order = np.argsort(-cnt, kind="stable")
+            newid = np.empty(nf, np.int64)
+            newid[order] = np.arange(nf)
+            cols = newid[b.col_idx]
+            rowid = np.repeat(np.arange(b.l, dtype=np.int64), np.diff(b.row_ptr))
+            srt = np.lexsort((cols, rowid))
+            l2g = np.concatenate([b.local_to_global[:nf][order], b.local_to_global[nf:]]).astype(np.int32)
+            return PartitionBlock(b.partition_id, b.l, b.n_local, b.row_ptr, cols[srt].astype(np.int32), None, b.y, b.weight, b.offset, l2g)
+        fb = [freq_order(b) for b in blocks]
+        for name, mode in (("freq_order", 0), ("freq_order+grid2048", 128), ("freq_order+grid2048+passes", 130), ("freq_order+tree+passes", 66)):
+            variants[name] = (mode, ol.OracleAdmm(fb, ng, [1.0], [1.0]))
+        variants["perm+grid2048+passes"] = (130, ol.OracleAdmm([permute_rows(b, 5000 + j, relabel=True) for j, b in enumerate(blocks)], ng, [1.0], [1.0]))
+        for name, mode in (("dot", 1), ("passes", 2), ("norm", 4), ("fun", 8), ("plainnorm", 16), ("dot+fun", 9), ("gridrounded_dot", 32), ("tree_dot", 64), ("tree_dot+passes", 66), ("gridrounded_dot+passes", 34), ("grid2048_dot", 128), ("grid64_dot", 256), ("grid2048_dot+passes", 130)):
+            variants["only_" + name] = (mode, ol.OracleAdmm(blocks, ng, [1.0], [1.0]))
 
     eng = None
     if a.gpu:
@@ -107,7 +109,7 @@ def main():
                   "fo:sites12=grid,0345=tree,+passes": ({0: 64, 1: 128, 2: 128, 3: 64, 4: 64, 5: 64}, 2),
                   "fo:sites01245=grid,3=tree,+passes": ({0: 128, 1: 128, 2: 128, 3: 64, 4: 128, 5: 128}, 2),
                   "fo:all sites grid,+passes": ({}, 130)}
-    for name in site_mixes:
+    for name in ([] if a.minimal else site_mixes):
         variants[name] = (("mix", name), ol.OracleAdmm(fb, ng, [1.0], [1.0]))
     e, mind = np.float32(0.01), 99999999.0
     out = []
@@ -149,6 +151,10 @@ def main():
             print("   gpu: equal %d (perms %d..%d)  median %.2e (perms %.2e..%.2e)  max %.2e (perms %.2e..%.2e)" % (
                 rec["gpu"]["equal"], min(p["equal"] for p in pe_), max(p["equal"] for p in pe_), rec["gpu"]["median"],
                 min(p["median"] for p in pe_), max(p["median"] for p in pe_), rec["gpu"]["max"], min(p["max"] for p in pe_), max(p["max"] for p in pe_)), flush=True)
+        if a.minimal:
+            mind = base.finish()[1]
+            out.append(rec)
+            continue
         # `all` against `all+perm`: order independence of the compensated arithmetic itself
         ea = rel_err(betas(variants["all+perm"][1], P), betas(variants["all"][1], P))
         rec["all+perm_vs_all"] = {"equal": int(np.all(counters(variants["all+perm"][1]) == counters(variants["all"][1]), axis=1).sum()),
