@@ -87,9 +87,7 @@ struct mlx_context {
     int step_threads = 256;
     int step_ch = 2048, step_max_nwg = 1;   // multi-workgroup CSR step: columns per workgroup, chunks of the widest CSR problem
     int cold_groups = 0;                    // > 0: row groups of the widest partition with cold column slices (k_rowcold launch)
-    bool seq_dots = true;                   // CSR step: d.Hd and r.r as grid-rounded sums (lookback_grid in mlx_kernels.hip); MLX_SEQ_DOTS=0: plain trees
-    unsigned step_seq = 0;                  // launch sequence number of the step phases (the look-back's tag; never 0)
-    int *d_stepctl = nullptr;               // [0] != 0: a look-back timed out
+    bool seq_dots = true;                   // CSR step: d.Hd and r.r as grid-rounded sums (grid_of_sum in mlx_kernels.hip); MLX_SEQ_DOTS=0: plain trees
 
     double *d_Z = nullptr;
     float *d_z32 = nullptr, *d_u = nullptr, *d_B = nullptr, *d_UPX = nullptr;
@@ -273,9 +271,8 @@ void launch_step(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
     mlxk_tron_step(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->step_threads, h->d_done);
     // (launching A, B, C per group of problems so that Hd / r' / s stay in the memory-side cache between phases was measured: every
     // group size is slower than one launch per phase, profiles/r3_notes.md)
-    if (++h->step_seq >= (1u << 30)) h->step_seq = 1;
     for (int which = 0; which < 4; which++)
-        mlxk_step_phase(h->stream, which, h->d_parts, h->d_probs, qcsr, nqc, h->step_ch, h->step_max_nwg, h->d_done, h->seq_dots, h->step_seq, h->d_stepctl);
+        mlxk_step_phase(h->stream, which, h->d_parts, h->d_probs, qcsr, nqc, h->step_ch, h->step_max_nwg, h->d_done, h->seq_dots);
 }
 
 // One-launch solves of small CSR problems (k_solve_small): launch, wait, relaunch while a problem needs more than
@@ -408,14 +405,6 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
     }
     HIPCHECK(h, hipStreamSynchronize(sA));
     HIPCHECK(h, hipGetLastError());
-    if (h->seq_dots && nqc > 0) {
-        int ctl = 0;
-        HIPCHECK(h, hipMemcpy(&ctl, h->d_stepctl, sizeof ctl, hipMemcpyDeviceToHost));
-        if (ctl != 0) {
-            hipMemset(h->d_stepctl, 0, sizeof(int));
-            return fail(h, MLX_ERR_HIP, "TRON step: a look-back over a problem's column chunks timed out (MLX_SEQ_DOTS=0 runs the step without it)");
-        }
-    }
     if (ticks_out) *ticks_out = ticks;
     return MLX_OK;
 }
@@ -1238,7 +1227,7 @@ int mlx_finalize(mlx_handle h)
     if (h->csr_small && getenv("MLX_NO_SMALL_LDS") == nullptr && !h->faithful) {
         int64_t need = 0;
         for (auto &p : h->parts)
-            if (!p.dense) need = std::max<int64_t>(need, 8LL * p.n_local + 3LL * p.l + p.n_items + 2LL * p.nblk);
+            if (!p.dense) need = std::max<int64_t>(need, 8LL * p.n_local + 3LL * p.l + p.n_items + 2LL * (h->csr_sell ? p.n_rgroups : p.nblk));
         if (need > 0 && need <= 18 * 1024) h->small_lds_doubles = (int)need;      // 144 KiB of the 160 KiB LDS, next to 9 KiB static
         // ... and the partition's own arrays when they fit as well (k_solve_small<.., XL>): narrow ids, see the kernel
         if (h->small_lds_doubles > 0 && getenv("MLX_NO_SMALL_X") == nullptr) {
@@ -1247,7 +1236,7 @@ int mlx_finalize(mlx_handle h)
             const int idsz = maxdim <= 256 ? 1 : 2;
             int64_t total = 0;
             for (auto &p : h->parts) if (!p.dense) {
-                const int64_t vec = 8LL * (8LL * p.n_local + 3LL * p.l + p.n_items + 2LL * p.nblk);
+                const int64_t vec = 8LL * (8LL * p.n_local + 3LL * p.l + p.n_items + 2LL * (h->csr_sell ? p.n_rgroups : p.nblk));
                 const int64_t xb = 4LL * ((int64_t)p.l + 1 + 2LL * p.n_items + 1 + p.n_feat + 1) + (p.hasval ? 8LL * p.nnz : 0) + 2LL * idsz * p.nnz + 9LL * p.l;
                 total = std::max(total, vec + xb + 16);
             }
@@ -1256,11 +1245,11 @@ int mlx_finalize(mlx_handle h)
             }
         }
     }
-    // Loss / coefficient-sum partials of a pass (lossp / csump): the sliced row pass of the tick kernels leaves one per 64-row group
-    // (a function of the partition alone), every other kernel one per row chunk / unit
+    // Loss / coefficient-sum partials of a pass (lossp / csump): on sliced CSR partitions one per 64-row group (a function of the
+    // partition alone; the one-launch solver leaves its single sum in slot 0 and zeroes the rest), otherwise one per row chunk / unit
     for (auto &p : h->parts) {
         p.dev.nblk = p.nblk;
-        p.dev.n_rowparts = (!p.dense && h->csr_sell && !h->csr_small) ? p.n_rgroups : p.nblk;
+        p.dev.n_rowparts = (!p.dense && h->csr_sell) ? p.n_rgroups : p.nblk;
     }
     std::vector<PartDev> pd(np);
     for (int k = 0; k < np; k++) pd[k] = h->parts[k].dev;
@@ -1314,7 +1303,7 @@ int mlx_finalize(mlx_handle h)
     auto step_nwg = [&](int n_local) { return (size_t)((n_local + h->step_ch - 1) / h->step_ch); };
     auto vec_bytes = [&](int n_local, int l, int64_t plen, int nblk, bool dense) {
         return 8 * carve_size((size_t)n_local) + (dense ? 2 : 3) * carve_size((size_t)l) + carve_size((size_t)plen) + 2 * carve_size((size_t)nblk) +
-               (dense ? 0 : carve_size((size_t)n_local) + 3 * carve_size(step_nwg(n_local) * STEP_NP) + carve_size(2 * step_nwg(n_local))) +
+               (dense ? 0 : carve_size((size_t)n_local) + 3 * carve_size(step_nwg(n_local) * STEP_NP)) +
                (h->faithful ? carve_size((size_t)l) + carve_size((size_t)n_local) : 0);
     };
     int scratch_blk = h->maxblk_csr;                       // partial sums of the widest partition (dense: units, not workgroups)
@@ -1338,7 +1327,6 @@ int mlx_finalize(mlx_handle h)
             pr.coef = carve((size_t)l);
             pr.rb[0] = pr.r; pr.rb[1] = carve((size_t)n_local);
             pr.pA = carve(step_nwg(n_local) * STEP_NP); pr.pB = carve(step_nwg(n_local) * STEP_NP); pr.pC = carve(step_nwg(n_local) * STEP_NP);
-            pr.lb = reinterpret_cast<unsigned long long *>(carve(2 * step_nwg(n_local)));
         }
         if (h->faithful) { pr.rowtmp = carve((size_t)l); pr.c0f = carve((size_t)n_local); }
         pr.parts = carve((size_t)plen);
@@ -1365,8 +1353,6 @@ int mlx_finalize(mlx_handle h)
 
     if ((rc = dev_alloc(h, &h->d_done, 1))) return rc;
     HIPCHECK(h, hipMemset(h->d_done, 0, sizeof(int)));
-    if ((rc = dev_alloc(h, &h->d_stepctl, 1))) return rc;
-    HIPCHECK(h, hipMemset(h->d_stepctl, 0, sizeof(int)));
 
     // c0 = X' t0: one EVAL pass at w = 0 on the first problem of every partition
     std::vector<int> qfirst_d, qfirst_c, qfirst_all;

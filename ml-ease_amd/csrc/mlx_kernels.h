@@ -18,10 +18,9 @@ void mlxk_tron_step(hipStream_t st, const PartDev *parts, ProbDev *probs, const 
                     int *done_counter);
 // the same for CSR problems, split over column chunks of `ch` columns (max_nwg chunks for the widest problem):
 // four launches per tick, which = 0 (A), 1 (B), 2 (C), 3 (commit)
-// emu: the dots Tron.dot computes sequentially (d.Hd, r.r) as grid-rounded sums with a look-back over the problem's chunks
-// (seq = the handle's launch sequence number, never 0: the look-back's tag; ctl[0] != 0 afterwards = a look-back timed out)
+// emu: the dots Tron.dot computes sequentially (d.Hd, r.r) as grid-rounded sums (grid_of_sum in mlx_kernels.hip)
 void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int ch,
-                     int max_nwg, int *done_counter, bool emu, unsigned seq, int *ctl);
+                     int max_nwg, int *done_counter, bool emu);
 // whole solves of small CSR problems in one launch (one workgroup per problem runs the tick loop)
 void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int first, bool hasval,
                       int max_ticks, int *done_counter, int lds_doubles, bool faithful, int xl, int lds_bytes_xl);

@@ -807,19 +807,26 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
             sell_lds_first<HASVAL, NT, GPW, KP>(acc, rs_idx, rs_val, base, L4, k, lane, vs, slw);
     }
     // ---- cold slices, unless k_rowcold (launched just before) left their sums in coef[]
+    // (inline, the cold sum runs in accumulators of its own and joins the hot sum once, as k_rowcold's does through coef[]: a row's sum
+    // is the same bits whichever way the handle's chunking sends it -- MLX_ROW_NG / DESIGN.md section 8)
     const bool add_cold = cold_sep && ncs > nhs;
-    if (!cold_sep) {
+    if (!cold_sep && ncs > nhs) {
+        double accc[GPW];
+#pragma unroll
+        for (int i = 0; i < GPW; i++) accc[i] = 0.0;
         for (int sl = nhs; sl < ncs; sl++) {
             offsets(sl);
             const double *__restrict__ src = v + (int64_t)nhs * slw + (int64_t)(sl - nhs) * 65535;
             // (GPW gathers x 4 in flight; 8 groups, or 4 valued ones, go in two halves: their 32 results do not fit beside the rest)
             constexpr int NIH = (GPW > 4 || (HASVAL && GPW > 2)) ? GPW / 2 : GPW;
             for (int k = 0; k < kmax; k++) {
-                sell_gather_round<HASVAL, NT, NIH>(acc, rs_idx, rs_val, base, L4, k, lane, src);
-                if (NIH < GPW) sell_gather_round<HASVAL, NT, NIH>(acc + NIH, rs_idx, rs_val, base + NIH, L4 + NIH, k, lane, src);
+                sell_gather_round<HASVAL, NT, NIH>(accc, rs_idx, rs_val, base, L4, k, lane, src);
+                if (NIH < GPW) sell_gather_round<HASVAL, NT, NIH>(accc + NIH, rs_idx, rs_val, base + NIH, L4 + NIH, k, lane, src);
             }
             PT_MARK(4);
         }
+#pragma unroll
+        for (int i = 0; i < GPW; i++) acc[i] = acc[i] + accc[i];
     }
     // row maps: the loads of (up to) four of the wave's rows are issued before the first is used (clamped, unconditional)
     // The loss and the coefficient sum (the intercept's column of X'c) leave the kernel as ONE partial per 64-row GROUP -- a wave
@@ -1683,66 +1690,36 @@ __device__ __forceinline__ void step_gather(const double *__restrict__ px, int n
 
 
 // ---- grid-rounded dots: what Tron.dot's SEQUENTIAL loop does to the small terms, without its dependency chain -------------------
-// `for (i) p += a[i]*b[i]` (bw/Tron.java:204-213) adds every term to a running sum that is already large after the first few hundred
+// `for (i) p += a[i]*b[i]` (bw/Tron.java:204-213) adds every term to a running sum that is already large after the first few dozen
 // (hot) columns: the term's bits below the running sum's ulp are rounded away on the spot. That rounding is a property of (term,
 // binade of the running sum), hardly of the order of the terms, so every row / feature order the reference may see reproduces almost
-// the same sum -- while a tree (or an exact sum) keeps those bits and lands 50-100 ulp away, enough to leave the reference's own
-// family of trajectories on one-hot data (measured: tools/sum_order_experiment.py, profiles/r4_notes.md; counters equal to the
-// oracle's in 58-65 of 96 full-size solves with tree dots, 67-77 for the oracle on permuted rows, 74-82 with this).
-// Here: the chunk's terms stay in registers; its raw sum is published as an 8-byte {tag, float} granule (relaxed agent-scope store:
-// write-through, no fence); the workgroup reads the granules of the chunks BEFORE it in the same problem (decoupled look-back: they
-// were dispatched earlier, so this cannot deadlock), takes the binade of that prefix, rounds its terms to that binade's ulp -- the
-// magic-constant trick (x + 1.5 * 2^52 u) - 1.5 * 2^52 u, exactly what the FPU does to x when it is added to a sum of that size --
-// and sums the rounded terms (all multiples of u: the tree is exact). The first chunk of a problem is not rounded (the running sum
-// starts at 0). The next launch adds the chunks' sums in chunk order as before. Results are deterministic (fixed trees, fixed
-// values); the tag is the handle's launch sequence number, so a granule of an earlier launch never matches.
-#define LB_SPIN_LIMIT (1 << 22)
-__device__ __forceinline__ double lookback_grid(unsigned long long *__restrict__ lb, int wg, int nwg, unsigned tag, double agg,
-                                                double *stage /* LDS [STEP_T] */, int *__restrict__ ctl)
+// the same sum -- while a tree (or an exact, compensated sum) keeps those bits and lands 50-100 ulp away: enough to leave the
+// reference's own family of TRON trajectories on one-hot data. Measured (tools/sum_order_experiment.py, profiles/r4_notes.md; solves
+// of full-size configs[2] partitions whose TRON counters equal the oracle's): oracle on permuted rows 253-269 of 384, this library
+// with tree dots 200, with compensated dots fewer still, with the dots below 242.
+// Every workgroup of a problem first adds the terms of the problem's first STEP_HEAD columns (the hottest: library ids are
+// frequency-sorted) -- redundantly, same tree, same value in every workgroup, a few KB of L2 hits -- and takes the ulp u of that head
+// sum's binade. Terms of the later columns are rounded to a multiple of u before they are added: the magic-constant form
+// (x + 1.5 * 2^52 u) - 1.5 * 2^52 u, exactly what the FPU does to x when it is added to a sum of that size. Sums of multiples of u
+// are exact, so the trees that follow add no rounding of their own. (The grid of the running sum after the first 64 / 256 / 2048 terms,
+// or of the true prefix at every 2048-column chunk, all follow the oracle equally well on CPU models of this arithmetic; the head
+// sum needs no exchange between workgroups. A first version published chunk sums through agent-scope granules and looked back over
+// them: same parity, 17 % of the sparse leg's throughput.)
+#define STEP_HEAD 256
+__device__ __forceinline__ double grid_of_sum(double h)
 {
-    typedef unsigned long long u64;
-    const int tid = threadIdx.x;
-    if (tid == 0 && wg + 1 < nwg)
-        __hip_atomic_store(lb + wg, ((u64)tag << 32) | (u64)__float_as_uint((float)agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (wg == 0) return 0.0;
-    double pre = 0.0;
-    for (int c0 = 0; c0 < wg; c0 += STEP_T) {
-        const int c = c0 + tid;
-        double v = 0.0;
-        if (c < wg) {
-            u64 g = 0;
-            int spins = 0;
-            for (;;) {
-                g = __hip_atomic_load(lb + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((unsigned)(g >> 32) == tag || ++spins >= LB_SPIN_LIMIT) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
-            if ((unsigned)(g >> 32) == tag) v = (double)__uint_as_float((unsigned)g);
-            else ctl[0] = 1;                                  // the host fails the solve: a predecessor never published
-        }
-        __syncthreads();
-        stage[tid] = v;
-        __syncthreads();
-        if (tid == 0) { const int cnt = min(STEP_T, wg - c0); for (int i = 0; i < cnt; i++) pre += stage[i]; }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double u = 0.0;
-        const double ap = fabs(pre);
-        if (ap > 0.0 && ap < 1e300) { int e; (void)frexp(ap, &e); u = ldexp(1.0, e - 53); }      // ap in [2^(e-1), 2^e): ulp = 2^(e-53)
-        stage[0] = u;
-    }
-    __syncthreads();
-    const double u = stage[0];
-    __syncthreads();
-    return u;
+    const double ah = fabs(h);
+    if (!(ah > 0.0) || !(ah < 1e300)) return 0.0;
+    int e;
+    (void)frexp(ah, &e);                                       // ah in [2^(e-1), 2^e): ulp = 2^(e-53)
+    return ldexp(1.0, e - 53);
 }
-// x as the FPU leaves it when it is added to a running sum whose ulp is u (round to nearest multiple of u, ties to even)
+// x as the FPU leaves it when it is added to a running sum whose ulp is u (round to nearest multiple of u, ties to even); u = 0: x
 __device__ __forceinline__ double round_to_grid(double x, double u)
 {
 #pragma clang fp contract(off)
     const double magic = 6755399441055744.0 * u;              // 1.5 * 2^52 * u
-    return (fabs(x) < 1125899906842624.0 * u) ? (x + magic) - magic : x;      // (|x| >= 2^50 u: x is a multiple of u/4 at most bits away: leave it)
+    return (fabs(x) < 1125899906842624.0 * u) ? (x + magic) - magic : x;      // (|x| >= 2^50 u, or u = 0: x as it is)
 }
 
 // sqrt of a sum of squares gathered in an update loop; a sum that overflowed (or is NaN) is reported as NaN so that the
@@ -1765,11 +1742,10 @@ __device__ __forceinline__ bool step_geom(const PartDev &pa, int ch, StepGeom &g
 // ---- phase A ------------------------------------------------------------------------------------
 template <bool EMU>
 __global__ void __launch_bounds__(STEP_T)
-k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int ch, unsigned seq, int *__restrict__ ctl)
+k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int ch)
 {
 #pragma clang fp contract(off)
     __shared__ double scratch[64];
-    __shared__ double lbstage[EMU ? STEP_T : 1];
     ProbDev &pr = probs[qlist[blockIdx.y]];
     const int phase = pr.phase;
     if (phase == PH_DONE) return;
@@ -1791,16 +1767,25 @@ k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
     const double pscal = pr.pinv;
     double *__restrict__ Hd = pr.Hd;
     double acc[3] = {0.0, 0.0, 0.0};
-    // EMU (ch == 2 * STEP_XB * STEP_T): the terms of the dot the reference computes sequentially -- d.Hd on a CG tick, g.g (= the
-    // r.r a trcg call starts from) on an EVAL tick -- stay in registers for lookback_grid's second pass
-    constexpr int NR = EMU ? 2 : 1;
-    double xt[NR * STEP_XB];
-#pragma unroll
-    for (int k = 0; k < NR * STEP_XB; k++) xt[k] = 0.0;
-#pragma unroll
-    for (int rnd = 0; rnd < (EMU ? 2 : 1 << 30); rnd++) {
-        const int jb = G.j0 + tid + rnd * (STEP_XB * STEP_T);
-        if (jb >= G.j1) break;
+    // EMU: the dot the reference computes sequentially -- d.Hd on a CG tick, g.g (= the r.r a trcg call starts from) on an EVAL tick --
+    // as a grid-rounded sum: u from the head columns (one per thread, the same expression as the main loop's)
+    double ugrid = 0.0;
+    if (EMU) {
+        double ht[1] = {0.0};
+        const int j = tid;
+        if (j < min(STEP_HEAD, n)) {
+            double xa = 0.0;
+            if (j < nf) { const int i0 = gld(cptr + j), i1 = gld(cptr + j + 1); for (int it = i0; it < i1; it++) xa += gld(segsum + it); }
+            else xa = csum_icpt;                               // (j == nf < STEP_HEAD: a one-chunk problem, this workgroup holds the intercept)
+            const double pjv = pvec ? gld(pvec + j) : pscal;
+            const double vj = gld(v + j);
+            if (cg) { const double hd = vj * pjv + xa; ht[0] = vj * hd; }
+            else { const double t = vj - gld(m + j); const double hd = t * pjv + xa; ht[0] = hd * hd; }
+        }
+        block_allreduce_sum<1>(ht, scratch);
+        ugrid = grid_of_sum(ht[0]);
+    }
+    for (int jb = G.j0 + tid; jb < G.j1; jb += STEP_XB * STEP_T) {
         int i0[STEP_XB], i1[STEP_XB];
         double vv[STEP_XB], mm[STEP_XB], pj[STEP_XB], cc[STEP_XB];
 #pragma unroll
@@ -1829,16 +1814,14 @@ k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
                 const double hd = vv[u] * pj[u] + xa;          // Hs[i] = (s[i]*priorVar_inv[i] + Hs[i]) * 1
                 SST(Hd + j, hd);
                 const double term = vv[u] * hd;
-                acc[0] += term;
-                if (EMU) xt[(EMU ? rnd : 0) * STEP_XB + u] = term;
+                acc[0] += (EMU && j >= STEP_HEAD) ? round_to_grid(term, ugrid) : term;
             } else {
                 const double t = vv[u] - mm[u];
                 acc[0] += t * t * pj[u];                       // fun :187-188
                 const double hd = t * pj[u] + xa;              // grad :224 (multiplier 1)
                 gst(Hd + j, hd);
                 const double term = hd * hd;
-                acc[1] += term;
-                if (EMU) xt[(EMU ? rnd : 0) * STEP_XB + u] = term;
+                acc[1] += (EMU && j >= STEP_HEAD) ? round_to_grid(term, ugrid) : term;
                 if (phase == PH_EVAL0) {
                     const double g0 = (0.0 - mm[u]) * pj[u] + cc[u];      // grad(0)
                     acc[2] += g0 * g0;
@@ -1847,17 +1830,6 @@ k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
         }
     }
     block_allreduce_sum<3>(acc, scratch);
-    if (EMU && G.nwg > 1) {
-        const int k = cg ? 0 : 1;
-        const double u = lookback_grid(pr.lb, G.wg, G.nwg, (seq << 2) | 1u, acc[k], lbstage, ctl);
-        if (u > 0.0) {
-            double rs[1] = {0.0};
-#pragma unroll
-            for (int q = 0; q < NR * STEP_XB; q++) rs[0] += round_to_grid(xt[q], u);
-            block_allreduce_sum<1>(rs, scratch);
-            acc[k] = rs[0];
-        }
-    }
     if (tid == 0) {
         double *__restrict__ px = pr.pA + G.wg * STEP_NP;
         px[0] = acc[0]; px[1] = acc[1]; px[2] = acc[2];
@@ -1969,7 +1941,7 @@ __device__ __forceinline__ CgDecision cg_decide(const ProbDev &pr, const double 
 // ---- phase B ------------------------------------------------------------------------------------
 template <bool EMU>
 __global__ void __launch_bounds__(STEP_T)
-k_step_b(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int ch, unsigned seq, int *__restrict__ ctl)
+k_step_b(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int ch)
 {
 #pragma clang fp contract(off)
     __shared__ double scratch[96];
@@ -1991,14 +1963,15 @@ k_step_b(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
         const double *__restrict__ rc = pr.rb[pr.rsel];
         double *__restrict__ rn = pr.rb[pr.rsel ^ 1];
         double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-        constexpr int NR = EMU ? 2 : 1;
-        double xt[NR * STEP_XB];                               // EMU: the terms of r'.r' (lookback_grid)
-#pragma unroll
-        for (int k = 0; k < NR * STEP_XB; k++) xt[k] = 0.0;
-#pragma unroll
-        for (int rnd = 0; rnd < (EMU ? 2 : 1 << 30); rnd++) {
-            const int jb = G.j0 + tid + rnd * (STEP_XB * STEP_T);
-            if (jb >= G.j1) break;
+        // EMU: r'.r' as a grid-rounded sum (see grid_of_sum): u from the head columns, one per thread
+        double ugrid = 0.0;
+        if (EMU) {
+            double ht[1] = {0.0};
+            if (tid < min(STEP_HEAD, G.n)) { const double r1 = gld(rc + tid) + nalpha * gld(Hd + tid); ht[0] = r1 * r1; }
+            block_allreduce_sum<1>(ht, scratch);
+            ugrid = grid_of_sum(ht[0]);
+        }
+        for (int jb = G.j0 + tid; jb < G.j1; jb += STEP_XB * STEP_T) {
             double dv[STEP_XB], sv[STEP_XB], rv[STEP_XB], hv[STEP_XB];
 #pragma unroll
             for (int u = 0; u < STEP_XB; u++) {
@@ -2019,21 +1992,10 @@ k_step_b(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
                 const double r1 = rv[u] + nalpha * hv[u];              // daxpy(-alpha, Hd, r)
                 SST(rn + j, r1);
                 const double term = r1 * r1;
-                acc[4] += term;
-                if (EMU) xt[(EMU ? rnd : 0) * STEP_XB + u] = term;
+                acc[4] += (EMU && j >= STEP_HEAD) ? round_to_grid(term, ugrid) : term;
             }
         }
         block_allreduce_sum<5>(acc, scratch);
-        if (EMU && G.nwg > 1) {
-            const double u = lookback_grid(pr.lb + G.nwg, G.wg, G.nwg, (seq << 2) | 2u, acc[4], stage, ctl);
-            if (u > 0.0) {
-                double rs[1] = {0.0};
-#pragma unroll
-                for (int q = 0; q < NR * STEP_XB; q++) rs[0] += round_to_grid(xt[q], u);
-                block_allreduce_sum<1>(rs, scratch);
-                acc[4] = rs[0];
-            }
-        }
         if (tid == 0) {
             double *__restrict__ px = pr.pB + G.wg * STEP_NP;
 #pragma unroll
@@ -2248,7 +2210,7 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
     if (XL != 0) { if (tid == 0) pal = pag; __syncthreads(); }
     const PartDev &pa = XL != 0 ? pal : pag;
     if (LDSV) {
-        const int n = pa.n_local, l0 = pa.l, ni = pa.n_items, nbk = pa.nblk;
+        const int n = pa.n_local, l0 = pa.l, ni = pa.n_items, nbk = pa.n_rowparts;
         if (tid == 0) {
             prl = prg;
             double *p = dyn;
@@ -2284,7 +2246,7 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
     if (XL != 0) {
         // carve the X region behind the vectors (same sizes the host summed: mlx_finalize) and copy, ids narrowed
         const int n = pag.n_local, nz = (int)pag.nnz, nf1 = pag.n_feat + 1;
-        char *xb = reinterpret_cast<char *>(dyn + (8 * n + 3 * l + nitems + 2 * pag.nblk));
+        char *xb = reinterpret_cast<char *>(dyn + (8 * n + 3 * l + nitems + 2 * pag.n_rowparts));
         int32_t *s_rp = reinterpret_cast<int32_t *>(xb); xb += 4 * (size_t)(l + 1);
         int32_t *s_ip = reinterpret_cast<int32_t *>(xb); xb += 4 * (size_t)(nitems + 1);
         int32_t *s_id = reinterpret_cast<int32_t *>(xb); xb += 4 * (size_t)nitems;
@@ -2316,7 +2278,7 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
     }
     using VP = typename std::conditional<LDSV, lds_dptr, double *>::type;      // see lds_dptr
     const VP coef = (VP)pr.coef, segsum = (VP)pr.parts;
-    for (int b = 1 + tid; b < pa.nblk; b += nt) { pr.lossp[b] = 0.0; pr.csump[b] = 0.0; }
+    for (int b = 1 + tid; b < pa.n_rowparts; b += nt) { pr.lossp[b] = 0.0; pr.csump[b] = 0.0; }      // (this kernel leaves ONE sum, in slot 0)
     // lane-group sum of sparse dot products: lane gl takes entries k0+gl, k0+gl+G, ...; fixed xor tree inside the group
     auto group_dot = [&](const IdT *__restrict__ idxs, const float *__restrict__ vals, const VP vec, int k0, int k1) -> double {
         double a = 0.0;
@@ -2975,17 +2937,16 @@ void mlxk_tron_step(hipStream_t st, const PartDev *parts, ProbDev *probs, const 
 }
 
 void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int ch,
-                     int max_nwg, int *done_counter, bool emu, unsigned seq, int *ctl)
+                     int max_nwg, int *done_counter, bool emu)
 {
     if (nq <= 0) return;
     const dim3 grid((unsigned)max_nwg, (unsigned)nq);
-    emu = emu && ch == 2 * STEP_XB * STEP_T;                   // the terms of a chunk must fit the kernels' register arrays
     if (which == 0) {
-        if (emu) hipLaunchKernelGGL(k_step_a<true>, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch, seq, ctl);
-        else hipLaunchKernelGGL(k_step_a<false>, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch, seq, ctl);
+        if (emu) hipLaunchKernelGGL(k_step_a<true>, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
+        else hipLaunchKernelGGL(k_step_a<false>, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
     } else if (which == 1) {
-        if (emu) hipLaunchKernelGGL(k_step_b<true>, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch, seq, ctl);
-        else hipLaunchKernelGGL(k_step_b<false>, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch, seq, ctl);
+        if (emu) hipLaunchKernelGGL(k_step_b<true>, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
+        else hipLaunchKernelGGL(k_step_b<false>, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
     }
     else if (which == 2) hipLaunchKernelGGL(k_step_c, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
     else hipLaunchKernelGGL(k_step_commit, dim3((unsigned)nq), dim3(STEP_T), 0, st, parts, probs, qlist, ch, done_counter);

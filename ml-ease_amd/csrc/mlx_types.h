@@ -96,7 +96,6 @@ struct ProbDev {
     double *rb[2];
     int32_t rsel;
     double *pA, *pB, *pC;  // [n_step_wg][STEP_NP] each
-    unsigned long long *lb;  // [2][n_step_wg] look-back granules {tag, float raw sum} of phases A and B (grid-rounded dots)
     double gsq;            // sum g_j^2 at the last accepted point (= rTr of the next trcg call)
     double snorm;          // ||s|| at the end of the last trcg call
     double *wd[2];         // [l] wt_i * D_i at the accepted / trial point

@@ -344,11 +344,13 @@ static double dot(int n, const double *a, const double *b)           /* :204-213
         }
         return rh + rl;
     }
-    if (g_sum_mode & (128 | 256)) {  /* experiment: grid-rounded terms, grid per block */
-        const int B = (g_sum_mode & 128) ? 2048 : 64;
-        double ph = 0, pl = 0, rh = 0, rl = 0;
+    if (g_sum_mode & (128 | 256 | 512 | 1024 | 2048 | 4096)) {  /* experiment: grid-rounded terms, grid per block (512 / 1024: the prefix stops growing after 1 / 4 blocks; 2048 / 4096: ONE grid from the sum of the first 256 / 64 terms) */
+        const int B = (g_sum_mode & 256) ? 64 : ((g_sum_mode & 2048) ? 256 : ((g_sum_mode & 4096) ? 64 : 2048));
+        const int K = (g_sum_mode & (512 | 2048 | 4096)) ? 1 : ((g_sum_mode & 1024) ? 4 : (1 << 30));
+        double ph = 0, pl = 0, rh = 0, rl = 0, pre_cap = 0;
         for (int c0 = 0; c0 < n; c0 += B) {
             double pre = ph + pl;
+            if (c0 / B <= K) pre_cap = pre; else pre = pre_cap;
             int e = 0;
             double u = 0;
             if (pre != 0) { frexp(pre, &e); u = ldexp(1.0, e - 53); }

@@ -106,6 +106,11 @@ def main():
     # per-call-site mixes on the frequency-ordered partitions (the library's column order): which dots must be grid-rounded?
     L.orc_set_dot_site_mode.argtypes = [__import__("ctypes").c_int, __import__("ctypes").c_int]
     site_mixes = {"fo:sites012=grid,345=tree,+passes": ({0: 128, 1: 128, 2: 128, 3: 64, 4: 64, 5: 64}, 2),
+                  "fo:sites012=gridK1,345=tree,+passes": ({0: 512, 1: 512, 2: 512, 3: 64, 4: 64, 5: 64}, 2),
+                  "fo:sites012=gridK4,345=tree,+passes": ({0: 1024, 1: 1024, 2: 1024, 3: 64, 4: 64, 5: 64}, 2),
+                  "fo:sites012=grid_first256,345=tree,+passes": ({0: 2048, 1: 2048, 2: 2048, 3: 64, 4: 64, 5: 64}, 2),
+                  "fo:sites012=grid_first64,345=tree,+passes": ({0: 4096, 1: 4096, 2: 4096, 3: 64, 4: 64, 5: 64}, 2),
+                  "fo:sites012=grid_first256,345=tree (tree passes)": ({0: 2048, 1: 2048, 2: 2048, 3: 64, 4: 64, 5: 64}, 0),
                   "fo:sites12=grid,0345=tree,+passes": ({0: 64, 1: 128, 2: 128, 3: 64, 4: 64, 5: 64}, 2),
                   "fo:sites01245=grid,3=tree,+passes": ({0: 128, 1: 128, 2: 128, 3: 64, 4: 128, 5: 128}, 2),
                   "fo:all sites grid,+passes": ({}, 130)}
