@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--sweep-warmup", type=int, default=1)
     ap.add_argument("--sweep-cpu-sample", type=int, default=8, help="partitions (x 8 lambdas) of the lambda-sweep CPU / parity sample (0 = skip)")
     ap.add_argument("--full-json", default="", help="where the full record goes (default: bench_full.json beside bench.py, + gpurun_out/)")
+    ap.add_argument("--envelope-partitions", type=int, default=32, help="partitions of the sparse leg's permutation envelope")
+    ap.add_argument("--envelope-perms", type=int, default=8, help="permuted oracles of that envelope")
     ap.add_argument("--sparse-cpu-sample", type=int, default=256, help="partitions of the sparse CPU-baseline / parity sample (0 = skip)")
     args = ap.parse_args()
 
@@ -1058,7 +1060,9 @@ def sparse_checks(args, C, eng, blocks, ng, Ptot, snap, eps_all, step_s, res, la
     P = len(blocks)
     lam, rho, nl = list(lam), list(rho), len(lam)
     ns = min(args.sparse_cpu_sample if ns is None else ns, P)
-    nv = min(8, ns)
+    nv = min(8, ns)                      # partitions of the order-faithful check and of the closed ADMM job
+    ne = min(args.envelope_partitions, ns) if full else min(8, ns)      # partitions of the permutation envelope
+    NPERM = args.envelope_perms if full else 2
     warm = args.sparse_warmup if warm is None else warm
     eps_timed = eps_all[warm:]
     Z0, u0 = snap
@@ -1081,7 +1085,9 @@ def sparse_checks(args, C, eng, blocks, ng, Ptot, snap, eps_all, step_s, res, la
         ui = np.stack([np.stack([eng.partition_model(k, li)[2] for li in range(nl)]) for k in range(ns)])
     # (c) + (b): oracle and row-permuted oracle from the same states
     oc = ol.OracleAdmm(blocks[:ns], ng, lam, rho, num_blocks=Ptot)
-    ocp = ol.OracleAdmm([permute_rows(b, 7 + i, relabel=True) for i, b in enumerate(blocks[:nv])], ng, lam, rho, num_blocks=Ptot)
+    # the oracle's own order envelope: NPERM copies of the first `ne` partitions with rows permuted and features renumbered
+    ocps = [ol.OracleAdmm([permute_rows(b, 1000 * k + 7 + i, relabel=True) for i, b in enumerate(blocks[:ne])], ng, lam, rho, num_blocks=Ptot)
+            for k in range(NPERM)]
     threads = min(usable_cores(), ns * nl)
     cdt, solves, passes = 0.0, 0, 0
     per_it, ob_all = [], []
@@ -1095,21 +1101,27 @@ def sparse_checks(args, C, eng, blocks, ng, Ptot, snap, eps_all, step_s, res, la
         passes += int(cc[:, 3].sum())
         ob = np.stack([oc.partition_model(k, li)[0] for k in range(ns) for li in range(nl)])
         ob_all.append(ob)
-        ocp.set_state(Zs, us[:nv])
-        ocp.solve_local(e, 1.0, nthreads=min(threads, nv * nl))
-        pb = np.stack([ocp.partition_model(k, li)[0] for k in range(nv) for li in range(nl)])
-        eg, ep = _rel_err(gb, ob), _rel_err(pb, ob[:nv * nl])
+        m = ne * nl
+        eg = _rel_err(gb, ob)
+        geq = np.all(gc == cc, axis=1)
+        perm_eq, perm_med, perm_max = [], [], []
+        easy = np.ones(m, bool)
+        for ocp in ocps:
+            ocp.set_state(Zs, us[:ne])
+            ocp.solve_local(e, 1.0, nthreads=min(threads, m))
+            pb = np.stack([ocp.partition_model(k, li)[0] for k in range(ne) for li in range(nl)])
+            ep = _rel_err(pb, ob[:m])
+            peq = np.all(cnts(ocp) == cc[:m], axis=1)
+            easy &= peq
+            perm_eq.append(int(peq.sum())); perm_med.append(float(np.median(ep))); perm_max.append(float(ep.max()))
         per_it.append({"iteration": warm + i + 1, "liblinear_epsilon": e,
-                       "gpu_vs_oracle": {"solves": ns * nl, "equal_counters": int(np.all(gc == cc, axis=1).sum()),
-                                         "within_1e-5": int((eg <= 1e-5).sum()), "median_rel_err_beta": float(np.median(eg)),
-                                         "max_rel_err_beta": float(eg.max()),
-                                         "max_abs_err_beta": float(np.max(np.abs(gb.astype(np.float64) - ob))),
-                                         "bit_identical_float32_fraction": round(float(np.mean(gb == ob)), 4)},
-                       "oracle_rowperm_vs_oracle": {"solves": nv * nl, "equal_counters": int(np.all(cnts(ocp) == cc[:nv * nl], axis=1).sum()),
-                                                    "within_1e-5": int((ep <= 1e-5).sum()), "median_rel_err_beta": float(np.median(ep)),
-                                                    "max_rel_err_beta": float(ep.max()),
-                                                    "max_abs_err_beta": float(np.max(np.abs(pb.astype(np.float64) - ob[:nv * nl]))),
-                                                    "bit_identical_float32_fraction": round(float(np.mean(pb == ob[:nv * nl])), 4)},
+                       "gpu_vs_oracle_all_sampled_solves": {"solves": ns * nl, "equal_counters": int(geq.sum()), "within_1e-5": int((eg <= 1e-5).sum()),
+                                                            "median_rel_err_beta": float(np.median(eg)), "max_rel_err_beta": float(eg.max()),
+                                                            "bit_identical_float32_fraction": round(float(np.mean(gb == ob)), 4)},
+                       "envelope": {"solves": m, "gpu_equal_counters": int(geq[:m].sum()), "perm_equal_counters": perm_eq,
+                                    "gpu_median_rel_err_beta": float(np.median(eg[:m])), "perm_median_rel_err_beta": perm_med,
+                                    "gpu_max_rel_err_beta": float(eg[:m].max()), "perm_max_rel_err_beta": perm_max,
+                                    "easy_solves": int(easy.sum()), "gpu_equal_on_easy_solves": int((geq[:m] & easy).sum())},
                        "max_abs_beta": float(np.max(np.abs(ob)))})
     v = solves / cdt
     g_rate = P * nl * len(step_s) / sum(step_s)
@@ -1120,17 +1132,26 @@ def sparse_checks(args, C, eng, blocks, ng, Ptot, snap, eps_all, step_s, res, la
                            "x_passes_ref_per_s": round(passes / cdt, 1), "host_cpus_listed": os.cpu_count(), "host_cores_usable": usable_cores()}
     res["gpu_over_cpu"] = {"same_iterations": [warm + 1, warm + len(recs)], "solves_per_s": round(g_rate / v, 2),
                            "gpu_solves_per_s": round(g_rate, 2), "cpu_seconds": round(cdt, 2)}
-    worst_g = max(r["gpu_vs_oracle"]["max_rel_err_beta"] for r in per_it)
-    worst_p = max(r["oracle_rowperm_vs_oracle"]["max_rel_err_beta"] for r in per_it)
+    env = [r["envelope"] for r in per_it]
+    g_tot = sum(x["gpu_equal_counters"] for x in env)
+    p_tot = [sum(x["perm_equal_counters"][k] for x in env) for k in range(NPERM)]
+    summary = {"solves": sum(x["solves"] for x in env), "permutations": NPERM,
+               "equal_counters_gpu": g_tot, "equal_counters_perm_min_max": [min(p_tot), max(p_tot)],
+               "gpu_within_envelope": bool(min(p_tot) <= g_tot),
+               "easy_solves": sum(x["easy_solves"] for x in env), "gpu_equal_on_easy_solves": sum(x["gpu_equal_on_easy_solves"] for x in env),
+               "median_rel_err_gpu_by_iteration": [float("%.2e" % x["gpu_median_rel_err_beta"]) for x in env],
+               "median_rel_err_perm_max_by_iteration": [float("%.2e" % max(x["perm_median_rel_err_beta"])) for x in env]}
     res["parity_check"] = {
         "what": "partitions of the timed job (%d rows x ~%d local features each), ADMM iterations %d..%d, every solve from the GPU's state at "
-                "that iteration" % (blocks[0].l, int(np.mean([b.n_local for b in blocks[:ns]])), warm + 1, warm + len(recs)),
+                "that iteration; envelope = the oracle on %d row-permuted / feature-renumbered copies of the first %d partitions (an order the "
+                "reference does not define: llf/LibLinearDataset.java:467-482); easy solves = those on which EVERY permuted oracle keeps the "
+                "base oracle's TRON trajectory" % (blocks[0].l, int(np.mean([b.n_local for b in blocks[:ns]])), warm + 1, warm + len(recs), NPERM, ne),
         "tolerance": 1e-5, "rel_err_floor": "1e-4 * max|beta_k|",
-        "product_path_solve_level": {"max_rel_err_beta_gpu_vs_oracle": worst_g, "max_rel_err_beta_oracle_rowperm_vs_oracle": worst_p,
-                                     "per_iteration": per_it},
-        "reading": "the product path sums in another order than the reference, and on this data the reference itself moves by the same order of "
-                   "magnitude when its rows are permuted (chaotic TRON trajectories at a 1e-2 stopping tolerance, DESIGN 5); the order-faithful "
-                   "mode shows the kernels compute the reference's arithmetic bit for bit"}
+        "summary": summary,
+        "product_path_solve_level": {"per_iteration": per_it},
+        "reading": "on this data the reference moves by 1e-3 .. 1 relative when its rows come in another order (chaotic TRON trajectories at a "
+                   "1e-2 stopping tolerance, DESIGN 5), so 1e-5 per solve is not a property the reference has with itself; the product path is "
+                   "measured against that envelope, and the order-faithful mode shows the kernels compute the reference's arithmetic bit for bit"}
     if not full:
         return
     # (a) order-faithful mode vs the oracle twin, same states

@@ -1697,14 +1697,15 @@ __device__ __forceinline__ void step_gather(const double *__restrict__ px, int n
 // reference's own family of TRON trajectories on one-hot data. Measured (tools/sum_order_experiment.py, profiles/r4_notes.md; solves
 // of full-size configs[2] partitions whose TRON counters equal the oracle's): oracle on permuted rows 253-269 of 384, this library
 // with tree dots 200, with compensated dots fewer still, with the dots below 242.
-// Every workgroup of a problem first adds the terms of the problem's first STEP_HEAD columns (the hottest: library ids are
-// frequency-sorted) -- redundantly, same tree, same value in every workgroup, a few KB of L2 hits -- and takes the ulp u of that head
-// sum's binade. Terms of the later columns are rounded to a multiple of u before they are added: the magic-constant form
+// The grid comes from the HEAD sum: the terms of the problem's first STEP_HEAD columns (the hottest: library ids are frequency-
+// sorted). For r.r every workgroup of phase B adds them itself (two loads per column, L2 hits); for d.Hd / g.g the head needs the
+// column sums of the hottest columns -- O(100) slots each -- so one small launch per tick (k_step_head, one workgroup per problem)
+// leaves it in the descriptor for phase A. u = the ulp of the head sum's binade. Terms of the later columns are rounded to a multiple of u before they are added: the magic-constant form
 // (x + 1.5 * 2^52 u) - 1.5 * 2^52 u, exactly what the FPU does to x when it is added to a sum of that size. Sums of multiples of u
 // are exact, so the trees that follow add no rounding of their own. (The grid of the running sum after the first 64 / 256 / 2048 terms,
 // or of the true prefix at every 2048-column chunk, all follow the oracle equally well on CPU models of this arithmetic; the head
 // sum needs no exchange between workgroups. A first version published chunk sums through agent-scope granules and looked back over
-// them: same parity, 17 % of the sparse leg's throughput.)
+// them: same parity, 17 % of the sparse leg's throughput; a second recomputed the d.Hd head in every workgroup of phase A: 9 %.)
 #define STEP_HEAD 256
 __device__ __forceinline__ double grid_of_sum(double h)
 {
@@ -1739,6 +1740,38 @@ __device__ __forceinline__ bool step_geom(const PartDev &pa, int ch, StepGeom &g
     return true;
 }
 
+// ---- head of phase A's grid-rounded dot: one workgroup per problem, one thread per head column (grid_of_sum) ----------------------
+__global__ void __launch_bounds__(STEP_T)
+k_step_head(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist)
+{
+#pragma clang fp contract(off)
+    __shared__ double scratch[64];
+    ProbDev &pr = probs[qlist[blockIdx.x]];
+    const int phase = pr.phase;
+    if (phase == PH_DONE) return;
+    const PartDev &pa = parts[pr.part];
+    const int n = pa.n_local, nf = pa.n_feat, j = threadIdx.x;
+    const bool cg = (phase == PH_CG);
+    double csum_icpt = 0.0;
+    if (nf < STEP_HEAD) csum_icpt = block_sum_array(pr.csump, pa.n_rowparts, scratch);       // (uniform: a problem of <= 256 columns)
+    const double *__restrict__ v = cg ? pr.d : pr.w_new;
+    double ht[1] = {0.0};
+    if (j < min(STEP_HEAD, n)) {
+        double xa = 0.0;
+        if (j < nf) {
+            const int i0 = gld(pa.col_ptr + j), i1 = gld(pa.col_ptr + j + 1);
+#pragma unroll 8
+            for (int it = i0; it < i1; it++) xa += gld(pr.parts + it);
+        } else xa = csum_icpt;
+        const double pjv = pr.pinv_vec ? gld(pr.pinv_vec + j) : pr.pinv;
+        const double vj = gld(v + j);
+        if (cg) { const double hd = vj * pjv + xa; ht[0] = vj * hd; }
+        else { const double t = vj - gld(pr.m + j); const double hd = t * pjv + xa; ht[0] = hd * hd; }
+    }
+    block_allreduce_sum<1>(ht, scratch);
+    if (threadIdx.x == 0) pr.head = ht[0];
+}
+
 // ---- phase A ------------------------------------------------------------------------------------
 template <bool EMU>
 __global__ void __launch_bounds__(STEP_T)
@@ -1768,23 +1801,8 @@ k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
     double *__restrict__ Hd = pr.Hd;
     double acc[3] = {0.0, 0.0, 0.0};
     // EMU: the dot the reference computes sequentially -- d.Hd on a CG tick, g.g (= the r.r a trcg call starts from) on an EVAL tick --
-    // as a grid-rounded sum: u from the head columns (one per thread, the same expression as the main loop's)
-    double ugrid = 0.0;
-    if (EMU) {
-        double ht[1] = {0.0};
-        const int j = tid;
-        if (j < min(STEP_HEAD, n)) {
-            double xa = 0.0;
-            if (j < nf) { const int i0 = gld(cptr + j), i1 = gld(cptr + j + 1); for (int it = i0; it < i1; it++) xa += gld(segsum + it); }
-            else xa = csum_icpt;                               // (j == nf < STEP_HEAD: a one-chunk problem, this workgroup holds the intercept)
-            const double pjv = pvec ? gld(pvec + j) : pscal;
-            const double vj = gld(v + j);
-            if (cg) { const double hd = vj * pjv + xa; ht[0] = vj * hd; }
-            else { const double t = vj - gld(m + j); const double hd = t * pjv + xa; ht[0] = hd * hd; }
-        }
-        block_allreduce_sum<1>(ht, scratch);
-        ugrid = grid_of_sum(ht[0]);
-    }
+    // as a grid-rounded sum: u from the head sum k_step_head left in the descriptor just before this launch
+    const double ugrid = EMU ? grid_of_sum(pr.head) : 0.0;
     for (int jb = G.j0 + tid; jb < G.j1; jb += STEP_XB * STEP_T) {
         int i0[STEP_XB], i1[STEP_XB];
         double vv[STEP_XB], mm[STEP_XB], pj[STEP_XB], cc[STEP_XB];
@@ -2942,6 +2960,7 @@ void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *p
     if (nq <= 0) return;
     const dim3 grid((unsigned)max_nwg, (unsigned)nq);
     if (which == 0) {
+        if (emu) hipLaunchKernelGGL(k_step_head, dim3((unsigned)nq), dim3(STEP_T), 0, st, parts, probs, qlist);
         if (emu) hipLaunchKernelGGL(k_step_a<true>, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
         else hipLaunchKernelGGL(k_step_a<false>, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
     } else if (which == 1) {

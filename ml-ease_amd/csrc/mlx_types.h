@@ -97,6 +97,7 @@ struct ProbDev {
     int32_t rsel;
     double *pA, *pB, *pC;  // [n_step_wg][STEP_NP] each
     double gsq;            // sum g_j^2 at the last accepted point (= rTr of the next trcg call)
+    double head;           // k_step_head: sum of the first STEP_HEAD terms of the dot phase A is about to add (its rounding grid)
     double snorm;          // ||s|| at the end of the last trcg call
     double *wd[2];         // [l] wt_i * D_i at the accepted / trial point
     double *coef;          // [l] row coefficients of the current pass (CSR path only)

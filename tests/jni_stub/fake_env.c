@@ -16,8 +16,8 @@ struct _jobject {
     jobject *elems;
     char name[96];
     jlong handle;
-    double dfields[16];
-    jlong lfields[16];
+    double dfields[32];
+    jlong lfields[32];
 };
 struct _jfieldID { char name[48]; };
 struct _jmethodID { char name[48]; };
@@ -85,9 +85,10 @@ static int slot_of(const char *name)
 {
     static char names[32][48];
     static int n;
-    for (int i = 0; i < n; i++) if (!strcmp(names[i], name)) return i % 16;
+    for (int i = 0; i < n; i++) if (!strcmp(names[i], name)) return i;
+    if (n >= 32) { fprintf(stderr, "fake JNI: more than 32 Stats fields\n"); abort(); }
     snprintf(names[n], 48, "%s", name);
-    return (n++) % 16;
+    return n++;
 }
 static void JNICALL SetLongField(JNIEnv *env, jobject obj, jfieldID f, jlong v) { (void)env; obj->lfields[slot_of(f->name)] = v; }
 static void JNICALL SetDoubleField(JNIEnv *env, jobject obj, jfieldID f, jdouble v) { (void)env; obj->dfields[slot_of(f->name)] = v; }

@@ -142,7 +142,9 @@ def main():
             o.set_state(Z, U)
             o.solve_local(eps, 1.0, nthreads=a.threads)
             er = rel_err(betas(o, P), bb)
-            rec[name] = {"equal": int(np.all(counters(o) == cb, axis=1).sum()), "median": float(np.median(er)), "max": float(er.max())}
+            eqv = np.all(counters(o) == cb, axis=1)
+            rec[name] = {"equal": int(eqv.sum()), "median": float(np.median(er)), "max": float(er.max()),
+                         "equal_by_solve": [int(x) for x in eqv], "err_by_solve": [float(x) for x in er]}
         L.orc_set_sum_mode(0)
         for st_ in range(6):
             L.orc_set_dot_site_mode(st_, -1)
@@ -151,8 +153,16 @@ def main():
             eng.solve_local(eps, 1.0)
             gb = np.stack([eng.partition_model(k, 0)[0] for k in range(P)])
             er = rel_err(gb, bb)
-            rec["gpu"] = {"equal": int(np.all(eng.solve_counters() == cb, axis=1).sum()), "median": float(np.median(er)), "max": float(er.max())}
+            eqv = np.all(eng.solve_counters() == cb, axis=1)
+            rec["gpu"] = {"equal": int(eqv.sum()), "median": float(np.median(er)), "max": float(er.max()),
+                          "equal_by_solve": [int(x) for x in eqv], "err_by_solve": [float(x) for x in er]}
+            easy = np.ones(P, bool)
+            for i in range(a.perms):
+                easy &= np.array(rec["perm%d" % i]["equal_by_solve"], bool)
+            rec["easy_solves"] = int(easy.sum())
+            rec["gpu_equal_on_easy_solves"] = int((eqv & easy).sum())
             pe_ = [rec["perm%d" % i] for i in range(a.perms)]
+            print("   easy solves (every permuted oracle keeps the trajectory): %d, the GPU keeps it on %d of them" % (rec["easy_solves"], rec["gpu_equal_on_easy_solves"]))
             print("   gpu: equal %d (perms %d..%d)  median %.2e (perms %.2e..%.2e)  max %.2e (perms %.2e..%.2e)" % (
                 rec["gpu"]["equal"], min(p["equal"] for p in pe_), max(p["equal"] for p in pe_), rec["gpu"]["median"],
                 min(p["median"] for p in pe_), max(p["median"] for p in pe_), rec["gpu"]["max"], min(p["max"] for p in pe_), max(p["max"] for p in pe_)), flush=True)
