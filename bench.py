@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--loglik-iters", type=int, default=20, help="ADMM iterations of the time-to-reference-loglik run (0 = skip)")
     ap.add_argument("--test-rows", type=int, default=100000)
     ap.add_argument("--no-sparse", action="store_true", help="skip the configs[2]/[3] leg")
+    ap.add_argument("--no-dense8", action="store_true", help="skip the 8-partitions-per-GPU dense shape (the 8-GPU share of configs[1])")
     ap.add_argument("--no-gram", action="store_true", help="skip the fp64-MFMA Gram measurement (posterior covariance of one partition)")
     ap.add_argument("--sparse-only", action="store_true", help="run only the sparse leg (development / profiling)")
     ap.add_argument("--sparse-steps", type=int, default=5)
@@ -340,6 +341,8 @@ def compact_record(full):
         c["time_to_ref_loglik"] = _pick(ll, ["seconds_to_ref_loglik", "reached_at_iteration", "seconds_all_iterations", "iterations"])
     if full.get("gram"):
         c["gram"] = _pick(full["gram"], ["achieved", "peak", "unit", "frac"])
+    if full.get("dense_8_per_gpu"):
+        c["dense_8_per_gpu"] = _pick(full["dense_8_per_gpu"], ["value", "ms_per_step", "whole_step_frac"])
     al = full.get("all_launches") or {}
     if al:
         c["all_xpass_launches"] = _pick(al, ["timed_by_events", "avg_us", "alg_bytes_timed_by_events"])
@@ -348,7 +351,7 @@ def compact_record(full):
     c["full_record"] = "bench_full.json (also on stderr)"
     c = _finite(c)
     # never exceed the limit: drop the optional blocks, least important first
-    for k in ("gram", "all_xpass_launches", "time_to_ref_loglik", "lambda_sweep", "sparse", "parity", "gpu_over_cpu"):
+    for k in ("gram", "dense_8_per_gpu", "all_xpass_launches", "time_to_ref_loglik", "lambda_sweep", "sparse", "parity", "gpu_over_cpu"):
         if len(json.dumps(c, allow_nan=False)) <= COMPACT_LIMIT:
             break
         c.pop(k, None)
@@ -610,6 +613,8 @@ def run_dense(args, C):
                "time_to_ref_loglik": loglik}
         if not args.no_gram:
             out["gram"] = gram_leg(eng, rows, nf)
+        if world == 1 and not args.no_dense8 and N == PARTS:
+            out["dense_8_per_gpu"] = dense8_leg(args, C, rows, nf)
         if want_cpu:
             cpu_leg(args, C, eng, out, sample, snap, eps_used, step_times, nf, N)
         # every k_xpass_dense launch of the process: the numbers a `rocprofv3 --kernel-trace --stats` of this command must show
@@ -623,6 +628,41 @@ def run_dense(args, C):
                                        "rocprofv3 counts the same launches (+ the Gram leg's none)"}
     eng.close()
     return out
+
+
+def dense8_leg(args, C, rows, nf):
+    """The share ONE of 8 GPUs holds of the strong-scaled configs[1] job: 8 partitions of 15 625 x 1000, run here as a closed 8-block
+    job on one GPU (no exchange): per-GPU rate at that shape, so that 8 x it is the ceiling of the 8-GPU run before any exchange cost.
+    Few problems must still fill 256 CUs: one 256-row unit per pass workgroup (496 workgroups), two tick streams."""
+    torch, dev, sd, admm = C["torch"], C["dev"], C["sd"], C["admm"]
+    try:
+        eng = C["HipAdmmEngine"](nf + 1, [1.0], [1.0], 8, device=C["local_rank"], stream=C["stream"])
+        for k in range(8):
+            X, y = sd.dense_rows_torch(torch, dev, 8 * k, rows, nf, stride=PARTS)          # partitions 0, 8, ..., 56 of the 64-partition job
+            torch.cuda.synchronize()
+            eng.add_partition_dense_device(k, X.data_ptr(), rows, nf, nf, y.data_ptr())
+            del X, y
+        eng.finalize()
+        sched = EpsSchedule(admm)
+        acc = dict(solves=0, alg=0.0)
+        for it in range(args.warmup + args.steps):
+            if it == args.warmup:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            st = eng.solve_local(sched.next(), 1.0)
+            sched.mindiff = eng.consensus_finish().mindiff
+            if it >= args.warmup:
+                acc["solves"] += st.solves; acc["alg"] += st.alg_bytes_dev
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        eng.close()
+        return {"workload": "8 partitions x %d rows x %d features on one GPU (the per-GPU share of configs[1] at 8 GPUs), closed 8-block job" % (rows, nf),
+                "value": round(acc["solves"] / dt, 2), "unit": "solves/s", "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(dt * 1e3 / args.steps, 3),
+                "whole_step_frac": round(acc["alg"] / dt / 1e9 / HBM_PEAK_GBS, 4),
+                "x8": round(8 * acc["solves"] / dt, 1)}
+    except Exception as ex:                                       # an extra: never takes the headline down
+        return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
 
 
 def gram_leg(eng, rows, nf):
