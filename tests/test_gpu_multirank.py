@@ -150,3 +150,74 @@ def test_two_handles_failed_rank_fails_both(monkeypatch):
     assert "another rank" in str(err[0]) and "another rank" not in str(err[1])
     for e in engs:
         e.close()
+
+
+def test_library_rccl_two_processes_on_two_devices(tmp_path):
+    """The library's OWN RCCL path with nranks = 2 (what the driver's 8-GPU run and a JVM host with `gpus=0,1,...` use): two
+    processes, one device each, mlx_comm_init over a file-shared unique id, mlx_naive_init + four mlx_admm_iterate -- against one
+    handle holding all eight partitions. Both ranks end with the SAME consensus, within 1e-5 of the one-handle run (the all-reduce
+    associates the two partial means differently). Skipped on a one-GPU box (RCCL refuses two ranks on one device; the in-process
+    communicator of the experimental build covers the control flow there)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two devices")
+    script = tmp_path / "rank.py"
+    script.write_text('''
+import os, sys, time
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import mlease_amd
+from mlease_amd.hip_engine import HipAdmmEngine
+from fixtures import load_c1
+rank, out = int(sys.argv[1]), sys.argv[2]
+c1 = load_c1()
+lam, rho = [1.0, 10.0], [1.0, 1.0]
+uidf = os.path.join(out, "uid.bin")
+if rank == 0:
+    uid = HipAdmmEngine.comm_unique_id()
+    with open(uidf + ".tmp", "wb") as fh:
+        fh.write(uid)
+    os.replace(uidf + ".tmp", uidf)
+else:
+    for _ in range(600):
+        if os.path.exists(uidf):
+            break
+        time.sleep(0.1)
+    uid = open(uidf, "rb").read()
+eng = HipAdmmEngine(c1.n_global, lam, rho, 8, device=rank)
+for b in c1.blocks[rank::2]:
+    eng.add_partition(b)
+eng.finalize()
+eng.comm_init(uid, 2, rank)
+eng.naive_init(0.01)
+md = []
+for it in range(4):
+    md.append(eng.iterate(0.01).maxdiff)
+np.savez(os.path.join(out, "rank%%d.npz" %% rank), z=eng.z()[0], maxdiff=np.array(md))
+eng.close()
+''' % (ROOT, ROOT))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("a rank is blocked in the exchange")
+        assert p.returncode == 0, e[-3000:]
+    c1 = load_c1()
+    ref = HipAdmmEngine(c1.n_global, [1.0, 10.0], [1.0, 1.0], 8)
+    for b in c1.blocks:
+        ref.add_partition(b)
+    ref.finalize()
+    ref.naive_init(0.01)
+    mdr = [ref.iterate(0.01).maxdiff for _ in range(4)]
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["z"], r1["z"]) and np.array_equal(r0["maxdiff"], r1["maxdiff"])
+    zr = ref.z()[0]
+    assert np.max(np.abs(r0["z"] - zr)) <= 1e-5 * np.max(np.abs(zr))
+    assert np.max(np.abs(r0["maxdiff"] - np.array(mdr))) <= 1e-9
+    ref.close()
