@@ -624,8 +624,8 @@ def run_dense(args, C):
                                "alg_bytes_without_events": allrun["untimed_alg_bytes"],
                                "alg_bytes": allrun["alg_bytes"] + allrun["untimed_alg_bytes"],
                                "launches": allrun["launches"] + allrun["untimed_launches"],
-                               "note": "k_xpass_dense launches of the whole dense leg (warm-up, timed, log-likelihood run, CPU-parity re-run): "
-                                       "rocprofv3 counts the same launches (+ the Gram leg's none)"}
+                               "note": "every k_xpass_dense launch of the process: the dense leg (warm-up, timed, log-likelihood run, CPU-parity "
+                                       "re-run; events on) and the 8-per-GPU leg + the finalize passes (no events): rocprofv3 counts the same launches"}
     eng.close()
     return out
 
@@ -643,6 +643,8 @@ def dense8_leg(args, C, rows, nf):
             eng.add_partition_dense_device(k, X.data_ptr(), rows, nf, nf, y.data_ptr())
             del X, y
         eng.finalize()
+        C["allrun_dense"]["untimed_launches"] += 1           # its c0 pass
+        C["allrun_dense"]["untimed_alg_bytes"] += 8 * (4.0 * rows * nf + 8.0 * rows + 8.0 * (nf + 1))
         sched = EpsSchedule(admm)
         acc = dict(solves=0, alg=0.0)
         for it in range(args.warmup + args.steps):
@@ -651,6 +653,7 @@ def dense8_leg(args, C, rows, nf):
                 t0 = time.perf_counter()
             st = eng.solve_local(sched.next(), 1.0)
             sched.mindiff = eng.consensus_finish().mindiff
+            C["account_dense"](st)                     # (this engine's launches are k_xpass_dense launches of the process too)
             if it >= args.warmup:
                 acc["solves"] += st.solves; acc["alg"] += st.alg_bytes_dev
         torch.cuda.synchronize()

@@ -114,6 +114,7 @@ struct mlx_context {
     std::vector<int> ev_sidx;               // the tick stream a mark was recorded on: an interval runs between consecutive marks of ONE stream
     size_t ev_used = 0;
     int mark_sidx = 0;                      // index of the stream h->stream currently points at (run_ticks)
+    int64_t n_xpass_launched = 0;           // dense-pass / row-pass launches since the solve began (exact, with or without events)
     bool prof_one_stream = false;           // MLX_PROFILE_ONE_STREAM=1: with events on, all ticks on one stream (a launch's duration is then its own)
     // scratch vectors of the solve_one problem
     double *sc_vec[8] = {nullptr}, *sc_pinv = nullptr;
@@ -254,6 +255,8 @@ int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
         mark(h, kind);
         return launch();
     };
+    if (nqd > 0) h->n_xpass_launched++;
+    if (nqc > 0) h->n_xpass_launched++;
     if (nqd > 0 && bracket(0, [&] { return mlxk_xpass_dense(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->maxblk_dense, h->max_nfeat_dense, h->n_lambda == 1); }))
         return fail(h, MLX_ERR_INVALID, "dense tile wider than 2048 features is not supported; use the CSR form");
     if (nqc > 0)
@@ -1462,7 +1465,7 @@ int mlx_admm_solve_local(mlx_handle h, double liblinear_epsilon, float rho_adapt
         HIPCHECK(h, hipStreamSynchronize(h->stream));     // pinv is a stack vector
         h->pinv_admm_last = pinv;
     }
-    h->ev_used = 0; h->ev_kind.clear(); h->ev_sidx.clear();
+    h->ev_used = 0; h->ev_kind.clear(); h->ev_sidx.clear(); h->n_xpass_launched = 0;
     HIPCHECK(h, hipEventRecord(h->ev_t0, h->stream));
     mlxk_setup(h->stream, h->d_parts, h->d_probs, h->nprob, nl, ng, h->max_nlocal, h->d_z32, h->d_u, h->d_pinv_l,
                liblinear_epsilon, DEFAULT_MAX_ITER);
@@ -1559,10 +1562,8 @@ static int collect_solve_stats(mlx_handle h, int64_t ticks, mlx_stats *stats, bo
         s.rowpass_busy_ms = union_ms(iv[1]); s.colpass_busy_ms = union_ms(iv[2]); s.step_busy_ms = union_ms(iv[3]);
         s.xpass_ms = acc[0] + acc[1] + acc[2];
         s.rowpass_ms = acc[1]; s.colpass_ms = acc[2]; s.step_ms = acc[3];
-        s.xpass_launches = std::max(cnt[0], cnt[1]);
-    } else {
-        s.xpass_launches = ticks;
     }
+    s.xpass_launches = h->n_xpass_launched;     // (exact: two tick streams launch a class twice per tick)
     h->last = s;
     if (stats) *stats = s;
     return MLX_OK;
@@ -1711,7 +1712,7 @@ int mlx_naive_solve_local(mlx_handle h, double liblinear_epsilon, double prior_m
     HIPCHECK(h, hipMemcpyAsync(h->d_pinv_l, pinv.data(), sizeof(double) * nl, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(h, hipMemcpyAsync(h->d_pinv_ovr, ovr.data(), sizeof(double) * ng, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
-    h->ev_used = 0; h->ev_kind.clear(); h->ev_sidx.clear();
+    h->ev_used = 0; h->ev_kind.clear(); h->ev_sidx.clear(); h->n_xpass_launched = 0;
     HIPCHECK(h, hipEventRecord(h->ev_t0, h->stream));
     mlxk_setup_naive(h->stream, h->d_parts, h->d_probs, h->nprob, h->max_nlocal, h->d_pinv_l, h->d_pinv_ovr,
                      h->d_naive_pinv, prior_mean, liblinear_epsilon, DEFAULT_MAX_ITER);

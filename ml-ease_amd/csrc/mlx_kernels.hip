@@ -1740,8 +1740,9 @@ __device__ __forceinline__ bool step_geom(const PartDev &pa, int ch, StepGeom &g
     return true;
 }
 
-// ---- head of phase A's grid-rounded dot: one workgroup per problem, one thread per head column (grid_of_sum) ----------------------
-__global__ void __launch_bounds__(STEP_T)
+// ---- head of phase A's grid-rounded dot: one workgroup per problem, FOUR threads per head column (grid_of_sum) -------------------
+// (the hottest columns have O(100) column-sum slots each: one thread per column spent 16 us per launch on the longest of them)
+__global__ void __launch_bounds__(4 * STEP_HEAD)
 k_step_head(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist)
 {
 #pragma clang fp contract(off)
@@ -1750,19 +1751,21 @@ k_step_head(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, cons
     const int phase = pr.phase;
     if (phase == PH_DONE) return;
     const PartDev &pa = parts[pr.part];
-    const int n = pa.n_local, nf = pa.n_feat, j = threadIdx.x;
+    const int n = pa.n_local, nf = pa.n_feat, j = threadIdx.x >> 2, q = threadIdx.x & 3;
     const bool cg = (phase == PH_CG);
     double csum_icpt = 0.0;
     if (nf < STEP_HEAD) csum_icpt = block_sum_array(pr.csump, pa.n_rowparts, scratch);       // (uniform: a problem of <= 256 columns)
     const double *__restrict__ v = cg ? pr.d : pr.w_new;
     double ht[1] = {0.0};
-    if (j < min(STEP_HEAD, n)) {
-        double xa = 0.0;
-        if (j < nf) {
-            const int i0 = gld(pa.col_ptr + j), i1 = gld(pa.col_ptr + j + 1);
-#pragma unroll 8
-            for (int it = i0; it < i1; it++) xa += gld(pr.parts + it);
-        } else xa = csum_icpt;
+    double xa = 0.0;
+    if (j < min(STEP_HEAD, nf)) {
+        const int i0 = gld(pa.col_ptr + j), i1 = gld(pa.col_ptr + j + 1);
+#pragma unroll 4
+        for (int it = i0 + q; it < i1; it += 4) xa += gld(pr.parts + it);
+    }
+    xa = group_allreduce_sum<4>(xa);                           // (all lanes take part; lanes without a column hold 0)
+    if (q == 0 && j < min(STEP_HEAD, n)) {
+        if (j == nf) xa = csum_icpt;
         const double pjv = pr.pinv_vec ? gld(pr.pinv_vec + j) : pr.pinv;
         const double vj = gld(v + j);
         if (cg) { const double hd = vj * pjv + xa; ht[0] = vj * hd; }
@@ -2960,7 +2963,7 @@ void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *p
     if (nq <= 0) return;
     const dim3 grid((unsigned)max_nwg, (unsigned)nq);
     if (which == 0) {
-        if (emu) hipLaunchKernelGGL(k_step_head, dim3((unsigned)nq), dim3(STEP_T), 0, st, parts, probs, qlist);
+        if (emu) hipLaunchKernelGGL(k_step_head, dim3((unsigned)nq), dim3(4 * STEP_HEAD), 0, st, parts, probs, qlist);
         if (emu) hipLaunchKernelGGL(k_step_a<true>, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
         else hipLaunchKernelGGL(k_step_a<false>, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
     } else if (which == 1) {
