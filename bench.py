@@ -443,6 +443,19 @@ def run_dense(args, C):
     rows = rows_total // N                                                  # rows per partition (row % N assignment)
     mine = [k for k in range(N) if k % world == rank]                       # partition k -> rank k mod G
     P = len(mine)
+    # The 8-per-GPU shape is measured FIRST, while nothing else lives on the device -- as the one job a rank of the 8-GPU run holds.
+    # (Run after the 64-partition engine had been built it measured 1.82 k solves/s instead of 2.6-2.8 k: an engine whose tiles are
+    # allocated behind 4 GB of other allocations streams 35 % slower -- smaller memory fragments, presumably; profiles/r4_notes.md.)
+    d8 = None
+    d8_launches = dict(untimed_launches=0, untimed_alg_bytes=0.0)
+    if world == 1 and not args.no_dense8 and args.partitions == PARTS and args.rows == ROWS and nf == NFEAT:
+        C["allrun_dense"] = d8_launches
+
+        def _acc8(st):
+            d8_launches["untimed_launches"] += st.xpass_launches
+            d8_launches["untimed_alg_bytes"] += st.alg_bytes_dev
+        C["account_dense"] = _acc8
+        d8 = dense8_leg(args, C, args.rows // args.partitions, nf)
     eng = C["HipAdmmEngine"](nf + 1, [1.0], [1.0], N, device=C["local_rank"], stream=C["stream"])
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     if want_cpu and mem_available_gb() < 48:
@@ -465,7 +478,7 @@ def run_dense(args, C):
                total_ms=0.0, launches=0, step_ms=0.0, step_busy_ms=0.0)
     # every k_xpass_dense launch of this leg that ran with events on: what a rocprofv3 --kernel-trace of this command must agree with
     # (it also sees finalize's one c0 launch, which runs without events)
-    allrun = dict(alg_bytes=0.0, launches=0, xpass_ms=0.0, busy_ms=0.0, untimed_launches=1, untimed_alg_bytes=P * (4.0 * rows * nf + 8.0 * rows + 8.0 * (nf + 1)))
+    allrun = dict(alg_bytes=0.0, launches=0, xpass_ms=0.0, busy_ms=0.0, untimed_launches=1 + d8_launches["untimed_launches"], untimed_alg_bytes=P * (4.0 * rows * nf + 8.0 * rows + 8.0 * (nf + 1)) + d8_launches["untimed_alg_bytes"])
     C["allrun_dense"] = allrun
     # At one GPU the HIP events that time k_xpass_dense are ON in the timed region itself (and in every other solve of this leg), on
     # the streams the kernel is launched on. The library ticks the two halves of the problems on two streams (production default:
@@ -613,8 +626,10 @@ def run_dense(args, C):
                "time_to_ref_loglik": loglik}
         if not args.no_gram:
             out["gram"] = gram_leg(eng, rows, nf)
-        if world == 1 and not args.no_dense8 and N == PARTS:
-            out["dense_8_per_gpu"] = dense8_leg(args, C, rows, nf)
+            allrun["untimed_launches"] += 3                    # mlx_posterior_variance evaluates D at w with one pass over its partition
+            allrun["untimed_alg_bytes"] += 3 * (4.0 * rows * nf + 8.0 * rows + 8.0 * (nf + 1))
+        if d8 is not None:
+            out["dense_8_per_gpu"] = d8
         if want_cpu:
             cpu_leg(args, C, eng, out, sample, snap, eps_used, step_times, nf, N)
         # every k_xpass_dense launch of the process: the numbers a `rocprofv3 --kernel-trace --stats` of this command must show
