@@ -150,7 +150,11 @@ void orc_dataset_destroy(orc_dataset *d)
  *               once the running sum is large (it absorbs their low bits), without the loop's dependency chain;
  *   bit 6 (64): Tron.dot as a pairwise tree (what a parallel reduction computes);
  *   bit 7 (128) / bit 8 (256): the grid-rounded sum with the grid taken from the prefix at the START of every block of 2048 / 64
- *               elements (cheaper for a kernel: no scan inside the block).
+ *               elements (cheaper for a kernel: no scan inside the block);
+ *   bits 9-12 (512 ... 4096): variants of it (see dot());
+ *   bit 13 (8192): the loss sum of fun as a tree over 256-row units (what the dense pass kernel computes);
+ *   bit 14 (16384): the loss sum of fun grid-rounded: terms behind the first 256 rows rounded to the ulp of those rows' sum, then added
+ *               exactly.
  * Used by tools/sum_order_experiment.py and tests/test_oracle.py to measure how far a summation order (or an exact sum) moves
  * the reference's TRON trajectory on one-hot data; never by a parity check. */
 static int g_sum_mode = 0;
@@ -251,6 +255,45 @@ static double fun(orc_func *f, const double *w, int count_pass)
     double s = 0;
     Xv(f, w, f->z);
     if (f->st) { f->st->fun_evals++; if (count_pass) f->st->x_passes++; }
+    if (g_sum_mode & (8192 | 16384)) {      /* experiment: the loss sum as a kernel would add it */
+        double tot = 0;
+        if (g_sum_mode & 8192) {
+            for (int u0 = 0; u0 < d->l; u0 += 256) {
+                double t[256];
+                int m = d->l - u0 < 256 ? d->l - u0 : 256;
+                for (int k = 0; k < 256; k++) t[k] = 0;
+                for (int k = 0; k < m; k++) {
+                    int i = u0 + k;
+                    f->z[i] += d->offset[i];
+                    double yz = d->y[i] * f->z[i];
+                    t[k] = (yz >= 0) ? f->weight[i] * log1p(exp(-yz)) : f->weight[i] * (-yz + log1p(exp(yz)));
+                }
+                for (int st = 128; st >= 1; st >>= 1) for (int k = 0; k < st; k++) t[k] += t[k + st];
+                tot += t[0];
+            }
+        } else {
+            double hh = 0, hl = 0, rh = 0, rl = 0, u = 0, magic = 0;
+            for (int i = 0; i < d->l; i++) {
+                f->z[i] += d->offset[i];
+                double yz = d->y[i] * f->z[i];
+                double x = (yz >= 0) ? f->weight[i] * log1p(exp(-yz)) : f->weight[i] * (-yz + log1p(exp(yz)));
+                if (i < 256) { acc2(&hh, &hl, x); acc2(&rh, &rl, x); }
+                else {
+                    if (i == 256) { double h = hh + hl; int e; if (h > 0) { frexp(h, &e); u = ldexp(1.0, e - 53); magic = 1.5 * ldexp(1.0, 52) * u; } }
+                    double xr = (u > 0 && fabs(x) < ldexp(1.0, 50) * u) ? ((x + magic) - magic) : x;
+                    acc2(&rh, &rl, xr);
+                }
+            }
+            tot = rh + rl;
+        }
+        s = 2.0 * tot;
+        for (int i = 0; i < d->n; i++) {
+            double t = w[i] - f->priorMean[i];
+            s += t * t * f->priorVar_inv[i];
+        }
+        s /= 2.0;
+        return f->multiplier * s;
+    }
     if (g_sum_mode & 8) {            /* experiment: compensated loss and prior sums */
         double hi = 0, lo = 0;
         for (int i = 0; i < d->l; i++) {
