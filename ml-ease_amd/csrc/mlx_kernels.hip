@@ -4,7 +4,7 @@
 // Execution model (DESIGN.md "Tick machine"): every (partition, lambda) problem advances in
 // lock-step TICKS. One tick = one pass over X for every unfinished problem (dense tiles: k_xpass_dense; sliced CSR
 // partitions: [k_rowcold +] k_rowpass_lds, then k_colpass_lds) followed by the TRON/CG step (dense: k_tron_step, one
-// workgroup per problem; CSR: k_step_a / b / c + k_step_commit over column chunks), which owns all of Tron's control flow
+// workgroup per problem; CSR: k_step_head + k_step_a / b / c + k_step_commit over column chunks), which owns all of Tron's control flow
 // (bw/Tron.java:30-179) for its problem and decides what the next pass computes:
 //     PH_CG    pass computes  X' diag(wt*D) X d          (the Hv of llf/LogisticRegressionL2.java:231-248)
 //     PH_EVAL  pass computes  loss(w_new), D(w_new), X' t(w_new)  (fun + grad fused, :156-225)
@@ -12,6 +12,10 @@
 //   * Hv reads X once (row tile in registers: dot, scale, rank-1 accumulate) instead of Xv + XTv;
 //   * fun and grad share one pass; after a rejected step the trial D is discarded (wd double buffer);
 //   * grad(0)'s data term X' t0 is a per-partition constant (c0), computed once at upload.
+// Arithmetic that is NOT a plain tree on purpose: the two n-long dots of a CG step on the CSR path (d.Hd, r.r) round their terms to the
+// running sum's grid first, as the reference's sequential loop does (grid_of_sum below).
+// Partial sums are functions of the partition alone (dense: per 256-row unit, added in pairs; CSR: per 64-row group), so results do
+// not depend on the chunking mlx_finalize picks for a handle.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -1649,6 +1653,11 @@ k_tron_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, cons
 // Norms are sqrt(sum v^2) of sums gathered inside the update loops (euclideanNorm's scaled form up to the last bits).
 // ------------------------------------------------------------------------------------------------
 #define STEP_T 256
+#ifdef STEP_MINW
+#define STEP_LB __launch_bounds__(STEP_T, STEP_MINW)      // A/B builds: minimum waves per SIMD of the streaming phases (tools/ablate_build.sh)
+#else
+#define STEP_LB __launch_bounds__(STEP_T)
+#endif
 // The step's n-vector streams are touched once per launch and not again before ~1 GB of other traffic has gone by: streaming
 // (non-temporal) loads and stores keep them from displacing the gathered vectors and index packs in L2 (config #3: step 316 -> 283 us per
 // tick, 5.06 k -> 5.29 k solves/s). NOT for what the next launch reads from L2: the column pass's slot stores and phase A's slot /
@@ -1706,7 +1715,11 @@ __device__ __forceinline__ void step_gather(const double *__restrict__ px, int n
 // or of the true prefix at every 2048-column chunk, all follow the oracle equally well on CPU models of this arithmetic; the head
 // sum needs no exchange between workgroups. A first version published chunk sums through agent-scope granules and looked back over
 // them: same parity, 17 % of the sparse leg's throughput; a second recomputed the d.Hd head in every workgroup of phase A: 9 %.)
-#define STEP_HEAD 256
+#define STEP_HEAD 256          // head columns of phase B's r.r (computed in the kernel) and, by default, of phase A's d.Hd (k_step_head)
+#ifndef STEP_HEAD_A
+#define STEP_HEAD_A STEP_HEAD
+#endif
+#define STEP_HEAD_LANES (1024 / STEP_HEAD_A)               // lanes of k_step_head per head column
 __device__ __forceinline__ double grid_of_sum(double h)
 {
     const double ah = fabs(h);
@@ -1740,9 +1753,9 @@ __device__ __forceinline__ bool step_geom(const PartDev &pa, int ch, StepGeom &g
     return true;
 }
 
-// ---- head of phase A's grid-rounded dot: one workgroup per problem, FOUR threads per head column (grid_of_sum) -------------------
+// ---- head of phase A's grid-rounded dot: one workgroup per problem, STEP_HEAD_LANES threads per head column (grid_of_sum) ---------
 // (the hottest columns have O(100) column-sum slots each: one thread per column spent 16 us per launch on the longest of them)
-__global__ void __launch_bounds__(4 * STEP_HEAD)
+__global__ void __launch_bounds__(1024)
 k_step_head(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist)
 {
 #pragma clang fp contract(off)
@@ -1751,20 +1764,21 @@ k_step_head(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, cons
     const int phase = pr.phase;
     if (phase == PH_DONE) return;
     const PartDev &pa = parts[pr.part];
-    const int n = pa.n_local, nf = pa.n_feat, j = threadIdx.x >> 2, q = threadIdx.x & 3;
+    constexpr int LN = STEP_HEAD_LANES;
+    const int n = pa.n_local, nf = pa.n_feat, j = threadIdx.x / LN, q = threadIdx.x % LN;
     const bool cg = (phase == PH_CG);
     double csum_icpt = 0.0;
-    if (nf < STEP_HEAD) csum_icpt = block_sum_array(pr.csump, pa.n_rowparts, scratch);       // (uniform: a problem of <= 256 columns)
+    if (nf < STEP_HEAD_A) csum_icpt = block_sum_array(pr.csump, pa.n_rowparts, scratch);     // (uniform: a problem of few columns)
     const double *__restrict__ v = cg ? pr.d : pr.w_new;
     double ht[1] = {0.0};
     double xa = 0.0;
-    if (j < min(STEP_HEAD, nf)) {
+    if (j < min(STEP_HEAD_A, nf)) {
         const int i0 = gld(pa.col_ptr + j), i1 = gld(pa.col_ptr + j + 1);
 #pragma unroll 4
-        for (int it = i0 + q; it < i1; it += 4) xa += gld(pr.parts + it);
+        for (int it = i0 + q; it < i1; it += LN) xa += gld(pr.parts + it);
     }
-    xa = group_allreduce_sum<4>(xa);                           // (all lanes take part; lanes without a column hold 0)
-    if (q == 0 && j < min(STEP_HEAD, n)) {
+    xa = group_allreduce_sum<LN>(xa);                          // (all lanes take part; lanes without a column hold 0)
+    if (q == 0 && j < min(STEP_HEAD_A, n)) {
         if (j == nf) xa = csum_icpt;
         const double pjv = pr.pinv_vec ? gld(pr.pinv_vec + j) : pr.pinv;
         const double vj = gld(v + j);
@@ -1777,7 +1791,7 @@ k_step_head(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, cons
 
 // ---- phase A ------------------------------------------------------------------------------------
 template <bool EMU>
-__global__ void __launch_bounds__(STEP_T)
+__global__ void STEP_LB
 k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int ch)
 {
 #pragma clang fp contract(off)
@@ -1835,14 +1849,14 @@ k_step_a(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
                 const double hd = vv[u] * pj[u] + xa;          // Hs[i] = (s[i]*priorVar_inv[i] + Hs[i]) * 1
                 SST(Hd + j, hd);
                 const double term = vv[u] * hd;
-                acc[0] += (EMU && j >= STEP_HEAD) ? round_to_grid(term, ugrid) : term;
+                acc[0] += (EMU && j >= STEP_HEAD_A) ? round_to_grid(term, ugrid) : term;
             } else {
                 const double t = vv[u] - mm[u];
                 acc[0] += t * t * pj[u];                       // fun :187-188
                 const double hd = t * pj[u] + xa;              // grad :224 (multiplier 1)
                 gst(Hd + j, hd);
                 const double term = hd * hd;
-                acc[1] += (EMU && j >= STEP_HEAD) ? round_to_grid(term, ugrid) : term;
+                acc[1] += (EMU && j >= STEP_HEAD_A) ? round_to_grid(term, ugrid) : term;
                 if (phase == PH_EVAL0) {
                     const double g0 = (0.0 - mm[u]) * pj[u] + cc[u];      // grad(0)
                     acc[2] += g0 * g0;
@@ -1961,7 +1975,7 @@ __device__ __forceinline__ CgDecision cg_decide(const ProbDev &pr, const double 
 
 // ---- phase B ------------------------------------------------------------------------------------
 template <bool EMU>
-__global__ void __launch_bounds__(STEP_T)
+__global__ void STEP_LB
 k_step_b(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int ch)
 {
 #pragma clang fp contract(off)
@@ -2058,7 +2072,7 @@ k_step_b(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const i
 }
 
 // ---- phase C (CG ticks only) ----------------------------------------------------------------------
-__global__ void __launch_bounds__(STEP_T)
+__global__ void STEP_LB
 k_step_c(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int ch)
 {
 #pragma clang fp contract(off)
@@ -2137,16 +2151,36 @@ k_step_commit(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
 #pragma clang fp contract(off)
     __shared__ double stage[STEP_T];
     __shared__ double totA[4], totB[5], totC[3];
+    constexpr int CW = 64;                                           // problems of <= CW chunks: all three partial arrays in ONE round trip
+    __shared__ double all3[3][CW * STEP_NP];
     ProbDev &pr = probs[qlist[blockIdx.x]];
     const int phase = pr.phase;
     if (phase == PH_DONE) return;
     const PartDev &pa = parts[pr.part];
     const int nwg = (pa.n_local + ch - 1) / ch;
-    step_gather<4>(pr.pA, nwg, totA, stage);
+    const bool batched = nwg <= CW;
+    if (batched) {
+        // this launch is one workgroup per problem on a mostly idle chip: a chain of dependent loads IS its duration. The chunk-ordered
+        // sums are those of step_gather (same order, same values).
+        const int cnt = nwg * STEP_NP;
+        for (int i = threadIdx.x; i < cnt; i += STEP_T) {
+            all3[0][i] = pr.pA[i];
+            all3[1][i] = (phase == PH_CG) ? pr.pB[i] : 0.0;
+            all3[2][i] = (phase == PH_CG) ? pr.pC[i] : 0.0;          // (read whether or not the trcg call ends: stale values are not used)
+        }
+        __syncthreads();
+        if (threadIdx.x < 12) {
+            const int arr = threadIdx.x < 4 ? 0 : (threadIdx.x < 9 ? 1 : 2), k = threadIdx.x - (arr == 0 ? 0 : (arr == 1 ? 4 : 9));
+            double a = 0.0;
+            for (int w = 0; w < nwg; w++) a += all3[arr][w * STEP_NP + k];
+            (arr == 0 ? totA : (arr == 1 ? totB : totC))[k] = a;
+        }
+        __syncthreads();
+    } else step_gather<4>(pr.pA, nwg, totA, stage);
     if (phase == PH_CG) {
-        step_gather<5>(pr.pB, nwg, totB, stage);
+        if (!batched) step_gather<5>(pr.pB, nwg, totB, stage);
         const CgDecision D = cg_decide(pr, totA, totB);
-        if (D.end_cg) step_gather<3>(pr.pC, nwg, totC, stage);        // (uniform: every thread holds the same D)
+        if (D.end_cg && !batched) step_gather<3>(pr.pC, nwg, totC, stage);        // (uniform: every thread holds the same D)
         if (threadIdx.x != 0) return;
         if (!D.boundary) pr.rTr = D.rnew;
         pr.rsel ^= 1;
@@ -2963,7 +2997,7 @@ void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *p
     if (nq <= 0) return;
     const dim3 grid((unsigned)max_nwg, (unsigned)nq);
     if (which == 0) {
-        if (emu) hipLaunchKernelGGL(k_step_head, dim3((unsigned)nq), dim3(4 * STEP_HEAD), 0, st, parts, probs, qlist);
+        if (emu) hipLaunchKernelGGL(k_step_head, dim3((unsigned)nq), dim3(1024), 0, st, parts, probs, qlist);
         if (emu) hipLaunchKernelGGL(k_step_a<true>, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
         else hipLaunchKernelGGL(k_step_a<false>, grid, dim3(STEP_T), 0, st, parts, probs, qlist, ch);
     } else if (which == 1) {
