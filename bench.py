@@ -289,6 +289,8 @@ def compact_record(full):
                 c["roofline"][k] = round(c["roofline"][k])
         c["roofline"]["avg_launch_ms"] = _r(c["roofline"].get("avg_launch_ms"), 5)
         c["roofline"]["measured_in"] = roof.get("measured_in_short", "timed region")
+        if roof.get("kernel_alone"):
+            c["roofline"]["frac_kernel_alone_one_stream"] = roof["kernel_alone"]["frac"]
     c["whole_step_frac"] = (full.get("whole_step") or {}).get("frac_of_hbm_peak")
     cb = full.get("cpu_baseline")
     if cb:
@@ -556,6 +558,30 @@ def run_dense(args, C):
         eng.set_profiling(False)
         prof["reproduced"] = bool(f2 is not None and f2.maxdiff == fin.maxdiff and prof["ticks"] == acc["ticks"] and np.array_equal(eng.z()[1], z32_end))
 
+    # ---- the kernel ALONE on the chip: a replay of the first timed iterations with events and all ticks on one stream (no second launch
+    # shares the memory system, no step launch runs beside the pass): the literal "bytes per launch / average launch duration"
+    alone = None
+    if prof_timed:
+        al = dict(alg=0.0, ms=0.0, launches=0, wall=0.0, iters=min(args.steps, 5))
+        eng.set_state(snap[0], snap[1])
+        eng.set_profiling(True, one_stream=True)
+        C["barrier"]()
+        ta = time.perf_counter()
+        for eps in eps_used[args.warmup:args.warmup + al["iters"]]:
+            st3 = eng.solve_local(eps, 1.0)
+            eng.consensus_finish()
+            account(st3)
+            al["alg"] += st3.alg_bytes_dev; al["ms"] += st3.xpass_ms; al["launches"] += st3.xpass_launches
+        C["barrier"]()
+        al["wall"] = time.perf_counter() - ta
+        eng.set_profiling(True)
+        if al["ms"] > 0:
+            alone = {"frac": round(al["alg"] / (al["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "achieved": round(al["alg"] / (al["ms"] * 1e-3) / 1e9, 1),
+                     "avg_launch_ms": round(al["ms"] / max(1, al["launches"]), 5), "launches": al["launches"],
+                     "ms_per_step": round(al["wall"] * 1e3 / al["iters"], 3),
+                     "measured_in": "a replay of the first %d timed iterations (same state, same epsilons) with events on and ALL ticks on one "
+                                    "stream: every k_xpass_dense launch has the chip to itself" % al["iters"]}
+
     # ---- metric (ii): ADMM wall-clock to the reference test log-likelihood: a full run from z = u = 0 with
     # the per-iteration test loglik (jobs/RegressionAdmmTrain.java:766-845) on the 100 000 held-out rows; the target is
     # the ORACLE's value after its 20th iteration on the same data (tests/golden/c2_ref_loglik.json). Outside the timed region.
@@ -601,6 +627,8 @@ def run_dense(args, C):
                                     "a replay of the %d timed iterations (same state, same epsilons; reproduced = %s) with events on: %.3f ms per "
                                     "iteration there against %.3f ms in the timed run (no events)" % (
                                         args.steps, prof["reproduced"], prof["wall"] * 1e3 / args.steps, dt * 1e3 / args.steps))}
+            if alone is not None:
+                roof["kernel_alone"] = alone
             if not timed:
                 roof["replay_ms_per_step"] = round(prof["wall"] * 1e3 / args.steps, 3)
                 roof["reproduced_timed_run"] = prof["reproduced"]

@@ -90,7 +90,8 @@ int mlx_destroy(mlx_handle h);
 const char *mlx_last_error(mlx_handle h);          /* valid until the next call on h; h may be NULL */
 /* Run all work of this handle on an existing hipStream_t (e.g. torch's current stream); NULL = own stream. */
 int mlx_set_stream(mlx_handle h, void *hip_stream);
-/* 1 = time the X-pass kernels with HIP events (stats.xpass_ms); costs one event pair per launch. */
+/* 1 = time the launch classes with HIP events (stats.*_ms / *_busy_ms; one mark per launch class and tick stream);
+ * 2 = the same with ALL ticks on one stream, so that a launch's duration is the kernel's alone (measurement only: slower). */
 int mlx_set_profiling(mlx_handle h, int enable);
 
 /* ---- problem definition -------------------------------------------------------------------

@@ -531,6 +531,8 @@ int mlx_set_profiling(mlx_handle h, int enable)
 {
     if (!h) return MLX_ERR_INVALID;
     h->profiling = enable != 0;
+    if (enable == 2) h->prof_one_stream = true;        // events AND all ticks on one stream: a launch's duration is the kernel's alone
+    else if (enable == 1) h->prof_one_stream = getenv("MLX_PROFILE_ONE_STREAM") != nullptr && atoi(getenv("MLX_PROFILE_ONE_STREAM")) != 0;
     return MLX_OK;
 }
 

@@ -1707,7 +1707,7 @@ __device__ __forceinline__ void step_gather(const double *__restrict__ px, int n
 // of full-size configs[2] partitions whose TRON counters equal the oracle's): oracle on permuted rows 253-269 of 384, this library
 // with tree dots 200, with compensated dots fewer still, with the dots below 242.
 // The grid comes from the HEAD sum: the terms of the problem's first STEP_HEAD columns (the hottest: library ids are frequency-
-// sorted). For r.r every workgroup of phase B adds them itself (two loads per column, L2 hits); for d.Hd / g.g the head needs the
+// sorted; STEP_HEAD = 64 of them). For r.r every workgroup of phase B adds them itself (two loads per column, L2 hits); for d.Hd / g.g the head needs the
 // column sums of the hottest columns -- O(100) slots each -- so one small launch per tick (k_step_head, one workgroup per problem)
 // leaves it in the descriptor for phase A. u = the ulp of the head sum's binade. Terms of the later columns are rounded to a multiple of u before they are added: the magic-constant form
 // (x + 1.5 * 2^52 u) - 1.5 * 2^52 u, exactly what the FPU does to x when it is added to a sum of that size. Sums of multiples of u
@@ -1715,7 +1715,9 @@ __device__ __forceinline__ void step_gather(const double *__restrict__ px, int n
 // or of the true prefix at every 2048-column chunk, all follow the oracle equally well on CPU models of this arithmetic; the head
 // sum needs no exchange between workgroups. A first version published chunk sums through agent-scope granules and looked back over
 // them: same parity, 17 % of the sparse leg's throughput; a second recomputed the d.Hd head in every workgroup of phase A: 9 %.)
-#define STEP_HEAD 256          // head columns of phase B's r.r (computed in the kernel) and, by default, of phase A's d.Hd (k_step_head)
+#ifndef STEP_HEAD
+#define STEP_HEAD 64           // head columns of phase B's r.r (computed in the kernel) and, by default, of phase A's d.Hd (k_step_head).
+#endif                         // (64 against 256: CPU model 132 against 120-130 of 192 solves followed, GPU 256 against 250 of 384; A/B: -DSTEP_HEAD=256)
 #ifndef STEP_HEAD_A
 #define STEP_HEAD_A STEP_HEAD
 #endif

@@ -197,9 +197,10 @@ class HipAdmmEngine:
                                                 None if offset_ptr is None else C.c_void_p(offset_ptr), _p(l2g), 1))
         self.nlocal += 1
 
-    def set_profiling(self, enable: bool):
-        """Per-launch-class HIP events on / off (they cost ~4 % of a sparse tick and keep the ticks on ONE stream)."""
-        self._ck(self.L.mlx_set_profiling(self.h, 1 if enable else 0))
+    def set_profiling(self, enable, one_stream: bool = False):
+        """Per-launch-class HIP events on / off (every tick stream carries its own chain of marks). one_stream=True also keeps all ticks
+        on ONE stream, so that a launch's duration is the kernel's alone (measurement only)."""
+        self._ck(self.L.mlx_set_profiling(self.h, (2 if one_stream else 1) if enable else 0))
 
     def finalize(self):
         self._ck(self.L.mlx_finalize(self.h))

@@ -484,3 +484,25 @@ def test_bench_and_tools_call_only_names_that_exist():
                 known.add(node.id)
         missing = sorted({n.func.id for n in ast.walk(tree) if isinstance(n, ast.Call) and isinstance(n.func, ast.Name)} - known)
         assert not missing, (rel, missing)
+
+
+def test_rocpd_summary_busy_time_is_the_union_of_the_dispatch_intervals(tmp_path):
+    """tools/rocpd_summary.py --busy: dispatches of one kernel on two streams overlap; busy time = the measure of the union of their
+    [start, end] intervals (bench.py's roofline uses the same definition from HIP events)."""
+    import sqlite3
+    db = str(tmp_path / "t.db")
+    con = sqlite3.connect(db)
+    con.execute("create table kernels (name text, start integer, end integer, duration integer, dispatch_id integer)")
+    rows = [("k_xpass_dense<4,4>", 0, 100, 100, 1), ("k_xpass_dense<4,4>", 50, 180, 130, 2), ("k_xpass_dense<4,4>", 300, 400, 100, 3),
+            ("k_tron_step", 100, 120, 20, 4), ("k_xpass_dense<4,4>", 390, 395, 5, 5)]
+    con.executemany("insert into kernels values (?,?,?,?,?)", rows)
+    con.commit()
+    con.close()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocpd_summary.py"), db, "--busy", "k_xpass_dense", "--busy", "k_tron_step"],
+                         capture_output=True, text=True, check=True).stdout
+    out = out[out.index("# busy time"):]
+    line = [ln for ln in out.splitlines() if ln.startswith("k_xpass_dense")][0]
+    # union = [0,180] + [300,400] = 280 ns; sum of durations = 335 ns
+    assert "dispatches=     4" in line and "sum_of_durations_ms=       0.000" in line
+    assert abs(float(line.split("in_flight=")[1].split()[0]) - 335.0 / 280.0) < 1e-3
+    assert [ln for ln in out.splitlines() if ln.startswith("k_tron_step")][0].split("in_flight=")[1].split()[0] == "1.000"
