@@ -305,7 +305,9 @@ def compact_record(full):
     pc = full.get("parity_check") or {}
     vo = ((full.get("time_to_ref_loglik") or {}).get("vs_oracle_run")) or {}
     if pc or vo:
-        par["config2"] = {"tolerance": 1e-5, "max_rel_err_z": _r(pc.get("max_rel_err_z"), 9), "tron_counters_equal": pc.get("tron_counters_equal"),
+        par["config2"] = {"tolerance": 1e-5, "iterations_checked": (full.get("gpu_over_cpu") or {}).get("same_iterations"),
+                          "max_rel_err_z": _r(pc.get("max_rel_err_z"), 9), "tron_counters_equal": pc.get("tron_counters_equal"),
+                          "counters_equal_through_iteration": pc.get("counters_equal_through_iteration"),
                           "bit_identical_f32": pc.get("bit_identical_float32_fraction"),
                           "run20_max_rel_err_through_eps_1e-6": _r(vo.get("max_rel_err_z32_through_epsilon_1e-6"), 9),
                           "run20_max_rel_err": _r(vo.get("max_rel_err_z32_over_iterations"), 9),
