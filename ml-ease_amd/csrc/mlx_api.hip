@@ -596,7 +596,6 @@ static RowHot row_hot_cols(int nf, int n_lambda)
     const int slmax = getenv("MLX_SLW") ? std::min(ROW_SLICE_MAX_COLS, std::max(64, atoi(getenv("MLX_SLW")) / 64 * 64)) : ROW_SLICE_MAX_COLS;
     R.slw = std::max(64, (std::min(nf, slmax) + 63) / 64 * 64);
     int nhs_want = getenv("MLX_NHOT") ? std::max(1, atoi(getenv("MLX_NHOT"))) : (nf <= 2 * R.slw ? 2 : 1);
-    if (n_lambda >= 2 && getenv("MLX_MULTI") != nullptr && atoi(getenv("MLX_MULTI")) != 0) nhs_want = 1;   // the shared row pass knows one
     R.n_hs = std::max(1, std::min(nhs_want, (nf + R.slw - 1) / R.slw));
     R.hot_cols = R.n_hs * R.slw;
     return R;
