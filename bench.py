@@ -173,6 +173,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
     stream = torch.cuda.current_stream().cuda_stream
+    if os.environ.get("MLX_BENCH_OWN_STREAM") == "1":          # (A/B: the library's own non-NULL stream instead of torch's current -- legacy default -- stream)
+        stream = None
 
     def _collective(t, op):
         if share:
@@ -447,9 +449,10 @@ def run_dense(args, C):
     rows = rows_total // N                                                  # rows per partition (row % N assignment)
     mine = [k for k in range(N) if k % world == rank]                       # partition k -> rank k mod G
     P = len(mine)
-    # The 8-per-GPU shape is measured FIRST, while nothing else lives on the device -- as the one job a rank of the 8-GPU run holds.
-    # (Run after the 64-partition engine had been built it measured 1.82 k solves/s instead of 2.6-2.8 k: an engine whose tiles are
-    # allocated behind 4 GB of other allocations streams 35 % slower -- smaller memory fragments, presumably; profiles/r4_notes.md.)
+    # The 8-per-GPU shape is measured FIRST, as the one job a rank of the 8-GPU run holds, and on a stream of the library's own.
+    # (Built after the 64-partition engine, with BOTH handles on torch's current stream -- the legacy default stream -- it measured
+    # 1.82 k solves/s instead of 2.8 k: every launch on that stream orders against the other handle's streams. On its own stream, or
+    # with the other handle closed, the order does not matter: attic/tools/d8_order_probe.py, profiles/r4_notes.md.)
     d8 = None
     d8_launches = dict(untimed_launches=0, untimed_alg_bytes=0.0)
     if world == 1 and not args.no_dense8 and args.partitions == PARTS and args.rows == ROWS and nf == NFEAT:
@@ -681,7 +684,7 @@ def dense8_leg(args, C, rows, nf):
     Few problems must still fill 256 CUs: one 256-row unit per pass workgroup (496 workgroups), two tick streams."""
     torch, dev, sd, admm = C["torch"], C["dev"], C["sd"], C["admm"]
     try:
-        eng = C["HipAdmmEngine"](nf + 1, [1.0], [1.0], 8, device=C["local_rank"], stream=C["stream"])
+        eng = C["HipAdmmEngine"](nf + 1, [1.0], [1.0], 8, device=C["local_rank"], stream=None)
         for k in range(8):
             X, y = sd.dense_rows_torch(torch, dev, 8 * k, rows, nf, stride=PARTS)          # partitions 0, 8, ..., 56 of the 64-partition job
             torch.cuda.synchronize()
