@@ -574,3 +574,35 @@ def test_driver_block_against_its_closed_form(c1):
         assert np.array_equal(Z, z), float(np.max(np.abs(Z - z)))
         u_next = np.stack([oc.partition_model(k, 0)[2] for k in range(N)])
         assert np.array_equal(u_next, (UPX.astype(np.float64) - z).astype(np.float32))
+
+
+def test_sequential_sum_is_the_exact_sum_of_grid_rounded_terms_within_a_binade():
+    """The mechanism behind the step kernels' grid-rounded dots (mlx_kernels.hip: round_to_grid): while a running
+    sum stays inside one binade, `s = fl(s + x)` equals `s + rnd_u(x)` EXACTLY, where rnd_u rounds x to the nearest multiple of u = ulp(s)
+    -- the rounding depends on (x, binade of s), not on the order of the terms -- and `(x + 1.5 * 2^52 u) - 1.5 * 2^52 u` computes
+    rnd_u(x). So the sequential loop of bw/Tron.java:204-213 and ANY parallel sum of the rounded terms give the same bits (sums of
+    multiples of u are exact), while the plain parallel (or exact) sum of the unrounded terms lands tens of ulp away."""
+    import math
+    rng = np.random.default_rng(7)
+    off = []
+    for trial in range(20):
+        s0 = float(rng.uniform(1.0, 1.2)) * 2.0 ** int(rng.integers(-20, 20))           # a running sum low in its binade
+        u = np.spacing(s0)
+        x = rng.lognormal(-14.0, 3.0, 20000) * s0 / 20000.0                                 # small positive terms: total growth < 2x
+        x = x[np.cumsum(x) < 0.7 * s0]                                                       # (stay inside the binade)
+        seq = s0
+        for v in x:                                                                          # the reference's loop
+            seq = seq + float(v)
+        magic = 1.5 * 2.0 ** 52 * u
+        xr = (x + magic) - magic                                                             # the kernels' round_to_grid
+        assert np.all(np.abs(xr - x) <= 0.5 * u) and np.all(np.round(xr / u) == xr / u)      # nearest multiples of u
+        for order in (np.arange(len(x)), rng.permutation(len(x)), np.argsort(x)):            # any order, any association
+            tree = xr[order].copy()
+            while len(tree) > 1:
+                if len(tree) % 2:
+                    tree = np.append(tree, 0.0)
+                tree = tree[0::2] + tree[1::2]
+            assert s0 + float(tree[0]) == seq, trial
+        off.append(abs(s0 + math.fsum(float(v) for v in x) - seq) / u)
+    # the exact sum of the UNROUNDED terms is somewhere else (ulps of s): the sequential loop's rounding errors are what it lacks
+    assert np.median(off) >= 3.0, off
