@@ -1533,17 +1533,18 @@ static int collect_solve_stats(mlx_handle h, int64_t ticks, mlx_stats *stats, bo
         int prev[mlx_context::MAX_TS];
         for (int &p : prev) p = -1;
         std::vector<std::pair<float, float>> iv[5];      // per class + [4] = all X-pass classes together
+        std::vector<float> at(h->ev_used, -1.0f);       // a mark's time since ev_t0 (one query per mark; durations are differences)
+        for (size_t i = 0; i < h->ev_used; i++)
+            if (hipEventElapsedTime(&at[i], h->ev_t0, h->ev_pool[i]) != hipSuccess) at[i] = -1.0f;
         for (size_t i = 0; i < h->ev_used; i++) {
             const int sx = h->ev_sidx[i];
             if (prev[sx] >= 0) {
-                float m2 = 0, t_a = 0;
                 const int kind = h->ev_kind[(size_t)prev[sx]];
-                if (kind >= 0 && hipEventElapsedTime(&m2, h->ev_pool[(size_t)prev[sx]], h->ev_pool[i]) == hipSuccess) {
-                    acc[kind] += m2; cnt[kind]++;
-                    if (hipEventElapsedTime(&t_a, h->ev_t0, h->ev_pool[(size_t)prev[sx]]) == hipSuccess) {
-                        iv[kind].emplace_back(t_a, t_a + m2);
-                        if (kind <= 2) iv[4].emplace_back(t_a, t_a + m2);
-                    }
+                const float t_a = at[(size_t)prev[sx]], t_b = at[i];
+                if (kind >= 0 && t_a >= 0.0f && t_b >= t_a) {
+                    acc[kind] += t_b - t_a; cnt[kind]++;
+                    iv[kind].emplace_back(t_a, t_b);
+                    if (kind <= 2) iv[4].emplace_back(t_a, t_b);
                 }
             }
             prev[sx] = (int)i;
