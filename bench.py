@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--loglik-iters", type=int, default=20, help="ADMM iterations of the time-to-reference-loglik run (0 = skip)")
     ap.add_argument("--test-rows", type=int, default=100000)
     ap.add_argument("--no-sparse", action="store_true", help="skip the configs[2]/[3] leg")
+    ap.add_argument("--no-handover", action="store_true", help="skip the host -> HBM handover measurement (PCIe-inclusive job rate)")
     ap.add_argument("--no-dense8", action="store_true", help="skip the 8-partitions-per-GPU dense shape (the 8-GPU share of configs[1])")
     ap.add_argument("--no-gram", action="store_true", help="skip the fp64-MFMA Gram measurement (posterior covariance of one partition)")
     ap.add_argument("--sparse-only", action="store_true", help="run only the sparse leg (development / profiling)")
@@ -349,6 +350,11 @@ def compact_record(full):
         c["gram"] = _pick(full["gram"], ["achieved", "peak", "unit", "frac"])
     if full.get("dense_8_per_gpu"):
         c["dense_8_per_gpu"] = _pick(full["dense_8_per_gpu"], ["value", "ms_per_step", "whole_step_frac"])
+    hh = full.get("host_handover") or {}
+    if hh.get("host_to_hbm_GB_s"):
+        c["pcie_inclusive"] = {"host_to_hbm_GB_s": hh["host_to_hbm_GB_s"],
+                               "solves_per_s_20_iterations_incl_handover": {k: hh.get("%s_solves_per_s_20_iterations_incl_handover" % k)
+                                                                            for k in hh["host_to_hbm_GB_s"]}}
     al = full.get("all_launches") or {}
     if al:
         c["all_xpass_launches"] = _pick(al, ["timed_by_events", "avg_us", "alg_bytes_timed_by_events"])
@@ -357,7 +363,7 @@ def compact_record(full):
     c["full_record"] = "bench_full.json (also on stderr)"
     c = _finite(c)
     # never exceed the limit: drop the optional blocks, least important first
-    for k in ("gram", "dense_8_per_gpu", "all_xpass_launches", "time_to_ref_loglik", "lambda_sweep", "sparse", "parity", "gpu_over_cpu"):
+    for k in ("gram", "pcie_inclusive", "dense_8_per_gpu", "all_xpass_launches", "time_to_ref_loglik", "lambda_sweep", "sparse", "parity", "gpu_over_cpu"):
         if len(json.dumps(c, allow_nan=False)) <= COMPACT_LIMIT:
             break
         c.pop(k, None)
@@ -663,6 +669,8 @@ def run_dense(args, C):
             allrun["untimed_alg_bytes"] += 3 * (4.0 * rows * nf + 8.0 * rows + 8.0 * (nf + 1))
         if d8 is not None:
             out["dense_8_per_gpu"] = d8
+        if world == 1 and not args.no_handover:
+            out["host_handover"] = handover_leg(args, C, rows, nf, N, dt / args.steps)
         if want_cpu:
             cpu_leg(args, C, eng, out, sample, snap, eps_used, step_times, nf, N)
         # every k_xpass_dense launch of the process: the numbers a `rocprofv3 --kernel-trace --stats` of this command must show
@@ -712,6 +720,40 @@ def dense8_leg(args, C, rows, nf):
                 "ms_per_step": round(dt * 1e3 / args.steps, 3),
                 "whole_step_frac": round(acc["alg"] / dt / 1e9 / HBM_PEAK_GBS, 4),
                 "x8": round(8 * acc["solves"] / dt, 1)}
+    except Exception as ex:                                       # an extra: never takes the headline down
+        return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+
+
+def handover_leg(args, C, rows, nf, N, s_per_step):
+    """What the timed region leaves out: the C-ABI takes HOST buffers (mlx_add_partition_dense copies a partition's float32 rows to HBM,
+    once per training run). Measured here with one partition handed over 4 times from pageable and from pinned host memory (no
+    finalize: no kernel of the solve runs), and folded into the rate of a whole 20-iteration job -- the PCIe-inclusive figure, never `value`."""
+    torch, dev, sd = C["torch"], C["dev"], C["sd"]
+    try:
+        X, y = sd.dense_rows_torch(torch, dev, 0, rows, nf, stride=N)
+        Xc, yc = X.cpu(), y.cpu()
+        del X, y
+        nbytes = 4.0 * rows * nf + rows
+        res = {}
+        for kind, Xh in (("pageable", Xc.numpy()), ("pinned", Xc.pin_memory().numpy())):
+            eng = C["HipAdmmEngine"](nf + 1, [1.0], [1.0], 5, device=C["local_rank"], stream=None)
+            eng.add_partition_dense(0, Xh, yc.numpy())               # first touch: allocations, staging buffers
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(1, 5):
+                eng.add_partition_dense(k, Xh, yc.numpy())
+            torch.cuda.synchronize()
+            res[kind] = 4 * nbytes / (time.perf_counter() - t0) / 1e9
+            eng.close()
+        job_iters = 20
+        o = {"bytes_per_partition": nbytes, "partitions": N, "host_to_hbm_GB_s": {k: round(v, 2) for k, v in res.items()}}
+        for kind, v in res.items():
+            t_in = N * nbytes / (v * 1e9)
+            o["%s_handover_s_whole_job" % kind] = round(t_in, 3)
+            o["%s_solves_per_s_%d_iterations_incl_handover" % (kind, job_iters)] = round(job_iters * N / (t_in + job_iters * s_per_step), 1)
+        o["note"] = ("mlx_add_partition_dense from host memory, 4 partitions after one untimed; the job figure = %d iterations x %d solves / "
+                     "(handover of all %d partitions at that rate + %d x the timed ms_per_step)" % (job_iters, N, N, job_iters))
+        return o
     except Exception as ex:                                       # an extra: never takes the headline down
         return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
 
