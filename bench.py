@@ -174,7 +174,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    if os.environ.get("MLX_BENCH_OWN_STREAM") == "1":          # (A/B: the library's own non-NULL stream instead of torch's current -- legacy default -- stream)
+    if os.environ.get("MLX_BENCH_OWN_STREAM") == "1":          # (no difference: torch's default stream is the NULL pointer = "own stream" for mlx_set_stream)
         stream = None
 
     def _collective(t, op):
@@ -455,10 +455,9 @@ def run_dense(args, C):
     rows = rows_total // N                                                  # rows per partition (row % N assignment)
     mine = [k for k in range(N) if k % world == rank]                       # partition k -> rank k mod G
     P = len(mine)
-    # The 8-per-GPU shape is measured FIRST, as the one job a rank of the 8-GPU run holds, and on a stream of the library's own.
-    # (Built after the 64-partition engine, with BOTH handles on torch's current stream -- the legacy default stream -- it measured
-    # 1.82 k solves/s instead of 2.8 k: every launch on that stream orders against the other handle's streams. On its own stream, or
-    # with the other handle closed, the order does not matter: attic/tools/d8_order_probe.py, profiles/r4_notes.md.)
+    # The 8-per-GPU shape is measured FIRST, as the one job a rank of the 8-GPU run holds. (Built after the 64-partition engine it once
+    # measured 1.82 k solves/s instead of 2.8 k: its two tick streams had landed on ONE hardware queue. The library now tests the pair and
+    # re-creates the second stream -- mlx_create, pick_tick_streams -- so the order no longer matters: attic/tools/hwqueue_probe2.py.)
     d8 = None
     d8_launches = dict(untimed_launches=0, untimed_alg_bytes=0.0)
     if world == 1 and not args.no_dense8 and args.partitions == PARTS and args.rows == ROWS and nf == NFEAT:

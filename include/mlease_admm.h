@@ -88,9 +88,13 @@ typedef struct mlx_stats {
 int mlx_create(int device_id, mlx_handle *out);
 int mlx_destroy(mlx_handle h);
 const char *mlx_last_error(mlx_handle h);          /* valid until the next call on h; h may be NULL */
-/* Run all work of this handle on an existing hipStream_t (e.g. torch's current stream); NULL = own stream.
- * Do not put TWO handles on the legacy default stream: every launch there orders against the other handle's streams
- * (measured: an 8-problem handle 2.8 k -> 1.8 k solves/s beside an idle 64-problem handle; profiles/r4_notes.md). */
+/* Run all work of this handle on an existing hipStream_t (e.g. a torch side stream); NULL = the handle's own stream (what
+ * mlx_create made; torch's DEFAULT stream is the NULL pointer, so passing it means "own stream" too).
+ * The handle ticks the halves of its problem list on two streams. The HIP runtime multiplexes a process's streams onto a few
+ * hardware queues, and two streams of one queue run in order: mlx_create / mlx_set_stream therefore test the pair (one idle 60 us
+ * wave on each: do they overlap?) and re-create the second stream until it sits on another queue (MLX_NO_STREAM_PROBE=1: no test).
+ * Measured without the test: an 8-problem handle 1.8 k instead of 2.8 k solves/s whenever the pair shared a queue -- which happened
+ * or not depending on the other streams alive in the process (profiles/r4_notes.md). */
 int mlx_set_stream(mlx_handle h, void *hip_stream);
 /* 1 = time the launch classes with HIP events (stats.*_ms / *_busy_ms; one mark per launch class and tick stream);
  * 2 = the same with ALL ticks on one stream, so that a launch's duration is the kernel's alone (measurement only: slower). */

@@ -107,6 +107,7 @@ struct mlx_context {
     hipEvent_t ev_batchx[MAX_TS][2] = {}, ev_fork = nullptr, ev_join[MAX_TS] = {};
     int *h_donex = nullptr;                 // [MAX_TS][2] pinned
     int nstreams = 1;
+    int stream_probe_rejects = 0;           // tick-stream candidates that shared a hardware queue with another tick stream (pick_tick_streams)
     int small_ticks = SMALL_TICKS_PER_LAUNCH;   // ticks one k_solve_small launch may run (MLX_SMALL_TICKS: the tests shrink it to walk the relaunch path)
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
     std::vector<hipEvent_t> ev_pool;        // profiling: a chain of marks; the interval from mark i to mark i+1 belongs to ev_kind[i]
@@ -447,6 +448,67 @@ const char *mlx_version(void) { return "mlease_hip gfx950 r4 (" __DATE__ ")"; }
 
 const char *mlx_last_error(mlx_handle h) { return h ? h->err.c_str() : g_err_nohandle.c_str(); }
 
+// ---- tick streams must sit on DIFFERENT hardware queues ----------------------------------------------------------------------------
+// The HIP runtime multiplexes a process's streams onto a few hardware queues; two streams of one queue run their launches in order.
+// When the handle's two tick streams land on one queue the halves serialise AND pay the fork / join events: an 8-problem dense handle
+// 1.8 k solves/s instead of 2.8 k (one stream: 2.3 k) -- seen whenever other streams were alive in the process (a second handle, torch's
+// side streams), not predictably (profiles/r4_notes.md). So the pair is tested -- one idle 60 us wave on each stream: do they overlap? --
+// and the second stream is re-created until it does not clash (the rejected ones stay alive during the search, so that the runtime
+// hands out another queue); no clash-free stream after 8 tries: one tick stream fewer. MLX_NO_STREAM_PROBE=1 skips the test.
+static bool streams_serialize(mlx_handle h, hipStream_t a, hipStream_t b)
+{
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device) != hipSuccess || khz <= 0) khz = 100000;
+    const double spin_us = 60.0;
+    const long long ticks = (long long)(spin_us * 1e-3 * khz);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { if (e0) hipEventDestroy(e0); return false; }
+    mlxk_spin(a, 1); mlxk_spin(b, 1);                       // (the first launch on a stream sets its queue up)
+    hipStreamSynchronize(a); hipStreamSynchronize(b);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; rep++) {
+        hipEventRecord(e0, a);
+        mlxk_spin(a, ticks);
+        mlxk_spin(b, ticks);
+        hipEventRecord(e1, b);
+        hipStreamSynchronize(a); hipStreamSynchronize(b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f) best = std::min(best, ms);      // (disturbances only lengthen it)
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    (void)hipGetLastError();
+    const bool clash = best < 1e29f && best * 1e3 > 1.6 * spin_us;
+    if (getenv("MLX_TRACE")) fprintf(stderr, "[mlx] stream probe: two %.0f us waves took %.1f us -> %s\n", spin_us, best * 1e3, clash ? "ONE hardware queue" : "overlap");
+    return clash;
+}
+
+static void pick_tick_streams(mlx_handle h)
+{
+    if (h->nstreams < 2 || (getenv("MLX_NO_STREAM_PROBE") && atoi(getenv("MLX_NO_STREAM_PROBE")) != 0)) return;
+    for (int t = 1; t < h->nstreams; t++) {
+        std::vector<hipStream_t> rejected;
+        bool clash = true;
+        for (int attempt = 0; attempt < 8 && h->xstream[t]; attempt++) {
+            clash = streams_serialize(h, h->stream, h->xstream[t]);
+            for (int u = 1; u < t && !clash; u++) clash = streams_serialize(h, h->xstream[u], h->xstream[t]);
+            if (!clash) break;
+            rejected.push_back(h->xstream[t]);
+            h->xstream[t] = nullptr;
+            if (hipStreamCreateWithFlags(&h->xstream[t], hipStreamNonBlocking) != hipSuccess) h->xstream[t] = nullptr;
+        }
+        h->stream_probe_rejects += (int)rejected.size();
+        if (clash) {                                          // fewer tick streams beat two on one queue
+            if (h->xstream[t]) rejected.push_back(h->xstream[t]);
+            for (int u = t + 1; u < h->nstreams; u++) if (h->xstream[u]) hipStreamDestroy(h->xstream[u]);
+            for (int u = t; u < mlx_context::MAX_TS; u++) h->xstream[u] = nullptr;
+            h->nstreams = t;
+        }
+        for (hipStream_t r : rejected) hipStreamDestroy(r);
+        if (clash) break;
+    }
+    if (getenv("MLX_TRACE")) fprintf(stderr, "[mlx] tick streams: %d (%d candidates shared a hardware queue)\n", h->nstreams, h->stream_probe_rejects);
+}
+
 int mlx_create(int device_id, mlx_handle *out)
 {
     if (!out) return fail(nullptr, MLX_ERR_INVALID, "out is NULL");
@@ -487,6 +549,7 @@ int mlx_create(int device_id, mlx_handle *out)
     }
     hipEventCreate(&h->ev_t0);
     hipEventCreate(&h->ev_t1);
+    pick_tick_streams(h);
     *out = h;
     return MLX_OK;
 }
@@ -521,9 +584,11 @@ int mlx_set_stream(mlx_handle h, void *hip_stream)
 {
     if (!h) return MLX_ERR_INVALID;
     hipSetDevice(h->device);
+    if (!hip_stream && h->own_stream && h->stream) return MLX_OK;          // NULL = "own stream": it has one
     if (h->own_stream && h->stream) { hipStreamSynchronize(h->stream); hipStreamDestroy(h->stream); }
     if (hip_stream) { h->stream = static_cast<hipStream_t>(hip_stream); h->own_stream = false; }
     else { HIPCHECK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    pick_tick_streams(h);                                                  // the pair changed: test it again
     return MLX_OK;
 }
 

@@ -54,6 +54,8 @@ void mlxk_hess_diag_items(hipStream_t st, int n_items, const int32_t *item_ptr, 
 void mlxk_gram_f64(hipStream_t st, const float *X, int64_t ld, int l, const double *wd, const int *blocks_xy, int nblocks,
                    int ksplit, int rows_per_split, double *P, int npad, int nf /* column nf = implicit ones (intercept) */);
 void mlxk_gram_finish(hipStream_t st, const double *P, int ksplit, int npad, int nf, const double *pinv, double *H);
+// one idle wave for `ticks` of the wall clock (stream / hardware-queue probe of mlx_api.hip)
+void mlxk_spin(hipStream_t st, long long ticks);
 // RegressionTest scoring: one float prediction per row
 void mlxk_score_rows(hipStream_t st, int l, const int64_t *rp, const int32_t *gi, const double *val, const double *off,
                      const double *z, double base, float *pred);

@@ -3123,6 +3123,16 @@ void mlxk_test_loglik(hipStream_t st, int l, int n_lambda, int n_global, const i
     else hipLaunchKernelGGL((k_test_loglik<false>), dim3(gx), dim3(256), 0, st, l, n_lambda, n_global, rp, gi, val, y, wt, off, Z, part);
 }
 
+// ---- one wave that does nothing for `ticks` of the constant-rate wall clock. mlx_api.hip launches one on each of two HIP streams to
+// find out whether the runtime put them on ONE hardware queue (then the second starts when the first ends): pick_tick_streams().
+__global__ void __launch_bounds__(64)
+k_spin(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+void mlxk_spin(hipStream_t st, long long ticks) { hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st, ticks); }
+
 void mlxk_round_z(hipStream_t st, int64_t n, const double *Z, float *z32)
 {
     const int gx = (int)max((int64_t)1, min((int64_t)1024, (n + 255) / 256));

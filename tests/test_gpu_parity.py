@@ -1128,6 +1128,44 @@ def test_two_tick_streams_are_bit_identical_to_one(kind, monkeypatch):
     assert outs[0][-1][0][:, 2].sum() > 0
 
 
+def test_tick_stream_pair_sits_on_two_hardware_queues():
+    """The HIP runtime multiplexes streams onto a few hardware queues; two tick streams on ONE queue serialise the halves (8 dense
+    problems: 1.8 k instead of 2.8 k solves/s, profiles/r4_notes.md). mlx_create tests its pair with two idle waves and re-creates the
+    second stream until they overlap: six handles alive at once (12 streams + torch's, more than the runtime has queues), every one must
+    end with a pair whose last test says "overlap", or with one stream."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import mlease_amd\n"
+            "from mlease_amd.hip_engine import HipAdmmEngine\n"
+            "import torch\n"
+            "side = [torch.cuda.Stream() for _ in range(3)]\n"
+            "[torch.zeros(8, device='cuda').add_(1) for s in side for _ in [torch.cuda.set_stream(s)]]\n"
+            "torch.cuda.synchronize()\n"
+            "engs = []\n"
+            "for i in range(6):\n"
+            "    sys.stderr.write('== handle %%d\\n' %% i); sys.stderr.flush()\n"
+            "    engs.append(HipAdmmEngine(11, [1.0], [1.0], 1))\n"
+            "sys.stderr.write('== done\\n')\n" % ROOT)
+    env = dict(os.environ, MLX_TRACE="1")
+    env.pop("MLX_NO_STREAM_PROBE", None)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    blocks = p.stderr.split("== handle ")[1:]
+    assert len(blocks) == 6
+    for blk in blocks:
+        lines = [ln for ln in blk.splitlines() if ln.startswith("[mlx] ")]
+        summary = [ln for ln in lines if ln.startswith("[mlx] tick streams:")]
+        probes = [ln for ln in lines if "stream probe" in ln]
+        assert len(summary) == 1 and probes, blk
+        n = int(summary[0].split(":")[1].split()[0])
+        assert n in (1, 2)
+        if n == 2:
+            assert probes[-1].endswith("overlap"), blk
+        else:
+            assert probes[-1].endswith("ONE hardware queue"), blk
+
+
 def test_row_and_cold_column_order_does_not_change_the_solve(monkeypatch):
     """Round 3: rows and cold columns are renumbered together by a depth-first walk (a locality matter for the cold gathers); with
     the walk, with the cold columns numbered by first row only (MLX_COLD_ROWS=0) and with the round-2 frequency order
