@@ -1050,11 +1050,17 @@ def sparse_rooflines(prof, n_mean, row_kernel, col_kernel):
                 "us_per_tick": round(1e3 * busy / max(1, prof["ticks"]), 1), "alg_bytes": alg_bytes, "note": note}
 
     step_model = 13.0 * 8.0 * n_mean * (prof["pdev"] / 2.0)        # 13 n-vector streams per problem and tick
-    return {"measured_in": "a replay of the timed iterations (same state, same epsilons, same two tick streams; reproduced_timed_run = %s) with "
-                           "per-launch-class HIP events on every tick stream, %.1f ms wall. The halves run concurrently: a class's time is the time "
-                           "during which at least one of its launches was running (busy_ms, union of the event intervals); it still shares the "
-                           "memory system with the OTHER classes of the other half, so the per-class fractions are lower bounds of a kernel alone "
-                           "on the chip (MLX_PROFILE_ONE_STREAM=1)" % (prof["reproduced_timed_run"], wall_ms),
+    if os.environ.get("MLX_PROFILE_ONE_STREAM", "0") not in ("", "0"):
+        how = ("a replay of the timed iterations (same state, same epsilons; reproduced_timed_run = %s) on ONE tick stream "
+               "(MLX_PROFILE_ONE_STREAM=1) with per-launch-class HIP events, %.1f ms wall: every launch runs alone on the chip, a class's time is "
+               "the sum of its launches' durations" % (prof["reproduced_timed_run"], wall_ms))
+    else:
+        how = ("a replay of the timed iterations (same state, same epsilons, same two tick streams; reproduced_timed_run = %s) with "
+               "per-launch-class HIP events on every tick stream, %.1f ms wall. The halves run concurrently: a class's time is the time "
+               "during which at least one of its launches was running (busy_ms, union of the event intervals); it still shares the "
+               "memory system with the OTHER classes of the other half, so the per-class fractions are lower bounds of a kernel alone "
+               "on the chip (MLX_PROFILE_ONE_STREAM=1)" % (prof["reproduced_timed_run"], wall_ms))
+    return {"measured_in": how,
             "kernels": [roof(row_kernel, prof["rbusy"], prof["rms"], half, "B_pass = nnz*4 + 8l + 8n per active problem; the cold column slices run as their own launch in front of the row kernel"),
                         roof(col_kernel, prof["cbusy"], prof["cms"], half, "B_pass = nnz*4 + 8l + 8n per active problem"),
                         roof("k_step_a+b+c+commit", prof["sbusy"], prof["sms"], 0.0,
