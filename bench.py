@@ -19,10 +19,13 @@ partition k -> rank k mod N (64/N per GPU), the consensus means [xbar | ubar] al
 backend "nccl"). --scaling weak keeps 64 partitions per GPU (num.blocks = 64 N).
 
 Keys of the full record beside the contract's:
-  roofline      dominant kernel of the headline (k_xpass_dense): algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak,
-                measured IN the timed region at one GPU (the library pipelines the dense ticks: passes back to back on one
-                stream, TRON steps on a second one, so a pass launch's event interval is the kernel's own duration);
-                N > 1: timed without events, events in a replay of the same iterations
+  roofline      dominant kernel of the headline (k_xpass_dense) against the 8 TB/s HBM peak. `frac` / `achieved` /
+                `alg_bytes_per_launch` / `avg_launch_ms` = the literal per-launch figure of a launch ALONE on the chip (a replay
+                of the first timed iterations with HIP events and all ticks on ONE stream) -- the definition of rounds 1-2,
+                frozen. In production the library ticks the two halves of the problem list on two streams and their launches
+                overlap: `frac_busy_union` = bytes / time during which at least one launch ran (union of the event intervals on
+                the two tick streams, measured IN the timed region at one GPU; N > 1: in a replay), `frac_by_launch_durations` =
+                bytes / sum of the overlapping launches' own durations (what a kernel trace's average gives)
   whole_step    algorithmic bytes of the timed iterations / their wall time
   cpu_baseline  the C oracle on the host cores, ALL 64 partitions, the SAME ADMM iterations as the first timed ones
                 (it starts from the GPU's state after the warm-up iterations), one thread per partition solve
@@ -286,13 +289,14 @@ def compact_record(full):
     roof = full.get("roofline")
     if roof:
         c["roofline"] = _pick(roof, ["kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "alg_bytes_per_launch", "avg_launch_ms",
-                                     "launches", "kernel_ms_per_step", "launches_in_flight", "frac_by_launch_durations"])
+                                     "launches", "frac_busy_union", "frac_by_launch_durations", "kernel_ms_per_step", "launches_in_flight"])
         for k in ("traffic", "alg_bytes_per_launch"):
             if isinstance(c["roofline"].get(k), float):
                 c["roofline"][k] = round(c["roofline"][k])
         c["roofline"]["avg_launch_ms"] = _r(c["roofline"].get("avg_launch_ms"), 5)
         c["roofline"]["measured_in"] = roof.get("measured_in_short", "timed region")
-        if roof.get("kernel_alone"):
+        c["roofline"]["traffic_source"] = None if not roof.get("traffic_source") else "profiles/traffic.json ratio x this run's bytes per launch (committed rocprofv3 --pmc passes; not a counter read in this run)"
+        if roof.get("kernel_alone") and "frac_busy_union" not in roof:      # (records of rounds 3-4: frac was the busy-union figure)
             c["roofline"]["frac_kernel_alone_one_stream"] = roof["kernel_alone"]["frac"]
     c["whole_step_frac"] = (full.get("whole_step") or {}).get("frac_of_hbm_peak")
     cb = full.get("cpu_baseline")
@@ -331,6 +335,9 @@ def compact_record(full):
             if name != "step":                      # (the step has no algorithmic bytes)
                 o[name + "_frac"] = k.get("frac")
             o[name + "_us_per_tick"] = k.get("us_per_tick")
+        al = (d.get("roofline") or {}).get("alone") or {}
+        if al:
+            o["roofline_alone"] = {"row": al.get("rowpass_frac"), "col": al.get("colpass_frac")}
         if d.get("cpu_baseline"):
             o["cpu_baseline"] = _pick(d["cpu_baseline"], ["value", "cores", "kind"])
             o["gpu_over_cpu"] = (d.get("gpu_over_cpu") or {}).get("solves_per_s")
@@ -571,7 +578,7 @@ def run_dense(args, C):
     # ---- the kernel ALONE on the chip: a replay of the first timed iterations with events and all ticks on one stream (no second launch
     # shares the memory system, no step launch runs beside the pass): the literal "bytes per launch / average launch duration"
     alone = None
-    if prof_timed:
+    if not args.no_profile:
         al = dict(alg=0.0, ms=0.0, launches=0, wall=0.0, iters=min(args.steps, 5))
         eng.set_state(snap[0], snap[1])
         eng.set_profiling(True, one_stream=True)
@@ -579,15 +586,17 @@ def run_dense(args, C):
         ta = time.perf_counter()
         for eps in eps_used[args.warmup:args.warmup + al["iters"]]:
             st3 = eng.solve_local(eps, 1.0)
+            C["all_reduce"](eng.consensus_tensor())
             eng.consensus_finish()
             account(st3)
             al["alg"] += st3.alg_bytes_dev; al["ms"] += st3.xpass_ms; al["launches"] += st3.xpass_launches
         C["barrier"]()
         al["wall"] = time.perf_counter() - ta
-        eng.set_profiling(True)
+        eng.set_profiling(prof_timed)
         if al["ms"] > 0:
             alone = {"frac": round(al["alg"] / (al["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "achieved": round(al["alg"] / (al["ms"] * 1e-3) / 1e9, 1),
                      "avg_launch_ms": round(al["ms"] / max(1, al["launches"]), 5), "launches": al["launches"],
+                     "alg_bytes_per_launch": al["alg"] / max(1, al["launches"]),
                      "ms_per_step": round(al["wall"] * 1e3 / al["iters"], 3),
                      "measured_in": "a replay of the first %d timed iterations (same state, same epsilons) with events on and ALL ticks on one "
                                     "stream: every k_xpass_dense launch has the chip to itself" % al["iters"]}
@@ -603,22 +612,32 @@ def run_dense(args, C):
     if rank == 0:
         value = tot_solves / dt
         roof = None
-        if prof is not None and prof["busy_ms"] > 0:
+        if prof is not None and prof["busy_ms"] > 0 and alone is not None:
             achieved = prof["alg_bytes"] / (prof["busy_ms"] * 1e-3) / 1e9
             traffic, tsrc = None, None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as fh:
                     tj = json.load(fh)
-                traffic = tj["hbm_bytes_per_alg_byte"] * prof["alg_bytes"] / max(1, prof["launches"])
+                traffic = tj["hbm_bytes_per_alg_byte"] * alone["alg_bytes_per_launch"]
                 tsrc = "profiles/traffic.json: (2 x FETCH_SIZE + WRITE_SIZE) / algorithmic bytes = %.4f from the committed rocprofv3 " \
                        "--pmc passes of `%s`, times this run's algorithmic bytes per launch (not a counter read in this run)" % (
                            tj["hbm_bytes_per_alg_byte"], tj.get("command", "bench.py"))
             timed = prof["where"] == "timed"
-            roof = {"bound": "hbm", "kernel": "k_xpass_dense<4,4>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
-                    "alg_bytes_per_launch": prof["alg_bytes"] / max(1, prof["launches"]),
-                    "avg_launch_ms": round(prof["xpass_ms"] / max(1, prof["launches"]), 5), "launches": prof["launches"],
+            # THE KEY IS FROZEN (rounds 1-2 definition): roofline.frac / achieved / alg_bytes_per_launch / avg_launch_ms /
+            # launches are the literal per-launch figure of a launch ALONE on the chip (one tick stream: algorithmic bytes per launch /
+            # average launch duration); what the same kernel reaches in production -- two tick streams, launches of the halves
+            # overlapping -- sits beside it: frac_busy_union (bytes / time with >= 1 launch running) and frac_by_launch_durations
+            # (bytes / sum of the overlapping launches' own durations: what a kernel trace's average gives).
+            roof = {"bound": "hbm", "kernel": "k_xpass_dense<4,4>", "achieved": alone["achieved"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": alone["frac"], "traffic": traffic, "traffic_source": tsrc,
+                    "alg_bytes_per_launch": alone["alg_bytes_per_launch"],
+                    "avg_launch_ms": alone["avg_launch_ms"], "launches": alone["launches"],
+                    "definition": "a launch alone on the chip: algorithmic bytes per launch / average launch duration (HIP events, all ticks on one stream)",
+                    "frac_busy_union": round(achieved / HBM_PEAK_GBS, 4),
+                    "achieved_busy_union": round(achieved, 1),
+                    "timed_region": {"alg_bytes_per_launch": prof["alg_bytes"] / max(1, prof["launches"]),
+                                     "avg_launch_ms": round(prof["xpass_ms"] / max(1, prof["launches"]), 5), "launches": prof["launches"]},
                     "kernel_ms_per_step": round(prof["busy_ms"] / args.steps, 3),
                     "launches_in_flight": round(prof["xpass_ms"] / prof["busy_ms"], 3),
                     "frac_by_launch_durations": round(prof["alg_bytes"] / (prof["xpass_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -626,9 +645,9 @@ def run_dense(args, C):
                     "tron_step_ms_per_step": round(acc["step_ms"] / args.steps, 3) if timed else None,
                     "tron_step_busy_ms_per_step": round(acc["step_busy_ms"] / args.steps, 3) if timed else None,
                     "timed_ms_per_step": round(dt * 1e3 / args.steps, 3),
-                    "measured_in_short": "timed region: HIP events on both tick streams, bytes / time with >= 1 launch running" if timed
-                                         else "replay of the timed iterations with events (N>1)",
-                    "measured_in": ("the TIMED region itself: HIP events on the streams the kernel is launched on, one mark in front of every k_xpass_dense "
+                    "measured_in_short": "frac: replay of the first timed iterations, one tick stream (launch alone); frac_busy_union / frac_by_launch_durations: " +
+                                         ("the timed region, events on both tick streams" if timed else "replay of the timed iterations with events (N>1)"),
+                    "measured_in": ("frac_busy_union, frac_by_launch_durations, kernel_ms_per_step, launches_in_flight: the TIMED region itself: HIP events on the streams the kernel is launched on, one mark in front of every k_xpass_dense "
                                     "launch and one behind it (the mark of the step launch). The two halves of the problems tick on two streams, so "
                                     "launches_in_flight k_xpass_dense launches run side by side on average: `achieved` = algorithmic bytes / "
                                     "kernel_ms_per_step, the time during which at least one launch was running (union of the event intervals, <= "
@@ -1033,6 +1052,24 @@ def sparse_timed_run(args, C, eng, blocks, lam, warmup, steps, snapshot):
     prof["reproduced_timed_run"] = bool(prof["maxdiff"] == fin.maxdiff and prof["ticks"] == acc["ticks"])
     allrun["alg"] += prof["alg"]
     allrun["ticks"] += prof["ticks"]
+    # ... and once more on ONE tick stream: every launch alone on the chip (a class's time = the sum of its launches' durations)
+    alone = dict(ticks=0, alg=0.0, rms=0.0, cms=0.0, sms=0.0, wall=0.0)
+    eng.set_profiling(True, one_stream=True)
+    eng.set_state(*snap)
+    C["barrier"]()
+    t0 = time.perf_counter()
+    for eps in eps_all[warmup:]:
+        st = eng.solve_local(eps, 1.0)
+        C["all_reduce"](eng.consensus_tensor())
+        eng.consensus_finish()
+        alone["ticks"] += st.ticks; alone["alg"] += st.alg_bytes_dev
+        alone["rms"] += st.rowpass_ms; alone["cms"] += st.colpass_ms; alone["sms"] += st.step_ms
+    C["barrier"]()
+    alone["wall"] = C["reduce_max"](time.perf_counter() - t0)
+    eng.set_profiling(False)
+    prof["alone"] = alone
+    allrun["alg"] += alone["alg"]
+    allrun["ticks"] += alone["ticks"]
     return acc, allrun, dt, fin, (snap if snapshot else None), eps_all, step_s, prof
 
 
@@ -1060,7 +1097,18 @@ def sparse_rooflines(prof, n_mean, row_kernel, col_kernel):
                "during which at least one of its launches was running (busy_ms, union of the event intervals); it still shares the "
                "memory system with the OTHER classes of the other half, so the per-class fractions are lower bounds of a kernel alone "
                "on the chip (MLX_PROFILE_ONE_STREAM=1)" % (prof["reproduced_timed_run"], wall_ms))
-    return {"measured_in": how,
+    alone = None
+    al = prof.get("alone")
+    if al and al["rms"] > 0 and al["cms"] > 0:
+        def afrac(ms):
+            return round(al["alg"] / 2.0 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        alone = {"measured_in": "a second replay of the timed iterations with ALL ticks on one stream: every launch has the chip to itself; "
+                                "fraction = algorithmic bytes of the class / sum of its launches' durations (the literal per-launch figure)",
+                 "rowpass_frac": afrac(al["rms"]), "colpass_frac": afrac(al["cms"]),
+                 "us_per_tick": {"rowpass": round(1e3 * al["rms"] / max(1, al["ticks"]), 1), "colpass": round(1e3 * al["cms"] / max(1, al["ticks"]), 1),
+                                 "step": round(1e3 * al["sms"] / max(1, al["ticks"]), 1)},
+                 "wall_ms": round(al["wall"] * 1e3, 1), "ticks": al["ticks"]}
+    return {"measured_in": how, "alone": alone,
             "kernels": [roof(row_kernel, prof["rbusy"], prof["rms"], half, "B_pass = nnz*4 + 8l + 8n per active problem; the cold column slices run as their own launch in front of the row kernel"),
                         roof(col_kernel, prof["cbusy"], prof["cms"], half, "B_pass = nnz*4 + 8l + 8n per active problem"),
                         roof("k_step_a+b+c+commit", prof["sbusy"], prof["sms"], 0.0,
@@ -1242,7 +1290,7 @@ def sparse_checks(args, C, eng, blocks, ng, Ptot, snap, eps_all, step_s, res, la
         m = ne * nl
         eg = _rel_err(gb, ob)
         geq = np.all(gc == cc, axis=1)
-        perm_eq, perm_med, perm_max = [], [], []
+        perm_eq, perm_med, perm_max, peqs = [], [], [], []
         easy = np.ones(m, bool)
         for ocp in ocps:
             ocp.set_state(Zs, us[:ne])
@@ -1251,7 +1299,17 @@ def sparse_checks(args, C, eng, blocks, ng, Ptot, snap, eps_all, step_s, res, la
             ep = _rel_err(pb, ob[:m])
             peq = np.all(cnts(ocp) == cc[:m], axis=1)
             easy &= peq
+            peqs.append(peq)
             perm_eq.append(int(peq.sum())); perm_med.append(float(np.median(ep))); perm_max.append(float(ep.max()))
+        # leave-one-out: the solves every OTHER permuted oracle keeps -- how many of those does permutation k keep, how many the GPU?
+        # (on the solves ALL of them keep a permuted oracle scores 100 % by construction; this is the unbiased comparison)
+        loo = []
+        for k in range(len(peqs)):
+            others = np.ones(m, bool)
+            for j, pq in enumerate(peqs):
+                if j != k:
+                    others &= pq
+            loo.append((int(others.sum()), int((peqs[k] & others).sum()), int((geq[:m] & others).sum())))
         per_it.append({"iteration": warm + i + 1, "liblinear_epsilon": e,
                        "gpu_vs_oracle_all_sampled_solves": {"solves": ns * nl, "equal_counters": int(geq.sum()), "within_1e-5": int((eg <= 1e-5).sum()),
                                                             "median_rel_err_beta": float(np.median(eg)), "max_rel_err_beta": float(eg.max()),
@@ -1259,7 +1317,8 @@ def sparse_checks(args, C, eng, blocks, ng, Ptot, snap, eps_all, step_s, res, la
                        "envelope": {"solves": m, "gpu_equal_counters": int(geq[:m].sum()), "perm_equal_counters": perm_eq,
                                     "gpu_median_rel_err_beta": float(np.median(eg[:m])), "perm_median_rel_err_beta": perm_med,
                                     "gpu_max_rel_err_beta": float(eg[:m].max()), "perm_max_rel_err_beta": perm_max,
-                                    "easy_solves": int(easy.sum()), "gpu_equal_on_easy_solves": int((geq[:m] & easy).sum())},
+                                    "easy_solves": int(easy.sum()), "gpu_equal_on_easy_solves": int((geq[:m] & easy).sum()),
+                                    "leave_one_out": loo},
                        "max_abs_beta": float(np.max(np.abs(ob)))})
     v = solves / cdt
     g_rate = P * nl * len(step_s) / sum(step_s)
@@ -1273,9 +1332,22 @@ def sparse_checks(args, C, eng, blocks, ng, Ptot, snap, eps_all, step_s, res, la
     env = [r["envelope"] for r in per_it]
     g_tot = sum(x["gpu_equal_counters"] for x in env)
     p_tot = [sum(x["perm_equal_counters"][k] for x in env) for k in range(NPERM)]
+    # leave-one-out rates: permutation k / the GPU on the solves all OTHER permutations keep (pooled over the iterations)
+    loo_n = [sum(x["leave_one_out"][k][0] for x in env) for k in range(NPERM)]
+    loo_p = [sum(x["leave_one_out"][k][1] for x in env) / max(1, loo_n[k]) for k in range(NPERM)]
+    loo_g = [sum(x["leave_one_out"][k][2] for x in env) / max(1, loo_n[k]) for k in range(NPERM)]
+    med_ok = all(x["gpu_median_rel_err_beta"] <= max(x["perm_median_rel_err_beta"]) for x in env)
+    counters_ok = bool(min(p_tot) <= g_tot)
+    easy_ok = bool(np.mean(loo_g) >= min(loo_p)) if NPERM > 1 else None
     summary = {"solves": sum(x["solves"] for x in env), "permutations": NPERM,
                "equal_counters_gpu": g_tot, "equal_counters_perm_min_max": [min(p_tot), max(p_tot)],
-               "gpu_within_envelope": bool(min(p_tot) <= g_tot),
+               # the envelope flag needs ALL of: counters (the GPU follows the oracle on at least as many solves as the worst permuted oracle),
+               # the easy solves (leave-one-out: on the solves every other permutation keeps, the GPU keeps at least the share the worst
+               # permutation keeps) and the errors (per iteration, the GPU's median relative error <= the worst permuted oracle's)
+               "gpu_within_envelope": bool(counters_ok and (easy_ok is not False) and med_ok),
+               "envelope_counters_ok": counters_ok, "envelope_easy_solves_ok": easy_ok, "envelope_median_err_ok": bool(med_ok),
+               "leave_one_out_keep_rate_perm_min_max": [round(min(loo_p), 4), round(max(loo_p), 4)] if NPERM > 1 else None,
+               "leave_one_out_keep_rate_gpu": round(float(np.mean(loo_g)), 4) if NPERM > 1 else None,
                "easy_solves": sum(x["easy_solves"] for x in env), "gpu_equal_on_easy_solves": sum(x["gpu_equal_on_easy_solves"] for x in env),
                "median_rel_err_gpu_by_iteration": [float("%.2e" % x["gpu_median_rel_err_beta"]) for x in env],
                "median_rel_err_perm_max_by_iteration": [float("%.2e" % max(x["perm_median_rel_err_beta"])) for x in env]}

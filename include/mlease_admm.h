@@ -71,10 +71,13 @@ typedef struct mlx_stats {
     int64_t x_passes_dev;    /* passes over X this library made: 1 + sum(cg+1) per solve               */
     int64_t ticks;           /* lock-step device ticks (one X pass of every unfinished problem)        */
     double alg_bytes_dev;    /* algorithmic HBM bytes of the X-pass kernels launched       */
-    double xpass_ms;         /* device time inside the X-pass kernels (HIP events), 0 if profiling off */
+    double xpass_ms;         /* profiling on: SUM of the X-pass launches' own mark-to-mark intervals (HIP events on the   */
+                             /* launch's tick stream; with two tick streams the intervals of the halves overlap and       */
+                             /* include queue wait -- use *_busy_ms for bandwidth, or mlx_set_profiling(h, 2)); else 0    */
     double total_ms;         /* device time of the whole call (HIP events)                             */
-    int64_t xpass_launches;  /* number of X-pass launches (ticks that launched one)                    */
-    double rowpass_ms;       /* CSR path, profiling on: device time of the row-pass launches           */
+    int64_t xpass_launches;  /* dense-pass + row-pass launches of the call: per tick one per tick stream and storage      */
+                             /* class (two tick streams: 2 per tick); 0 for the one-launch solves of small CSR problems   */
+    double rowpass_ms;       /* CSR path, profiling on: summed intervals of the row-pass launches      */
     double colpass_ms;       /*   ... of the column-pass launches (xpass_ms = dense + row + column)    */
     double step_ms;          /*   ... of the TRON/CG step launches                                     */
     /* With several tick streams the launches of a class overlap each other: the *_ms fields above sum the launches' own       */
@@ -95,10 +98,46 @@ const char *mlx_last_error(mlx_handle h);          /* valid until the next call 
  * wave on each: do they overlap?) and re-create the second stream until it sits on another queue (MLX_NO_STREAM_PROBE=1: no test).
  * Measured without the test: an 8-problem handle 1.8 k instead of 2.8 k solves/s whenever the pair shared a queue -- which happened
  * or not depending on the other streams alive in the process (profiles/r4_notes.md). */
+/* The test launches two idle waves and SYNCHRONIZES both streams: on a caller-owned stream it is skipped when that stream is
+ * capturing a graph or still has work queued (the pair is then used untested; mlx_get_option "tick_streams" /
+ * "stream_probe_rejects" report what the handle runs on). */
 int mlx_set_stream(mlx_handle h, void *hip_stream);
 /* 1 = time the launch classes with HIP events (stats.*_ms / *_busy_ms; one mark per launch class and tick stream);
  * 2 = the same with ALL ticks on one stream, so that a launch's duration is the kernel's alone (measurement only: slower). */
 int mlx_set_profiling(mlx_handle h, int enable);
+
+/* ---- numerics contract and other per-handle behaviour a host chooses -----------------------------------------------
+ * MLX_NUMERICS_FAST (default): every reduction of the reference -- the row / column sums of Xv / XTv
+ * (liblinearfunc/LogisticRegressionL2.java:115-150), Tron.dot and euclideanNorm (de/bwaldvogel/liblinear/Tron.java:204-252), the loss
+ * sum of fun (:172-189) -- is a fixed parallel tree (the two dots of a CG step grid-rounded); everything else
+ * is the reference's arithmetic statement for statement. Results are bit-reproducible and independent of the GPU count, and
+ * differ from the Java code by summation order only.
+ * MLX_NUMERICS_REFERENCE_ORDER: those reductions run as the reference's SEQUENTIAL loops -- feature ids and rows in the caller's
+ * order (liblinearfunc/LibLinearDataset.java:464-482), a row's entries in ascending id, a column's entries in row order, dots and
+ * norms in index order -- on the same tick kernels (csrc/mlx_ro_kernels.h), with exp / log1p evaluated by portable +,-,*,/
+ * sequences (csrc/portable_math.h; device and host libm differ in the last bit). Every output is then bit-identical to the
+ * reference algorithm evaluated with the same elementary functions (oracle/liboracle_pm.so). Slower (the sequential chains).
+ * Dense tiles are stored and summed like CSR partitions in this mode.
+ * MLX_NUMERICS_REFERENCE_ORDER_ONE_LAUNCH: the same arithmetic on the one-workgroup-per-problem verification kernel (one thread per
+ * reduction; orders of magnitude slower) -- the independent cross-check of the mode above; one row block per partition.
+ * Call before the first mlx_add_partition_* (the HBM layout depends on it). The Java driver's job key: mlease.numerics. */
+enum { MLX_NUMERICS_FAST = 0, MLX_NUMERICS_REFERENCE_ORDER = 1, MLX_NUMERICS_REFERENCE_ORDER_ONE_LAUNCH = 2 };
+int mlx_set_numerics(mlx_handle h, int32_t mode);
+/* String-keyed options, so that a host can choose per handle what the MLX_* environment variables choose per process (those only
+ * seed the defaults at mlx_create; no reference counterpart -- the Java job passes everything through JobConf strings likewise):
+ *   "numerics"            fast | reference_order | reference_order_one_launch          (= mlx_set_numerics)
+ *   "tick_streams"        1..4   HIP streams the halves of the problem list tick on (default 2; re-tests the hardware queues)
+ *   "stream_probe"        0 | 1  test that the tick streams sit on different hardware queues (default 1)
+ *   "grid_rounded_dots"   0 | 1  d.Hd / r.r of the CSR step as grid-rounded sums (default 1; 0 = plain trees, A/B and tests)
+ *   "profile_one_stream"  0 | 1  with profiling on, all ticks on one stream (= mlx_set_profiling(h, 2))
+ *   "one_launch_small"    0 | 1  small CSR problems solve in one launch (default 1); before mlx_finalize
+ *   "small_ticks"         ticks one such launch may run before the host looks (default 16384)
+ *   "comm_always"         0 | 1  run the RCCL exchange at nranks == 1 too (tests)
+ *   "trace"               0 | 1  tick progress and stream-probe results on stderr
+ * mlx_get_option additionally answers "numerics_kernels" (after mlx_finalize: fast | reference_order_ticks |
+ * reference_order_one_launch: what the handle actually runs) and "stream_probe_rejects". Unknown key: MLX_ERR_INVALID. */
+int mlx_set_option(mlx_handle h, const char *key, const char *value);
+int mlx_get_option(mlx_handle h, const char *key, char *out, size_t out_len);
 
 /* ---- problem definition -------------------------------------------------------------------
  * num_blocks  = num.blocks of the job: the FIXED divisor of the consensus mean

@@ -58,6 +58,13 @@ public final class MleaseHip implements AutoCloseable
   public native void setStream(long hipStreamOrZero) throws IOException;                    // mlx_set_stream
   public native void setProfiling(boolean enable) throws IOException;                       // mlx_set_profiling
   public static native String version();                                                    // mlx_version
+  /** Numerics contract: 0 = fast (default), 1 = reference order (every sum a sequential loop as in bw/Tron.java and
+   *  liblinearfunc/LogisticRegressionL2.java; bit-identical to the Java algorithm up to Math.exp / Math.log1p), 2 = the same on the
+   *  one-launch verification kernel. Before the first partition is added. Job key: mlease.numerics. */
+  public static final int NUMERICS_FAST = 0, NUMERICS_REFERENCE_ORDER = 1, NUMERICS_REFERENCE_ORDER_ONE_LAUNCH = 2;
+  public native void setNumerics(int mode) throws IOException;                              // mlx_set_numerics
+  public native void setOption(String key, String value) throws IOException;                // mlx_set_option
+  public native String getOption(String key) throws IOException;                            // mlx_get_option
 
   // ---- problem definition ---------------------------------------------------------------------------------------
   /** lambda ascending; lambdaMap = null or per-global-feature lambda with NaN = "use the global lambda". */

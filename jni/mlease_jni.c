@@ -163,6 +163,37 @@ JFN(void, setProfiling)(JNIEnv *env, jobject self, jboolean enable)
     throw_for(env, h, mlx_set_profiling(h, enable ? 1 : 0));
 }
 
+/* numerics contract / per-handle options (include/mlease_admm.h: mlx_set_numerics, mlx_set_option, mlx_get_option); the job key
+ * mlease.numerics of the patched driver goes through setOption("numerics", ...) */
+JFN(void, setNumerics)(JNIEnv *env, jobject self, jint mode)
+{
+    mlx_handle h = handle_of(env, self);
+    throw_for(env, h, mlx_set_numerics(h, (int32_t)mode));
+}
+
+JFN(void, setOption)(JNIEnv *env, jobject self, jstring key, jstring value)
+{
+    mlx_handle h = handle_of(env, self);
+    if (!key || !value) { bad_arg(env, "setOption: key or value is null"); return; }
+    const char *k = (*env)->GetStringUTFChars(env, key, NULL), *v = (*env)->GetStringUTFChars(env, value, NULL);
+    const int rc = (k && v) ? mlx_set_option(h, k, v) : MLX_ERR_INVALID;
+    if (v) (*env)->ReleaseStringUTFChars(env, value, v);
+    if (k) (*env)->ReleaseStringUTFChars(env, key, k);
+    throw_for(env, h, rc);
+}
+
+JFN(jstring, getOption)(JNIEnv *env, jobject self, jstring key)
+{
+    mlx_handle h = handle_of(env, self);
+    if (!key) { bad_arg(env, "getOption: key is null"); return NULL; }
+    char buf[64];
+    const char *k = (*env)->GetStringUTFChars(env, key, NULL);
+    const int rc = k ? mlx_get_option(h, k, buf, sizeof buf) : MLX_ERR_INVALID;
+    if (k) (*env)->ReleaseStringUTFChars(env, key, k);
+    if (rc) { throw_for(env, h, rc); return NULL; }
+    return (*env)->NewStringUTF(env, buf);
+}
+
 JFN(jstring, version)(JNIEnv *env, jclass cls)
 {
     (void)cls;

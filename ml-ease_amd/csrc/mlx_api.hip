@@ -60,7 +60,15 @@ struct mlx_context {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool profiling = false;
-    bool faithful = false;                 // MLX_FAITHFUL=1: order-faithful verification mode, CSR partitions only
+    bool faithful = false;                 // reference-order numerics (mlx_set_numerics / MLX_FAITHFUL)
+    int ro_mode = 1;                       // 1: on the tick kernels wherever every partition can be sliced (mlx_ro_kernels.h); 2: the one-launch
+                                           // verification kernel only (k_solve_small<.., SEQ>; MLX_FAITHFUL=2: the independent cross-check)
+    bool ro_ticks = false;                 // decided at mlx_finalize: this handle runs the reference-order TICK kernels
+    int ro_blocks = 0;                     // ... whose column pass runs once per row block: the largest n_rblk
+    // host-selectable behaviour (mlx_set_option; the MLX_* environment variables only seed these defaults at mlx_create)
+    bool trace = false;                    // "trace": tick progress / stream probe on stderr
+    bool stream_probe = true;              // "stream_probe": test that the tick streams sit on different hardware queues
+    bool use_small = true;                 // "one_launch_small": small CSR problems solve in one launch (k_solve_small)
     std::string err;
 
     int n_global = 0, n_lambda = 0, num_blocks = 0, penalize_intercept = 0, regularizer = 2;
@@ -263,7 +271,8 @@ int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
     if (nqc > 0)
         for (int which = 1; which <= 2; which++)
             bracket(which, [&] {
-                return mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_short, h->max_long, h->rowgroup, h->csr_hasval, h->csr_sell, h->max_cunits, h->max_rblk_rows, h->max_row_lds, h->row_ngc, h->n_lambda == 1, which, h->cold_groups);
+                return mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_short, h->max_long, h->rowgroup, h->csr_hasval, h->csr_sell, h->max_cunits, h->max_rblk_rows, h->max_row_lds, h->row_ngc, h->n_lambda == 1, which, h->cold_groups,
+                                      h->ro_ticks ? h->ro_blocks : 0);
             });
     return MLX_OK;
 }
@@ -272,6 +281,7 @@ int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
 void launch_step(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int nqc)
 {
     mark(h, 3);
+    if (h->ro_ticks) { mlxk_ro_step(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->d_done); return; }      // (no dense tiles in this mode)
     mlxk_tron_step(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->step_threads, h->d_done);
     // (launching A, B, C per group of problems so that Hd / r' / s stay in the memory-side cache between phases was measured: every
     // group size is slower than one launch per phase, profiles/r3_notes.md)
@@ -395,7 +405,7 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
                 HIPCHECK(h, hipEventSynchronize(h->ev_batchx[t][slot ^ 1]));
                 done = std::max(done, h->h_donex[t * 2 + (slot ^ 1)]);        // snapshots of ONE monotone counter: the largest is the latest
             }
-            if (getenv("MLX_TRACE")) fprintf(stderr, "[mlx] ticks=%lld done=%d/%d\n", (long long)(ticks - batch), done, count);
+            if (h->trace) fprintf(stderr, "[mlx] ticks=%lld done=%d/%d\n", (long long)(ticks - batch), done, count);
             if (done >= count) break;      // the batch just queued runs as no-ops
         }
         have_prev = true;
@@ -478,13 +488,20 @@ static bool streams_serialize(mlx_handle h, hipStream_t a, hipStream_t b)
     hipEventDestroy(e0); hipEventDestroy(e1);
     (void)hipGetLastError();
     const bool clash = best < 1e29f && best * 1e3 > 1.6 * spin_us;
-    if (getenv("MLX_TRACE")) fprintf(stderr, "[mlx] stream probe: two %.0f us waves took %.1f us -> %s\n", spin_us, best * 1e3, clash ? "ONE hardware queue" : "overlap");
+    if (h->trace) fprintf(stderr, "[mlx] stream probe: two %.0f us waves took %.1f us -> %s\n", spin_us, best * 1e3, clash ? "ONE hardware queue" : "overlap");
     return clash;
 }
 
 static void pick_tick_streams(mlx_handle h)
 {
-    if (h->nstreams < 2 || (getenv("MLX_NO_STREAM_PROBE") && atoi(getenv("MLX_NO_STREAM_PROBE")) != 0)) return;
+    if (h->nstreams < 2 || !h->stream_probe) return;
+    // A caller-owned stream may be capturing a graph (a launch + synchronize would be illegal) or hold queued work (the probe's
+    // synchronize would wait for it): no test then; mlx_get_option("tick_streams" / "stream_probe_rejects") shows what the handle runs on.
+    if (!h->own_stream) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(h->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
+        if (hipStreamQuery(h->stream) != hipSuccess) { (void)hipGetLastError(); return; }
+    }
     for (int t = 1; t < h->nstreams; t++) {
         std::vector<hipStream_t> rejected;
         bool clash = true;
@@ -506,7 +523,26 @@ static void pick_tick_streams(mlx_handle h)
         for (hipStream_t r : rejected) hipStreamDestroy(r);
         if (clash) break;
     }
-    if (getenv("MLX_TRACE")) fprintf(stderr, "[mlx] tick streams: %d (%d candidates shared a hardware queue)\n", h->nstreams, h->stream_probe_rejects);
+    if (h->trace) fprintf(stderr, "[mlx] tick streams: %d (%d candidates shared a hardware queue)\n", h->nstreams, h->stream_probe_rejects);
+}
+
+// (re)create the side tick streams 1 .. n-1 with their events, then test the set (pick_tick_streams)
+static void setup_tick_streams(mlx_handle h, int n)
+{
+    n = std::max(1, std::min(n, (int)mlx_context::MAX_TS));
+    if (!h->h_donex || !h->ev_fork) n = 1;
+    for (int t = 1; t < mlx_context::MAX_TS; t++) {
+        if (h->xstream[t]) { hipStreamSynchronize(h->xstream[t]); hipStreamDestroy(h->xstream[t]); h->xstream[t] = nullptr; }
+        if (t < n && !h->ev_join[t]) {
+            hipEventCreateWithFlags(&h->ev_batchx[t][0], hipEventDisableTiming);
+            hipEventCreateWithFlags(&h->ev_batchx[t][1], hipEventDisableTiming);
+            hipEventCreateWithFlags(&h->ev_join[t], hipEventDisableTiming);
+        }
+    }
+    h->nstreams = n;
+    for (int t = 1; t < n; t++)
+        if (hipStreamCreateWithFlags(&h->xstream[t], hipStreamNonBlocking) != hipSuccess) { h->xstream[t] = nullptr; h->nstreams = t; break; }
+    pick_tick_streams(h);
 }
 
 int mlx_create(int device_id, mlx_handle *out)
@@ -522,7 +558,7 @@ int mlx_create(int device_id, mlx_handle *out)
         return fail(nullptr, MLX_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", device_id, prop.gcnArchName);
     mlx_context *h = new mlx_context();
     h->device = device_id;
-    h->faithful = getenv("MLX_FAITHFUL") != nullptr && atoi(getenv("MLX_FAITHFUL")) != 0;
+    if (const char *fe = getenv("MLX_FAITHFUL")) { h->faithful = atoi(fe) != 0; h->ro_mode = atoi(fe) == 2 ? 2 : 1; }    // default of mlx_set_numerics
     if (hipSetDevice(device_id) != hipSuccess) { delete h; return fail(nullptr, MLX_ERR_HIP, "hipSetDevice failed"); }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(nullptr, MLX_ERR_HIP, "hipStreamCreate failed"); }
     h->own_stream = true;
@@ -532,24 +568,21 @@ int mlx_create(int device_id, mlx_handle *out)
     // 2.67 k -> 2.81 k; MLX_STREAMS=1: one). The halves run free: holding them half a tick apart with cross-stream events (the passes of
     // one beside the step of the other) measured SLOWER than one stream -- the gain is launch tails and gaps being filled, and a dense
     // half's one-workgroup-per-problem step running beside the other half's pass (profiles/r3_notes.md).
-    h->nstreams = 2;
+    int want_streams = 2;
+    // the environment seeds the defaults of mlx_set_option (A/B runs of unmodified hosts); a host sets them per handle
     if (const char *te = getenv("MLX_SMALL_TICKS")) h->small_ticks = std::max(1, atoi(te));
-    if (const char *se = getenv("MLX_STREAMS")) h->nstreams = std::max(1, std::min(atoi(se), (int)mlx_context::MAX_TS));
+    if (const char *se = getenv("MLX_STREAMS")) want_streams = std::max(1, std::min(atoi(se), (int)mlx_context::MAX_TS));
     if (const char *pe = getenv("MLX_PROFILE_ONE_STREAM")) h->prof_one_stream = atoi(pe) != 0;
     if (const char *pe = getenv("MLX_SEQ_DOTS")) h->seq_dots = atoi(pe) != 0;
-    if (h->nstreams > 1) {
-        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
-        if (hipHostMalloc((void **)&h->h_donex, mlx_context::MAX_TS * 2 * sizeof(int)) != hipSuccess) h->nstreams = 1;
-        for (int t = 1; t < h->nstreams; t++) {
-            if (hipStreamCreateWithFlags(&h->xstream[t], hipStreamNonBlocking) != hipSuccess) { h->nstreams = t; break; }
-            hipEventCreateWithFlags(&h->ev_batchx[t][0], hipEventDisableTiming);
-            hipEventCreateWithFlags(&h->ev_batchx[t][1], hipEventDisableTiming);
-            hipEventCreateWithFlags(&h->ev_join[t], hipEventDisableTiming);
-        }
-    }
+    if (const char *pe = getenv("MLX_TRACE")) h->trace = atoi(pe) != 0 || pe[0] == '\0';
+    if (const char *pe = getenv("MLX_NO_STREAM_PROBE")) h->stream_probe = atoi(pe) == 0;
+    if (getenv("MLX_NO_SMALL")) h->use_small = false;
+    if (const char *pe = getenv("MLX_COMM_ALWAYS")) h->comm_always = atoi(pe) != 0;
+    hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+    if (hipHostMalloc((void **)&h->h_donex, mlx_context::MAX_TS * 2 * sizeof(int)) != hipSuccess) { h->h_donex = nullptr; want_streams = 1; }
     hipEventCreate(&h->ev_t0);
     hipEventCreate(&h->ev_t1);
-    pick_tick_streams(h);
+    setup_tick_streams(h, want_streams);
     *out = h;
     return MLX_OK;
 }
@@ -588,7 +621,73 @@ int mlx_set_stream(mlx_handle h, void *hip_stream)
     if (h->own_stream && h->stream) { hipStreamSynchronize(h->stream); hipStreamDestroy(h->stream); }
     if (hip_stream) { h->stream = static_cast<hipStream_t>(hip_stream); h->own_stream = false; }
     else { HIPCHECK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
-    pick_tick_streams(h);                                                  // the pair changed: test it again
+    pick_tick_streams(h);                                                  // the pair changed: test it again (not on a capturing / busy stream)
+    return MLX_OK;
+}
+
+// ---- host-selectable behaviour: what a JVM (or any) host chooses PER HANDLE; the MLX_* environment variables of the same names
+// only seed the defaults (A/B runs of an unmodified host). Layout / tuning knobs of the kernels stay environment-only.
+int mlx_set_numerics(mlx_handle h, int32_t mode)
+{
+    if (!h) return MLX_ERR_INVALID;
+    if (!h->parts.empty() || h->finalized) return fail(h, MLX_ERR_INVALID, "mlx_set_numerics must be called before the first partition is added (the layout depends on it)");
+    if (mode == MLX_NUMERICS_FAST) { h->faithful = false; h->ro_mode = 1; }
+    else if (mode == MLX_NUMERICS_REFERENCE_ORDER) { h->faithful = true; h->ro_mode = 1; }
+    else if (mode == MLX_NUMERICS_REFERENCE_ORDER_ONE_LAUNCH) { h->faithful = true; h->ro_mode = 2; }
+    else return fail(h, MLX_ERR_INVALID, "mlx_set_numerics: unknown mode %d", (int)mode);
+    return MLX_OK;
+}
+
+int mlx_set_option(mlx_handle h, const char *key, const char *value)
+{
+    if (!h || !key || !value) return fail(h, MLX_ERR_INVALID, "mlx_set_option: NULL argument");
+    hipSetDevice(h->device);
+    const std::string k(key), v(value);
+    const int iv = atoi(value);
+    if (k == "numerics") {
+        if (v == "fast") return mlx_set_numerics(h, MLX_NUMERICS_FAST);
+        if (v == "reference_order") return mlx_set_numerics(h, MLX_NUMERICS_REFERENCE_ORDER);
+        if (v == "reference_order_one_launch") return mlx_set_numerics(h, MLX_NUMERICS_REFERENCE_ORDER_ONE_LAUNCH);
+        return fail(h, MLX_ERR_INVALID, "numerics must be fast, reference_order or reference_order_one_launch (got '%s')", value);
+    }
+    if (k == "tick_streams") {
+        if (iv < 1 || iv > (int)mlx_context::MAX_TS) return fail(h, MLX_ERR_INVALID, "tick_streams must be 1..%d", (int)mlx_context::MAX_TS);
+        hipStreamSynchronize(h->stream);
+        setup_tick_streams(h, iv);
+        return MLX_OK;
+    }
+    if (k == "stream_probe") { h->stream_probe = iv != 0; return MLX_OK; }
+    if (k == "grid_rounded_dots") { h->seq_dots = iv != 0; return MLX_OK; }
+    if (k == "profile_one_stream") { h->prof_one_stream = iv != 0; return MLX_OK; }
+    if (k == "trace") { h->trace = iv != 0; return MLX_OK; }
+    if (k == "comm_always") { h->comm_always = iv != 0; return MLX_OK; }
+    if (k == "small_ticks") { if (iv < 1) return fail(h, MLX_ERR_INVALID, "small_ticks must be >= 1"); h->small_ticks = iv; return MLX_OK; }
+    if (k == "one_launch_small") {
+        if (h->finalized) return fail(h, MLX_ERR_INVALID, "one_launch_small must be set before mlx_finalize");
+        h->use_small = iv != 0; return MLX_OK;
+    }
+    return fail(h, MLX_ERR_INVALID, "mlx_set_option: unknown key '%s'", key);
+}
+
+int mlx_get_option(mlx_handle h, const char *key, char *out, size_t out_len)
+{
+    if (!h || !key || !out || out_len == 0) return fail(h, MLX_ERR_INVALID, "mlx_get_option: NULL argument");
+    const std::string k(key);
+    std::string v;
+    if (k == "numerics") v = !h->faithful ? "fast" : (h->ro_mode == 2 ? "reference_order_one_launch" : "reference_order");
+    else if (k == "numerics_kernels") v = !h->finalized ? "undecided" : (!h->faithful ? "fast" : (h->ro_ticks ? "reference_order_ticks" : "reference_order_one_launch"));
+    else if (k == "tick_streams") v = std::to_string(h->nstreams);
+    else if (k == "stream_probe_rejects") v = std::to_string(h->stream_probe_rejects);
+    else if (k == "stream_probe") v = h->stream_probe ? "1" : "0";
+    else if (k == "grid_rounded_dots") v = h->seq_dots ? "1" : "0";
+    else if (k == "profile_one_stream") v = h->prof_one_stream ? "1" : "0";
+    else if (k == "trace") v = h->trace ? "1" : "0";
+    else if (k == "comm_always") v = h->comm_always ? "1" : "0";
+    else if (k == "small_ticks") v = std::to_string(h->small_ticks);
+    else if (k == "one_launch_small") v = h->use_small ? "1" : "0";
+    else return fail(h, MLX_ERR_INVALID, "mlx_get_option: unknown key '%s'", key);
+    if (v.size() + 1 > out_len) return fail(h, MLX_ERR_INVALID, "mlx_get_option: buffer too small");
+    memcpy(out, v.c_str(), v.size() + 1);
     return MLX_OK;
 }
 
@@ -634,6 +733,7 @@ int mlx_set_regularizer(mlx_handle h, int32_t regularizer)
 struct CsrPrep {
     PartHost ph;
     std::vector<int32_t> rp, pcol, cri, item_ptr, item_dst, col_ptr, ishort, ilong, l2g_perm, rs_ptr, cs_ptr, cw_blk, cw_slice;
+    std::vector<int32_t> item_init, item_last;   // reference-order numerics on the tick kernels (PartDev::item_init / item_last)
     std::vector<uint16_t> rs_idx, cs_idx;
     std::vector<float> pvalv, cval, rs_val, cs_val;
     std::vector<int32_t> rowperm;            // library row i = the caller's row rowperm[i] (empty: identity)
@@ -655,12 +755,13 @@ struct CsrPrep {
 
 // Hot slices of the row pass (columns of the gathered vector staged in LDS): width, count, columns covered.
 struct RowHot { int slw, n_hs, hot_cols; };
-static RowHot row_hot_cols(int nf, int n_lambda)
+static RowHot row_hot_cols(int nf, int n_lambda, bool all_hot = false)
 {
     RowHot R;
     const int slmax = getenv("MLX_SLW") ? std::min(ROW_SLICE_MAX_COLS, std::max(64, atoi(getenv("MLX_SLW")) / 64 * 64)) : ROW_SLICE_MAX_COLS;
     R.slw = std::max(64, (std::min(nf, slmax) + 63) / 64 * 64);
     int nhs_want = getenv("MLX_NHOT") ? std::max(1, atoi(getenv("MLX_NHOT"))) : (nf <= 2 * R.slw ? 2 : 1);
+    if (all_hot) nhs_want = (nf + R.slw - 1) / R.slw;      // reference-order numerics: one running sum per row over ALL its entries
     R.n_hs = std::max(1, std::min(nhs_want, (nf + R.slw - 1) / R.slw));
     R.hot_cols = R.n_hs * R.slw;
     return R;
@@ -668,8 +769,9 @@ static RowHot row_hot_cols(int nf, int n_lambda)
 
 static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t l, int32_t n_local, int64_t nnz,
                     const int64_t *row_ptr, const int32_t *col_idx, const float *val, const int8_t *y,
-                    const int32_t *local_to_global, bool faithful, int n_lambda)
+                    const int32_t *local_to_global, int ro /* 0: product; 1 / 2: reference-order numerics, sliced / one-launch form */, int n_lambda)
 {
+    const bool faithful = ro != 0;
     if (!row_ptr || (nnz > 0 && !col_idx) || !y) return P.fail(MLX_ERR_INVALID, "NULL row data");
     if (row_ptr[0] != 0 || row_ptr[l] != nnz) return P.fail(MLX_ERR_INVALID, "row_ptr[0] must be 0 and row_ptr[l] == nnz");
     if (nnz >= (int64_t)std::numeric_limits<int32_t>::max()) return P.fail(MLX_ERR_INVALID, "partition nnz must be < 2^31");
@@ -811,8 +913,10 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
     // inside block b, rows ascending, cut into segments of <= CSC_SEG entries; items numbered block-major, each block
     // padded to a multiple of 64 items. cri/cval are re-ordered into item order so item_ptr is monotone.
     // (verification mode: one row block, unsplit columns -- a column's sum then runs over its rows in ascending order, XTv's order)
+    // (reference-order numerics, sliced form: unsplit columns inside row blocks that fit in LDS, chained from block to block by the
+    // column pass -- item_init below; MLX_RBMAX lets the tests cut small partitions into several blocks)
     const int seg = faithful ? std::numeric_limits<int32_t>::max() : (getenv("MLX_SEG") ? atoi(getenv("MLX_SEG")) : CSC_SEG);
-    int rbmax = faithful ? std::numeric_limits<int32_t>::max() - 64 : (getenv("MLX_RBMAX") ? std::min(RBLK_MAX_ROWS, std::max(64, atoi(getenv("MLX_RBMAX")))) : RBLK_MAX_ROWS);
+    int rbmax = ro == 2 ? std::numeric_limits<int32_t>::max() - 64 : (getenv("MLX_RBMAX") ? std::min(RBLK_MAX_ROWS, std::max(64, atoi(getenv("MLX_RBMAX")))) : RBLK_MAX_ROWS);
     const int nb = std::max(1, (l + rbmax - 1) / rbmax);
     const int RB = std::max(64, ((l + nb - 1) / nb + 63) / 64 * 64);
     ph.n_rblk = nb; ph.rblk_rows = RB;
@@ -823,10 +927,25 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
         std::vector<int32_t> pos(cp.begin(), cp.end() - 1);      // next unconsumed entry of each column
         item_ptr.reserve((size_t)nf + (size_t)(nnz / CSC_SEG) + 64 * (size_t)nb + 2);
         int32_t w = 0;                                           // write position in item order
+        std::vector<int32_t> jorder((size_t)nf), cntb;
+        for (int j = 0; j < nf; j++) jorder[(size_t)j] = j;
         for (int bk = 0; bk < nb; bk++) {
             blk_item0[(size_t)bk] = (int32_t)item_ptr.size();
             const int32_t rend = (int32_t)std::min<int64_t>(l, (int64_t)(bk + 1) * RB);
-            for (int j = 0; j < nf; j++) {
+            if (ro == 1) {
+                // the caller's column order is not sorted by length: order the block's items by length so that the 64 items of a
+                // slice are padded to similar lengths (the order of the ITEMS is free: item_dst says where a sum goes)
+                cntb.assign((size_t)nf, 0);
+                for (int j = 0; j < nf; j++) {
+                    int32_t q = pos[(size_t)j];
+                    while (q < cp[(size_t)j + 1] && cri[(size_t)q] < rend) q++;
+                    cntb[(size_t)j] = q - pos[(size_t)j];
+                }
+                for (int j = 0; j < nf; j++) jorder[(size_t)j] = j;
+                std::stable_sort(jorder.begin(), jorder.end(), [&](int32_t a, int32_t b) { return cntb[(size_t)a] > cntb[(size_t)b]; });
+            }
+            for (int jj = 0; jj < nf; jj++) {
+                const int j = jorder[(size_t)jj];
                 int32_t q = pos[(size_t)j];
                 const int32_t e = cp[(size_t)j + 1];
                 int32_t cnt = 0;
@@ -855,6 +974,18 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
         for (int it = 0; it < ph.n_items; it++)
             if (item_col[(size_t)it] >= 0) item_dst[(size_t)it] = nxt[(size_t)item_col[(size_t)it]]++;
         ph.n_slots = col_ptr[(size_t)nf];
+    }
+    std::vector<int32_t> item_init, item_last;
+    if (ro == 1) {
+        // a column's slots are in block order (one item per block at most): the item of a later block continues the earlier sum
+        item_init.assign((size_t)ph.n_items, -1); item_last.assign((size_t)ph.n_items, -1);
+        for (int it = 0; it < ph.n_items; it++) {
+            const int32_t c = item_col[(size_t)it];
+            if (c < 0) continue;
+            const int32_t slot = item_dst[(size_t)it];
+            if (slot > col_ptr[(size_t)c]) item_init[(size_t)it] = slot - 1;
+            if (slot == col_ptr[(size_t)c + 1] - 1) item_last[(size_t)it] = c;
+        }
     }
     cri.swap(cri_b);
     cval.swap(cval_b);
@@ -893,7 +1024,7 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
     std::vector<float> rs_val, cs_val;
     {
         const int ngr = (l + 63) / 64;
-        const RowHot RH = row_hot_cols(nf, n_lambda);
+        const RowHot RH = row_hot_cols(nf, n_lambda, ro == 1);
         const int slw = RH.slw;
         // hot slices (each slw columns, staged in LDS one after the other), then cold slices of 65 535 columns (gathered from L2,
         // which serves ~190 G random 8-byte requests/s chip-wide). A second hot slice pays when it leaves NO cold columns
@@ -927,9 +1058,13 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
                 padded += (int64_t)((mx + 3) / 4) * 256;    // entries in packs of 4 per lane: one 8-byte load = 4 ids
                 rs_ptr[(size_t)sl * ngr + g + 1] = (int32_t)std::min<int64_t>(padded, std::numeric_limits<int32_t>::max());
             }
-        ph.sell = nnz > 0 && (double)padded <= 2.0 * (double)nnz + 4096.0 && padded < (int64_t)std::numeric_limits<int32_t>::max() &&
+        // (reference-order numerics accept more padding: there the sliced form is the only fast one)
+        ph.sell = nnz > 0 && (double)padded <= (ro == 1 ? 8.0 : 2.0) * (double)nnz + 4096.0 && padded < (int64_t)std::numeric_limits<int32_t>::max() &&
                   (int64_t)nnz + 64LL * ph.n_items < (int64_t)std::numeric_limits<int32_t>::max() / 2 && getenv("MLX_NO_SELL") == nullptr &&
-                  !faithful;
+                  ro != 2;
+        if (ro == 1 && !ph.sell && nb > 1)
+            return P.fail(MLX_ERR_INVALID, "reference-order numerics: partition %d (%d rows, %lld non-zeros) is too ragged to slice and too long for "
+                                           "one row block", partition_id, l, (long long)nnz);
         if (ph.sell) {
             // (+256 entries of padding behind the last block: a wave whose trailing groups do not exist issues its unconditional,
             // clamped pack load at the END offset -- one 512-byte pack that must still be inside the allocation)
@@ -972,6 +1107,7 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
                 // work units of ~CUNIT_ENTRIES padded entries, never across blocks
                 const int sb0 = blk_item0[(size_t)bk] / 64, sb1 = blk_item0[(size_t)bk + 1] / 64;
                 int s0 = sb0;
+                if (ro == 1 && sb0 == sb1) { cw_blk.push_back(bk); cw_slice.push_back(sb0); }      // (an empty unit: the intercept's chain still runs through the block)
                 while (s0 < sb1) {
                     int s1 = s0 + 1;
                     while (s1 < sb1 && cs_ptr[(size_t)s1 + 1] - cs_ptr[(size_t)s0] <= cunit_entries) s1++;
@@ -992,6 +1128,7 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
     P.hasval = (val != nullptr);
     P.rp = std::move(rp); P.pcol = std::move(pcol); P.pvalv = std::move(pvalv); P.cri = std::move(cri); P.cval = std::move(cval);
     P.item_ptr = std::move(item_ptr); P.item_dst = std::move(item_dst); P.col_ptr = std::move(col_ptr); P.ishort = std::move(ishort); P.ilong = std::move(ilong);
+    P.item_init = std::move(item_init); P.item_last = std::move(item_last);
     P.l2g_perm = std::move(l2g_perm);
     P.rowperm = std::move(rowperm);
     P.rs_ptr = std::move(rs_ptr); P.rs_idx = std::move(rs_idx); P.rs_val = std::move(rs_val);
@@ -1040,6 +1177,13 @@ static int commit_csr(mlx_handle h, CsrPrep &P, int32_t l, int32_t n_local, int6
         }
         ph.dev.rs_ptr = d_a; ph.dev.rs_idx = d_b; ph.dev.cs_ptr = d_c; ph.dev.cs_idx = d_d; ph.dev.cw_blk = d_e; ph.dev.cw_slice = d_h; ph.dev.n_cunits = ph.n_cunits;
         ph.dev.rs_val = d_f; ph.dev.cs_val = d_g;
+    }
+    ph.dev.item_init = nullptr; ph.dev.item_last = nullptr;
+    if (!P.item_init.empty()) {
+        int32_t *d_ii, *d_il;
+        if ((rc = dev_upload(h, &d_ii, P.item_init.data(), P.item_init.size()))) return rc;
+        if ((rc = dev_upload(h, &d_il, P.item_last.data(), P.item_last.size()))) return rc;
+        ph.dev.item_init = d_ii; ph.dev.item_last = d_il;
     }
     ph.dev.items_short = d_ishort; ph.dev.items_long = d_ilong; ph.dev.n_short = ph.n_short; ph.dev.n_long = ph.n_long;
     ph.dev.item_ptr = d_item; ph.dev.item_dst = d_itemdst; ph.dev.col_ptr = d_colptr; ph.dev.n_slots = ph.n_slots; ph.dev.l2g = d_l2g; ph.dev.X = nullptr;
@@ -1100,7 +1244,7 @@ int mlx_add_partition_csr(mlx_handle h, int32_t partition_id, int32_t l, int32_t
     if (rc) return rc;
     if (!h->faithful && csr_is_dense_enough(l, n_local, nnz, row_ptr, col_idx)) return add_csr_as_dense_tile(h, partition_id, l, n_local, row_ptr, col_idx, val, y, weight, offset, local_to_global);
     CsrPrep P;
-    if ((rc = prep_csr(P, h->n_global, partition_id, l, n_local, nnz, row_ptr, col_idx, val, y, local_to_global, h->faithful, h->n_lambda)))
+    if ((rc = prep_csr(P, h->n_global, partition_id, l, n_local, nnz, row_ptr, col_idx, val, y, local_to_global, h->faithful ? h->ro_mode : 0, h->n_lambda)))
         return fail(h, rc, "%s", P.error.c_str());
     return commit_csr(h, P, l, n_local, nnz, y, weight, offset);
 }
@@ -1135,7 +1279,7 @@ int mlx_add_partitions_csr(mlx_handle h, int32_t count, const int32_t *partition
                 const int k = b0 + j;
                 if (!h->faithful && csr_is_dense_enough(l[k], n_local[k], nnz[k], row_ptr[k], col_idx[k])) { as_tile[(size_t)j] = 1; return; }
                 prep_csr(preps[(size_t)j], h->n_global, partition_id[k], l[k], n_local[k], nnz[k], row_ptr[k], col_idx[k],
-                         val ? val[k] : nullptr, y[k], local_to_global[k], h->faithful, h->n_lambda);
+                         val ? val[k] : nullptr, y[k], local_to_global[k], h->faithful ? h->ro_mode : 0, h->n_lambda);
             });
         for (auto &t : th) t.join();
         for (int j = 0; j < nb; j++) {
@@ -1163,8 +1307,8 @@ int mlx_add_partition_dense(mlx_handle h, int32_t partition_id, int32_t l, int32
     int rc = check_common_rows(h, partition_id, l, local_to_global, n_local);
     if (rc) return rc;
     if (!X || !y || n_feat < 1 || ld < n_feat) return fail(h, MLX_ERR_INVALID, "bad dense tile arguments");
-    if (h->faithful) return fail(h, MLX_ERR_INVALID, "MLX_FAITHFUL (verification mode) supports CSR partitions only");
-    if (n_feat > 2048) {
+    if (n_feat > 2048 || h->faithful) {
+        // (reference-order numerics: a tile's rows and columns are summed entry by entry like any other partition's)
         // The fused dense pass keeps a row's slice in registers (<= 2048 columns); wider tiles run the sparse passes on their
         // non-zero entries (same sums: the zeros they skip add +0.0), every column still present (n_local = n_feat + 1).
         std::vector<float> Xh((size_t)l * n_feat), wv, ov;
@@ -1231,6 +1375,12 @@ int mlx_finalize(mlx_handle h)
             return fail(h, MLX_ERR_INVALID, "%s: that code was measured slower and left the library in round 4 (attic/csrc, profiles/r2_notes.md)", sw);
     h->csr_sell = true;
     for (auto &p : h->parts) if (!p.dense) h->csr_sell = h->csr_sell && p.sell;
+    h->ro_ticks = h->faithful && h->ro_mode == 1 && h->csr_sell;
+    if (h->faithful && !h->ro_ticks)
+        for (auto &p : h->parts)
+            if (p.n_rblk > 1) return fail(h, MLX_ERR_INVALID, "reference-order numerics: partition %d has %d row blocks but the handle runs the one-launch "
+                                                               "kernel (a partition could not be sliced)", p.pid, p.n_rblk);
+    for (auto &p : h->parts) if (!p.dense) h->ro_blocks = std::max(h->ro_blocks, p.n_rblk);
     if (h->csr_sell) {
         int64_t total_groups = 0;
         for (auto &p : h->parts) if (!p.dense) total_groups += (int64_t)nl * p.n_rgroups;
@@ -1289,10 +1439,10 @@ int mlx_finalize(mlx_handle h)
     }
     // a single row-group width / value mode for all CSR partitions of the handle
     for (auto &p : h->parts) if (!p.dense) { h->max_cunits = std::max(h->max_cunits, p.n_cunits); h->max_rblk_rows = std::max(h->max_rblk_rows, p.rblk_rows); }
-    h->csr_small = getenv("MLX_NO_SMALL") == nullptr;
+    h->csr_small = h->use_small;
     for (auto &p : h->parts)
         if (!p.dense && (p.nnz > SMALL_MAX_NNZ || p.l > SMALL_MAX_DIM || p.n_local > SMALL_MAX_DIM)) h->csr_small = false;
-    if (h->faithful) h->csr_small = true;                   // the verification kernel is the one-launch solve, whatever the size
+    if (h->faithful) h->csr_small = !h->ro_ticks;           // the verification kernel is the one-launch solve, whatever the size
     if (h->csr_small && getenv("MLX_NO_SMALL_LDS") == nullptr && !h->faithful) {
         int64_t need = 0;
         for (auto &p : h->parts)
@@ -1447,7 +1597,7 @@ int mlx_finalize(mlx_handle h)
         rc = launch_xpass(h, d_qfd, (int)qfirst_d.size(), d_qfc, (int)qfirst_c.size());
         h->profiling = prof;
         if (rc) return rc;
-        mlxk_collect_c0(h->stream, h->d_parts, h->d_probs, d_qfa, (int)qfirst_all.size(), d_c0);
+        mlxk_collect_c0(h->stream, h->d_parts, h->d_probs, d_qfa, (int)qfirst_all.size(), d_c0, h->ro_ticks);
         HIPCHECK(h, hipStreamSynchronize(h->stream));
         HIPCHECK(h, hipGetLastError());
     }
@@ -2319,7 +2469,7 @@ int mlx_comm_init(mlx_handle h, const char unique_id[MLX_UNIQUE_ID_BYTES], int32
         if (!c) { c = std::make_shared<LocalComm>(); c->nranks = nranks; c->buf.resize((size_t)nranks); g_lcomms[key] = c; }
         if (c->nranks != nranks) return fail(h, MLX_ERR_COMM, "mlx_comm_init: local communicator has %d ranks, not %d", c->nranks, nranks);
         h->lcomm = c; h->has_lcomm = true; h->lrank = rank; h->comm_nranks = nranks;
-        h->comm_always = getenv("MLX_COMM_ALWAYS") != nullptr && atoi(getenv("MLX_COMM_ALWAYS")) != 0;
+        if (const char *ce = getenv("MLX_COMM_ALWAYS")) h->comm_always = h->comm_always || atoi(ce) != 0;     // (tests set it after mlx_create)
         return MLX_OK;
 #endif
     }
@@ -2328,7 +2478,7 @@ int mlx_comm_init(mlx_handle h, const char unique_id[MLX_UNIQUE_ID_BYTES], int32
     ncclResult_t r = ncclCommInitRank(&h->comm, nranks, id, rank);
     if (r != ncclSuccess) return fail(h, MLX_ERR_COMM, "ncclCommInitRank failed: %s", ncclGetErrorString(r));
     h->comm_nranks = nranks;
-    h->comm_always = getenv("MLX_COMM_ALWAYS") != nullptr && atoi(getenv("MLX_COMM_ALWAYS")) != 0;
+    if (const char *ce = getenv("MLX_COMM_ALWAYS")) h->comm_always = h->comm_always || atoi(ce) != 0;         // (tests set it after mlx_create)
     return MLX_OK;
 }
 

@@ -12,7 +12,10 @@ int mlxk_xpass_dense(hipStream_t st, const PartDev *parts, ProbDev *probs, const
 int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
                    int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cunits, int max_rblk_rows, int row_slw, int row_ngc, bool stream_once,
                    int which /* 1 = row pass, 2 = column pass, 3 = both */,
-                   int cold_groups /* > 0: the row pass's cold slices run as their own launch (k_rowcold) over that many row groups */);
+                   int cold_groups /* > 0: the row pass's cold slices run as their own launch (k_rowcold) over that many row groups */,
+                   int ro_blocks /* > 0: reference-order numerics (mlx_ro_kernels.h); the column pass runs once per row block, that many times */);
+// TRON/CG step of the reference-order numerics: one workgroup per problem, every reduction folded in index order
+void mlxk_ro_step(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int *done_counter);
 // TRON/CG control flow for the problems in qlist: one workgroup per problem (dense tiles)
 void mlxk_tron_step(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int threads,
                     int *done_counter);
@@ -25,7 +28,7 @@ void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *p
 void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int first, bool hasval,
                       int max_ticks, int *done_counter, int lds_doubles, bool faithful, int xl, int lds_bytes_xl);
 void mlxk_collect_c0(hipStream_t st, const PartDev *parts, const ProbDev *probs, const int *qlist, int nq,
-                     double *const *c0_ptrs);
+                     double *const *c0_ptrs, bool ro);
 void mlxk_setup(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int n_lambda, int n_global,
                 int max_nlocal, const float *z32, const float *u, const double *pinv_l, double epsilon, int max_iter);
 void mlxk_setup_naive(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int max_nlocal,

@@ -735,7 +735,10 @@ __device__ __forceinline__ void sell_gather_round(double *a, const uint16_t *__r
 #ifndef ROW_KP
 #define ROW_KP 1       // packs per group and round of the hot slice
 #endif
-template <bool HASVAL, bool NT, int GPW>
+// RO (reference-order numerics, mlx_ro_kernels.h): every slice is hot, so a row's entries join ONE running sum in ascending column
+// id -- Xv's order (llf/LogisticRegressionL2.java:115-129); the row map evaluates the portable exp / log1p the oracle's twin uses and
+// leaves the row's loss in rowtmp[] for the step's sequential fold; no per-group partial sums.
+template <bool HASVAL, bool NT, int GPW, bool RO = false>
 __global__ void __launch_bounds__(1024)
 k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx,
               int cold_sep)
@@ -865,12 +868,13 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
                     cfv = wdv0[i] * t;
                 } else {
                     double wdv;
-                    row_eval(t + (double)offv[i], yv[i], (double)wtv[i], lossv, wdv, cfv);
+                    row_eval<RO>(t + (double)offv[i], yv[i], (double)wtv[i], lossv, wdv, cfv);
                     gst(wdnew + rowi[i], wdv);
+                    if (RO) gst(pr.rowtmp + rowi[i], lossv);
                 }
                 gst(coef + rowi[i], cfv);
             }
-            if (wg0 + i0 + i < gcount) {                       // (wave-uniform)
+            if (!RO && wg0 + i0 + i < gcount) {                // (wave-uniform)
                 const double cs = wave_allreduce_sum(cfv);
                 const double ls = cg ? 0.0 : wave_allreduce_sum(lossv);
                 if (lane == 0) { pr.csump[g0 + wg0 + i0 + i] = cs; if (!cg) pr.lossp[g0 + wg0 + i0 + i] = ls; }
@@ -936,9 +940,14 @@ k_rowcold(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
 // (<= 20 160 doubles) is staged once, then every wave walks item slices of that block: one THREAD per item, entry k of
 // the 64 items one coalesced 128-B index load, the gather served by LDS instead of the L2 request path (which is what
 // bounds the global-gather form: ~250 G random 8-byte requests/s chip-wide). Sums run in row order, contraction off.
-template <bool HASVAL, bool NT>
+// RO (reference-order numerics, mlx_ro_kernels.h): launched once per row block (only_blk), in block order. Items are unsplit inside
+// a block and start from the sum their column reached in the earlier blocks (item_init), so a column's sum is ONE chain over its rows
+// in ascending order -- XTv's order (llf/LogisticRegressionL2.java:140-145); a column's last item also stores the sum at xtc[column]
+// (ProbDev::c0f). The intercept's column (the sum of all coefficients in row order) is folded by one lane of the block's first
+// work unit from the staged block, chained through csump[block].
+template <bool HASVAL, bool NT, bool RO = false>
 __global__ void __launch_bounds__(1024)
-k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx)
+k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx, int only_blk)
 {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) double cf[];      // [rblk_rows + 1]: the block's coefficients, then the zero slot
@@ -951,6 +960,7 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     const PartDev &pa = parts[pr.part];
     if (bx_ >= pa.n_cunits) return;
     const int blk = pa.cw_blk[bx_];
+    if (RO && blk != only_blk) return;
     const int s0 = pa.cw_slice[bx_], s1 = pa.cw_slice[bx_ + 1];
     const int r0 = blk * pa.rblk_rows;
     const int nr = min(pa.rblk_rows, pa.l - r0);
@@ -969,14 +979,30 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     const int32_t *__restrict__ item_dst = pa.item_dst;
     double *__restrict__ out = pr.parts;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (RO && wave == 15 && (bx_ == 0 || pa.cw_blk[bx_ - 1] != blk)) {
+        // the intercept's column: out[n-1] += v[i] for every row i in order (the bias entry closes every row)
+        double a = blk > 0 ? gld(pr.csump + blk - 1) : 0.0;
+        int i = 0;
+        for (; i + 8 <= nr; i += 8) {
+            double c8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) c8[u] = cf[i + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) a = a + c8[u];
+        }
+        for (; i < nr; i++) a = a + cf[i];
+        if (lane == 0) gst(pr.csump + blk, a);
+    }
     // COL_B item slices per wave and round: their offsets, then their destinations and first packs, are fetched together
     // (three dependent latencies per round instead of per slice); items longer than the first packs continue in the deep loop
     constexpr int COL_B = 8, KP = HASVAL ? 1 : 2;
     const int zs = pa.rblk_rows;
+    const int32_t *__restrict__ item_init = pa.item_init, *__restrict__ item_last = pa.item_last;
+    double *__restrict__ xtc = pr.c0f;
     // (slice s0 + wave + 16 t: slices are sorted by length, so this deals the long ones evenly; batches of consecutive slices
     // per wave -- one offset load instead of 16 -- put a hot unit's 16 long slices on 2 waves: 196 -> 278 us)
     for (int sb = s0 + wave; sb < s1; sb += 16 * COL_B) {
-        int base[COL_B], L4[COL_B], dst[COL_B];
+        int base[COL_B], L4[COL_B], dst[COL_B], dlast[COL_B];
         double a[COL_B];
 #pragma unroll
         for (int u = 0; u < COL_B; u++) {
@@ -988,6 +1014,12 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
             const int dl = gld_nt(item_dst + sc * 64 + lane);   // unconditional, clamped; read once per tick
             dst[u] = (sl < s1) ? dl : -1;
             a[u] = 0.0;
+            dlast[u] = -1;
+            if (RO) {
+                const int di = gld(item_init + sc * 64 + lane);
+                dlast[u] = (sl < s1) ? gld(item_last + sc * 64 + lane) : -1;
+                if (sl < s1 && di >= 0) a[u] = gld(out + di);  // (written by the previous block's launch)
+            }
         }
         PT_MARK(9);
         sell_lds_first<HASVAL, NT, COL_B, KP>(a, cs_idx, cs_val, base, L4, 0, lane, cf, zs);
@@ -996,6 +1028,7 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
         for (int u = 0; u < COL_B; u++) {
             if (L4[u] > KP) a[u] = sell_lds_sum<HASVAL, NT>(a[u], cs_idx, cs_val, base[u], KP, L4[u], lane, cf, zs);
             if (dst[u] >= 0) gst(out + dst[u], a[u]);          // (plain store: phase A reads the slots from L2 right after; a streaming store cost the pass 13 %)
+            if (RO && dlast[u] >= 0) gst(xtc + dlast[u], a[u]);
         }
         PT_MARK(11);
     }
@@ -2897,6 +2930,8 @@ static void per_device_once(int slot, F &&fn)
     fn();
     done[slot][dev] = true;
 }
+#include "mlx_ro_kernels.h"
+
 static void set_max_lds(const void *func, int bytes)
 {
     const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -2933,10 +2968,41 @@ static void launch_rowpass(hipStream_t st, const PartDev *parts, ProbDev *probs,
 
 int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
                    int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cunits, int max_rblk_rows, int row_slw, int row_ngc, bool stream_once, int which,
-                   int cold_groups)
+                   int cold_groups, int ro_blocks)
 {
     const bool do_row = which & 1, do_col = which & 2;
     if (nq <= 0) return 0;
+    if (sell && ro_blocks > 0) {
+        // reference-order numerics (mlx_ro_kernels.h): every slice of the row pass hot, the column pass once per row block
+        const size_t lds_col = ((size_t)max_rblk_rows + 1) * sizeof(double), lds_row = ((size_t)row_slw + 1) * sizeof(double);
+        per_device_once(6, [&] {
+#define SETLDS_RO(HV)                                                                                                                          \
+            set_max_lds(reinterpret_cast<const void *>(&k_colpass_lds<HV, false, true>), 160 * 1024 - 64); \
+            set_max_lds(reinterpret_cast<const void *>(&k_rowpass_lds<HV, false, 1, true>), 160 * 1024 - 512); \
+            set_max_lds(reinterpret_cast<const void *>(&k_rowpass_lds<HV, false, 2, true>), 160 * 1024 - 512); \
+            set_max_lds(reinterpret_cast<const void *>(&k_rowpass_lds<HV, false, 4, true>), 160 * 1024 - 512); \
+            set_max_lds(reinterpret_cast<const void *>(&k_rowpass_lds<HV, false, 8, true>), 160 * 1024 - 512)
+            SETLDS_RO(true); SETLDS_RO(false);
+#undef SETLDS_RO
+        });
+#define LAUNCH_ROW_RO(HV, GP) hipLaunchKernelGGL((k_rowpass_lds<HV, false, GP, true>), dim3(XGRID(nq, maxblk)), dim3(1024), lds_row, st, parts, probs, qlist, nq, maxblk, 0)
+#define LAUNCH_RO(HV)                                                                                                                          \
+        do {                                                                                                                                   \
+            if (do_row) switch (row_ngc) {                                                                                                     \
+                case 16: LAUNCH_ROW_RO(HV, 1); break;                                                                                          \
+                case 32: LAUNCH_ROW_RO(HV, 2); break;                                                                                          \
+                case 64: LAUNCH_ROW_RO(HV, 4); break;                                                                                          \
+                default: LAUNCH_ROW_RO(HV, 8); break;                                                                                          \
+            }                                                                                                                                  \
+            if (do_col && max_cunits > 0)                                                                                                      \
+                for (int b = 0; b < ro_blocks; b++)                                                                                            \
+                    hipLaunchKernelGGL((k_colpass_lds<HV, false, true>), dim3(XGRID(nq, max_cunits)), dim3(1024), lds_col, st, parts, probs, qlist, nq, max_cunits, b); \
+        } while (0)
+        if (hasval) LAUNCH_RO(true); else LAUNCH_RO(false);
+#undef LAUNCH_RO
+#undef LAUNCH_ROW_RO
+        return 0;
+    }
     if (sell) {
         const size_t lds_col = ((size_t)max_rblk_rows + 1) * sizeof(double), lds_row = ((size_t)row_slw + 1) * sizeof(double);
         per_device_once(1, [&] {
@@ -2961,7 +3027,7 @@ int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const i
                 default: LAUNCH_ROW(HV, NTF, 8); break;                                                                                        \
             }                                                                                                                                  \
             if (do_col && max_cunits > 0)                                                                                                      \
-                hipLaunchKernelGGL((k_colpass_lds<HV, NTF>), dim3(XGRID(nq, max_cunits)), dim3(1024), lds_col, st, parts, probs, qlist, nq, max_cunits); \
+                hipLaunchKernelGGL((k_colpass_lds<HV, NTF>), dim3(XGRID(nq, max_cunits)), dim3(1024), lds_col, st, parts, probs, qlist, nq, max_cunits, -1); \
         } while (0)
         if (hasval) { if (stream_once) LAUNCH_SELL(true, true); else LAUNCH_SELL(true, false); }
         else { if (stream_once) LAUNCH_SELL(false, true); else LAUNCH_SELL(false, false); }
@@ -3049,9 +3115,18 @@ void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, int 
 }
 
 void mlxk_collect_c0(hipStream_t st, const PartDev *parts, const ProbDev *probs, const int *qlist, int nq,
-                     double *const *c0_ptrs)
+                     double *const *c0_ptrs, bool ro)
 {
-    if (nq > 0) hipLaunchKernelGGL(k_collect_c0, dim3(nq), dim3(256), 0, st, parts, probs, qlist, c0_ptrs);
+    if (nq <= 0) return;
+    if (ro) hipLaunchKernelGGL(k_ro_collect_c0, dim3(nq), dim3(256), 0, st, parts, probs, qlist, c0_ptrs);
+    else hipLaunchKernelGGL(k_collect_c0, dim3(nq), dim3(256), 0, st, parts, probs, qlist, c0_ptrs);
+}
+
+void mlxk_ro_step(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int *done_counter)
+{
+    if (nq <= 0) return;
+    per_device_once(7, [&] { set_max_lds(reinterpret_cast<const void *>(&k_ro_step), (int)sizeof(RoLds)); });
+    hipLaunchKernelGGL(k_ro_step, dim3((unsigned)nq), dim3(RO_T), sizeof(RoLds), st, parts, probs, qlist, nq, done_counter);
 }
 
 void mlxk_setup(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int n_lambda, int n_global,

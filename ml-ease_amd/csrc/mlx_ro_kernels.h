@@ -1,0 +1,453 @@
+// mlx_ro_kernels.h -- REFERENCE-ORDER numerics (MLX_NUMERICS_REFERENCE_ORDER) on the tick kernels; included by mlx_kernels.hip.
+//
+// The product path differs from the reference in ONE respect: reductions are trees (or grid-rounded sums) where the Java code runs
+// sequential loops. This mode removes that difference at tick-kernel speed instead of the one-thread-per-reduction verification kernel
+// (k_solve_small<.., SEQ>, which stays as the independent cross-check and for partitions that cannot be sliced):
+//   * library column ids = the caller's (first-seen) ids, library rows = the caller's rows (mlx_api.hip: prep_csr);
+//   * row sums (Xv, llf/LogisticRegressionL2.java:115-129): k_rowpass_lds<.., RO> with EVERY column slice staged in LDS one after the
+//     other, one thread per row, one running sum over the row's entries in ascending column id, the bias entry last;
+//   * column sums (XTv, :131-150): k_colpass_lds<.., RO>, one launch per row block in block order; an item = ALL entries of a column
+//     inside the block, one thread per item, rows ascending, started from the sum the column reached in the earlier blocks
+//     (PartDev::item_init) -- one chain per column over all its rows; the intercept's column is one lane's chain over the staged
+//     coefficients (csump[block]);
+//   * every n- or l-long dot / norm / loss sum of Tron.tron / trcg / fun (bw/Tron.java:30-252, llf/LogisticRegressionL2.java:156-193):
+//     k_ro_step below -- one 256-thread workgroup per problem walks the vectors in chunks of 1024 elements; all threads do the
+//     elementwise work of the chunk (the daxpy / scale statements, Hs[i] = s[i]*priorVar_inv[i] + Hs[i], the products a[i]*b[i] of
+//     Tron.dot) and leave the chunk's TERMS in LDS; up to six lanes of the first wave then fold one term array each IN INDEX ORDER
+//     (p += term: the loop of Tron.dot :204-213), so the six reductions a CG step needs at once cost one chain, not six.
+//     euclideanNorm (:220-252) keeps a running scale: its update is `sum = 1 + sum*(scale/a)^2` when |v_i| exceeds the scale and
+//     `sum += (a/scale)^2` otherwise. The scale before element i is the running maximum of |v| -- an exclusive prefix maximum, exact
+//     in any association -- so the chunk's threads compute it by a scan, form every element's (m, c) with sum' = c + sum*m in
+//     parallel (the divisions are off the chain), and the folding lane runs the chain; chunks without a new maximum (all but the
+//     first few) take the plain `sum += c` loop.
+//   * exp / log1p: the portable forms of portable_math.h, as the oracle's verification twin evaluates them (device and host libm
+//     differ in the last bit).
+// Same statements in the same order as tron_step_body<SEQ> (which is bit-identical to the oracle): the tests run both.
+#pragma once
+
+constexpr int RO_T = 256, RO_CH = 1024, RO_CHP = RO_CH + 2, RO_NF = 6, RO_NN = 2;
+struct RoLds {
+    double C[RO_NF][RO_CHP];       // terms of the chunk, one array per folding lane (norm arrays first)
+    double M[RO_NN][RO_CHP];       // multipliers of the norm arrays (1.0 except where the running scale changes)
+    double wtot[RO_NN][4];         // scan: the waves' maxima
+    double res[RO_NF];
+};
+struct RoV4 { double v[4]; };
+
+// four consecutive elements j0 .. j0+3 of a 32-byte aligned vector (the work vectors: 256-byte aligned pieces of the slab, padded so
+// that the last quad stays inside the piece -- mlx_finalize's carve_size)
+__device__ __forceinline__ RoV4 ro_ld4(const double *__restrict__ p, int j0)
+{
+    typedef double d2v_t __attribute__((ext_vector_type(2)));
+    const d2v_t a = gld(reinterpret_cast<const d2v_t *>(p + j0)), b = gld(reinterpret_cast<const d2v_t *>(p + j0 + 2));
+    RoV4 r; r.v[0] = a.x; r.v[1] = a.y; r.v[2] = b.x; r.v[3] = b.y;
+    return r;
+}
+__device__ __forceinline__ RoV4 ro_ld4s(const double *__restrict__ p, int j0, int n)      // any alignment, clamped
+{
+    RoV4 r;
+#pragma unroll
+    for (int e = 0; e < 4; e++) r.v[e] = gld(p + min(j0 + e, n - 1));
+    return r;
+}
+__device__ __forceinline__ void ro_st4(double *__restrict__ p, int j0, int n, const double (&x)[4])
+{
+#pragma unroll
+    for (int e = 0; e < 4; e++) if (j0 + e < n) gst(p + j0 + e, x[e]);
+}
+
+// One pass over elements 0 .. len-1. load(j0, R) fetches the operands of elements j0 .. j0+3 (clamped to the last quad of the
+// vector), emit(j0, R, ct, nv) does their elementwise work (stores included, elements >= len masked) and returns the terms of the
+// dot arrays ct[k][e] (k >= NN) and the raw values of the norm arrays nv[q][e] (q < NN). Lane k of the first wave folds array k:
+// norms from sum = 1, dots from init[k]. result[k] (every thread): the norm scale*sqrt(sum) / the dot.
+template <int NF, int NN, typename R, typename LD, typename EM>
+__device__ __forceinline__ void ro_pass(RoLds &sh, int len, const double *init, double *result, LD load, EM emit)
+{
+#pragma clang fp contract(off)
+    static_assert(NF <= RO_NF && NN <= RO_NN && NN <= NF, "fold arrays");
+    constexpr int NFX = NF > 0 ? NF : 1, NNX = NN > 0 ? NN : 1;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double acc = 0.0;
+    if (NF > 0) acc = (lane < NN) ? 1.0 : init[lane < NF ? lane : 0];
+    double mc[NNX];
+#pragma unroll
+    for (int q = 0; q < NNX; q++) mc[q] = 0.0;
+    const int lastq = ((len - 1) >> 2) << 2;
+    R regs;
+    load(min(4 * tid, lastq), regs);
+    for (int base = 0; base < len; base += RO_CH) {
+        const int j0 = base + 4 * tid;
+        double ct[NFX][4], nv[NNX][4];
+        emit(j0, regs, ct, nv);
+        if (base + RO_CH < len) load(min(j0 + RO_CH, lastq), regs);      // next chunk's operands: in flight during the scan and the fold
+        int flag = 0;
+        if (NN > 0) {
+            // euclideanNorm's running scale in front of every element = exclusive prefix maximum of |v| (zeros never raise it)
+            double a[NNX][4], x[NNX];
+#pragma unroll
+            for (int q = 0; q < NN; q++) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) a[q][e] = (j0 + e < len) ? fabs(nv[q][e]) : 0.0;
+                x[q] = fmax(fmax(a[q][0], a[q][1]), fmax(a[q][2], a[q][3]));
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const double y = __shfl_up(x[q], d);
+                    if (lane >= d) x[q] = fmax(x[q], y);
+                }
+                if (lane == 63) sh.wtot[q][wave] = x[q];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NN; q++) {
+                double ex = __shfl_up(x[q], 1);
+                if (lane == 0) ex = 0.0;
+                double P = fmax(mc[q], ex);
+                for (int w = 0; w < 4; w++) {
+                    const double t = sh.wtot[q][w];
+                    if (w < wave) P = fmax(P, t);
+                    mc[q] = fmax(mc[q], t);
+                }
+                double mm[4], cc[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const double ae = a[q][e];
+                    if (!(ae != 0.0)) { mm[e] = 1.0; cc[e] = 0.0; }               // v[i] == 0: skipped
+                    else if (P < ae) { const double t = P / ae; mm[e] = t * t; cc[e] = 1.0; flag = 1; }      // sum = 1 + sum * (t * t); scale = a
+                    else { const double t = ae / P; mm[e] = 1.0; cc[e] = t * t; }                                // sum += t * t
+                    P = fmax(P, ae);
+                }
+                typedef double d2v_t __attribute__((ext_vector_type(2)));
+                d2v_t *cp = reinterpret_cast<d2v_t *>(&sh.C[q][4 * tid]), *mp = reinterpret_cast<d2v_t *>(&sh.M[q][4 * tid]);
+                cp[0] = (d2v_t){cc[0], cc[1]}; cp[1] = (d2v_t){cc[2], cc[3]};
+                mp[0] = (d2v_t){mm[0], mm[1]}; mp[1] = (d2v_t){mm[2], mm[3]};
+            }
+        }
+#pragma unroll
+        for (int k = NN; k < NF; k++) {
+            typedef double d2v_t __attribute__((ext_vector_type(2)));
+            d2v_t *cp = reinterpret_cast<d2v_t *>(&sh.C[k][4 * tid]);
+            cp[0] = (d2v_t){ct[k][0], ct[k][1]}; cp[1] = (d2v_t){ct[k][2], ct[k][3]};
+        }
+        const int any = __syncthreads_or(flag);
+        if (NF > 0 && wave == 0 && lane < NF) {
+            const int cnt = min(RO_CH, len - base);
+            const double *cp = &sh.C[lane][0];
+            double s = acc;
+            if (!any) {
+                int i = 0;
+                for (; i + 8 <= cnt; i += 8) {
+                    double c8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) c8[u] = cp[i + u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) s = s + c8[u];
+                }
+                for (; i < cnt; i++) s = s + cp[i];
+            } else {
+                const double *mp = &sh.M[lane < NN ? lane : 0][0];
+                const bool isn = lane < NN;
+                for (int i = 0; i < cnt; i++) {
+                    const double m = isn ? mp[i] : 1.0;
+                    s = cp[i] + s * m;
+                }
+            }
+            acc = s;
+        }
+        __syncthreads();
+    }
+    if (NF > 0) {
+        if (wave == 0 && lane < NF) {
+            double r = acc;
+#pragma unroll
+            for (int q = 0; q < NN; q++) if (lane == q) r = mc[q] * sqrt(acc);
+            sh.res[lane] = r;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NF; k++) result[k] = sh.res[k];
+        __syncthreads();
+    }
+}
+
+// The TRON/CG step of one tick, reference-order numerics: one workgroup per problem (bw/Tron.java:30-179; statement order of
+// tron_step_body<SEQ>).
+__global__ void __launch_bounds__(RO_T)
+k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq,
+          int *__restrict__ done_counter)
+{
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) unsigned char ro_smem[];
+    RoLds &sh = *reinterpret_cast<RoLds *>(ro_smem);
+    if ((int)blockIdx.x >= nq) return;
+    ProbDev &pr = probs[qlist[blockIdx.x]];
+    const int phase = pr.phase;
+    if (phase == PH_DONE) return;
+    const PartDev &pa = parts[pr.part];
+    const int n = pa.n_local, nf = pa.n_feat, l = pa.l, tid = threadIdx.x;
+    const double *__restrict__ xtc = pr.c0f;                      // X'c of this tick, columns 0 .. nf-1 (k_colpass_lds<.., RO>)
+    const double csum = pr.csump[pa.n_rblk - 1];                  // ... and of the intercept's column
+    const double *__restrict__ pvec = pr.pinv_vec;
+    const double pscal = pr.pinv;
+    double *__restrict__ w = pr.w, *__restrict__ w_new = pr.w_new, *__restrict__ g = pr.g, *__restrict__ s = pr.s,
+           *__restrict__ d = pr.d, *__restrict__ Hd = pr.Hd;
+    const double *__restrict__ m = pr.m;
+    const double zero6[RO_NF] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double res[RO_NF];
+
+    if (phase == PH_CG) {
+        // ---- one trip of trcg's loop (bw/Tron.java:145-175)
+        struct RA { RoV4 d, x, p; };
+        ro_pass<1, 0, RA>(sh, n, zero6, res,
+            [&](int j0, RA &R) { R.d = ro_ld4(d, j0); R.x = ro_ld4(xtc, j0); if (pvec) R.p = ro_ld4s(pvec, j0, n); },
+            [&](int j0, RA &R, double (&ct)[1][4], double (&nv)[1][4]) {
+                double hd[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int j = j0 + e;
+                    const double xa = (j == nf) ? csum : R.x.v[e];
+                    hd[e] = R.d.v[e] * (pvec ? R.p.v[e] : pscal) + xa;      // Hs[i] = (s[i]*priorVar_inv[i] + Hs[i]) * 1
+                    ct[0][e] = R.d.v[e] * hd[e];                             // Tron.dot(d, Hd)
+                }
+                ro_st4(Hd, j0, n, hd);
+            });
+        const double rTr0 = pr.rTr, delta0 = pr.delta, cgtol0 = pr.cgtol;
+        double alpha = rTr0 / res[0];
+        const double nalpha = -alpha;
+        const double *__restrict__ rc = pr.rb[pr.rsel];
+        double *__restrict__ rn = pr.rb[pr.rsel ^ 1];
+        // daxpy(alpha, d, s); the norm of s; and, from the same operands, both continuations: r' = r - alpha Hd with r'.r' and |r'|
+        // (:169-171, :144 of the next trip) and the three dots of the boundary case on the stepped-back s (:152-155)
+        struct RB { RoV4 d, s, r, h; };
+        ro_pass<6, 2, RB>(sh, n, zero6, res,
+            [&](int j0, RB &R) { R.d = ro_ld4(d, j0); R.s = ro_ld4(s, j0); R.r = ro_ld4(rc, j0); R.h = ro_ld4(Hd, j0); },
+            [&](int j0, RB &R, double (&ct)[6][4], double (&nv)[2][4]) {
+                double s1[4], r1[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    s1[e] = R.s.v[e] + alpha * R.d.v[e];                     // daxpy(alpha, d, s)
+                    r1[e] = R.r.v[e] + nalpha * R.h.v[e];                    // daxpy(-alpha, Hd, r)
+                    const double sb = s1[e] + nalpha * R.d.v[e];             // the boundary case steps back first (:153)
+                    nv[0][e] = s1[e]; nv[1][e] = r1[e];
+                    ct[2][e] = r1[e] * r1[e];
+                    ct[3][e] = sb * R.d.v[e]; ct[4][e] = sb * sb; ct[5][e] = R.d.v[e] * R.d.v[e];
+                }
+                ro_st4(s, j0, n, s1);
+                ro_st4(rn, j0, n, r1);
+            });
+        const double snorm = res[0];
+        bool boundary = false, end_cg = false, nan = !(snorm == snorm);
+        double alpha2 = 0.0, beta = 0.0;
+        const double rnew = res[2];
+        if (snorm > delta0) {
+            // cg reaches trust region boundary (:150-168)
+            const double std_ = res[3], sts = res[4], dtd = res[5];
+            const double dsq = delta0 * delta0;
+            const double rad = sqrt(std_ * std_ + dtd * (dsq - sts));
+            if (std_ >= 0) alpha2 = (dsq - sts) / (std_ + rad);
+            else alpha2 = (rad - std_) / dtd;
+            boundary = true; end_cg = true;
+        } else {
+            beta = rnew / rTr0;
+            if (res[1] <= cgtol0) end_cg = true;                 // loop-top test of the next trip (:144)
+        }
+        if (nan) end_cg = true;
+        const double nalpha2 = -alpha2;
+        struct RC { RoV4 d, s, r1, r, h, w, g; };
+        auto ldc = [&](int j0, RC &R) {
+            R.d = ro_ld4(d, j0);
+            if (boundary) { R.s = ro_ld4(s, j0); R.r = ro_ld4(rc, j0); R.h = ro_ld4(Hd, j0); }
+            else { R.r1 = ro_ld4(rn, j0); if (end_cg) R.s = ro_ld4(s, j0); }
+            if (end_cg) { R.w = ro_ld4(w, j0); R.g = ro_ld4(g, j0); }
+        };
+        auto emc = [&](int j0, RC &R, double (&ct)[3][4], double (&nv)[1][4]) {
+            double sf[4], rf[4], dn[4], wn[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                sf[e] = R.s.v[e]; rf[e] = R.r1.v[e];
+                if (boundary) {
+                    const double sb = R.s.v[e] + nalpha * R.d.v[e];          // daxpy(-alpha, d, s)
+                    sf[e] = sb + alpha2 * R.d.v[e];                           // daxpy(alpha', d, s)
+                    rf[e] = R.r.v[e] + nalpha2 * R.h.v[e];                    // daxpy(-alpha', Hd, r)
+                } else {
+                    double dj = R.d.v[e];
+                    if (beta != 1.0) dj = dj * beta;                          // scale(beta, d)
+                    dn[e] = dj + 1.0 * R.r1.v[e];                             // daxpy(one, r, d)
+                }
+                if (end_cg) {
+                    wn[e] = R.w.v[e] + 1.0 * sf[e];                           // w_new = w + s (:69-70)
+                    nv[0][e] = sf[e];
+                    ct[1][e] = R.g.v[e] * sf[e];                              // gs = dot(g, s)
+                    ct[2][e] = sf[e] * rf[e];                                 // dot(s, r)
+                } else { nv[0][e] = 0.0; ct[1][e] = 0.0; ct[2][e] = 0.0; }
+            }
+            if (boundary) { ro_st4(s, j0, n, sf); ro_st4(rn, j0, n, rf); }
+            else ro_st4(d, j0, n, dn);
+            if (end_cg) ro_st4(w_new, j0, n, wn);
+        };
+        if (end_cg) ro_pass<3, 1, RC>(sh, n, zero6, res, ldc, emc);
+        else ro_pass<0, 0, RC>(sh, n, zero6, res, ldc,
+                               [&](int j0, RC &R, double (&ct)[1][4], double (&nv)[1][4]) { double c3[3][4], n1[1][4]; emc(j0, R, c3, n1); });
+        if (tid == 0) {
+            if (!boundary) pr.rTr = rnew;
+            pr.rsel ^= 1;
+            pr.cg_iter += 1;
+            pr.ticks += 1;
+            if (nan) pr.status = ST_NAN;          // the EVAL tick that follows still runs; the host reports the status
+            if (end_cg) {
+                pr.gs = res[1];
+                pr.prered = -0.5 * (res[1] - res[2]);
+                pr.snorm = res[0];                // euclideanNorm(s) of tron() (:80): the same loop over the same vector
+                pr.newton += 1;
+                pr.cg_total += pr.cg_iter;
+                pr.phase = PH_EVAL;
+            }
+        }
+        return;
+    }
+
+    // ---- PH_EVAL0 / PH_EVAL: fun(w_new) and the gradient candidate (llf/LogisticRegressionL2.java:156-225)
+    const double *__restrict__ rowtmp = pr.rowtmp;
+    struct RR { RoV4 x; };
+    ro_pass<1, 0, RR>(sh, l, zero6, res,
+        [&](int j0, RR &R) { R.x = ro_ld4(rowtmp, j0); },
+        [&](int j0, RR &R, double (&ct)[1][4], double (&nv)[1][4]) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) ct[0][e] = R.x.v[e];                 // f += weight * log(1 + exp(..)) in row order (:172-183)
+        });
+    double fnew = 2.0 * res[0];
+    const double init4[RO_NF] = {0.0, 0.0, fnew, 0.0, 0.0, 0.0};
+    const double *__restrict__ c0 = pa.c0;
+    const bool e0 = (phase == PH_EVAL0);
+    struct RE { RoV4 w, m, x, p, c; };
+    ro_pass<4, 2, RE>(sh, n, init4, res,
+        [&](int j0, RE &R) {
+            R.w = ro_ld4(w_new, j0); R.m = ro_ld4(m, j0); R.x = ro_ld4(xtc, j0);
+            if (pvec) R.p = ro_ld4s(pvec, j0, n);
+            if (e0) R.c = ro_ld4s(c0, j0, n);
+        },
+        [&](int j0, RE &R, double (&ct)[4][4], double (&nv)[2][4]) {
+            double hd[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int j = j0 + e;
+                const double xa = (j == nf) ? csum : R.x.v[e];
+                const double pj = pvec ? R.p.v[e] : pscal;
+                const double t = R.w.v[e] - R.m.v[e];
+                ct[2][e] = t * t * pj;                                       // fun :187-188, added to the running f
+                hd[e] = t * pj + xa;                                         // grad :224 (multiplier 1)
+                nv[0][e] = hd[e];                                            // euclideanNorm(g)
+                ct[3][e] = hd[e] * hd[e];                                    // r.r of the trcg call that starts from this g (r = -g)
+                nv[1][e] = e0 ? (0.0 - R.m.v[e]) * pj + R.c.v[e] : 0.0;      // grad(0) (bw/Tron.java:50-53)
+            }
+            ro_st4(Hd, j0, n, hd);
+        });
+    fnew = res[2] / 2.0;
+    const double gnorm_c = res[0], gsq_c = res[3];
+    bool start_trcg = false, finished = false, copy_w = false, copy_g = false;
+    double gnorm_cur = pr.gnorm, gsq = pr.gsq;
+    if (e0) {
+        // Tron prologue (:47-62)
+        const double gnorm1 = res[1];
+        if (tid == 0) { pr.f = fnew; pr.gnorm1 = gnorm1; pr.gnorm = gnorm_c; pr.delta = gnorm_c; pr.dsel ^= 1; pr.ticks += 1; }
+        gnorm_cur = gnorm_c; gsq = gsq_c;
+        copy_g = true;
+        if (gnorm_c <= pr.eps * gnorm1) finished = true;           // search = 0
+        else start_trcg = true;
+        if (!(fnew == fnew) || !(gnorm_c == gnorm_c) || !(gnorm1 == gnorm1)) { finished = true; start_trcg = false; if (tid == 0) pr.status = ST_NAN; }
+    } else {
+        const double eta0 = 1e-4, eta1 = 0.25, eta2 = 0.75;
+        const double sigma1 = 0.25, sigma2 = 0.5, sigma3 = 4;
+        double f = pr.f, delta = pr.delta, gnorm = gnorm_cur;
+        const double gs = pr.gs, prered = pr.prered;
+        const double actred = f - fnew;
+        const double snorm = pr.snorm;
+        if (pr.iter == 1) delta = fmin(delta, snorm);
+        double alpha;
+        if (fnew - f - gs <= 0) alpha = sigma3;
+        else alpha = fmax(sigma1, -0.5 * (gs / (fnew - f - gs)));
+        if (actred < eta0 * prered) delta = fmin(fmax(alpha, sigma1) * snorm, sigma2 * delta);
+        else if (actred < eta1 * prered) delta = fmax(sigma1 * delta, fmin(alpha * snorm, sigma2 * delta));
+        else if (actred < eta2 * prered) delta = fmax(sigma1 * delta, fmin(alpha * snorm, sigma3 * delta));
+        else delta = fmax(delta, fmin(alpha * snorm, sigma3 * delta));
+        int iter = pr.iter;
+        bool brk = false;
+        const bool accept = actred > eta0 * prered;
+        if (accept) {
+            iter++;
+            copy_w = copy_g = true;
+            f = fnew;
+            gnorm = gnorm_c; gsq = gsq_c;
+            if (gnorm <= pr.eps * pr.gnorm1) brk = true;
+        }
+        if (!brk) {
+            if (f < -1.0e+32) brk = true;
+            else if (fabs(actred) <= 0 && prered <= 0) brk = true;
+            else if (fabs(actred) <= 1.0e-12 * fabs(f) && fabs(prered) <= 1.0e-12 * fabs(f)) brk = true;
+        }
+        const int max_iter = pr.max_iter;
+        __syncthreads();
+        if (tid == 0) {
+            pr.f = f; pr.delta = delta; pr.gnorm = gnorm; pr.iter = iter; pr.ticks += 1;
+            if (accept) { pr.accepted += 1; pr.dsel ^= 1; }
+        }
+        if (!(fnew == fnew) || !(gnorm == gnorm)) { brk = true; if (tid == 0) pr.status = ST_NAN; }
+        gnorm_cur = gnorm;
+        if (brk || iter > max_iter) finished = true;               // while (iter <= max_iter && search)
+        else start_trcg = true;
+    }
+    const bool nullstep = start_trcg && gnorm_cur <= 0.1 * gnorm_cur;      // trcg leaves its loop at once (:144): only for g = 0
+    if (copy_w || copy_g || start_trcg) {
+        // w = w_new, g = grad(w_new); trcg prologue (:133-141): s = 0, r = -g, d = r
+        double *__restrict__ r0 = pr.rb[0];
+        struct RT { RoV4 h, g, wn, w; };
+        ro_pass<0, 0, RT>(sh, n, zero6, res,
+            [&](int j0, RT &R) {
+                R.h = ro_ld4(Hd, j0);
+                if (!copy_g) R.g = ro_ld4(g, j0);
+                if (copy_w || nullstep) R.wn = ro_ld4(w_new, j0);
+                if (nullstep && !copy_w) R.w = ro_ld4(w, j0);
+            },
+            [&](int j0, RT &R, double (&ct)[1][4], double (&nv)[1][4]) {
+                double z4[4], rj[4], wz[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const double gj = copy_g ? R.h.v[e] : R.g.v[e];
+                    z4[e] = 0.0; rj[e] = -gj;
+                    wz[e] = (copy_w ? R.wn.v[e] : R.w.v[e]) + 1.0 * 0.0;
+                }
+                if (copy_w) ro_st4(w, j0, n, R.wn.v);
+                if (copy_g) ro_st4(g, j0, n, R.h.v);
+                if (start_trcg) {
+                    ro_st4(s, j0, n, z4); ro_st4(r0, j0, n, rj); ro_st4(d, j0, n, rj);
+                    if (nullstep) ro_st4(w_new, j0, n, wz);       // the (null) step is evaluated like any other
+                }
+            });
+    }
+    if (tid == 0) {
+        pr.gsq = gsq;
+        if (start_trcg) {
+            pr.rTr = gsq;                      // r = -g: Tron.dot(r, r) adds the same products in the same order as g.g
+            pr.cgtol = 0.1 * gnorm_cur;
+            pr.cg_iter = 0;
+            pr.rsel = 0;
+            if (nullstep) { pr.gs = 0.0; pr.prered = -0.5 * (0.0 - 0.0); pr.snorm = 0.0; pr.newton += 1; pr.phase = PH_EVAL; }
+            else pr.phase = PH_CG;
+        }
+        if (finished) {
+            pr.phase = PH_DONE;
+            atomicAdd(done_counter, 1);
+        }
+    }
+}
+
+// c0 = X' t0 (the data part of grad(0)) from an EVAL pass at w = 0 through the reference-order passes: the chained column sums
+__global__ void __launch_bounds__(256)
+k_ro_collect_c0(const PartDev *__restrict__ parts, const ProbDev *__restrict__ probs, const int *__restrict__ qlist,
+                double *const *__restrict__ c0_ptrs)
+{
+    const ProbDev &pr = probs[qlist[blockIdx.x]];
+    const PartDev &pa = parts[pr.part];
+    double *__restrict__ out = c0_ptrs[blockIdx.x];
+    for (int j = threadIdx.x; j < pa.n_feat; j += blockDim.x) out[j] = pr.c0f[j];
+    if (threadIdx.x == 0) out[pa.n_feat] = pr.csump[pa.n_rblk - 1];
+}

@@ -67,6 +67,12 @@ struct PartDev {
     int32_t n_cunits;          // work units of the LDS column pass: unit u = slices [cw_slice[u], cw_slice[u+1]) of block cw_blk[u]
     const int32_t *cw_blk;     // [n_cunits]
     const int32_t *cw_slice;   // [n_cunits+1]
+    // Reference-order numerics (MLX_NUMERICS_REFERENCE_ORDER, mlx_ro_kernels.h): a column's sum is ONE sequential chain over its
+    // rows (XTv, llf/LogisticRegressionL2.java:140-145). Items are unsplit inside a row block; the item of block b starts from the
+    // sum its column had reached in the earlier blocks (slot item_init[t], -1: from 0.0) and the column's LAST item also stores
+    // its sum densely at xtc[item_last[t]] (item_last[t] = column id, -1 otherwise). The column pass runs once per row block.
+    const int32_t *item_init;  // [n_items] or nullptr
+    const int32_t *item_last;  // [n_items] or nullptr
     int32_t rowgroup;      // lanes per row in the CSR row pass (8..64)
     const int8_t *y;       // +1/-1
     const float *wt;       // instance weight
@@ -92,7 +98,8 @@ struct ProbDev {
     // multi-workgroup step (k_step_a/b/c, CSR tick path): the residual is double buffered (rb[rsel] = r of the current CG
     // step, rb[rsel^1] receives r - alpha*Hd, so the trust-region boundary case can still see the old r), per-workgroup
     // partial sums of the three phases, and the scalars the fused phases carry from one tick to the next.
-    double *rowtmp, *c0f;  // verification mode only (MLX_FAITHFUL): per-row losses [l], grad(0)'s data part [n_local]
+    double *rowtmp, *c0f;  // reference-order numerics only: per-row losses [l]; [n_local]: grad(0)'s data part (one-launch kernel) /
+                           // the dense X'c the chained column pass leaves (tick kernels: xtc)
     double *rb[2];
     int32_t rsel;
     double *pA, *pB, *pC;  // [n_step_wg][STEP_NP] each

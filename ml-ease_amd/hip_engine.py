@@ -19,7 +19,7 @@ UNIQUE_ID_BYTES = 128
 
 # every entry point include/mlease_admm.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "mlx_create", "mlx_destroy", "mlx_last_error", "mlx_set_stream", "mlx_set_profiling", "mlx_set_problem",
+    "mlx_create", "mlx_destroy", "mlx_last_error", "mlx_set_stream", "mlx_set_profiling", "mlx_set_numerics", "mlx_set_option", "mlx_get_option", "mlx_set_problem",
     "mlx_set_regularizer", "mlx_add_partition_csr", "mlx_add_partitions_csr", "mlx_add_partition_dense", "mlx_finalize", "mlx_set_state",
     "mlx_admm_iterate", "mlx_admm_solve_local", "mlx_naive_init", "mlx_naive_solve_local", "mlx_naive_finish", "mlx_consensus_buffer", "mlx_admm_consensus_finish", "mlx_get_z",
     "mlx_get_partition_model", "mlx_get_solve_counters", "mlx_get_dims", "mlx_set_test_data", "mlx_test_loglik", "mlx_solve_one", "mlx_posterior_variance", "mlx_score_rows", "mlx_comm_get_unique_id", "mlx_comm_init",
@@ -65,6 +65,9 @@ def load_library(experimental: Optional[bool] = None):
     L.mlx_destroy.argtypes = [vp]
     L.mlx_set_stream.argtypes = [vp, vp]
     L.mlx_set_profiling.argtypes = [vp, C.c_int]
+    L.mlx_set_numerics.argtypes = [vp, i32]
+    L.mlx_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.mlx_get_option.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_size_t]
     L.mlx_set_problem.argtypes = [vp, i32, i32, vp, vp, i32, i32, vp]
     L.mlx_set_regularizer.argtypes = [vp, i32]
     L.mlx_add_partition_csr.argtypes = [vp, i32, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp]
@@ -103,7 +106,10 @@ class HipAdmmEngine:
 
     def __init__(self, n_global: int, lambdas: Sequence[float], rhos: Sequence[float], num_blocks: int,
                  penalize_intercept: bool = False, device: int = 0, regularizer: int = 2,
-                 lambda_map: Optional[np.ndarray] = None, stream: Optional[int] = None, profiling: bool = False):
+                 lambda_map: Optional[np.ndarray] = None, stream: Optional[int] = None, profiling: bool = False,
+                 numerics: Optional[str] = None, options: Optional[dict] = None):
+        """numerics: None (the library's default: fast, or what MLX_FAITHFUL seeds), "fast", "reference_order" or
+        "reference_order_one_launch" (include/mlease_admm.h: mlx_set_numerics); options: mlx_set_option key -> value."""
         self.L = load_library()
         self.h = C.c_void_p()
         rc = self.L.mlx_create(int(device), C.byref(self.h))
@@ -116,6 +122,10 @@ class HipAdmmEngine:
         self.nlocal = 0
         self.device = int(device)
         lm = None if lambda_map is None else np.ascontiguousarray(lambda_map, np.float32)
+        if numerics is not None:
+            self.set_option("numerics", numerics)
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
         if stream is not None:
             self._ck(self.L.mlx_set_stream(self.h, C.c_void_p(stream)))
         self._ck(self.L.mlx_set_problem(self.h, self.n_global, self.n_lambda, _p(self.lambdas), _p(self.rhos),
@@ -196,6 +206,17 @@ class HipAdmmEngine:
                                                 None if weight_ptr is None else C.c_void_p(weight_ptr),
                                                 None if offset_ptr is None else C.c_void_p(offset_ptr), _p(l2g), 1))
         self.nlocal += 1
+
+    def set_option(self, key: str, value) -> None:
+        """mlx_set_option: per-handle behaviour (numerics, tick_streams, grid_rounded_dots, ...)."""
+        if isinstance(value, bool):
+            value = int(value)
+        self._ck(self.L.mlx_set_option(self.h, str(key).encode(), str(value).encode()))
+
+    def get_option(self, key: str) -> str:
+        buf = C.create_string_buffer(64)
+        self._ck(self.L.mlx_get_option(self.h, str(key).encode(), buf, 64))
+        return buf.value.decode()
 
     def set_profiling(self, enable, one_stream: bool = False):
         """Per-launch-class HIP events on / off (every tick stream carries its own chain of marks). one_stream=True also keeps all ticks

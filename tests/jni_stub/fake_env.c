@@ -93,6 +93,10 @@ static int slot_of(const char *name)
 static void JNICALL SetLongField(JNIEnv *env, jobject obj, jfieldID f, jlong v) { (void)env; obj->lfields[slot_of(f->name)] = v; }
 static void JNICALL SetDoubleField(JNIEnv *env, jobject obj, jfieldID f, jdouble v) { (void)env; obj->dfields[slot_of(f->name)] = v; }
 static jstring JNICALL NewStringUTF(JNIEnv *env, const char *utf) { (void)env; jobject s = new_obj(4); s->data = strdup(utf ? utf : ""); return s; }
+static const char *JNICALL GetStringUTFChars(JNIEnv *env, jstring s, jboolean *isCopy) { (void)env; if (isCopy) *isCopy = 0; g_pins++; return (const char *)s->data; }
+static void JNICALL ReleaseStringUTFChars(JNIEnv *env, jstring s, const char *c) { (void)env; (void)s; (void)c; g_pins--; }
+jobject fake_new_string(const char *utf) { return NewStringUTF(NULL, utf); }
+const char *fake_string_chars(jobject s) { return s ? (const char *)s->data : ""; }
 static jsize JNICALL GetArrayLength(JNIEnv *env, jarray a) { (void)env; return a->len; }
 static jobject JNICALL GetObjectArrayElement(JNIEnv *env, jobjectArray a, jsize i) { (void)env; return (i >= 0 && i < a->len) ? a->elems[i] : NULL; }
 static jint JNICALL EnsureLocalCapacity(JNIEnv *env, jint cap) { (void)env; (void)cap; return 0; }
@@ -117,7 +121,7 @@ FAKE_ARRAY_FNS(jdouble, Double)
 static const struct JNINativeInterface_ g_table = {
     .FindClass = FindClass, .Throw = Throw, .ThrowNew = ThrowNew, .NewObject = NewObject, .GetObjectClass = GetObjectClass,
     .GetMethodID = GetMethodID, .GetFieldID = GetFieldID, .GetLongField = GetLongField, .SetLongField = SetLongField,
-    .SetDoubleField = SetDoubleField, .NewStringUTF = NewStringUTF, .GetArrayLength = GetArrayLength,
+    .SetDoubleField = SetDoubleField, .NewStringUTF = NewStringUTF, .GetStringUTFChars = GetStringUTFChars, .ReleaseStringUTFChars = ReleaseStringUTFChars, .GetArrayLength = GetArrayLength,
     .GetObjectArrayElement = GetObjectArrayElement, .EnsureLocalCapacity = EnsureLocalCapacity, .DeleteLocalRef = DeleteLocalRef,
     TABLE_ARRAY_FNS(Byte), TABLE_ARRAY_FNS(Int), TABLE_ARRAY_FNS(Long), TABLE_ARRAY_FNS(Float), TABLE_ARRAY_FNS(Double),
 };

@@ -64,6 +64,8 @@ struct JNINativeInterface_ {
     void(JNICALL *SetLongField)(JNIEnv *env, jobject obj, jfieldID fieldID, jlong val);
     void(JNICALL *SetDoubleField)(JNIEnv *env, jobject obj, jfieldID fieldID, jdouble val);
     jstring(JNICALL *NewStringUTF)(JNIEnv *env, const char *utf);
+    const char *(JNICALL *GetStringUTFChars)(JNIEnv *env, jstring str, jboolean *isCopy);
+    void(JNICALL *ReleaseStringUTFChars)(JNIEnv *env, jstring str, const char *chars);
     jsize(JNICALL *GetArrayLength)(JNIEnv *env, jarray array);
     jobject(JNICALL *GetObjectArrayElement)(JNIEnv *env, jobjectArray array, jsize index);
     jint(JNICALL *EnsureLocalCapacity)(JNIEnv *env, jint capacity);

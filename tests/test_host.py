@@ -464,6 +464,34 @@ def test_bench_headline_line_is_compact_strict_json():
     json.dumps(bench._finite(full), allow_nan=False)
 
 
+def test_bench_roofline_keys_are_frozen():
+    """`roofline.frac` meant the by-duration figure in rounds 1-2 and the busy-union figure in rounds 3-4. It is
+    now pinned to the per-launch figure of a launch alone on the chip, with frac_busy_union / frac_by_launch_durations and the
+    traffic's source beside it in the compact line, and the sparse leg carries its kernels' alone fractions too."""
+    import json
+    import bench
+    roof = {"bound": "hbm", "kernel": "k_xpass_dense<4,4>", "achieved": 6100.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.7625, "traffic": 3.29e9,
+            "traffic_source": "profiles/traffic.json: ...", "alg_bytes_per_launch": 3.27e9, "avg_launch_ms": 0.536, "launches": 188,
+            "frac_busy_union": 0.81, "frac_by_launch_durations": 0.67, "kernel_ms_per_step": 20.1, "launches_in_flight": 1.2,
+            "measured_in_short": "x", "kernel_alone": {"frac": 0.7625}}
+    sp = {"value": 5500.0, "unit": "solves/s", "steps": 5, "warmup": 1, "ms_per_step": 46.0, "whole_step": {"frac_of_hbm_peak": 0.31},
+          "roofline": {"alone": {"rowpass_frac": 0.52, "colpass_frac": 0.54}, "kernels": [{"frac": 0.3, "us_per_tick": 200.0}, {"frac": 0.31, "us_per_tick": 190.0}, {"us_per_tick": 300.0}]}}
+    full = {"metric": "m", "value": 2900.0, "unit": "solves/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 22.0, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": "BASELINE configs[1]: ..."},
+            "roofline": roof, "cpu_baseline": {"value": 20.0, "unit": "solves/s", "cores": 16, "kind": "port", "sample": "s"}, "sparse": sp}
+    rec = json.loads(json.dumps(bench.compact_record(full), allow_nan=False))
+    r = rec["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "alg_bytes_per_launch", "avg_launch_ms", "launches",
+                "frac_busy_union", "frac_by_launch_durations"):
+        assert key in r, key
+    assert r["frac"] == 0.7625 and "frac_kernel_alone_one_stream" not in r
+    # the literal formula a reader applies to the line reproduces frac
+    assert abs(r["alg_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9 / r["peak"] - r["frac"]) < 2e-3
+    assert rec["sparse"]["roofline_alone"] == {"row": 0.52, "col": 0.54} and rec["sparse"]["rowpass_frac"] == 0.3
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'roof = {"bound": "hbm", "kernel": "k_xpass_dense<4,4>", "achieved": alone["achieved"]' in src      # frac comes from the one-stream replay
+
+
 def test_bench_and_tools_call_only_names_that_exist():
     """bench.py cannot run here (no GPU), so a function lost in an edit shows up only on the GPU box (round 4: run_sparse).
     Static check: every plain-name call in bench.py and the tools resolves to a definition, an import, an assignment or a builtin."""
