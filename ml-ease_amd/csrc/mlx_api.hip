@@ -44,6 +44,7 @@ struct PartHost {
     int64_t nnz = 0, ld = 0;
     int n_short = 0, n_long = 0;
     bool sell = false;
+    bool small = false;                    // CSR partition solved by the one-launch kernel (k_solve_small): decided per PARTITION at mlx_finalize
     std::vector<int32_t> new2old;          // CSR partitions: library local id -> caller's local id (features only)
     std::vector<int32_t> col_ptr_h;        // CSR partitions: host copy of col_ptr (slots of each column)
     int n_cs = 1, n_hs = 1, slw = 64, n_rgroups = 0, n_cslices = 0, n_rblk = 1, rblk_rows = 0, n_cunits = 0;
@@ -69,6 +70,7 @@ struct mlx_context {
     bool trace = false;                    // "trace": tick progress / stream probe on stderr
     bool stream_probe = true;              // "stream_probe": test that the tick streams sit on different hardware queues
     bool use_small = true;                 // "one_launch_small": small CSR problems solve in one launch (k_solve_small)
+    bool streams_explicit = false;         // the tick-stream count was chosen by the host (MLX_STREAMS / "tick_streams"): numerics do not change it
     std::string err;
 
     int n_global = 0, n_lambda = 0, num_blocks = 0, penalize_intercept = 0, regularizer = 2;
@@ -83,7 +85,8 @@ struct mlx_context {
     std::vector<ProbDev> h_probs;
     bool h_probs_pinned = false;
     int *d_qdense = nullptr, *d_qcsr = nullptr, *d_qscratch = nullptr;
-    int nq_dense = 0, nq_csr = 0;
+    int *d_qsmall = nullptr, *d_qcsr_all = nullptr;   // problems of the small CSR partitions (one-launch kernel); every CSR problem (ticks for all: profiling)
+    int nq_dense = 0, nq_csr = 0, nq_small = 0, nq_csr_all = 0;
     int maxblk_dense = 0, maxblk_csr = 0, max_nfeat_dense = 0, max_items = 0, max_short = 0, max_long = 0, rowgroup = 64, max_nlocal = 0, max_l = 0;
     int64_t max_parts_len = 0;
     bool csr_hasval = false, any_absent = false, csr_sell = false, csr_small = false;
@@ -291,11 +294,11 @@ void launch_step(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
 
 // One-launch solves of small CSR problems (k_solve_small): launch, wait, relaunch while a problem needs more than
 // SMALL_TICKS_PER_LAUNCH ticks (d_done keeps counting across the launches; finished problems leave at once).
-static int run_ticks_small_more(mlx_handle h, int first, int count, int64_t *ticks_out)
+static int run_ticks_small_more(mlx_handle h, int first, int count, const int *qsmall, int nqs, int64_t *ticks_out)
 {
     int64_t ticks = 0;
     for (;;) {
-        mlxk_solve_small(h->stream, h->d_parts, h->d_probs, count, first, h->csr_hasval, h->small_ticks, h->d_done, h->small_lds_doubles, h->faithful,
+        mlxk_solve_small(h->stream, h->d_parts, h->d_probs, qsmall, nqs, h->csr_hasval, h->small_ticks, h->d_done, h->small_lds_doubles, h->faithful,
                          h->small_xl, h->small_xl_bytes);
         ticks += h->small_ticks;
         HIPCHECK(h, hipMemcpyAsync(&h->h_done[0], h->d_done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -318,22 +321,35 @@ static int run_ticks_small_more(mlx_handle h, int first, int count, int64_t *tic
 // true, *ticks_out untouched); the caller enqueues its tail behind it and collect_solve_stats() -- one synchronisation for the
 // whole iteration -- finds out whether every problem finished (it returns MLX_MORE_TICKS if not; then run_ticks_small_more()).
 constexpr int MLX_MORE_TICKS = 1;      // internal, never crosses the C-ABI
-int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, const int *qcsr, int nqc, int64_t *ticks_out, bool *deferred = nullptr)
+// qsmall / nqs: the problems of SMALL CSR partitions, solved by the one-launch kernel -- a property of the partition, not of the
+// handle: a small partition takes that path (and its arithmetic: tree dots) whatever else the handle holds; beside larger
+// partitions the launch is enqueued in front of the ticks and once more per batch (a no-op once its problems are done).
+int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, const int *qcsr, int nqc, const int *qsmall, int nqs,
+              int64_t *ticks_out, bool *deferred = nullptr)
 {
     HIPCHECK(h, hipMemsetAsync(h->d_done, 0, sizeof(int), h->stream));
     h->h_done[0] = h->h_done[1] = 0;
-    if (h->csr_small && nqd == 0 && nqc == count && (!h->profiling || h->faithful)) {
-        // small CSR problems: the whole solve in one launch (k_solve_small), relaunched only if a problem needs more
+    if (nqs > 0 && h->profiling && !h->faithful) {
+        // per-launch-class events: every CSR problem on the tick kernels (whole-handle calls only)
+        if (count != h->nprob) return fail(h, MLX_ERR_INVALID, "internal: profiling reroutes whole-handle solves only");
+        qcsr = h->d_qcsr_all; nqc = h->nq_csr_all; nqs = 0;
+    }
+    auto launch_small = [&] {
+        mlxk_solve_small(h->stream, h->d_parts, h->d_probs, qsmall, nqs, h->csr_hasval, h->small_ticks, h->d_done, h->small_lds_doubles, h->faithful,
+                         h->small_xl, h->small_xl_bytes);
+    };
+    if (nqs > 0 && nqd == 0 && nqc == 0) {
+        // small CSR problems only: the whole solve in one launch (k_solve_small), relaunched only if a problem needs more
         // than SMALL_TICKS_PER_LAUNCH ticks
         if (deferred) {
-            mlxk_solve_small(h->stream, h->d_parts, h->d_probs, count, first, h->csr_hasval, h->small_ticks, h->d_done, h->small_lds_doubles, h->faithful,
-                             h->small_xl, h->small_xl_bytes);
+            launch_small();
             HIPCHECK(h, hipGetLastError());          // a launch that failed (LDS budget, ...) must not read as "needs more ticks" later
             *deferred = true;
             return MLX_OK;
         }
-        return run_ticks_small_more(h, first, count, ticks_out);
+        return run_ticks_small_more(h, first, count, qsmall, nqs, ticks_out);
     }
+    if (nqs > 0) { launch_small(); HIPCHECK(h, hipGetLastError()); }
     const int batch = 4;
     int64_t ticks = 0;
     int slot = 0;
@@ -392,6 +408,7 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
         }
         for (int t = 0; t < NS; t++) { on(t); mark(h, -1); }
         on(0);
+        if (nqs > 0) launch_small();                  // (problems short of DONE after small_ticks ticks go on; finished ones leave at once)
         HIPCHECK(h, hipMemcpyAsync(&h->h_done[slot], h->d_done, sizeof(int), hipMemcpyDeviceToHost, sA));
         HIPCHECK(h, hipEventRecord(h->ev_batch[slot], sA));
         for (int t = 1; t < NS; t++) {
@@ -571,7 +588,10 @@ int mlx_create(int device_id, mlx_handle *out)
     int want_streams = 2;
     // the environment seeds the defaults of mlx_set_option (A/B runs of unmodified hosts); a host sets them per handle
     if (const char *te = getenv("MLX_SMALL_TICKS")) h->small_ticks = std::max(1, atoi(te));
-    if (const char *se = getenv("MLX_STREAMS")) want_streams = std::max(1, std::min(atoi(se), (int)mlx_context::MAX_TS));
+    if (const char *se = getenv("MLX_STREAMS")) { want_streams = std::max(1, std::min(atoi(se), (int)mlx_context::MAX_TS)); h->streams_explicit = true; }
+    // (reference-order numerics tick on four streams: their launches are chains of dependent operations, bound by latency, and
+    // what fills the chip is more of them side by side -- csrc/mlx_ro_kernels.h)
+    if (h->faithful && !h->streams_explicit) want_streams = 4;
     if (const char *pe = getenv("MLX_PROFILE_ONE_STREAM")) h->prof_one_stream = atoi(pe) != 0;
     if (const char *pe = getenv("MLX_SEQ_DOTS")) h->seq_dots = atoi(pe) != 0;
     if (const char *pe = getenv("MLX_TRACE")) h->trace = atoi(pe) != 0 || pe[0] == '\0';
@@ -635,6 +655,12 @@ int mlx_set_numerics(mlx_handle h, int32_t mode)
     else if (mode == MLX_NUMERICS_REFERENCE_ORDER) { h->faithful = true; h->ro_mode = 1; }
     else if (mode == MLX_NUMERICS_REFERENCE_ORDER_ONE_LAUNCH) { h->faithful = true; h->ro_mode = 2; }
     else return fail(h, MLX_ERR_INVALID, "mlx_set_numerics: unknown mode %d", (int)mode);
+    if (!h->streams_explicit) {
+        // the tick kernels of the reference-order numerics are latency-bound chains: four lists of problems side by side fill the
+        // chip better than two (the product path: two, measured -- profiles/r3_notes.md, r4_notes.md)
+        const int want = h->faithful ? 4 : 2;
+        if (want != h->nstreams) { hipSetDevice(h->device); hipStreamSynchronize(h->stream); setup_tick_streams(h, want); }
+    }
     return MLX_OK;
 }
 
@@ -654,6 +680,7 @@ int mlx_set_option(mlx_handle h, const char *key, const char *value)
         if (iv < 1 || iv > (int)mlx_context::MAX_TS) return fail(h, MLX_ERR_INVALID, "tick_streams must be 1..%d", (int)mlx_context::MAX_TS);
         hipStreamSynchronize(h->stream);
         setup_tick_streams(h, iv);
+        h->streams_explicit = true;
         return MLX_OK;
     }
     if (k == "stream_probe") { h->stream_probe = iv != 0; return MLX_OK; }
@@ -1107,7 +1134,6 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
                 // work units of ~CUNIT_ENTRIES padded entries, never across blocks
                 const int sb0 = blk_item0[(size_t)bk] / 64, sb1 = blk_item0[(size_t)bk + 1] / 64;
                 int s0 = sb0;
-                if (ro == 1 && sb0 == sb1) { cw_blk.push_back(bk); cw_slice.push_back(sb0); }      // (an empty unit: the intercept's chain still runs through the block)
                 while (s0 < sb1) {
                     int s1 = s0 + 1;
                     while (s1 < sb1 && cs_ptr[(size_t)s1 + 1] - cs_ptr[(size_t)s0] <= cunit_entries) s1++;
@@ -1435,26 +1461,33 @@ int mlx_finalize(mlx_handle h)
             h->max_short = std::max(h->max_short, p.n_short); h->max_long = std::max(h->max_long, p.n_long);
             h->csr_hasval = h->csr_hasval || p.hasval;
         }
-        for (int li = 0; li < nl; li++) (p.dense ? qd : qc).push_back(k * nl + li);
+        if (p.dense) for (int li = 0; li < nl; li++) qd.push_back(k * nl + li);
     }
     // a single row-group width / value mode for all CSR partitions of the handle
     for (auto &p : h->parts) if (!p.dense) { h->max_cunits = std::max(h->max_cunits, p.n_cunits); h->max_rblk_rows = std::max(h->max_rblk_rows, p.rblk_rows); }
-    h->csr_small = h->use_small;
-    for (auto &p : h->parts)
-        if (!p.dense && (p.nnz > SMALL_MAX_NNZ || p.l > SMALL_MAX_DIM || p.n_local > SMALL_MAX_DIM)) h->csr_small = false;
-    if (h->faithful) h->csr_small = !h->ro_ticks;           // the verification kernel is the one-launch solve, whatever the size
+    // Which CSR partitions solve in one launch (k_solve_small) is a property of the PARTITION (round-4 advisor finding: it was
+    // decided from the handle's largest partition, so a small partition's bits depended on what else its handle -- its rank --
+    // held): <= 64 K non-zeros and <= 16 K rows / columns. Reference-order numerics: the one-launch verification kernel for every
+    // partition when the handle cannot run the tick form, none otherwise.
+    h->csr_small = false;
+    for (auto &p : h->parts) {
+        if (p.dense) continue;
+        if (h->faithful) p.small = !h->ro_ticks;
+        else p.small = h->use_small && p.nnz <= SMALL_MAX_NNZ && p.l <= SMALL_MAX_DIM && p.n_local <= SMALL_MAX_DIM;
+        h->csr_small = h->csr_small || p.small;
+    }
     if (h->csr_small && getenv("MLX_NO_SMALL_LDS") == nullptr && !h->faithful) {
         int64_t need = 0;
         for (auto &p : h->parts)
-            if (!p.dense) need = std::max<int64_t>(need, 8LL * p.n_local + 3LL * p.l + p.n_items + 2LL * (h->csr_sell ? p.n_rgroups : p.nblk));
+            if (p.small) need = std::max<int64_t>(need, 8LL * p.n_local + 3LL * p.l + p.n_items + 2LL * (h->csr_sell ? p.n_rgroups : p.nblk));
         if (need > 0 && need <= 18 * 1024) h->small_lds_doubles = (int)need;      // 144 KiB of the 160 KiB LDS, next to 9 KiB static
         // ... and the partition's own arrays when they fit as well (k_solve_small<.., XL>): narrow ids, see the kernel
         if (h->small_lds_doubles > 0 && getenv("MLX_NO_SMALL_X") == nullptr) {
             int maxdim = 0;
-            for (auto &p : h->parts) if (!p.dense) maxdim = std::max(maxdim, std::max(p.l, p.n_local));
+            for (auto &p : h->parts) if (p.small) maxdim = std::max(maxdim, std::max(p.l, p.n_local));
             const int idsz = maxdim <= 256 ? 1 : 2;
             int64_t total = 0;
-            for (auto &p : h->parts) if (!p.dense) {
+            for (auto &p : h->parts) if (p.small) {
                 const int64_t vec = 8LL * (8LL * p.n_local + 3LL * p.l + p.n_items + 2LL * (h->csr_sell ? p.n_rgroups : p.nblk));
                 const int64_t xb = 4LL * ((int64_t)p.l + 1 + 2LL * p.n_items + 1 + p.n_feat + 1) + (p.hasval ? 8LL * p.nnz : 0) + 2LL * idsz * p.nnz + 9LL * p.l;
                 total = std::max(total, vec + xb + 16);
@@ -1484,20 +1517,31 @@ int mlx_finalize(mlx_handle h)
     // Order of the CSR work list = XCD placement (xcd_map in mlx_kernels.hip puts list position i on XCD i % 8):
     // the n_lambda problems of one partition share its index streams, so they go to the SAME XCD, back to back:
     // CSR partition number c (c-th in add order) -> XCD c % 8, and within that XCD the sequence (c / 8, lambda).
-    if (nl > 1 && !qc.empty()) {
-        const int ncp = (int)qc.size() / nl;             // qc holds, per CSR partition in add order, its nl problems
+    auto xcd_order = [&](std::vector<int> &q) {
+        if (nl <= 1 || q.empty()) return;
+        const int ncp = (int)q.size() / nl;              // q holds, per CSR partition in add order, its nl problems
         const int rounds = (ncp + 7) / 8;
         std::vector<int> ordered((size_t)rounds * nl * 8, -1);
         for (int c = 0; c < ncp; c++)
             for (int li = 0; li < nl; li++)
-                ordered[((size_t)(c / 8) * nl + li) * 8 + (size_t)(c % 8)] = qc[(size_t)c * nl + li];
+                ordered[((size_t)(c / 8) * nl + li) * 8 + (size_t)(c % 8)] = q[(size_t)c * nl + li];
         // holes (when ncp is not a multiple of 8) are dropped: placement is a speed matter only
-        qc.clear();
-        for (int q : ordered) if (q >= 0) qc.push_back(q);
+        q.clear();
+        for (int x : ordered) if (x >= 0) q.push_back(x);
+    };
+    std::vector<int> qs, qall;                           // one-launch problems; every CSR problem (ticks for all under profiling)
+    for (int k = 0; k < np; k++) {
+        const PartHost &p = h->parts[k];
+        if (p.dense) continue;
+        for (int li = 0; li < nl; li++) { (p.small ? qs : qc).push_back(k * nl + li); qall.push_back(k * nl + li); }
     }
-    h->nq_dense = (int)qd.size(); h->nq_csr = (int)qc.size();
+    xcd_order(qc);
+    xcd_order(qall);
+    h->nq_dense = (int)qd.size(); h->nq_csr = (int)qc.size(); h->nq_small = (int)qs.size(); h->nq_csr_all = (int)qall.size();
     if ((rc = dev_upload(h, &h->d_qdense, qd.data(), qd.size()))) return rc;
     if ((rc = dev_upload(h, &h->d_qcsr, qc.data(), qc.size()))) return rc;
+    if ((rc = dev_upload(h, &h->d_qsmall, qs.data(), qs.size()))) return rc;
+    if ((rc = dev_upload(h, &h->d_qcsr_all, qall.data(), qall.size()))) return rc;
     h->step_threads = (h->max_nlocal > 4096 || (h->nq_dense > 0 && h->max_nlocal >= 512)) ? 1024 : 256;
     // column chunks of the multi-workgroup CSR step (k_step_a/b/c): 2048 columns (8 per thread) unless that would be more
     // than 256 chunks per problem
@@ -1687,7 +1731,7 @@ int mlx_admm_solve_local(mlx_handle h, double liblinear_epsilon, float rho_adapt
                liblinear_epsilon, DEFAULT_MAX_ITER);
     int64_t ticks = 0;
     bool deferred = false;
-    int rc = run_ticks(h, 0, h->nprob, h->d_qdense, h->nq_dense, h->d_qcsr, h->nq_csr, &ticks, &deferred);
+    int rc = run_ticks(h, 0, h->nprob, h->d_qdense, h->nq_dense, h->d_qcsr, h->nq_csr, h->d_qsmall, h->nq_small, &ticks, &deferred);
     if (rc) return rc;
     for (;;) {
         mlxk_outputs(h->stream, h->d_parts, h->d_probs, h->nprob, nl, ng, h->max_nlocal, h->any_absent, h->d_z32, h->d_u,
@@ -1698,7 +1742,7 @@ int mlx_admm_solve_local(mlx_handle h, double liblinear_epsilon, float rho_adapt
         // (a problem of the one-launch path needs more than SMALL_TICKS_PER_LAUNCH ticks: finish it, then redo the outputs --
         // both output kernels are pure functions of the problems' state)
         deferred = false;
-        if ((rc = run_ticks_small_more(h, 0, h->nprob, &ticks))) return rc;
+        if ((rc = run_ticks_small_more(h, 0, h->nprob, h->d_qsmall, h->nq_small, &ticks))) return rc;
     }
 }
 
@@ -1934,7 +1978,7 @@ int mlx_naive_solve_local(mlx_handle h, double liblinear_epsilon, double prior_m
     mlxk_setup_naive(h->stream, h->d_parts, h->d_probs, h->nprob, h->max_nlocal, h->d_pinv_l, h->d_pinv_ovr,
                      h->d_naive_pinv, prior_mean, liblinear_epsilon, DEFAULT_MAX_ITER);
     int64_t ticks = 0;
-    rc = run_ticks(h, 0, h->nprob, h->d_qdense, h->nq_dense, h->d_qcsr, h->nq_csr, &ticks);
+    rc = run_ticks(h, 0, h->nprob, h->d_qdense, h->nq_dense, h->d_qcsr, h->nq_csr, h->d_qsmall, h->nq_small, &ticks);
     if (rc) return rc;
     const size_t zl = (size_t)nl * ng;
     HIPCHECK(h, hipMemsetAsync(h->d_B, 0, sizeof(float) * zl * np, h->stream));
@@ -2090,7 +2134,7 @@ int mlx_solve_one(mlx_handle h, int32_t local_index, double *w, const double *pr
     HIPCHECK(h, hipMemcpy(h->d_probs + h->nprob, &pr, sizeof(ProbDev), hipMemcpyHostToDevice));
     const bool prof = h->profiling;
     h->profiling = false;
-    int rc = run_ticks(h, h->nprob, 1, h->d_qscratch, p.dense ? 1 : 0, h->d_qscratch, p.dense ? 0 : 1, nullptr);
+    int rc = run_ticks(h, h->nprob, 1, h->d_qscratch, p.dense ? 1 : 0, h->d_qscratch, (!p.dense && !p.small) ? 1 : 0, h->d_qscratch, p.small ? 1 : 0, nullptr);
     h->profiling = prof;
     if (rc) return rc;
     HIPCHECK(h, hipMemcpy(&pr, h->d_probs + h->nprob, sizeof(ProbDev), hipMemcpyDeviceToHost));

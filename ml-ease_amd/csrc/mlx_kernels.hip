@@ -631,6 +631,39 @@ __device__ __forceinline__ double sell_lds_sum(double a, const uint16_t *__restr
     return a;
 }
 
+// The same for the UNSPLIT column items of the reference-order numerics (thousands of entries: one chain per item, so the loop is
+// bound by the latency of its index loads unless many are in flight): U packs are added while the next U are being fetched.
+template <bool HASVAL, bool NT>
+__device__ __forceinline__ double sell_lds_sum_pipe(double a, const uint16_t *__restrict__ idx, const float *__restrict__ val, int base,
+                                                    int kb, int L4, int lane, const double *__restrict__ lds, int zslot)
+{
+#pragma clang fp contract(off)
+    const unsigned zz = (unsigned)zslot | ((unsigned)zslot << 16);
+    constexpr int U = HASVAL ? 4 : 12;
+    u2v_t q[U];
+    f4v_t xv[U];
+    auto fetch = [&](int k, u2v_t (&qq)[U], f4v_t (&xx)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int kk = min(k + u, L4 - 1);
+            qq[u] = pack_load<NT>(idx, base, kk, lane);
+            if (HASVAL) xx[u] = pack_load_val<NT>(val, base, kk, lane);
+            if (k + u >= L4) { qq[u].x = zz; qq[u].y = zz; }
+        }
+    };
+    if (kb < L4) fetch(kb, q, xv);
+    for (int k = kb; k < L4; k += U) {
+        u2v_t qn[U];
+        f4v_t xn[U];
+        fetch(min(k + U, L4 - 1), qn, xn);                  // (behind the last batch: one re-read of the last pack, unused)
+#pragma unroll
+        for (int u = 0; u < U; u++) a = pack_sum<HASVAL>(a, q[u], xv[u], lds);
+#pragma unroll
+        for (int u = 0; u < U; u++) { q[u] = qn[u]; if (HASVAL) xv[u] = xn[u]; }
+    }
+    return a;
+}
+
 // The first KP packs of NI work items at once (NI*KP loads in flight, ONE memory latency for all of them): what makes
 // the short items -- the 0-3 entries a row has in a cold column slice, the rare features' column items -- cheap, where a
 // loop over items pays a full dependent-load latency per item. bases / L4s are wave-uniform.
@@ -943,8 +976,7 @@ k_rowcold(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
 // RO (reference-order numerics, mlx_ro_kernels.h): launched once per row block (only_blk), in block order. Items are unsplit inside
 // a block and start from the sum their column reached in the earlier blocks (item_init), so a column's sum is ONE chain over its rows
 // in ascending order -- XTv's order (llf/LogisticRegressionL2.java:140-145); a column's last item also stores the sum at xtc[column]
-// (ProbDev::c0f). The intercept's column (the sum of all coefficients in row order) is folded by one lane of the block's first
-// work unit from the staged block, chained through csump[block].
+// (ProbDev::c0f). (The intercept's column -- the sum of all coefficients in row order -- is folded by the step kernel, k_ro_step.)
 template <bool HASVAL, bool NT, bool RO = false>
 __global__ void __launch_bounds__(1024)
 k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx, int only_blk)
@@ -979,20 +1011,6 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     const int32_t *__restrict__ item_dst = pa.item_dst;
     double *__restrict__ out = pr.parts;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (RO && wave == 15 && (bx_ == 0 || pa.cw_blk[bx_ - 1] != blk)) {
-        // the intercept's column: out[n-1] += v[i] for every row i in order (the bias entry closes every row)
-        double a = blk > 0 ? gld(pr.csump + blk - 1) : 0.0;
-        int i = 0;
-        for (; i + 8 <= nr; i += 8) {
-            double c8[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) c8[u] = cf[i + u];
-#pragma unroll
-            for (int u = 0; u < 8; u++) a = a + c8[u];
-        }
-        for (; i < nr; i++) a = a + cf[i];
-        if (lane == 0) gst(pr.csump + blk, a);
-    }
     // COL_B item slices per wave and round: their offsets, then their destinations and first packs, are fetched together
     // (three dependent latencies per round instead of per slice); items longer than the first packs continue in the deep loop
     constexpr int COL_B = 8, KP = HASVAL ? 1 : 2;
@@ -1026,7 +1044,9 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
         PT_MARK(10);
 #pragma unroll
         for (int u = 0; u < COL_B; u++) {
-            if (L4[u] > KP) a[u] = sell_lds_sum<HASVAL, NT>(a[u], cs_idx, cs_val, base[u], KP, L4[u], lane, cf, zs);
+            // (the read-ahead loop only for long items: on a medium one its two batches in flight are mostly clamped re-reads)
+            if (L4[u] > KP) a[u] = (RO && L4[u] > 48) ? sell_lds_sum_pipe<HASVAL, NT>(a[u], cs_idx, cs_val, base[u], KP, L4[u], lane, cf, zs)
+                                                      : sell_lds_sum<HASVAL, NT>(a[u], cs_idx, cs_val, base[u], KP, L4[u], lane, cf, zs);
             if (dst[u] >= 0) gst(out + dst[u], a[u]);          // (plain store: phase A reads the slots from L2 right after; a streaming store cost the pass 13 %)
             if (RO && dlast[u] >= 0) gst(xtc + dlast[u], a[u]);
         }
@@ -2272,7 +2292,7 @@ k_step_commit(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
 // round trips.
 template <bool HASVAL, bool LDSV, bool SEQ, int XL = 0>
 __global__ void __launch_bounds__(1024)
-k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, int nprob, int max_ticks,
+k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nprob, int max_ticks,
               int *__restrict__ done_counter, int wave_step)
 {
 #pragma clang fp contract(off)
@@ -2288,8 +2308,8 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, in
     // grows past the budget must fail the build, not the launch
     static_assert(sizeof(ProbDev) + sizeof(PartDev) + (64 + 1024) * sizeof(double) + 256 <= (160 - 150) * 1024,
                   "k_solve_small: static LDS + 150 KiB dynamic LDS exceed the 160 KiB of a CU");
-    const int q = blockIdx.x;
-    if (q >= nprob) return;
+    if ((int)blockIdx.x >= nprob) return;
+    const int q = qlist[blockIdx.x];
     ProbDev &prg = probs[q];                 // the descriptor in global memory
     const PartDev &pag = parts[prg.part];
     // (nt a CONSTANT: with nt = blockDim.x the same source compiled -- ROCm 7.2 -- to a kernel whose results sat 1e-6 off on
@@ -3076,9 +3096,10 @@ void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *p
     else hipLaunchKernelGGL(k_step_commit, dim3((unsigned)nq), dim3(STEP_T), 0, st, parts, probs, qlist, ch, done_counter);
 }
 
-void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int first, bool hasval,
+void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nprob, bool hasval,
                       int max_ticks, int *done_counter, int lds_doubles, bool faithful, int xl, int lds_bytes_xl)
 {
+    if (nprob <= 0) return;
     static const int wave_step = getenv("MLX_SMALL_WAVE_STEP") ? atoi(getenv("MLX_SMALL_WAVE_STEP")) : 1;     // A/B switch
     if (xl != 0 && lds_doubles > 0 && !faithful) {
         // vectors AND the partition's arrays in LDS (lds_bytes_xl = what the largest problem needs)
@@ -3088,15 +3109,15 @@ void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, int 
             set_max_lds(reinterpret_cast<const void *>(&k_solve_small<true, true, false, 2>), 150 * 1024);
             set_max_lds(reinterpret_cast<const void *>(&k_solve_small<false, true, false, 2>), 150 * 1024);
         });
-#define LSMALL(HV, X) hipLaunchKernelGGL((k_solve_small<HV, true, false, X>), dim3(nprob), dim3(1024), (size_t)lds_bytes_xl, st, parts, probs + first, nprob, max_ticks, done_counter, wave_step)
+#define LSMALL(HV, X) hipLaunchKernelGGL((k_solve_small<HV, true, false, X>), dim3(nprob), dim3(1024), (size_t)lds_bytes_xl, st, parts, probs, qlist, nprob, max_ticks, done_counter, wave_step)
         if (hasval) { if (xl == 1) LSMALL(true, 1); else LSMALL(true, 2); }
         else { if (xl == 1) LSMALL(false, 1); else LSMALL(false, 2); }
 #undef LSMALL
         return;
     }
     if (faithful) {
-        if (hasval) hipLaunchKernelGGL((k_solve_small<true, false, true>), dim3(nprob), dim3(1024), 0, st, parts, probs + first, nprob, max_ticks, done_counter, wave_step);
-        else hipLaunchKernelGGL((k_solve_small<false, false, true>), dim3(nprob), dim3(1024), 0, st, parts, probs + first, nprob, max_ticks, done_counter, wave_step);
+        if (hasval) hipLaunchKernelGGL((k_solve_small<true, false, true>), dim3(nprob), dim3(1024), 0, st, parts, probs, qlist, nprob, max_ticks, done_counter, wave_step);
+        else hipLaunchKernelGGL((k_solve_small<false, false, true>), dim3(nprob), dim3(1024), 0, st, parts, probs, qlist, nprob, max_ticks, done_counter, wave_step);
         return;
     }
     // lds_doubles > 0: the work vectors of every problem fit in LDS (that many doubles for the largest) -> LDS-resident solve
@@ -3106,12 +3127,12 @@ void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, int 
             set_max_lds(reinterpret_cast<const void *>(&k_solve_small<false, true, false>), 150 * 1024);
         });
         const size_t bytes = (size_t)lds_doubles * sizeof(double);
-        if (hasval) hipLaunchKernelGGL((k_solve_small<true, true, false>), dim3(nprob), dim3(1024), bytes, st, parts, probs + first, nprob, max_ticks, done_counter, wave_step);
-        else hipLaunchKernelGGL((k_solve_small<false, true, false>), dim3(nprob), dim3(1024), bytes, st, parts, probs + first, nprob, max_ticks, done_counter, wave_step);
+        if (hasval) hipLaunchKernelGGL((k_solve_small<true, true, false>), dim3(nprob), dim3(1024), bytes, st, parts, probs, qlist, nprob, max_ticks, done_counter, wave_step);
+        else hipLaunchKernelGGL((k_solve_small<false, true, false>), dim3(nprob), dim3(1024), bytes, st, parts, probs, qlist, nprob, max_ticks, done_counter, wave_step);
         return;
     }
-    if (hasval) hipLaunchKernelGGL((k_solve_small<true, false, false>), dim3(nprob), dim3(1024), 0, st, parts, probs + first, nprob, max_ticks, done_counter, wave_step);
-    else hipLaunchKernelGGL((k_solve_small<false, false, false>), dim3(nprob), dim3(1024), 0, st, parts, probs + first, nprob, max_ticks, done_counter, wave_step);
+    if (hasval) hipLaunchKernelGGL((k_solve_small<true, false, false>), dim3(nprob), dim3(1024), 0, st, parts, probs, qlist, nprob, max_ticks, done_counter, wave_step);
+    else hipLaunchKernelGGL((k_solve_small<false, false, false>), dim3(nprob), dim3(1024), 0, st, parts, probs, qlist, nprob, max_ticks, done_counter, wave_step);
 }
 
 void mlxk_collect_c0(hipStream_t st, const PartDev *parts, const ProbDev *probs, const int *qlist, int nq,

@@ -31,6 +31,8 @@ struct RoLds {
     double M[RO_NN][RO_CHP];       // multipliers of the norm arrays (1.0 except where the running scale changes)
     double wtot[RO_NN][4];         // scan: the waves' maxima
     double res[RO_NF];
+    unsigned mask[2];              // bit b: terms 32 b .. 32 b + 31 of the chunk hold a change of a norm's running scale
+    double pad[64];                // ro_fold32 reads up to 48 doubles ahead of the last term it adds
 };
 struct RoV4 { double v[4]; };
 
@@ -42,6 +44,10 @@ __device__ __forceinline__ RoV4 ro_ld4(const double *__restrict__ p, int j0)
     const d2v_t a = gld(reinterpret_cast<const d2v_t *>(p + j0)), b = gld(reinterpret_cast<const d2v_t *>(p + j0 + 2));
     RoV4 r; r.v[0] = a.x; r.v[1] = a.y; r.v[2] = b.x; r.v[3] = b.y;
     return r;
+}
+__device__ __forceinline__ RoV4 ro_ld4c(const double *__restrict__ p, int j0, int n)       // ... of a vector of n elements, clamped to its last quad
+{
+    return ro_ld4(p, min(j0, ((n - 1) >> 2) << 2));
 }
 __device__ __forceinline__ RoV4 ro_ld4s(const double *__restrict__ p, int j0, int n)      // any alignment, clamped
 {
@@ -56,12 +62,95 @@ __device__ __forceinline__ void ro_st4(double *__restrict__ p, int j0, int n, co
     for (int e = 0; e < 4; e++) if (j0 + e < n) gst(p + j0 + e, x[e]);
 }
 
-// One pass over elements 0 .. len-1. load(j0, R) fetches the operands of elements j0 .. j0+3 (clamped to the last quad of the
-// vector), emit(j0, R, ct, nv) does their elementwise work (stores included, elements >= len masked) and returns the terms of the
-// dot arrays ct[k][e] (k >= NN) and the raw values of the norm arrays nv[q][e] (q < NN). Lane k of the first wave folds array k:
-// norms from sum = 1, dots from init[k]. result[k] (every thread): the norm scale*sqrt(sum) / the dot.
+// s += t[0]; s += t[1]; ... over 32 * nit consecutive doubles at the LDS address t, one dependent v_add_f64 per term: 16 terms are
+// added while the ds_reads of the next 16 are in flight (written as one asm block: the compiler sinks a read-ahead written in C back
+// into the iteration that uses it, which costs one LDS latency per batch -- 16 cycles per term instead of 8). nit is wave-uniform,
+// >= 1; the last trip reads 16 doubles ahead of its terms (inside the LDS allocation: RoLds is padded), unused.
+__device__ __forceinline__ double ro_fold32(double s, const double *t, int nit)
+{
+    unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) const double *)t;
+    // registers v[192:223] / v[224:255] hold 16 terms each; the eight 16-byte reads of one half are issued between the first adds of
+    // the other half (an add waits for its predecessor anyway: the reads ride in those stalls)
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "ds_read_b128 v[192:195], %[a] offset:0\n\t"
+        "ds_read_b128 v[196:199], %[a] offset:16\n\t"
+        "ds_read_b128 v[200:203], %[a] offset:32\n\t"
+        "ds_read_b128 v[204:207], %[a] offset:48\n\t"
+        "ds_read_b128 v[208:211], %[a] offset:64\n\t"
+        "ds_read_b128 v[212:215], %[a] offset:80\n\t"
+        "ds_read_b128 v[216:219], %[a] offset:96\n\t"
+        "ds_read_b128 v[220:223], %[a] offset:112\n\t"
+        "1:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_add_f64 %[s], %[s], v[192:193]\n\t"
+        "ds_read_b128 v[224:227], %[a] offset:128\n\t"
+        "v_add_f64 %[s], %[s], v[194:195]\n\t"
+        "ds_read_b128 v[228:231], %[a] offset:144\n\t"
+        "v_add_f64 %[s], %[s], v[196:197]\n\t"
+        "ds_read_b128 v[232:235], %[a] offset:160\n\t"
+        "v_add_f64 %[s], %[s], v[198:199]\n\t"
+        "ds_read_b128 v[236:239], %[a] offset:176\n\t"
+        "v_add_f64 %[s], %[s], v[200:201]\n\t"
+        "ds_read_b128 v[240:243], %[a] offset:192\n\t"
+        "v_add_f64 %[s], %[s], v[202:203]\n\t"
+        "ds_read_b128 v[244:247], %[a] offset:208\n\t"
+        "v_add_f64 %[s], %[s], v[204:205]\n\t"
+        "ds_read_b128 v[248:251], %[a] offset:224\n\t"
+        "v_add_f64 %[s], %[s], v[206:207]\n\t"
+        "ds_read_b128 v[252:255], %[a] offset:240\n\t"
+        "v_add_f64 %[s], %[s], v[208:209]\n\t"
+        "v_add_f64 %[s], %[s], v[210:211]\n\t"
+        "v_add_f64 %[s], %[s], v[212:213]\n\t"
+        "v_add_f64 %[s], %[s], v[214:215]\n\t"
+        "v_add_f64 %[s], %[s], v[216:217]\n\t"
+        "v_add_f64 %[s], %[s], v[218:219]\n\t"
+        "v_add_f64 %[s], %[s], v[220:221]\n\t"
+        "v_add_f64 %[s], %[s], v[222:223]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_add_u32 %[a], 0x100, %[a]\n\t"
+        "s_sub_u32 %[n], %[n], 1\n\t"
+        "v_add_f64 %[s], %[s], v[224:225]\n\t"
+        "ds_read_b128 v[192:195], %[a] offset:0\n\t"
+        "v_add_f64 %[s], %[s], v[226:227]\n\t"
+        "ds_read_b128 v[196:199], %[a] offset:16\n\t"
+        "v_add_f64 %[s], %[s], v[228:229]\n\t"
+        "ds_read_b128 v[200:203], %[a] offset:32\n\t"
+        "v_add_f64 %[s], %[s], v[230:231]\n\t"
+        "ds_read_b128 v[204:207], %[a] offset:48\n\t"
+        "v_add_f64 %[s], %[s], v[232:233]\n\t"
+        "ds_read_b128 v[208:211], %[a] offset:64\n\t"
+        "v_add_f64 %[s], %[s], v[234:235]\n\t"
+        "ds_read_b128 v[212:215], %[a] offset:80\n\t"
+        "v_add_f64 %[s], %[s], v[236:237]\n\t"
+        "ds_read_b128 v[216:219], %[a] offset:96\n\t"
+        "v_add_f64 %[s], %[s], v[238:239]\n\t"
+        "ds_read_b128 v[220:223], %[a] offset:112\n\t"
+        "v_add_f64 %[s], %[s], v[240:241]\n\t"
+        "v_add_f64 %[s], %[s], v[242:243]\n\t"
+        "v_add_f64 %[s], %[s], v[244:245]\n\t"
+        "v_add_f64 %[s], %[s], v[246:247]\n\t"
+        "v_add_f64 %[s], %[s], v[248:249]\n\t"
+        "v_add_f64 %[s], %[s], v[250:251]\n\t"
+        "v_add_f64 %[s], %[s], v[252:253]\n\t"
+        "v_add_f64 %[s], %[s], v[254:255]\n\t"
+        "s_cmp_lg_u32 %[n], 0\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : [s] "+v"(s), [a] "+v"(a), [n] "+s"(nit)
+        :
+        : "memory", "scc",
+          "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
+    return s;
+}
+
+// One pass over elements 0 .. len-1. load(j0, R) fetches the operands of elements j0 .. j0+3 (it clamps to the last quad of each
+// vector itself), emit(j0, R, ct, nv) does their elementwise work (stores included, elements beyond a vector's end masked) and
+// returns the terms of the dot arrays ct[k][e] (k >= NN) and the raw values of the norm arrays nv[q][e] (q < NN). Lane k of the
+// first wave folds array k over its first lens[k] elements (lens == nullptr: len for all): norms from sum = 1, dots from init[k].
+// result[k] (every thread): the norm scale*sqrt(sum) / the dot.
 template <int NF, int NN, typename R, typename LD, typename EM>
-__device__ __forceinline__ void ro_pass(RoLds &sh, int len, const double *init, double *result, LD load, EM emit)
+__device__ __forceinline__ void ro_pass(RoLds &sh, int len, const int *lens, const double *init, double *result, LD load, EM emit)
 {
 #pragma clang fp contract(off)
     static_assert(NF <= RO_NF && NN <= RO_NN && NN <= NF, "fold arrays");
@@ -72,22 +161,38 @@ __device__ __forceinline__ void ro_pass(RoLds &sh, int len, const double *init, 
     double mc[NNX];
 #pragma unroll
     for (int q = 0; q < NNX; q++) mc[q] = 0.0;
-    const int lastq = ((len - 1) >> 2) << 2;
+    if (NF == 0) {
+        // elementwise only: no terms, no barriers; four quads per thread in flight (a single one leaves every trip waiting for HBM)
+        for (int base = 0; base < len; base += 4 * RO_CH) {
+            R r4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) load(base + u * RO_CH + 4 * tid, r4[u]);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                double ct[NFX][4], nv[NNX][4];
+                emit(base + u * RO_CH + 4 * tid, r4[u], ct, nv);
+            }
+        }
+        __syncthreads();
+        return;
+    }
+    const int mylen = (NF > 0 && lens != nullptr) ? lens[lane < NF ? lane : 0] : len;      // (wave 0: the array this lane folds)
     R regs;
-    load(min(4 * tid, lastq), regs);
+    load(4 * tid, regs);
     for (int base = 0; base < len; base += RO_CH) {
         const int j0 = base + 4 * tid;
         double ct[NFX][4], nv[NNX][4];
         emit(j0, regs, ct, nv);
-        if (base + RO_CH < len) load(min(j0 + RO_CH, lastq), regs);      // next chunk's operands: in flight during the scan and the fold
+        if (base + RO_CH < len) load(j0 + RO_CH, regs);      // next chunk's operands: in flight during the scan and the fold
         int flag = 0;
+        if (NN > 0 && tid == 0) sh.mask[0] = 0u;              // (the scan's barrier below orders this before the atomicOr)
         if (NN > 0) {
             // euclideanNorm's running scale in front of every element = exclusive prefix maximum of |v| (zeros never raise it)
             double a[NNX][4], x[NNX];
 #pragma unroll
             for (int q = 0; q < NN; q++) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) a[q][e] = (j0 + e < len) ? fabs(nv[q][e]) : 0.0;
+                for (int e = 0; e < 4; e++) a[q][e] = (j0 + e < (lens != nullptr ? lens[q] : len)) ? fabs(nv[q][e]) : 0.0;
                 x[q] = fmax(fmax(a[q][0], a[q][1]), fmax(a[q][2], a[q][3]));
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) {
@@ -128,25 +233,52 @@ __device__ __forceinline__ void ro_pass(RoLds &sh, int len, const double *init, 
             d2v_t *cp = reinterpret_cast<d2v_t *>(&sh.C[k][4 * tid]);
             cp[0] = (d2v_t){ct[k][0], ct[k][1]}; cp[1] = (d2v_t){ct[k][2], ct[k][3]};
         }
-        const int any = __syncthreads_or(flag);
+        if (NN > 0 && flag) atomicOr(&sh.mask[0], 1u << (tid >> 3));      // this thread's four terms sit in sub-block tid / 8
+        __syncthreads();
         if (NF > 0 && wave == 0 && lane < NF) {
-            const int cnt = min(RO_CH, len - base);
+            const int cnt = max(0, min(RO_CH, mylen - base));
             const double *cp = &sh.C[lane][0];
+            const double *mp = &sh.M[lane < NN ? lane : 0][0];
+            const bool isn = lane < NN;
+            const unsigned mask = NN > 0 ? sh.mask[0] : 0u;
             double s = acc;
-            if (!any) {
-                int i = 0;
-                for (; i + 8 <= cnt; i += 8) {
-                    double c8[8];
+            {
+                // p += term: ONE dependent add per element. Sub-blocks of 32 terms common to the folding lanes run in ro_fold32 (the LDS
+                // reads of the next 16 terms in flight while 16 are added) -- except the few sub-blocks in which a norm's running scale
+                // changes (euclideanNorm's `sum = 1 + sum * (scale/a)^2`: about ln n of them per vector): those, and what is left of a
+                // lane's chunk behind the common part, take the per-term form sum = c + sum * m (m = 1.0 wherever nothing changes:
+                // c + sum * 1.0 is sum + c bit for bit).
+                int T = RO_CH / 32;
 #pragma unroll
-                    for (int u = 0; u < 8; u++) c8[u] = cp[i + u];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) s = s + c8[u];
+                for (int k = 0; k < NF; k++) {
+                    const int ck = __shfl(cnt, k);
+                    if (ck >= 32) T = min(T, ck >> 5);
                 }
-                for (; i < cnt; i++) s = s + cp[i];
-            } else {
-                const double *mp = &sh.M[lane < NN ? lane : 0][0];
-                const bool isn = lane < NN;
-                for (int i = 0; i < cnt; i++) {
+                T = __builtin_amdgcn_readfirstlane(T);
+                int i = 0;
+                if (cnt >= 32) {
+                    int b = 0;
+                    while (b < T) {
+                        const unsigned rest = mask >> b;
+                        if (rest & 1u) {
+                            for (int e = 32 * b; e < 32 * b + 32; e += 8) {
+                                double c8[8], m8[8];
+#pragma unroll
+                                for (int u = 0; u < 8; u++) { c8[u] = cp[e + u]; m8[u] = isn ? mp[e + u] : 1.0; }
+#pragma unroll
+                                for (int u = 0; u < 8; u++) s = c8[u] + s * m8[u];
+                            }
+                            b += 1;
+                        } else {
+                            int run = rest == 0u ? T - b : min(T - b, (int)__builtin_ctz(rest));
+                            run = __builtin_amdgcn_readfirstlane(run);
+                            s = ro_fold32(s, cp + 32 * b, run);
+                            b += run;
+                        }
+                    }
+                    i = T << 5;
+                }
+                for (; i < cnt; i++) {
                     const double m = isn ? mp[i] : 1.0;
                     s = cp[i] + s * m;
                 }
@@ -185,7 +317,7 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
     const PartDev &pa = parts[pr.part];
     const int n = pa.n_local, nf = pa.n_feat, l = pa.l, tid = threadIdx.x;
     const double *__restrict__ xtc = pr.c0f;                      // X'c of this tick, columns 0 .. nf-1 (k_colpass_lds<.., RO>)
-    const double csum = pr.csump[pa.n_rblk - 1];                  // ... and of the intercept's column
+    const double *__restrict__ coef = pr.coef;                    // the row coefficients: their sum in row order is the intercept's column
     const double *__restrict__ pvec = pr.pinv_vec;
     const double pscal = pr.pinv;
     double *__restrict__ w = pr.w, *__restrict__ w_new = pr.w_new, *__restrict__ g = pr.g, *__restrict__ s = pr.s,
@@ -196,30 +328,37 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
 
     if (phase == PH_CG) {
         // ---- one trip of trcg's loop (bw/Tron.java:145-175)
-        struct RA { RoV4 d, x, p; };
-        ro_pass<1, 0, RA>(sh, n, zero6, res,
-            [&](int j0, RA &R) { R.d = ro_ld4(d, j0); R.x = ro_ld4(xtc, j0); if (pvec) R.p = ro_ld4s(pvec, j0, n); },
-            [&](int j0, RA &R, double (&ct)[1][4], double (&nv)[1][4]) {
+        // Hd for the feature columns and the first nf terms of Tron.dot(d, Hd) on one lane; beside it, on a second lane, the intercept's
+        // column of XTv: the sum of the row coefficients in row order (the bias entry closes every row). The dot's last term needs
+        // that sum and is added after the pass: the same chain.
+        struct RA { RoV4 d, x, p, c; };
+        const int lensA[2] = {nf, l};
+        ro_pass<2, 0, RA>(sh, max(nf, l), lensA, zero6, res,
+            [&](int j0, RA &R) { R.d = ro_ld4c(d, j0, n); R.x = ro_ld4c(xtc, j0, n); if (pvec) R.p = ro_ld4s(pvec, j0, n); R.c = ro_ld4c(coef, j0, l); },
+            [&](int j0, RA &R, double (&ct)[2][4], double (&nv)[1][4]) {
                 double hd[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const int j = j0 + e;
-                    const double xa = (j == nf) ? csum : R.x.v[e];
-                    hd[e] = R.d.v[e] * (pvec ? R.p.v[e] : pscal) + xa;      // Hs[i] = (s[i]*priorVar_inv[i] + Hs[i]) * 1
-                    ct[0][e] = R.d.v[e] * hd[e];                             // Tron.dot(d, Hd)
+                    hd[e] = R.d.v[e] * (pvec ? R.p.v[e] : pscal) + R.x.v[e];      // Hs[i] = (s[i]*priorVar_inv[i] + Hs[i]) * 1
+                    ct[0][e] = R.d.v[e] * hd[e];                                   // Tron.dot(d, Hd)
+                    ct[1][e] = R.c.v[e];                                           // XTv[n-1] += v[i]
                 }
-                ro_st4(Hd, j0, n, hd);
+                ro_st4(Hd, j0, nf, hd);
             });
         const double rTr0 = pr.rTr, delta0 = pr.delta, cgtol0 = pr.cgtol;
-        double alpha = rTr0 / res[0];
+        const double d_icpt = d[nf];
+        const double hd_icpt = d_icpt * (pvec ? pvec[nf] : pscal) + res[1];
+        if (tid == 0) Hd[nf] = hd_icpt;
+        __syncthreads();
+        double alpha = rTr0 / (res[0] + d_icpt * hd_icpt);
         const double nalpha = -alpha;
         const double *__restrict__ rc = pr.rb[pr.rsel];
         double *__restrict__ rn = pr.rb[pr.rsel ^ 1];
         // daxpy(alpha, d, s); the norm of s; and, from the same operands, both continuations: r' = r - alpha Hd with r'.r' and |r'|
         // (:169-171, :144 of the next trip) and the three dots of the boundary case on the stepped-back s (:152-155)
         struct RB { RoV4 d, s, r, h; };
-        ro_pass<6, 2, RB>(sh, n, zero6, res,
-            [&](int j0, RB &R) { R.d = ro_ld4(d, j0); R.s = ro_ld4(s, j0); R.r = ro_ld4(rc, j0); R.h = ro_ld4(Hd, j0); },
+        ro_pass<6, 2, RB>(sh, n, nullptr, zero6, res,
+            [&](int j0, RB &R) { R.d = ro_ld4c(d, j0, n); R.s = ro_ld4c(s, j0, n); R.r = ro_ld4c(rc, j0, n); R.h = ro_ld4c(Hd, j0, n); },
             [&](int j0, RB &R, double (&ct)[6][4], double (&nv)[2][4]) {
                 double s1[4], r1[4];
 #pragma unroll
@@ -254,10 +393,10 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
         const double nalpha2 = -alpha2;
         struct RC { RoV4 d, s, r1, r, h, w, g; };
         auto ldc = [&](int j0, RC &R) {
-            R.d = ro_ld4(d, j0);
-            if (boundary) { R.s = ro_ld4(s, j0); R.r = ro_ld4(rc, j0); R.h = ro_ld4(Hd, j0); }
-            else { R.r1 = ro_ld4(rn, j0); if (end_cg) R.s = ro_ld4(s, j0); }
-            if (end_cg) { R.w = ro_ld4(w, j0); R.g = ro_ld4(g, j0); }
+            R.d = ro_ld4c(d, j0, n);
+            if (boundary) { R.s = ro_ld4c(s, j0, n); R.r = ro_ld4c(rc, j0, n); R.h = ro_ld4c(Hd, j0, n); }
+            else { R.r1 = ro_ld4c(rn, j0, n); if (end_cg) R.s = ro_ld4c(s, j0, n); }
+            if (end_cg) { R.w = ro_ld4c(w, j0, n); R.g = ro_ld4c(g, j0, n); }
         };
         auto emc = [&](int j0, RC &R, double (&ct)[3][4], double (&nv)[1][4]) {
             double sf[4], rf[4], dn[4], wn[4];
@@ -284,8 +423,8 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
             else ro_st4(d, j0, n, dn);
             if (end_cg) ro_st4(w_new, j0, n, wn);
         };
-        if (end_cg) ro_pass<3, 1, RC>(sh, n, zero6, res, ldc, emc);
-        else ro_pass<0, 0, RC>(sh, n, zero6, res, ldc,
+        if (end_cg) ro_pass<3, 1, RC>(sh, n, nullptr, zero6, res, ldc, emc);
+        else ro_pass<0, 0, RC>(sh, n, nullptr, zero6, res, ldc,
                                [&](int j0, RC &R, double (&ct)[1][4], double (&nv)[1][4]) { double c3[3][4], n1[1][4]; emc(j0, R, c3, n1); });
         if (tid == 0) {
             if (!boundary) pr.rTr = rnew;
@@ -307,21 +446,25 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
 
     // ---- PH_EVAL0 / PH_EVAL: fun(w_new) and the gradient candidate (llf/LogisticRegressionL2.java:156-225)
     const double *__restrict__ rowtmp = pr.rowtmp;
-    struct RR { RoV4 x; };
-    ro_pass<1, 0, RR>(sh, l, zero6, res,
-        [&](int j0, RR &R) { R.x = ro_ld4(rowtmp, j0); },
-        [&](int j0, RR &R, double (&ct)[1][4], double (&nv)[1][4]) {
+    struct RR { RoV4 x, c; };
+    ro_pass<2, 0, RR>(sh, l, nullptr, zero6, res,
+        [&](int j0, RR &R) { R.x = ro_ld4c(rowtmp, j0, l); R.c = ro_ld4c(coef, j0, l); },
+        [&](int j0, RR &R, double (&ct)[2][4], double (&nv)[1][4]) {
 #pragma unroll
-            for (int e = 0; e < 4; e++) ct[0][e] = R.x.v[e];                 // f += weight * log(1 + exp(..)) in row order (:172-183)
+            for (int e = 0; e < 4; e++) {
+                ct[0][e] = R.x.v[e];                                         // f += weight * log(1 + exp(..)) in row order (:172-183)
+                ct[1][e] = R.c.v[e];                                         // the intercept's column of XTv: the coefficients in row order
+            }
         });
     double fnew = 2.0 * res[0];
+    const double csum = res[1];
     const double init4[RO_NF] = {0.0, 0.0, fnew, 0.0, 0.0, 0.0};
     const double *__restrict__ c0 = pa.c0;
     const bool e0 = (phase == PH_EVAL0);
     struct RE { RoV4 w, m, x, p, c; };
-    ro_pass<4, 2, RE>(sh, n, init4, res,
+    ro_pass<4, 2, RE>(sh, n, nullptr, init4, res,
         [&](int j0, RE &R) {
-            R.w = ro_ld4(w_new, j0); R.m = ro_ld4(m, j0); R.x = ro_ld4(xtc, j0);
+            R.w = ro_ld4c(w_new, j0, n); R.m = ro_ld4c(m, j0, n); R.x = ro_ld4c(xtc, j0, n);
             if (pvec) R.p = ro_ld4s(pvec, j0, n);
             if (e0) R.c = ro_ld4s(c0, j0, n);
         },
@@ -400,12 +543,12 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
         // w = w_new, g = grad(w_new); trcg prologue (:133-141): s = 0, r = -g, d = r
         double *__restrict__ r0 = pr.rb[0];
         struct RT { RoV4 h, g, wn, w; };
-        ro_pass<0, 0, RT>(sh, n, zero6, res,
+        ro_pass<0, 0, RT>(sh, n, nullptr, zero6, res,
             [&](int j0, RT &R) {
-                R.h = ro_ld4(Hd, j0);
-                if (!copy_g) R.g = ro_ld4(g, j0);
-                if (copy_w || nullstep) R.wn = ro_ld4(w_new, j0);
-                if (nullstep && !copy_w) R.w = ro_ld4(w, j0);
+                R.h = ro_ld4c(Hd, j0, n);
+                if (!copy_g) R.g = ro_ld4c(g, j0, n);
+                if (copy_w || nullstep) R.wn = ro_ld4c(w_new, j0, n);
+                if (nullstep && !copy_w) R.w = ro_ld4c(w, j0, n);
             },
             [&](int j0, RT &R, double (&ct)[1][4], double (&nv)[1][4]) {
                 double z4[4], rj[4], wz[4];
@@ -449,5 +592,9 @@ k_ro_collect_c0(const PartDev *__restrict__ parts, const ProbDev *__restrict__ p
     const PartDev &pa = parts[pr.part];
     double *__restrict__ out = c0_ptrs[blockIdx.x];
     for (int j = threadIdx.x; j < pa.n_feat; j += blockDim.x) out[j] = pr.c0f[j];
-    if (threadIdx.x == 0) out[pa.n_feat] = pr.csump[pa.n_rblk - 1];
+    if (threadIdx.x == 0) {
+        double a = 0.0;                                   // the intercept's column: the coefficients in row order (once per partition)
+        for (int i = 0; i < pa.l; i++) a = a + pr.coef[i];
+        out[pa.n_feat] = a;
+    }
 }

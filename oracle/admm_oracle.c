@@ -43,13 +43,7 @@
 #include <omp.h>
 #endif
 
-#ifdef ORC_PORTABLE_MATH
-/* Verification twin (liboracle_pm.so): exp / log1p from the +,-,*,/ implementations that the HIP library's order-faithful
- * mode (MLX_FAITHFUL=1) evaluates as well, so that the two can be compared bit for bit (tests/test_gpu_parity.py). */
-#include "portable_math.h"
-#define exp pm_exp
-#define log1p pm_log1p
-#endif
+#include "oracle_hooks.h"      /* orc_dataset, the portable exp / log1p of the verification twin, the experiment hooks */
 
 /* which exp / log1p this build evaluates: tests assert "portable" on liboracle_pm.so and "libm" on liboracle.so, so a
  * twin built without -DORC_PORTABLE_MATH (or with the define lost behind another guard) cannot pass for the other */
@@ -61,18 +55,6 @@ const char *orc_math_kind(void)
     return "libm";
 #endif
 }
-
-typedef struct { int index; double value; } orc_node;   /* bw/FeatureNode.java */
-
-typedef struct orc_dataset {
-    int l, n;            /* rows; features incl. intercept (llf/LibLinearDataset.java:590-594) */
-    int binary;          /* LibLinearBinaryDataset */
-    int64_t *rp;         /* row pointer into nodes/idx, l+1 */
-    orc_node *nodes;     /* non-binary */
-    int *idx;            /* binary: 1-based indices */
-    int *y;              /* +1/-1 (llf/LibLinearDataset.java:419-423) */
-    double *weight, *offset;
-} orc_dataset;
 
 typedef struct orc_tron_stats {
     int newton_iters;    /* accepted + rejected trcg calls (loop trips of bw/Tron.java:66) */
@@ -137,41 +119,10 @@ void orc_dataset_destroy(orc_dataset *d)
     free(d->rp); free(d->nodes); free(d->idx); free(d->y); free(d->weight); free(d->offset); free(d);
 }
 
-/* ------------------------------------------------- summation-order experiments (NOT the reference's arithmetic)
- * orc_set_sum_mode(m), default 0 = the reference's sequential loops, which is what every parity test compares against.
- *   bit 0 (1): Tron.dot as a compensated sum (TwoSum error-free transformation: the sum of the SAME rounded terms, rounded
- *              once -- order-independent up to second-order effects);
- *   bit 1 (2): the row sums of Xv and the column sums of XTv the same way;
- *   bit 2 (4): Tron.euclideanNorm as sqrt of the compensated sum of squares;
- *   bit 3 (8): the loss and prior sums of fun as compensated sums;
- *   bit 4 (16): Tron.euclideanNorm as sqrt of the plain sequential sum of squares (no running scale);
- *   bit 5 (32): Tron.dot as the GRID-ROUNDED sum a parallel kernel can compute: term j rounded to the ulp of the (exact) prefix
- *               sum's binade, the rounded terms added exactly -- an emulation of what the sequential loop does to small terms
- *               once the running sum is large (it absorbs their low bits), without the loop's dependency chain;
- *   bit 6 (64): Tron.dot as a pairwise tree (what a parallel reduction computes);
- *   bit 7 (128) / bit 8 (256): the grid-rounded sum with the grid taken from the prefix at the START of every block of 2048 / 64
- *               elements (cheaper for a kernel: no scan inside the block);
- *   bits 9-12 (512 ... 4096): variants of it (see dot());
- *   bit 13 (8192): the loss sum of fun as a tree over 256-row units (what the dense pass kernel computes);
- *   bit 14 (16384): the loss sum of fun grid-rounded: terms behind the first 256 rows rounded to the ulp of those rows' sum, then added
- *               exactly.
- * Used by tools/sum_order_experiment.py and tests/test_oracle.py to measure how far a summation order (or an exact sum) moves
- * the reference's TRON trajectory on one-hot data; never by a parity check. */
-static int g_sum_mode = 0;
-/* per call site of Tron.dot (0: r.r at the start of trcg, 1: d.Hd, 2: r.r in the loop, 3: the three boundary dots, 4: g.s, 5: s.r):
- * dot-related bits (1, 32, 64, 128, 256) that replace those of the global mode at that site; -1 = use the global mode */
-static int g_site_mode[6] = {-1, -1, -1, -1, -1, -1};
-static _Thread_local int t_site = 0;
-void orc_set_sum_mode(int m) { g_sum_mode = m; }
-void orc_set_dot_site_mode(int site, int m) { if (site >= 0 && site < 6) g_site_mode[site] = m; }
-int orc_get_sum_mode(void) { return g_sum_mode; }
-static inline void acc2(double *hi, double *lo, double x)
-{
-    double s = *hi + x;
-    double bb = s - *hi;
-    *lo += (*hi - (s - bb)) + (x - bb);
-    *hi = s;
-}
+/* Summation-order experiments live in oracle/experiments.c and reach the functions below through orc_hooks (oracle_hooks.h):
+ * all NULL unless a tool installs them; no parity check does. */
+orc_exp_hooks orc_hooks = {0};
+static _Thread_local int t_site = 0;   /* call site of the next Tron.dot (see orc_exp_hooks.dot) */
 
 /* ------------------------------------------------- LogisticRegressionL2 object */
 
@@ -210,15 +161,7 @@ static void func_destroy(orc_func *f)
 static void Xv(orc_func *f, const double *v, double *out)
 {
     const orc_dataset *d = f->data;
-    if (g_sum_mode & 2) {            /* experiment: compensated row sums */
-        for (int i = 0; i < d->l; i++) {
-            double hi = 0, lo = 0;
-            if (d->binary) for (int64_t k = d->rp[i]; k < d->rp[i + 1]; k++) acc2(&hi, &lo, v[d->idx[k] - 1]);
-            else for (int64_t k = d->rp[i]; k < d->rp[i + 1]; k++) acc2(&hi, &lo, v[d->nodes[k].index - 1] * d->nodes[k].value);
-            out[i] = hi + lo;
-        }
-        return;
-    }
+    if (orc_hooks.Xv && orc_hooks.Xv(d, v, out)) return;
     for (int i = 0; i < d->l; i++) {
         double acc = 0;
         if (d->binary) for (int64_t k = d->rp[i]; k < d->rp[i + 1]; k++) acc += v[d->idx[k] - 1];
@@ -232,16 +175,7 @@ static void XTv(orc_func *f, const double *v, double *out)
 {
     const orc_dataset *d = f->data;
     for (int i = 0; i < d->n; i++) out[i] = 0;
-    if (g_sum_mode & 2) {            /* experiment: compensated column sums */
-        double *lo = (double *)calloc((size_t)d->n, sizeof(double));
-        for (int i = 0; i < d->l; i++) {
-            if (d->binary) for (int64_t k = d->rp[i]; k < d->rp[i + 1]; k++) acc2(&out[d->idx[k] - 1], &lo[d->idx[k] - 1], v[i]);
-            else for (int64_t k = d->rp[i]; k < d->rp[i + 1]; k++) acc2(&out[d->nodes[k].index - 1], &lo[d->nodes[k].index - 1], v[i] * d->nodes[k].value);
-        }
-        for (int i = 0; i < d->n; i++) out[i] += lo[i];
-        free(lo);
-        return;
-    }
+    if (orc_hooks.XTv && orc_hooks.XTv(d, v, out)) return;
     for (int i = 0; i < d->l; i++) {
         if (d->binary) for (int64_t k = d->rp[i]; k < d->rp[i + 1]; k++) out[d->idx[k] - 1] += v[i];
         else for (int64_t k = d->rp[i]; k < d->rp[i + 1]; k++) out[d->nodes[k].index - 1] += v[i] * d->nodes[k].value;
@@ -255,63 +189,7 @@ static double fun(orc_func *f, const double *w, int count_pass)
     double s = 0;
     Xv(f, w, f->z);
     if (f->st) { f->st->fun_evals++; if (count_pass) f->st->x_passes++; }
-    if (g_sum_mode & (8192 | 16384)) {      /* experiment: the loss sum as a kernel would add it */
-        double tot = 0;
-        if (g_sum_mode & 8192) {
-            for (int u0 = 0; u0 < d->l; u0 += 256) {
-                double t[256];
-                int m = d->l - u0 < 256 ? d->l - u0 : 256;
-                for (int k = 0; k < 256; k++) t[k] = 0;
-                for (int k = 0; k < m; k++) {
-                    int i = u0 + k;
-                    f->z[i] += d->offset[i];
-                    double yz = d->y[i] * f->z[i];
-                    t[k] = (yz >= 0) ? f->weight[i] * log1p(exp(-yz)) : f->weight[i] * (-yz + log1p(exp(yz)));
-                }
-                for (int st = 128; st >= 1; st >>= 1) for (int k = 0; k < st; k++) t[k] += t[k + st];
-                tot += t[0];
-            }
-        } else {
-            double hh = 0, hl = 0, rh = 0, rl = 0, u = 0, magic = 0;
-            for (int i = 0; i < d->l; i++) {
-                f->z[i] += d->offset[i];
-                double yz = d->y[i] * f->z[i];
-                double x = (yz >= 0) ? f->weight[i] * log1p(exp(-yz)) : f->weight[i] * (-yz + log1p(exp(yz)));
-                if (i < 256) { acc2(&hh, &hl, x); acc2(&rh, &rl, x); }
-                else {
-                    if (i == 256) { double h = hh + hl; int e; if (h > 0) { frexp(h, &e); u = ldexp(1.0, e - 53); magic = 1.5 * ldexp(1.0, 52) * u; } }
-                    double xr = (u > 0 && fabs(x) < ldexp(1.0, 50) * u) ? ((x + magic) - magic) : x;
-                    acc2(&rh, &rl, xr);
-                }
-            }
-            tot = rh + rl;
-        }
-        s = 2.0 * tot;
-        for (int i = 0; i < d->n; i++) {
-            double t = w[i] - f->priorMean[i];
-            s += t * t * f->priorVar_inv[i];
-        }
-        s /= 2.0;
-        return f->multiplier * s;
-    }
-    if (g_sum_mode & 8) {            /* experiment: compensated loss and prior sums */
-        double hi = 0, lo = 0;
-        for (int i = 0; i < d->l; i++) {
-            f->z[i] += d->offset[i];
-            double yz = d->y[i] * f->z[i];
-            if (yz >= 0) acc2(&hi, &lo, f->weight[i] * log1p(exp(-yz)));
-            else acc2(&hi, &lo, f->weight[i] * (-yz + log1p(exp(yz))));
-        }
-        double ph = 0, pl = 0;
-        for (int i = 0; i < d->n; i++) {
-            double t = w[i] - f->priorMean[i];
-            acc2(&ph, &pl, t * t * f->priorVar_inv[i]);
-        }
-        s = 2.0 * (hi + lo);
-        s += ph + pl;
-        s /= 2.0;
-        return f->multiplier * s;
-    }
+    if (orc_hooks.fun_sums && orc_hooks.fun_sums(d, f->weight, f->z, w, f->priorMean, f->priorVar_inv, &s)) return f->multiplier * s;
     for (int i = 0; i < d->l; i++) {
         f->z[i] += d->offset[i];
         double yz = d->y[i] * f->z[i];
@@ -362,63 +240,7 @@ static void daxpy(int n, double c, const double *v1, double *v2)     /* :190-197
 }
 static double dot(int n, const double *a, const double *b)           /* :204-213 */
 {
-    const int g_sum_mode_global = g_sum_mode;
-    const int g_sum_mode = g_site_mode[t_site] >= 0 ? g_site_mode[t_site] : g_sum_mode_global;     /* (experiments only; shadows the global) */
-    if (g_sum_mode & 1) {            /* experiment: compensated */
-        double hi = 0, lo = 0;
-        for (int i = 0; i < n; i++) acc2(&hi, &lo, a[i] * b[i]);
-        return hi + lo;
-    }
-    if (g_sum_mode & 32) {           /* experiment: grid-rounded terms */
-        double ph = 0, pl = 0;       /* exact prefix (what a scan would provide) */
-        double rh = 0, rl = 0;       /* exact sum of the rounded terms */
-        for (int i = 0; i < n; i++) {
-            double x = a[i] * b[i];
-            acc2(&ph, &pl, x);
-            double pre = ph + pl;
-            if (pre != 0 && x != 0) {
-                int e;
-                frexp(pre, &e);                          /* |pre| in [2^(e-1), 2^e): ulp = 2^(e-53) */
-                double u = ldexp(1.0, e - 53);
-                double magic = 1.5 * ldexp(1.0, 52) * u; /* (x + magic) - magic rounds x to a multiple of u (|x| < 2^51 u) */
-                double xr = (fabs(x) < ldexp(1.0, 50) * u) ? ((x + magic) - magic) : x;
-                acc2(&rh, &rl, xr);
-            } else acc2(&rh, &rl, x);
-        }
-        return rh + rl;
-    }
-    if (g_sum_mode & (128 | 256 | 512 | 1024 | 2048 | 4096)) {  /* experiment: grid-rounded terms, grid per block (512 / 1024: the prefix stops growing after 1 / 4 blocks; 2048 / 4096: ONE grid from the sum of the first 256 / 64 terms) */
-        const int B = (g_sum_mode & 256) ? 64 : ((g_sum_mode & 2048) ? 256 : ((g_sum_mode & 4096) ? 64 : 2048));
-        const int K = (g_sum_mode & (512 | 2048 | 4096)) ? 1 : ((g_sum_mode & 1024) ? 4 : (1 << 30));
-        double ph = 0, pl = 0, rh = 0, rl = 0, pre_cap = 0;
-        for (int c0 = 0; c0 < n; c0 += B) {
-            double pre = ph + pl;
-            if (c0 / B <= K) pre_cap = pre; else pre = pre_cap;
-            int e = 0;
-            double u = 0;
-            if (pre != 0) { frexp(pre, &e); u = ldexp(1.0, e - 53); }
-            double magic = 1.5 * ldexp(1.0, 52) * u;
-            int m = n - c0 < B ? n - c0 : B;
-            for (int q = 0; q < m; q++) {
-                double x = a[c0 + q] * b[c0 + q];
-                acc2(&ph, &pl, x);
-                double xr = (u > 0 && fabs(x) < ldexp(1.0, 50) * u) ? ((x + magic) - magic) : x;
-                acc2(&rh, &rl, xr);
-            }
-        }
-        return rh + rl;
-    }
-    if (g_sum_mode & 64) {           /* experiment: pairwise tree over 8-strided blocks of 2048 */
-        double tot = 0;
-        for (int c0 = 0; c0 < n; c0 += 2048) {
-            double t[256];
-            int m = n - c0 < 2048 ? n - c0 : 2048;
-            for (int k = 0; k < 256; k++) { double p = 0; for (int q = k; q < m; q += 256) p += a[c0 + q] * b[c0 + q]; t[k] = p; }
-            for (int st = 128; st >= 1; st >>= 1) for (int k = 0; k < st; k++) t[k] += t[k + st];
-            tot += t[0];
-        }
-        return tot;
-    }
+    if (orc_hooks.dot) { double r; if (orc_hooks.dot(n, a, b, t_site, &r)) return r; }
     double p = 0;
     for (int i = 0; i < n; i++) p += a[i] * b[i];
     return p;
@@ -427,16 +249,7 @@ static double euclideanNorm(int n, const double *v)                  /* :220-252
 {
     if (n < 1) return 0;
     if (n == 1) return fabs(v[0]);
-    if (g_sum_mode & 4) {            /* experiment: sqrt of the compensated sum of squares */
-        double hi = 0, lo = 0;
-        for (int i = 0; i < n; i++) acc2(&hi, &lo, v[i] * v[i]);
-        return sqrt(hi + lo);
-    }
-    if (g_sum_mode & 16) {           /* experiment: sqrt of the plain sum of squares */
-        double p = 0;
-        for (int i = 0; i < n; i++) p += v[i] * v[i];
-        return sqrt(p);
-    }
+    if (orc_hooks.norm) { double r; if (orc_hooks.norm(n, v, &r)) return r; }
     double scale = 0, sum = 1;
     for (int i = 0; i < n; i++) {
         if (v[i] != 0) {

@@ -221,3 +221,55 @@ eng.close()
     assert np.max(np.abs(r0["z"] - zr)) <= 1e-5 * np.max(np.abs(zr))
     assert np.max(np.abs(r0["maxdiff"] - np.array(mdr))) <= 1e-9
     ref.close()
+
+
+@pytest.mark.parametrize("kind", ["dense", "onehot"])
+def test_one_two_four_eight_shards_give_the_same_bits(kind):
+    """the 64-partition job strong-scaled over 1 / 2 / 4 / 8 GPUs must be ONE computation. Since round 4 a
+    partition's partial sums do not depend on the chunking its handle picks, and with num.blocks a power of two the consensus sums
+    (float32 values times 1 / num.blocks, added in double) are exact, so their association over ranks cannot matter either. Here:
+    N handles on one device, partition k -> handle k mod N, the split API (solve_local, the caller's sum of the [xbar | ubar]
+    buffers in rank order, consensus_finish) for 3 iterations: the double z, maxdiff and every partition's TRON counters are
+    identical for N = 1, 2, 4, 8 -- dense tiles (k_xpass_dense + k_tron_step) and one-hot CSR partitions on the tick kernels."""
+    import torch
+    from fixtures import dense_blocks, onehot_blocks
+    if kind == "dense":
+        pd, eps = dense_blocks(8 * 4200, 96, 8), [1e-2, 1e-2, 1e-4]
+    else:
+        pd, eps = onehot_blocks(8 * 8000, 8), [1e-2, 1e-2, 1e-2]
+        assert all(len(b.col_idx) > 65536 for b in pd.blocks)           # large enough for the tick kernels
+    runs = {}
+    for N in (1, 2, 4, 8):
+        engs = []
+        for r in range(N):
+            e = HipAdmmEngine(pd.n_global, [1.0], [1.0], 8)
+            for b in pd.blocks[r::N]:
+                e.add_partition(b)
+            e.finalize()
+            engs.append(e)
+        rec = []
+        for ep in eps:
+            for e in engs:
+                e.solve_local(ep, 1.0)
+            bufs = [e.consensus_tensor() for e in engs]
+            tot = bufs[0].clone()
+            for t in bufs[1:]:
+                tot += t
+            for t in bufs:
+                t.copy_(tot)
+            torch.cuda.synchronize()
+            fins = [e.consensus_finish() for e in engs]
+            cnt = np.zeros((8, 4), np.int64)
+            for r, e in enumerate(engs):
+                cnt[r::N] = e.solve_counters()
+            zs = [e.z()[0].copy() for e in engs]
+            assert all(np.array_equal(z, zs[0]) for z in zs) and all(f.maxdiff == fins[0].maxdiff for f in fins)
+            rec.append((zs[0], fins[0].maxdiff, cnt))
+        runs[N] = rec
+        for e in engs:
+            e.close()
+    for N in (2, 4, 8):
+        for it, (a, b) in enumerate(zip(runs[1], runs[N])):
+            assert np.array_equal(a[2], b[2]), "%s, %d shards, iteration %d: TRON counters differ from the one-shard run" % (kind, N, it + 1)
+            assert np.array_equal(a[0], b[0]) and a[1] == b[1], "%s, %d shards, iteration %d: z (double) differs" % (kind, N, it + 1)
+    assert runs[1][-1][2][:, 2].sum() > 0

@@ -1305,3 +1305,47 @@ def test_results_do_not_depend_on_the_chunking_the_handle_picks(kind, monkeypatc
             for x, y in zip(a[2], b[2]):
                 assert np.array_equal(x, y), "iteration %d: a partition model differs" % (it + 1)
     assert outs[0][-1][0][:, 2].sum() > 0
+
+
+def test_a_small_partition_takes_the_same_kernel_whatever_else_its_handle_holds():
+    """Round-4 advisor finding: whether a CSR partition ran the one-launch solver (tree dots) or the tick kernels (grid-rounded d.Hd /
+    r.r) was decided from the LARGEST partition of its handle, so a small partition's bits depended on what else the handle -- i.e.
+    its rank -- held. The choice is per partition now (<= 64 K non-zeros, <= 16 K rows / columns: one launch): three small partitions
+    give bit-identical solves (the LibLinear.train seam, mlx_solve_one) alone and beside a 40 000-row one-hot partition, which itself
+    runs the tick kernels; an ADMM iteration of the mixed handle finishes with every problem done."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth_data as sd
+    from mlease_amd.dataset import PartitionBlock
+    pd = synth_sparse(31, 3000, 400, 8, 3, binary=True)
+    rp, ci, y, l2g, ng = sd.onehot_partition(5, 40000)
+    big = PartitionBlock(3, 40000, len(l2g), rp, ci, None, y, np.ones(40000, np.float32), np.zeros(40000, np.float32), l2g)
+    assert pd.n_global < ng
+    smalls = []
+    for b in pd.blocks:                                       # the same rows in the big job's global index space (intercept last)
+        g = np.asarray(b.local_to_global, np.int32).copy()
+        g[-1] = ng - 1
+        smalls.append(PartitionBlock(b.partition_id, b.l, b.n_local, b.row_ptr, b.col_idx, b.val, b.y, b.weight, b.offset, g))
+    alone = HipAdmmEngine(ng, [1.0], [1.0], 4)
+    for b in smalls:
+        alone.add_partition(b)
+    alone.finalize()
+    mixed = HipAdmmEngine(ng, [1.0], [1.0], 4)
+    for b in smalls + [big]:
+        mixed.add_partition(b)
+    mixed.finalize()
+    rng = np.random.default_rng(3)
+    for k, b in enumerate(smalls):
+        n = b.n_local
+        init, pm, pv = rng.normal(0, 0.1, n), rng.normal(0, 0.1, n), rng.uniform(0.5, 2.0, n)
+        wa, ca, fa = alone.solve_one(k, init, pm, pv, 0.01)
+        wm, cm, fm = mixed.solve_one(k, init, pm, pv, 0.01)
+        assert np.array_equal(ca, cm) and np.array_equal(wa, wm) and fa == fm, "small partition %d: its solve depends on the handle" % k
+    st = mixed.iterate(0.01)
+    assert st.solves == 4 and st.cg_iters > 0
+    oc = ol.OracleAdmm(smalls + [big], ng, [1.0], [1.0])
+    oc.iterate(0.01, 1.0, nthreads=4)
+    assert np.array_equal(mixed.solve_counters()[:3], _counters(oc)[:3])
+    # (the one-hot partition's solve at epsilon 0.01 is in the chaotic regime of DESIGN 5: the consensus is held to the loose bound)
+    zo = oc.z()[1][0].astype(np.float64)
+    assert np.max(np.abs(mixed.z()[1][0].astype(np.float64) - zo)) <= 1e-2 * np.max(np.abs(zo))
+    alone.close(); mixed.close()

@@ -606,3 +606,31 @@ def test_sequential_sum_is_the_exact_sum_of_grid_rounded_terms_within_a_binade()
         off.append(abs(s0 + math.fsum(float(v) for v in x) - seq) / u)
     # the exact sum of the UNROUNDED terms is somewhere else (ulps of s): the sequential loop's rounding errors are what it lacks
     assert np.median(off) >= 3.0, off
+
+
+def test_experiment_switches_live_in_their_own_translation_unit(c1):
+    """the summation-order experiments (tools/sum_order_experiment.py) sat inside the checker's hot functions. They are
+    oracle/experiments.c now; admm_oracle.c keeps one `if (orc_hooks.x)` line per function, NULL by default. The hooks still work
+    (a compensated Tron.dot changes last bits, not the solution) and switching them off restores the reference's bits."""
+    import ctypes
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(ROOT, "oracle", "admm_oracle.c")).read()
+    for word in ("acc2", "g_sum_mode", "magic", "frexp"):
+        assert word not in src, word
+    assert src.count("orc_hooks.") == 10 and "orc_set_sum_mode" in open(os.path.join(ROOT, "oracle", "experiments.c")).read()
+    L = ol.lib()
+    L.orc_set_sum_mode.argtypes = [ctypes.c_int]
+    L.orc_get_sum_mode.restype = ctypes.c_int
+    assert L.orc_get_sum_mode() == 0
+    b = c1.blocks[0]
+    ds = ol.OracleDataset.from_block(b)
+    init, pm, pv = np.zeros(b.n_local), np.zeros(b.n_local), np.ones(b.n_local)
+    w0, st0 = ds.train(init, pm, pv, 1e-6)
+    try:
+        L.orc_set_sum_mode(1 | 2 | 4 | 8)                 # compensated dots, pass sums, norms, loss
+        w1, st1 = ds.train(init, pm, pv, 1e-6)
+    finally:
+        L.orc_set_sum_mode(0)
+    w2, st2 = ds.train(init, pm, pv, 1e-6)
+    assert np.array_equal(w0, w2) and st0.cg_iters == st2.cg_iters
+    assert not np.array_equal(w0, w1) and np.max(np.abs(w1 - w0)) <= 1e-9 * max(1.0, np.max(np.abs(w0)))
