@@ -1017,9 +1017,64 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     const int zs = pa.rblk_rows;
     const int32_t *__restrict__ item_init = pa.item_init, *__restrict__ item_last = pa.item_last;
     double *__restrict__ xtc = pr.c0f;
+    int s0n = s0;                                           // first slice of the loop below
+    if (RO) {
+        // The LONG slices of the unit (unsplit columns of thousands of entries; a block's slices are sorted by length) as a RELAY over
+        // the 16 waves. A column's sum is one chain of dependent adds, so a slice cannot be split between waves -- but only the adds
+        // are sequential: wave w takes the batches b = w, w + 16, ... of PB packs, fetches its index packs and gathers its coefficients
+        // from LDS at once, and when batch b - 1 is through (relay_turn) continues the 64 running sums (relay_run) with its 4 PB
+        // adds per lane and hands on. One wave alone on such a slice waits for HBM every 12 packs (measured: ~350 us for the hottest
+        // slice of a configs[2] block); here 16 batches are in flight and the chain runs at the speed of the adds.
+        __shared__ double relay_run[64];
+        __shared__ volatile int relay_turn;
+        constexpr int PB = HASVAL ? 2 : 8, LONG_T = 64;
+        for (; s0n < s1; s0n++) {
+            const int b0 = __builtin_amdgcn_readfirstlane(gld(cs_ptr + s0n));
+            const int L = (__builtin_amdgcn_readfirstlane(gld(cs_ptr + s0n + 1)) - b0) >> 8;
+            if (L <= LONG_T) break;
+            const int dl = gld_nt(item_dst + s0n * 64 + lane), di = gld(item_init + s0n * 64 + lane), dla = gld(item_last + s0n * 64 + lane);
+            if (wave == 0) relay_run[lane] = di >= 0 ? gld(out + di) : 0.0;      // (the column's sum over the earlier blocks)
+            if (threadIdx.x == 0) relay_turn = 0;
+            __syncthreads();
+            const unsigned zz = (unsigned)zs | ((unsigned)zs << 16);
+            const int nbatch = (L + PB - 1) / PB;
+            for (int b = wave; b < nbatch; b += 16) {
+                u2v_t q[PB];
+                f4v_t xv[PB];
+                double c[PB][4];
+#pragma unroll
+                for (int u = 0; u < PB; u++) {
+                    const int kk = b * PB + u;
+                    q[u] = pack_load<NT>(cs_idx, b0, min(kk, L - 1), lane);
+                    if (HASVAL) xv[u] = pack_load_val<NT>(cs_val, b0, min(kk, L - 1), lane);
+                    if (kk >= L) { q[u].x = zz; q[u].y = zz; }
+                }
+#pragma unroll
+                for (int u = 0; u < PB; u++) {
+                    c[u][0] = cf[q[u].x & 0xFFFFu]; c[u][1] = cf[q[u].x >> 16]; c[u][2] = cf[q[u].y & 0xFFFFu]; c[u][3] = cf[q[u].y >> 16];
+                    if (HASVAL) { c[u][0] = c[u][0] * (double)xv[u].x; c[u][1] = c[u][1] * (double)xv[u].y; c[u][2] = c[u][2] * (double)xv[u].z; c[u][3] = c[u][3] * (double)xv[u].w; }
+                }
+                while (relay_turn != b) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                double a = relay_run[lane];
+#pragma unroll
+                for (int u = 0; u < PB; u++) { a = a + c[u][0]; a = a + c[u][1]; a = a + c[u][2]; a = a + c[u][3]; }
+                relay_run[lane] = a;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) relay_turn = b + 1;
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const double a = relay_run[lane];
+                if (dl >= 0 && di != -2) gst(out + dl, a);
+                if (dla >= 0) gst(xtc + dla, a);
+            }
+            __syncthreads();
+        }
+    }
     // (slice s0 + wave + 16 t: slices are sorted by length, so this deals the long ones evenly; batches of consecutive slices
     // per wave -- one offset load instead of 16 -- put a hot unit's 16 long slices on 2 waves: 196 -> 278 us)
-    for (int sb = s0 + wave; sb < s1; sb += 16 * COL_B) {
+    for (int sb = s0n + wave; sb < s1; sb += 16 * COL_B) {
         int base[COL_B], L4[COL_B], dst[COL_B], dlast[COL_B];
         double a[COL_B];
 #pragma unroll
@@ -2997,7 +3052,7 @@ int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const i
         const size_t lds_col = ((size_t)max_rblk_rows + 1) * sizeof(double), lds_row = ((size_t)row_slw + 1) * sizeof(double);
         per_device_once(6, [&] {
 #define SETLDS_RO(HV)                                                                                                                          \
-            set_max_lds(reinterpret_cast<const void *>(&k_colpass_lds<HV, false, true>), 160 * 1024 - 64); \
+            set_max_lds(reinterpret_cast<const void *>(&k_colpass_lds<HV, false, true>), 160 * 1024 - 1024);   /* (+ 528 bytes of static LDS: the relay) */ \
             set_max_lds(reinterpret_cast<const void *>(&k_rowpass_lds<HV, false, 1, true>), 160 * 1024 - 512); \
             set_max_lds(reinterpret_cast<const void *>(&k_rowpass_lds<HV, false, 2, true>), 160 * 1024 - 512); \
             set_max_lds(reinterpret_cast<const void *>(&k_rowpass_lds<HV, false, 4, true>), 160 * 1024 - 512); \
