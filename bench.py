@@ -310,14 +310,14 @@ def compact_record(full):
                 c["roofline"][k] = round(c["roofline"][k])
         c["roofline"]["avg_launch_ms"] = _r(c["roofline"].get("avg_launch_ms"), 5)
         c["roofline"]["measured_in"] = roof.get("measured_in_short", "timed region")
-        c["roofline"]["traffic_source"] = None if not roof.get("traffic_source") else "profiles/traffic.json ratio x this run's bytes per launch (committed rocprofv3 --pmc passes; not a counter read in this run)"
+        c["roofline"]["traffic_source"] = None if not roof.get("traffic_source") else "profiles/traffic.json ratio (committed rocprofv3 --pmc passes) x this run's bytes per launch"
         if roof.get("kernel_alone") and "frac_busy_union" not in roof:      # (records of rounds 3-4: frac was the busy-union figure)
             c["roofline"]["frac_kernel_alone_one_stream"] = roof["kernel_alone"]["frac"]
     c["whole_step_frac"] = (full.get("whole_step") or {}).get("frac_of_hbm_peak")
     cb = full.get("cpu_baseline")
     if cb:
         c["cpu_baseline"] = _pick(cb, ["value", "unit", "cores", "kind"])
-        c["cpu_baseline"]["sample"] = cb.get("sample_short", cb.get("sample", ""))[:160]
+        c["cpu_baseline"]["sample"] = cb.get("sample_short", cb.get("sample", ""))[:110]
         c["gpu_over_cpu"] = (full.get("gpu_over_cpu") or {}).get("solves_per_s")
     par = {}
     c1 = full.get("config1_latency") or {}
@@ -343,12 +343,20 @@ def compact_record(full):
     sp = full.get("sparse") or {}
     spc = sp.get("parity_check") or {}
     if spc:
-        par["config3"] = spc.get("summary") or {}
+        sm = spc.get("summary") or {}
+        if "gpu_within_envelope" in sm:          # (short keys here; the per-iteration lists and the long names stay in the full record)
+            par["config3"] = {"solves": sm.get("solves"), "perms": sm.get("permutations"), "counters_gpu": sm.get("equal_counters_gpu"),
+                              "counters_perm_min_max": sm.get("equal_counters_perm_min_max"), "gpu_within_envelope": sm.get("gpu_within_envelope"),
+                              "ok": {"counters": sm.get("envelope_counters_ok"), "easy_loo": sm.get("envelope_easy_solves_ok"), "median_err": sm.get("envelope_median_err_ok")},
+                              "loo_keep": {"perm_min_max": sm.get("leave_one_out_keep_rate_perm_min_max"), "gpu": sm.get("leave_one_out_keep_rate_gpu")},
+                              "reference_order": sm.get("reference_order")}
+        else:
+            par["config3"] = sm
     if par:
         c["parity"] = par
 
     def leg(d):
-        o = _pick(d, ["value", "unit", "steps", "warmup", "ms_per_step"])
+        o = _pick(d, ["value", "ms_per_step"])
         o["whole_step_frac"] = (d.get("whole_step") or {}).get("frac_of_hbm_peak")
         ks = ((d.get("roofline") or {}).get("kernels")) or []
         for name, k in zip(("rowpass", "colpass", "step"), ks):
@@ -402,7 +410,7 @@ def compact_record(full):
     c["full_record"] = "bench_full.json (also on stderr)"
     c = _finite(c)
     # never exceed the limit: drop the optional blocks, least important first
-    for k in ("gram", "pcie_inclusive", "dense_8_per_gpu", "all_xpass_launches", "time_to_ref_loglik", "lambda_sweep", "sparse", "parity", "gpu_over_cpu"):
+    for k in ("all_xpass_launches", "gram", "pcie_inclusive", "dense_8_per_gpu", "time_to_ref_loglik", "lambda_sweep", "sparse", "parity", "gpu_over_cpu"):
         if len(json.dumps(c, allow_nan=False)) <= COMPACT_LIMIT:
             break
         c.pop(k, None)
@@ -678,8 +686,7 @@ def run_dense(args, C):
                     "tron_step_ms_per_step": round(acc["step_ms"] / args.steps, 3) if timed else None,
                     "tron_step_busy_ms_per_step": round(acc["step_busy_ms"] / args.steps, 3) if timed else None,
                     "timed_ms_per_step": round(dt * 1e3 / args.steps, 3),
-                    "measured_in_short": "frac: replay of the first timed iterations, one tick stream (launch alone); frac_busy_union / frac_by_launch_durations: " +
-                                         ("the timed region, events on both tick streams" if timed else "replay of the timed iterations with events (N>1)"),
+                    "measured_in_short": "frac: launch alone (one-stream replay); busy_union / by_durations: " + ("timed region, both tick streams" if timed else "replay with events (N>1)"),
                     "measured_in": ("frac_busy_union, frac_by_launch_durations, kernel_ms_per_step, launches_in_flight: the TIMED region itself: HIP events on the streams the kernel is launched on, one mark in front of every k_xpass_dense "
                                     "launch and one behind it (the mark of the step launch). The two halves of the problems tick on two streams, so "
                                     "launches_in_flight k_xpass_dense launches run side by side on average: `achieved` = algorithmic bytes / "

@@ -183,6 +183,15 @@ int run_job(const JobConfig &props)
     if (G > 1 && mlx_comm_get_unique_id(uid) != MLX_OK) throw Fail(std::string("RCCL: ") + mlx_last_error(nullptr));
     for (int g = 0; g < G; g++) {
         if (mlx_create(devs[(size_t)g], &hs[(size_t)g]) != MLX_OK) throw Fail(std::string("mlx_create: ") + mlx_last_error(nullptr));
+        // mlease.numerics = fast (default) | reference_order: every reduction a sequential loop as in the Java code (include/mlease_admm.h:
+        // mlx_set_numerics) -- the drop-in's own key, no counterpart in the reference's job files; mlease.option.<key> = <value> passes
+        // any other mlx_set_option key through
+        const std::string numerics = props.get_string("mlease.numerics", "");
+        if (!numerics.empty()) ck(hs[(size_t)g], mlx_set_option(hs[(size_t)g], "numerics", numerics.c_str()), "mlx_set_option(numerics)");
+        for (const char *key : {"tick_streams", "grid_rounded_dots", "one_launch_small", "trace"}) {
+            const std::string v = props.get_string(std::string("mlease.option.") + key, "");
+            if (!v.empty()) ck(hs[(size_t)g], mlx_set_option(hs[(size_t)g], key, v.c_str()), "mlx_set_option");
+        }
         mlx_handle h = hs[(size_t)g];
         ck(h, mlx_set_problem(h, ng, nl, lam.data(), rho.data(), nblocks, props.get_bool("penalize.intercept", false) ? 1 : 0,
                               lambda_map.empty() ? nullptr : lambda_map.data()), "mlx_set_problem");

@@ -220,6 +220,31 @@ def test_cli_end_to_end_matches_golden(tmp_path, c1):
 
 
 @pytest.mark.gpu
+def test_cli_job_key_selects_the_reference_order_numerics(tmp_path, c1):
+    """mlease.numerics=reference_order in the .job file (-> mlx_set_option before the partitions are added): the CLI's final-model is
+    bit-identical to the oracle twin's 5-iteration run of the same job (portable exp / log1p on both sides); an unknown value fails
+    the job with the library's message."""
+    import oracle_lib as ol
+    subprocess.check_call(["make", "-C", HOST, "-s"])
+    recs = c1_raw_records(c1)
+    avro_io.write_container(str(tmp_path / "in" / "part-00000.avro"), PIG_SCHEMA, recs, codec="deflate")
+    job = tmp_path / "ro.job"
+    text = ("input.paths=%s\noutput.base.path=%s\nnum.blocks=8\nlambda=1.0\nnum.iters=5\nregularizer=2\nmap.key=pkey\n"
+            "force.output.overwrite=true\nmlease.numerics=%%s\n" % (tmp_path / "in", tmp_path / "out"))
+    job.write_text(text % "reference_order")
+    r = subprocess.run([os.path.join(HOST, "mlease_admm_train"), str(job)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    models = admm.read_linear_models(str(tmp_path / "out" / "final-model" / "part-r-00000.avro"), c1.feature_names)
+    oc = ol.OracleAdmm(c1.blocks, c1.n_global, [1.0], [1.0], pm=True)
+    for it in range(5):
+        oc.iterate(0.01, 1.0, nthreads=2)
+    assert np.array_equal(models["1.0"].astype(np.float32), oc.z()[1][0]), "reference-order job: final-model differs from the oracle twin"
+    job.write_text(text % "fastest")
+    r = subprocess.run([os.path.join(HOST, "mlease_admm_train"), str(job)], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "numerics must be" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
 def test_cli_writes_the_iteration_files(tmp_path, c1):
     """write.iter.files=true: iter-<i>/{u, init-value, model} as the reference leaves them (jobs/RegressionAdmmTrain.java:309-334,
     reducer output avro/RegressionTrainOutput.avsc:17-39; keys "<lambda>" and "<lambda>#<partition>") -- checked against the committed
