@@ -25,13 +25,14 @@
 // Same statements in the same order as tron_step_body<SEQ> (which is bit-identical to the oracle): the tests run both.
 #pragma once
 
-constexpr int RO_T = 256, RO_CH = 1024, RO_CHP = RO_CH + 2, RO_NF = 6, RO_NN = 2;
+constexpr int RO_T = 320, RO_CH = 1024, RO_CHP = RO_CH + 2, RO_NF = 6, RO_NN = 2;      // one folding wave + four staging waves
 struct RoLds {
-    double C[RO_NF][RO_CHP];       // terms of the chunk, one array per folding lane (norm arrays first)
-    double M[RO_NN][RO_CHP];       // multipliers of the norm arrays (1.0 except where the running scale changes)
-    double wtot[RO_NN][4];         // scan: the waves' maxima
-    double res[RO_NF];
-    unsigned mask[2];              // bit b: terms 32 b .. 32 b + 31 of the chunk hold a change of a norm's running scale
+    double C[2][RO_NF][RO_CHP];    // terms of a chunk, one array per folding lane (norm arrays first); two buffers: folded / being staged
+    double M[2][RO_NN][RO_CHP];    // multipliers of the norm arrays (1.0 except where the running scale changes)
+    double wtot[RO_NN][4];         // scan: the staging waves' maxima of the chunk being staged
+    double res[RO_NF], mcfin[RO_NN];
+    volatile int seq[4];           // chunk number (+ 1) each staging wave has published its maximum for
+    unsigned mask8[2][4];          // per buffer and staging wave, bit k: terms 32 k .. 32 k + 31 of its quarter hold a change of a running scale
     double pad[64];                // ro_fold32 reads up to 48 doubles ahead of the last term it adds
 };
 struct RoV4 { double v[4]; };
@@ -156,36 +157,43 @@ __device__ __forceinline__ void ro_pass(RoLds &sh, int len, const int *lens, con
     static_assert(NF <= RO_NF && NN <= RO_NN && NN <= NF, "fold arrays");
     constexpr int NFX = NF > 0 ? NF : 1, NNX = NN > 0 ? NN : 1;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    double acc = 0.0;
-    if (NF > 0) acc = (lane < NN) ? 1.0 : init[lane < NF ? lane : 0];
-    double mc[NNX];
-#pragma unroll
-    for (int q = 0; q < NNX; q++) mc[q] = 0.0;
     if (NF == 0) {
         // elementwise only: no terms, no barriers; four quads per thread in flight (a single one leaves every trip waiting for HBM)
-        for (int base = 0; base < len; base += 4 * RO_CH) {
+        for (int base = 0; base < len; base += 16 * RO_T) {
             R r4[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) load(base + u * RO_CH + 4 * tid, r4[u]);
+            for (int u = 0; u < 4; u++) load(base + u * 4 * RO_T + 4 * tid, r4[u]);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 double ct[NFX][4], nv[NNX][4];
-                emit(base + u * RO_CH + 4 * tid, r4[u], ct, nv);
+                emit(base + u * 4 * RO_T + 4 * tid, r4[u], ct, nv);
             }
         }
         __syncthreads();
         return;
     }
-    const int mylen = (NF > 0 && lens != nullptr) ? lens[lane < NF ? lane : 0] : len;      // (wave 0: the array this lane folds)
-    R regs;
-    load(4 * tid, regs);
-    for (int base = 0; base < len; base += RO_CH) {
-        const int j0 = base + 4 * tid;
+    // Wave 0 FOLDS; waves 1-4 (256 threads) STAGE: while the folding wave runs the chains of chunk c out of one LDS buffer, the staging
+    // waves load, compute and store chunk c + 1 into the other (their work -- memory latency, the scan, the divisions of the norms'
+    // terms -- is off the chains' critical path: one barrier per chunk, the folding wave never stages). The staging waves agree on the
+    // running maximum of a norm's operand among themselves: each publishes its quarter's maximum in LDS and its chunk number behind it
+    // (sh.seq), and reads the others' when all four numbers are there.
+    const bool folder = wave == 0;
+    const int sw = wave - 1, stid = tid - 64;                 // staging wave 0..3, staging thread 0..255
+    const int nch = (len + RO_CH - 1) / RO_CH;
+    const int mylen = (folder && lens != nullptr) ? lens[lane < NF ? lane : 0] : len;      // (wave 0: the array this lane folds)
+    double acc = 0.0;
+    if (folder) acc = (lane < NN) ? 1.0 : init[lane < NF ? lane : 0];
+    double mc[NNX];
+#pragma unroll
+    for (int q = 0; q < NNX; q++) mc[q] = 0.0;
+    auto stage = [&](int c) {
+        const int b = c & 1;
+        const int j0 = c * RO_CH + 4 * stid;
+        R regs;
+        load(j0, regs);
         double ct[NFX][4], nv[NNX][4];
         emit(j0, regs, ct, nv);
-        if (base + RO_CH < len) load(j0 + RO_CH, regs);      // next chunk's operands: in flight during the scan and the fold
         int flag = 0;
-        if (NN > 0 && tid == 0) sh.mask[0] = 0u;              // (the scan's barrier below orders this before the atomicOr)
         if (NN > 0) {
             // euclideanNorm's running scale in front of every element = exclusive prefix maximum of |v| (zeros never raise it)
             double a[NNX][4], x[NNX];
@@ -199,9 +207,12 @@ __device__ __forceinline__ void ro_pass(RoLds &sh, int len, const int *lens, con
                     const double y = __shfl_up(x[q], d);
                     if (lane >= d) x[q] = fmax(x[q], y);
                 }
-                if (lane == 63) sh.wtot[q][wave] = x[q];
+                if (lane == 63) sh.wtot[q][sw] = x[q];
             }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) sh.seq[sw] = c + 1;
+            for (int w = 0; w < 4; w++) while (sh.seq[w] < c + 1) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
             for (int q = 0; q < NN; q++) {
                 double ex = __shfl_up(x[q], 1);
@@ -209,7 +220,7 @@ __device__ __forceinline__ void ro_pass(RoLds &sh, int len, const int *lens, con
                 double P = fmax(mc[q], ex);
                 for (int w = 0; w < 4; w++) {
                     const double t = sh.wtot[q][w];
-                    if (w < wave) P = fmax(P, t);
+                    if (w < sw) P = fmax(P, t);
                     mc[q] = fmax(mc[q], t);
                 }
                 double mm[4], cc[4];
@@ -222,83 +233,91 @@ __device__ __forceinline__ void ro_pass(RoLds &sh, int len, const int *lens, con
                     P = fmax(P, ae);
                 }
                 typedef double d2v_t __attribute__((ext_vector_type(2)));
-                d2v_t *cp = reinterpret_cast<d2v_t *>(&sh.C[q][4 * tid]), *mp = reinterpret_cast<d2v_t *>(&sh.M[q][4 * tid]);
+                d2v_t *cp = reinterpret_cast<d2v_t *>(&sh.C[b][q][4 * stid]), *mp = reinterpret_cast<d2v_t *>(&sh.M[b][q][4 * stid]);
                 cp[0] = (d2v_t){cc[0], cc[1]}; cp[1] = (d2v_t){cc[2], cc[3]};
                 mp[0] = (d2v_t){mm[0], mm[1]}; mp[1] = (d2v_t){mm[2], mm[3]};
             }
+            // which of this wave's eight 32-term sub-blocks hold a change of a running scale (lanes 8 k .. 8 k + 7 own sub-block k)
+            const unsigned long long bal = __ballot(flag != 0);
+            unsigned m8 = 0u;
+#pragma unroll
+            for (int k = 0; k < 8; k++) if ((bal >> (8 * k)) & 0xFFull) m8 |= 1u << k;
+            if (lane == 0) sh.mask8[b][sw] = m8;
         }
 #pragma unroll
         for (int k = NN; k < NF; k++) {
             typedef double d2v_t __attribute__((ext_vector_type(2)));
-            d2v_t *cp = reinterpret_cast<d2v_t *>(&sh.C[k][4 * tid]);
+            d2v_t *cp = reinterpret_cast<d2v_t *>(&sh.C[b][k][4 * stid]);
             cp[0] = (d2v_t){ct[k][0], ct[k][1]}; cp[1] = (d2v_t){ct[k][2], ct[k][3]};
         }
-        if (NN > 0 && flag) atomicOr(&sh.mask[0], 1u << (tid >> 3));      // this thread's four terms sit in sub-block tid / 8
-        __syncthreads();
-        if (NF > 0 && wave == 0 && lane < NF) {
+    };
+    if (NN > 0 && tid < 4) sh.seq[tid] = 0;
+    __syncthreads();
+    if (!folder) stage(0);
+    __syncthreads();
+    for (int c = 0; c < nch; c++) {
+        if (!folder) {
+            if (c + 1 < nch) stage(c + 1);
+        } else if (lane < NF) {
+            const int b = c & 1, base = c * RO_CH;
             const int cnt = max(0, min(RO_CH, mylen - base));
-            const double *cp = &sh.C[lane][0];
-            const double *mp = &sh.M[lane < NN ? lane : 0][0];
+            const double *cp = &sh.C[b][lane][0];
+            const double *mp = &sh.M[b][lane < NN ? lane : 0][0];
             const bool isn = lane < NN;
-            const unsigned mask = NN > 0 ? sh.mask[0] : 0u;
+            const unsigned mask = NN > 0 ? (sh.mask8[b][0] | (sh.mask8[b][1] << 8) | (sh.mask8[b][2] << 16) | (sh.mask8[b][3] << 24)) : 0u;
             double s = acc;
-            {
-                // p += term: ONE dependent add per element. Sub-blocks of 32 terms common to the folding lanes run in ro_fold32 (the LDS
-                // reads of the next 16 terms in flight while 16 are added) -- except the few sub-blocks in which a norm's running scale
-                // changes (euclideanNorm's `sum = 1 + sum * (scale/a)^2`: about ln n of them per vector): those, and what is left of a
-                // lane's chunk behind the common part, take the per-term form sum = c + sum * m (m = 1.0 wherever nothing changes:
-                // c + sum * 1.0 is sum + c bit for bit).
-                int T = RO_CH / 32;
+            // p += term: ONE dependent add per element. Sub-blocks of 32 terms common to the folding lanes run in ro_fold32 (the LDS
+            // reads of the next 16 terms in flight while 16 are added) -- except the few sub-blocks in which a norm's running scale
+            // changes (euclideanNorm's `sum = 1 + sum * (scale/a)^2`: about ln n of them per vector): those, and what is left of a
+            // lane's chunk behind the common part, take the per-term form sum = c + sum * m (m = 1.0 wherever nothing changes:
+            // c + sum * 1.0 is sum + c bit for bit).
+            int T = RO_CH / 32;
 #pragma unroll
-                for (int k = 0; k < NF; k++) {
-                    const int ck = __shfl(cnt, k);
-                    if (ck >= 32) T = min(T, ck >> 5);
-                }
-                T = __builtin_amdgcn_readfirstlane(T);
-                int i = 0;
-                if (cnt >= 32) {
-                    int b = 0;
-                    while (b < T) {
-                        const unsigned rest = mask >> b;
-                        if (rest & 1u) {
-                            for (int e = 32 * b; e < 32 * b + 32; e += 8) {
-                                double c8[8], m8[8];
+            for (int k = 0; k < NF; k++) {
+                const int ck = __shfl(cnt, k);
+                if (ck >= 32) T = min(T, ck >> 5);
+            }
+            T = __builtin_amdgcn_readfirstlane(T);
+            int i = 0;
+            if (cnt >= 32) {
+                int bq = 0;
+                while (bq < T) {
+                    const unsigned rest = mask >> bq;
+                    if (rest & 1u) {
+                        for (int e = 32 * bq; e < 32 * bq + 32; e += 8) {
+                            double c8[8], m8[8];
 #pragma unroll
-                                for (int u = 0; u < 8; u++) { c8[u] = cp[e + u]; m8[u] = isn ? mp[e + u] : 1.0; }
+                            for (int u = 0; u < 8; u++) { c8[u] = cp[e + u]; m8[u] = isn ? mp[e + u] : 1.0; }
 #pragma unroll
-                                for (int u = 0; u < 8; u++) s = c8[u] + s * m8[u];
-                            }
-                            b += 1;
-                        } else {
-                            int run = rest == 0u ? T - b : min(T - b, (int)__builtin_ctz(rest));
-                            run = __builtin_amdgcn_readfirstlane(run);
-                            s = ro_fold32(s, cp + 32 * b, run);
-                            b += run;
+                            for (int u = 0; u < 8; u++) s = c8[u] + s * m8[u];
                         }
+                        bq += 1;
+                    } else {
+                        int run = rest == 0u ? T - bq : min(T - bq, (int)__builtin_ctz(rest));
+                        run = __builtin_amdgcn_readfirstlane(run);
+                        s = ro_fold32(s, cp + 32 * bq, run);
+                        bq += run;
                     }
-                    i = T << 5;
                 }
-                for (; i < cnt; i++) {
-                    const double m = isn ? mp[i] : 1.0;
-                    s = cp[i] + s * m;
-                }
+                i = T << 5;
+            }
+            for (; i < cnt; i++) {
+                const double m = isn ? mp[i] : 1.0;
+                s = cp[i] + s * m;
             }
             acc = s;
         }
         __syncthreads();
     }
-    if (NF > 0) {
-        if (wave == 0 && lane < NF) {
-            double r = acc;
+    if (folder && lane < NF) sh.res[lane] = acc;
+    if (NN > 0 && stid == 0) {
 #pragma unroll
-            for (int q = 0; q < NN; q++) if (lane == q) r = mc[q] * sqrt(acc);
-            sh.res[lane] = r;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < NF; k++) result[k] = sh.res[k];
-        __syncthreads();
+        for (int q = 0; q < NN; q++) sh.mcfin[q] = mc[q];
     }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NF; k++) result[k] = (k < NN) ? sh.mcfin[k] * sqrt(sh.res[k]) : sh.res[k];
+    __syncthreads();
 }
 
 // The TRON/CG step of one tick, reference-order numerics: one workgroup per problem (bw/Tron.java:30-179; statement order of

@@ -1349,3 +1349,53 @@ def test_a_small_partition_takes_the_same_kernel_whatever_else_its_handle_holds(
     zo = oc.z()[1][0].astype(np.float64)
     assert np.max(np.abs(mixed.z()[1][0].astype(np.float64) - zo)) <= 1e-2 * np.max(np.abs(zo))
     alone.close(); mixed.close()
+
+
+@pytest.mark.parametrize("variant", ["boost_lambda_map", "l1_penalized", "solve_one"])
+def test_reference_order_numerics_cover_the_remaining_solver_modes(c1, variant):
+    """The reference-order contract is a property of the whole C-ABI, not of mlx_admm_iterate alone: the mean-model warm start with
+    lambda.map overrides and the boost rate (N4), the L1 consensus with a penalised intercept, and the LibLinear.train seam with
+    per-coordinate prior variances and a warm start (mlx_solve_one) -- each bit-identical to the oracle twin (portable exp / log1p)."""
+    lam, rho = [0.5, 30.0], [1.0, 2.0]
+    if variant == "solve_one":
+        eng = make_engine(c1, [1.0], [1.0], numerics="reference_order")
+        assert eng.get_option("numerics_kernels") == "reference_order_ticks"
+        rng = np.random.default_rng(11)
+        for k in (0, 5):
+            b = c1.blocks[k]
+            n = b.n_local
+            init, pm, pv = rng.normal(0, 0.2, n), rng.normal(0, 0.1, n), rng.uniform(0.25, 4.0, n)
+            ds = ol.OracleDataset.from_block(b, pm=True)
+            for eps in (1e-2, 1e-6):
+                wo, st = ds.train(init, pm, pv, eps)
+                wg, cnt, (f, gn, gn1) = eng.solve_one(k, init, pm, pv, eps)
+                assert (cnt[0], cnt[1], cnt[2]) == (st.newton_iters, st.accepted, st.cg_iters), (k, eps)
+                assert np.array_equal(wg, wo) and f == st.f and gn == st.gnorm and gn1 == st.gnorm1, (k, eps)
+        eng.close()
+        return
+    kw = {}
+    if variant == "boost_lambda_map":
+        lm = np.full(c1.n_global, np.nan, np.float32)
+        lm[::5] = 40.0
+        lm[2] = 0.25
+        kw = dict(lambda_map=lm)
+    else:
+        kw = dict(regularizer=1, penalize_intercept=True)
+    eng = make_engine(c1, lam, rho, numerics="reference_order", **kw)
+    oc = ol.OracleAdmm(c1.blocks, c1.n_global, lam, rho, pm=True, **kw)
+    if variant == "boost_lambda_map":
+        oc.naive_solve_local(0.01, 0.0, nthreads=4)
+        oc.naive_finish()
+        eng.naive_init(0.01, 0.0)
+        assert np.array_equal(eng.solve_counters(), _counters(oc)) and np.array_equal(eng.z()[0], oc.z()[0]), "mean model"
+    for it in range(3):
+        rate = 2.5 if (it == 0 and variant == "boost_lambda_map") else 1.0
+        mo = oc.iterate(0.01, rate, nthreads=4)
+        st = eng.iterate(0.01, rate)
+        assert np.array_equal(eng.solve_counters(), _counters(oc)), "%s iteration %d" % (variant, it + 1)
+        assert np.array_equal(eng.z()[0], oc.z()[0]) and st.maxdiff == mo[0], "%s iteration %d: z" % (variant, it + 1)
+        for k in (0, 7):
+            for li in range(2):
+                for a, b in zip(eng.partition_model(k, li), oc.partition_model(k, li)):
+                    assert np.array_equal(a, b), "%s iteration %d partition %d lambda %d" % (variant, it + 1, k, li)
+    eng.close()
