@@ -18,10 +18,10 @@ __global__ void __launch_bounds__(256) k_probe(double *out, long long *cyc, int 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     RoLds &sh = *reinterpret_cast<RoLds *>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int k = 0; k < RO_NF; k++) for (int i = tid; i < RO_CHP; i += 256) sh.C[k][i] = 1.0 / (double)(1 + i + 7 * k);
+    for (int k = 0; k < RO_NF; k++) for (int i = tid; i < RO_CHP; i += 256) sh.C[0][k][i] = 1.0 / (double)(1 + i + 7 * k);
     __syncthreads();
     if (wave == 0 && lane < 6) {
-        const double *cp = &sh.C[lane][0];
+        const double *cp = &sh.C[0][lane][0];
         double s = 0.0;
         long long t0 = clock64();
         for (int r = 0; r < reps; r++) s = ro_fold32(s, cp, 32);

@@ -299,7 +299,7 @@ static int run_ticks_small_more(mlx_handle h, int first, int count, const int *q
     int64_t ticks = 0;
     for (;;) {
         mlxk_solve_small(h->stream, h->d_parts, h->d_probs, qsmall, nqs, h->csr_hasval, h->small_ticks, h->d_done, h->small_lds_doubles, h->faithful,
-                         h->small_xl, h->small_xl_bytes);
+                         h->small_xl, h->small_xl_bytes, h->seq_dots);
         ticks += h->small_ticks;
         HIPCHECK(h, hipMemcpyAsync(&h->h_done[0], h->d_done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(h, hipStreamSynchronize(h->stream));
@@ -336,7 +336,7 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
     }
     auto launch_small = [&] {
         mlxk_solve_small(h->stream, h->d_parts, h->d_probs, qsmall, nqs, h->csr_hasval, h->small_ticks, h->d_done, h->small_lds_doubles, h->faithful,
-                         h->small_xl, h->small_xl_bytes);
+                         h->small_xl, h->small_xl_bytes, h->seq_dots);
     };
     if (nqs > 0 && nqd == 0 && nqc == 0) {
         // small CSR problems only: the whole solve in one launch (k_solve_small), relaunched only if a problem needs more

@@ -27,7 +27,7 @@ void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *p
 // whole solves of small CSR problems in one launch (one workgroup per problem runs the tick loop)
 // (qlist: the problems to solve, one workgroup each)
 void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, bool hasval,
-                      int max_ticks, int *done_counter, int lds_doubles, bool faithful, int xl, int lds_bytes_xl);
+                      int max_ticks, int *done_counter, int lds_doubles, bool faithful, int xl, int lds_bytes_xl, bool grid_dots);
 void mlxk_collect_c0(hipStream_t st, const PartDev *parts, const ProbDev *probs, const int *qlist, int nq,
                      double *const *c0_ptrs, bool ro);
 void mlxk_setup(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int n_lambda, int n_global,

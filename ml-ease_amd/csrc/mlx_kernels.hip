@@ -1286,6 +1286,67 @@ k_collect_c0(const PartDev *__restrict__ parts, const ProbDev *__restrict__ prob
     assemble_out(parts[pr.part], pr, c0_ptrs[blockIdx.x], scratch, stage);
 }
 
+// ---- grid-rounded dots: what Tron.dot's SEQUENTIAL loop does to the small terms, without its dependency chain -------------------
+// `for (i) p += a[i]*b[i]` (bw/Tron.java:204-213) adds every term to a running sum that is already large after the first few dozen
+// (hot) columns: the term's bits below the running sum's ulp are rounded away on the spot. That rounding is a property of (term,
+// binade of the running sum), hardly of the order of the terms, so every row / feature order the reference may see reproduces almost
+// the same sum -- while a tree (or an exact, compensated sum) keeps those bits and lands 50-100 ulp away: enough to leave the
+// reference's own family of TRON trajectories on one-hot data. Measured (tools/sum_order_experiment.py, profiles/r4_notes.md; solves
+// of full-size configs[2] partitions whose TRON counters equal the oracle's): oracle on permuted rows 253-269 of 384, this library
+// with tree dots 200, with compensated dots fewer still, with the dots below 242.
+// The grid comes from the HEAD sum: the terms of the problem's first STEP_HEAD columns (the hottest: library ids are frequency-
+// sorted; STEP_HEAD = 64 of them). For r.r every workgroup of phase B adds them itself (two loads per column, L2 hits); for d.Hd / g.g the head needs the
+// column sums of the hottest columns -- O(100) slots each -- so one small launch per tick (k_step_head, one workgroup per problem)
+// leaves it in the descriptor for phase A. u = the ulp of the head sum's binade. Terms of the later columns are rounded to a multiple of u before they are added: the magic-constant form
+// (x + 1.5 * 2^52 u) - 1.5 * 2^52 u, exactly what the FPU does to x when it is added to a sum of that size. Sums of multiples of u
+// are exact, so the trees that follow add no rounding of their own. (The grid of the running sum after the first 64 / 256 / 2048 terms,
+// or of the true prefix at every 2048-column chunk, all follow the oracle equally well on CPU models of this arithmetic; the head
+// sum needs no exchange between workgroups. A first version published chunk sums through agent-scope granules and looked back over
+// them: same parity, 17 % of the sparse leg's throughput; a second recomputed the d.Hd head in every workgroup of phase A: 9 %.)
+#ifndef STEP_HEAD
+#define STEP_HEAD 64           // head columns of phase B's r.r (computed in the kernel) and, by default, of phase A's d.Hd (k_step_head).
+#endif                         // (64 against 256: CPU model 132 against 120-130 of 192 solves followed, GPU 256 against 250 of 384; A/B: -DSTEP_HEAD=256)
+#ifndef STEP_HEAD_A
+#define STEP_HEAD_A STEP_HEAD
+#endif
+#define STEP_HEAD_LANES (1024 / STEP_HEAD_A)               // lanes of k_step_head per head column
+__device__ __forceinline__ double grid_of_sum(double h)
+{
+    const double ah = fabs(h);
+    if (!(ah > 0.0) || !(ah < 1e300)) return 0.0;
+    int e;
+    (void)frexp(ah, &e);                                       // ah in [2^(e-1), 2^e): ulp = 2^(e-53)
+    return ldexp(1.0, e - 53);
+}
+// x as the FPU leaves it when it is added to a running sum whose ulp is u (round to nearest multiple of u, ties to even); u = 0: x
+__device__ __forceinline__ double round_to_grid(double x, double u)
+{
+#pragma clang fp contract(off)
+    const double magic = 6755399441055744.0 * u;              // 1.5 * 2^52 * u
+    return (fabs(x) < 1125899906842624.0 * u) ? (x + magic) - magic : x;      // (|x| >= 2^50 u, or u = 0: x as it is)
+}
+
+// The same dot for the one-workgroup solver (k_solve_small; its vectors are whole in front of the team): head sum of the first
+// STEP_HEAD columns, then every later term rounded to that sum's grid -- k_step_head + phase A / phase B of the tick kernels in one place.
+// (Every thread reads the elements it wrote itself in the loop before: j = tid mod nt in both.)
+template <typename T, typename VP>
+__device__ __forceinline__ double team_grid_dot(VP x, VP y, int n, double *scratch)
+{
+#pragma clang fp contract(off)
+    const int tid = T::tid(), nt = T::nt();
+    double h[1] = {0.0};
+    for (int j = tid; j < min(n, STEP_HEAD); j += nt) h[0] += x[j] * y[j];
+    T::template allreduce<1>(h, scratch);
+    const double u = grid_of_sum(h[0]);
+    double a[1] = {0.0};
+    for (int j = tid; j < n; j += nt) {
+        const double term = x[j] * y[j];
+        a[0] += (j >= STEP_HEAD) ? round_to_grid(term, u) : term;
+    }
+    T::template allreduce<1>(a, scratch);
+    return a[0];
+}
+
 // ---- order-faithful verification mode (MLX_FAITHFUL=1): every n- or l-long reduction is done by
 // ONE thread in the reference's sequential order, with the reference's formulas (bw/Tron.java:204-252). Slow by design.
 // The operands are staged through LDS 1024 at a time by all threads (coalesced loads, products formed in parallel -- an
@@ -1352,7 +1413,7 @@ __device__ __forceinline__ double seq_norm(const double *v, int n, double *scrat
 
 template <bool SEQ, typename T = BlockTeam, typename VP = double *>
 __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, double *scratch, double *stage,
-                                               int *__restrict__ done_counter)
+                                               int *__restrict__ done_counter, bool grid_dots = false)
 {
 #pragma clang fp contract(off)
     const int phase = pr.phase;
@@ -1448,6 +1509,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
         T::template allreduce<1>(a1, scratch);
         SPROF2(1);      // its reduction
         if (SEQ) a1[0] = seq_dot(pr.d, pr.Hd, n, scratch, stage);
+        else if (grid_dots) a1[0] = team_grid_dot<T>(d, Hd, n, scratch);       // the fast contract's d.Hd (grid_of_sum)
         double alpha = rTr0 / a1[0];
         double ss1[1] = {0.0};
         for (int jb = tid; jb < n; jb += SB * nt) {
@@ -1511,6 +1573,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
             }
             T::template allreduce<1>(a2, scratch);
             if (SEQ) a2[0] = seq_dot(pr.r, pr.r, n, scratch, stage);
+            else if (grid_dots) a2[0] = team_grid_dot<T>(r, r, n, scratch);     // ... and its r'.r'
             const double rnew = a2[0];
             const double beta = rnew / rTr0;
             for (int jb = tid; jb < n; jb += SB * nt) {
@@ -1707,6 +1770,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
         }
         T::template allreduce<1>(a2, scratch);
         if (SEQ) a2[0] = seq_dot(pr.r, pr.r, n, scratch, stage);
+        else if (grid_dots) a2[0] = team_grid_dot<T>(r, r, n, scratch);         // ... and the r.r a trcg call starts from
         const double gn = gnorm_cur;      // ||r|| = ||-g|| = ||g||
         if (tid == 0) {
             pr.rTr = a2[0];
@@ -1805,46 +1869,6 @@ __device__ __forceinline__ void step_gather(const double *__restrict__ px, int n
     __syncthreads();
 }
 
-
-// ---- grid-rounded dots: what Tron.dot's SEQUENTIAL loop does to the small terms, without its dependency chain -------------------
-// `for (i) p += a[i]*b[i]` (bw/Tron.java:204-213) adds every term to a running sum that is already large after the first few dozen
-// (hot) columns: the term's bits below the running sum's ulp are rounded away on the spot. That rounding is a property of (term,
-// binade of the running sum), hardly of the order of the terms, so every row / feature order the reference may see reproduces almost
-// the same sum -- while a tree (or an exact, compensated sum) keeps those bits and lands 50-100 ulp away: enough to leave the
-// reference's own family of TRON trajectories on one-hot data. Measured (tools/sum_order_experiment.py, profiles/r4_notes.md; solves
-// of full-size configs[2] partitions whose TRON counters equal the oracle's): oracle on permuted rows 253-269 of 384, this library
-// with tree dots 200, with compensated dots fewer still, with the dots below 242.
-// The grid comes from the HEAD sum: the terms of the problem's first STEP_HEAD columns (the hottest: library ids are frequency-
-// sorted; STEP_HEAD = 64 of them). For r.r every workgroup of phase B adds them itself (two loads per column, L2 hits); for d.Hd / g.g the head needs the
-// column sums of the hottest columns -- O(100) slots each -- so one small launch per tick (k_step_head, one workgroup per problem)
-// leaves it in the descriptor for phase A. u = the ulp of the head sum's binade. Terms of the later columns are rounded to a multiple of u before they are added: the magic-constant form
-// (x + 1.5 * 2^52 u) - 1.5 * 2^52 u, exactly what the FPU does to x when it is added to a sum of that size. Sums of multiples of u
-// are exact, so the trees that follow add no rounding of their own. (The grid of the running sum after the first 64 / 256 / 2048 terms,
-// or of the true prefix at every 2048-column chunk, all follow the oracle equally well on CPU models of this arithmetic; the head
-// sum needs no exchange between workgroups. A first version published chunk sums through agent-scope granules and looked back over
-// them: same parity, 17 % of the sparse leg's throughput; a second recomputed the d.Hd head in every workgroup of phase A: 9 %.)
-#ifndef STEP_HEAD
-#define STEP_HEAD 64           // head columns of phase B's r.r (computed in the kernel) and, by default, of phase A's d.Hd (k_step_head).
-#endif                         // (64 against 256: CPU model 132 against 120-130 of 192 solves followed, GPU 256 against 250 of 384; A/B: -DSTEP_HEAD=256)
-#ifndef STEP_HEAD_A
-#define STEP_HEAD_A STEP_HEAD
-#endif
-#define STEP_HEAD_LANES (1024 / STEP_HEAD_A)               // lanes of k_step_head per head column
-__device__ __forceinline__ double grid_of_sum(double h)
-{
-    const double ah = fabs(h);
-    if (!(ah > 0.0) || !(ah < 1e300)) return 0.0;
-    int e;
-    (void)frexp(ah, &e);                                       // ah in [2^(e-1), 2^e): ulp = 2^(e-53)
-    return ldexp(1.0, e - 53);
-}
-// x as the FPU leaves it when it is added to a running sum whose ulp is u (round to nearest multiple of u, ties to even); u = 0: x
-__device__ __forceinline__ double round_to_grid(double x, double u)
-{
-#pragma clang fp contract(off)
-    const double magic = 6755399441055744.0 * u;              // 1.5 * 2^52 * u
-    return (fabs(x) < 1125899906842624.0 * u) ? (x + magic) - magic : x;      // (|x| >= 2^50 u, or u = 0: x as it is)
-}
 
 // sqrt of a sum of squares gathered in an update loop; a sum that overflowed (or is NaN) is reported as NaN so that the
 // caller stops the solve with ST_NAN instead of comparing against inf
@@ -2348,7 +2372,7 @@ k_step_commit(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
 template <bool HASVAL, bool LDSV, bool SEQ, int XL = 0>
 __global__ void __launch_bounds__(1024)
 k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nprob, int max_ticks,
-              int *__restrict__ done_counter, int wave_step)
+              int *__restrict__ done_counter, int wave_step, int grid_dots)
 {
 #pragma clang fp contract(off)
     static_assert(XL == 0 || (LDSV && !SEQ), "X in LDS rides on the LDS-resident vectors");
@@ -2570,12 +2594,12 @@ k_solve_small(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
                     for (int w = 0; w < nt / 64; w++) { a0 += scratch[w]; a1 += scratch[16 + w]; }
                     if (tid == 0) { pr.lossp[0] = a0; pr.csump[0] = a1; }
                     __builtin_amdgcn_wave_barrier();
-                    tron_step_body<SEQ, WaveTeam, VP>(pa, pr, scratch, stage, done_counter);
+                    tron_step_body<SEQ, WaveTeam, VP>(pa, pr, scratch, stage, done_counter, grid_dots != 0);
                 }
             }
-            else tron_step_body<SEQ, BlockTeam, VP>(pa, pr, scratch, stage, done_counter);
+            else tron_step_body<SEQ, BlockTeam, VP>(pa, pr, scratch, stage, done_counter, grid_dots != 0);
         } else {
-            tron_step_body<SEQ, BlockTeam, VP>(pa, pr, scratch, stage, done_counter);
+            tron_step_body<SEQ, BlockTeam, VP>(pa, pr, scratch, stage, done_counter, grid_dots != 0);
         }
         SPROF(3);                            // step
     }
@@ -3152,7 +3176,7 @@ void mlxk_step_phase(hipStream_t st, int which, const PartDev *parts, ProbDev *p
 }
 
 void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nprob, bool hasval,
-                      int max_ticks, int *done_counter, int lds_doubles, bool faithful, int xl, int lds_bytes_xl)
+                      int max_ticks, int *done_counter, int lds_doubles, bool faithful, int xl, int lds_bytes_xl, bool grid_dots)
 {
     if (nprob <= 0) return;
     static const int wave_step = getenv("MLX_SMALL_WAVE_STEP") ? atoi(getenv("MLX_SMALL_WAVE_STEP")) : 1;     // A/B switch
@@ -3164,15 +3188,15 @@ void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, cons
             set_max_lds(reinterpret_cast<const void *>(&k_solve_small<true, true, false, 2>), 150 * 1024);
             set_max_lds(reinterpret_cast<const void *>(&k_solve_small<false, true, false, 2>), 150 * 1024);
         });
-#define LSMALL(HV, X) hipLaunchKernelGGL((k_solve_small<HV, true, false, X>), dim3(nprob), dim3(1024), (size_t)lds_bytes_xl, st, parts, probs, qlist, nprob, max_ticks, done_counter, wave_step)
+#define LSMALL(HV, X) hipLaunchKernelGGL((k_solve_small<HV, true, false, X>), dim3(nprob), dim3(1024), (size_t)lds_bytes_xl, st, parts, probs, qlist, nprob, max_ticks, done_counter, wave_step, grid_dots ? 1 : 0)
         if (hasval) { if (xl == 1) LSMALL(true, 1); else LSMALL(true, 2); }
         else { if (xl == 1) LSMALL(false, 1); else LSMALL(false, 2); }
 #undef LSMALL
         return;
     }
     if (faithful) {
-        if (hasval) hipLaunchKernelGGL((k_solve_small<true, false, true>), dim3(nprob), dim3(1024), 0, st, parts, probs, qlist, nprob, max_ticks, done_counter, wave_step);
-        else hipLaunchKernelGGL((k_solve_small<false, false, true>), dim3(nprob), dim3(1024), 0, st, parts, probs, qlist, nprob, max_ticks, done_counter, wave_step);
+        if (hasval) hipLaunchKernelGGL((k_solve_small<true, false, true>), dim3(nprob), dim3(1024), 0, st, parts, probs, qlist, nprob, max_ticks, done_counter, wave_step, grid_dots ? 1 : 0);
+        else hipLaunchKernelGGL((k_solve_small<false, false, true>), dim3(nprob), dim3(1024), 0, st, parts, probs, qlist, nprob, max_ticks, done_counter, wave_step, grid_dots ? 1 : 0);
         return;
     }
     // lds_doubles > 0: the work vectors of every problem fit in LDS (that many doubles for the largest) -> LDS-resident solve
@@ -3182,12 +3206,12 @@ void mlxk_solve_small(hipStream_t st, const PartDev *parts, ProbDev *probs, cons
             set_max_lds(reinterpret_cast<const void *>(&k_solve_small<false, true, false>), 150 * 1024);
         });
         const size_t bytes = (size_t)lds_doubles * sizeof(double);
-        if (hasval) hipLaunchKernelGGL((k_solve_small<true, true, false>), dim3(nprob), dim3(1024), bytes, st, parts, probs, qlist, nprob, max_ticks, done_counter, wave_step);
-        else hipLaunchKernelGGL((k_solve_small<false, true, false>), dim3(nprob), dim3(1024), bytes, st, parts, probs, qlist, nprob, max_ticks, done_counter, wave_step);
+        if (hasval) hipLaunchKernelGGL((k_solve_small<true, true, false>), dim3(nprob), dim3(1024), bytes, st, parts, probs, qlist, nprob, max_ticks, done_counter, wave_step, grid_dots ? 1 : 0);
+        else hipLaunchKernelGGL((k_solve_small<false, true, false>), dim3(nprob), dim3(1024), bytes, st, parts, probs, qlist, nprob, max_ticks, done_counter, wave_step, grid_dots ? 1 : 0);
         return;
     }
-    if (hasval) hipLaunchKernelGGL((k_solve_small<true, false, false>), dim3(nprob), dim3(1024), 0, st, parts, probs, qlist, nprob, max_ticks, done_counter, wave_step);
-    else hipLaunchKernelGGL((k_solve_small<false, false, false>), dim3(nprob), dim3(1024), 0, st, parts, probs, qlist, nprob, max_ticks, done_counter, wave_step);
+    if (hasval) hipLaunchKernelGGL((k_solve_small<true, false, false>), dim3(nprob), dim3(1024), 0, st, parts, probs, qlist, nprob, max_ticks, done_counter, wave_step, grid_dots ? 1 : 0);
+    else hipLaunchKernelGGL((k_solve_small<false, false, false>), dim3(nprob), dim3(1024), 0, st, parts, probs, qlist, nprob, max_ticks, done_counter, wave_step, grid_dots ? 1 : 0);
 }
 
 void mlxk_collect_c0(hipStream_t st, const PartDev *parts, const ProbDev *probs, const int *qlist, int nq,
