@@ -128,7 +128,7 @@ int mlx_set_numerics(mlx_handle h, int32_t mode);
  *   "numerics"            fast | reference_order | reference_order_one_launch          (= mlx_set_numerics)
  *   "tick_streams"        1..4   HIP streams the halves of the problem list tick on (default 2; re-tests the hardware queues)
  *   "stream_probe"        0 | 1  test that the tick streams sit on different hardware queues (default 1)
- *   "grid_rounded_dots"   0 | 1  d.Hd / r.r of the CSR step as grid-rounded sums (default 1; 0 = plain trees, A/B and tests)
+ *   "grid_rounded_dots"   0 | 1  d.Hd / r.r of every CSR solve (tick kernels and the one-launch solver of small partitions) as grid-rounded sums (default 1; 0 = plain trees, A/B and tests)
  *   "profile_one_stream"  0 | 1  with profiling on, all ticks on one stream (= mlx_set_profiling(h, 2))
  *   "one_launch_small"    0 | 1  small CSR problems solve in one launch (default 1); before mlx_finalize
  *   "small_ticks"         ticks one such launch may run before the host looks (default 16384)

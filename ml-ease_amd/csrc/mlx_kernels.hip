@@ -1326,25 +1326,20 @@ __device__ __forceinline__ double round_to_grid(double x, double u)
     return (fabs(x) < 1125899906842624.0 * u) ? (x + magic) - magic : x;      // (|x| >= 2^50 u, or u = 0: x as it is)
 }
 
-// The same dot for the one-workgroup solver (k_solve_small; its vectors are whole in front of the team): head sum of the first
-// STEP_HEAD columns, then every later term rounded to that sum's grid -- k_step_head + phase A / phase B of the tick kernels in one place.
-// (Every thread reads the elements it wrote itself in the loop before: j = tid mod nt in both.)
+// The same dot for the one-workgroup solver (k_solve_small; its vectors are whole in front of the team): the update loop in front adds
+// the terms of the first STEP_HEAD columns only (`head`), this adds every later term rounded to that sum's grid -- k_step_head + phase A /
+// phase B of the tick kernels in one place. (Multiples of u add exactly: head + tail is one rounding. Every thread reads the elements
+// it wrote itself in the loop before: j = tid mod nt in both.)
 template <typename T, typename VP>
-__device__ __forceinline__ double team_grid_dot(VP x, VP y, int n, double *scratch)
+__device__ __forceinline__ double team_grid_dot_tail(VP x, VP y, int n, double head, double *scratch)
 {
 #pragma clang fp contract(off)
-    const int tid = T::tid(), nt = T::nt();
-    double h[1] = {0.0};
-    for (int j = tid; j < min(n, STEP_HEAD); j += nt) h[0] += x[j] * y[j];
-    T::template allreduce<1>(h, scratch);
-    const double u = grid_of_sum(h[0]);
+    if (n <= STEP_HEAD) return head;
+    const double u = grid_of_sum(head);
     double a[1] = {0.0};
-    for (int j = tid; j < n; j += nt) {
-        const double term = x[j] * y[j];
-        a[0] += (j >= STEP_HEAD) ? round_to_grid(term, u) : term;
-    }
+    for (int j = STEP_HEAD + T::tid(); j < n; j += T::nt()) a[0] += round_to_grid(x[j] * y[j], u);
     T::template allreduce<1>(a, scratch);
-    return a[0];
+    return head + a[0];
 }
 
 // ---- order-faithful verification mode (MLX_FAITHFUL=1): every n- or l-long reduction is done by
@@ -1501,7 +1496,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
                 if (j < n) {
                     const double hd = dv[u] * pv[u] + xa[u];             // Hs[i] = (s[i]*priorVar_inv[i] + Hs[i]) * 1
                     Hd[j] = hd;
-                    a1[0] += dv[u] * hd;
+                    if (!grid_dots || j < STEP_HEAD) a1[0] += dv[u] * hd;
                 }
             }
         }
@@ -1509,7 +1504,7 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
         T::template allreduce<1>(a1, scratch);
         SPROF2(1);      // its reduction
         if (SEQ) a1[0] = seq_dot(pr.d, pr.Hd, n, scratch, stage);
-        else if (grid_dots) a1[0] = team_grid_dot<T>(d, Hd, n, scratch);       // the fast contract's d.Hd (grid_of_sum)
+        else if (grid_dots) a1[0] = team_grid_dot_tail<T>(d, Hd, n, a1[0], scratch);       // the fast contract's d.Hd (grid_of_sum)
         double alpha = rTr0 / a1[0];
         double ss1[1] = {0.0};
         for (int jb = tid; jb < n; jb += SB * nt) {
@@ -1567,13 +1562,13 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
                     if (j < n) {
                         const double rj = rv[u] + alpha * hv[u];
                         r[j] = rj;
-                        a2[0] += rj * rj;
+                        if (!grid_dots || j < STEP_HEAD) a2[0] += rj * rj;
                     }
                 }
             }
             T::template allreduce<1>(a2, scratch);
             if (SEQ) a2[0] = seq_dot(pr.r, pr.r, n, scratch, stage);
-            else if (grid_dots) a2[0] = team_grid_dot<T>(r, r, n, scratch);     // ... and its r'.r'
+            else if (grid_dots) a2[0] = team_grid_dot_tail<T>(r, r, n, a2[0], scratch);     // ... and its r'.r'
             const double rnew = a2[0];
             const double beta = rnew / rTr0;
             for (int jb = tid; jb < n; jb += SB * nt) {
@@ -1764,13 +1759,13 @@ __device__ __forceinline__ void tron_step_body(const PartDev &pa, ProbDev &pr, d
                 if (j < n) {
                     const double rj = -gv[u];
                     s[j] = 0.0; r[j] = rj; d[j] = rj;
-                    a2[0] += rj * rj;
+                    if (!grid_dots || j < STEP_HEAD) a2[0] += rj * rj;
                 }
             }
         }
         T::template allreduce<1>(a2, scratch);
         if (SEQ) a2[0] = seq_dot(pr.r, pr.r, n, scratch, stage);
-        else if (grid_dots) a2[0] = team_grid_dot<T>(r, r, n, scratch);         // ... and the r.r a trcg call starts from
+        else if (grid_dots) a2[0] = team_grid_dot_tail<T>(r, r, n, a2[0], scratch);         // ... and the r.r a trcg call starts from
         const double gn = gnorm_cur;      // ||r|| = ||-g|| = ||g||
         if (tid == 0) {
             pr.rTr = a2[0];
