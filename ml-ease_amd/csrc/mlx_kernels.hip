@@ -2782,7 +2782,8 @@ k_gram_f64(const float *__restrict__ X, int64_t ld, int l, const double *__restr
     const int split = blockIdx.y * 2 + grp;
     const int ii = lane & 15, kk = lane >> 4;
     const int m0 = bb.x * 128 + (wave >> 1) * 64, n0 = bb.y * 128 + (wave & 1) * 64;
-    const int r0 = min(l, split * rows_per_split), r1 = min(l, r0 + rows_per_split);
+    // (the row range is the same for a whole wave: as scalars, the row bases of the operand loads are scalar arithmetic too)
+    const int r0 = __builtin_amdgcn_readfirstlane(min(l, split * rows_per_split)), r1 = __builtin_amdgcn_readfirstlane(min(l, r0 + rows_per_split));
     d4_t acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; a++)
@@ -2796,31 +2797,42 @@ k_gram_f64(const float *__restrict__ X, int64_t ld, int l, const double *__restr
     const bool aq = cma <= nf;                                // the lane's A columns reach into [0, nf]
     // EDGE = the block touches column nf (the ones column) or the padding behind it: only those blocks (8 of 36 at n = 1001) pay
     // for the per-operand selects -- 96 v_cndmask per 64 MFMAs in the main loop of the one-size-fits-all form
+    // Two operand buffers of 4 KU rows used in turn (no register copies between them): while the 16 KU MFMAs of one run, the loads of
+    // the other -- issued a whole batch earlier -- land. (The first form rotated `next -> current` registers at the loop top; the
+    // compiler moved part of those copies into the body behind the fresh loads, so every trip waited for loads it had just issued.)
+    // Full batches run without any row test or clamp (uniform row base + one 32-bit lane offset); the last, partial batch of a split
+    // takes the clamped form once. (A ring of 8 single k-step slots refilled one by one -- loads issued 112 instead of 64 MFMAs ahead,
+    // pinned in place with sched_barrier -- was no faster: 0.650 against 0.665 of peak; profiles/r5_notes.md.)
+    struct GramOps { float4 a[KU], b[KU]; double q[KU]; };
+    const unsigned offa = (unsigned)kk * (unsigned)ld + (unsigned)cm, offb = (unsigned)kk * (unsigned)ld + (unsigned)cn;    // (< 2^31: 4 rows of the tile)
     auto run = [&](auto edge_tag) {
         constexpr bool EDGE = decltype(edge_tag)::value;
-        float4 ca[KU], cb[KU], na[KU], nb[KU];      // operands of the current / the next 4 KU rows
-        double cq[KU], nq[KU];
-        auto fetch = [&](int r) {
+        auto fetch_full = [&](GramOps &o, int r) {          // rows r .. r + 4 KU - 1, all below r1 (r uniform)
+#pragma unroll
+            for (int u = 0; u < KU; u++) {
+                const float *__restrict__ xr = X + (int64_t)(r + 4 * u) * ld;
+                o.a[u] = *reinterpret_cast<const float4 *>(xr + offa);
+                o.b[u] = *reinterpret_cast<const float4 *>(xr + offb);
+                o.q[u] = wd[r + 4 * u + kk];
+            }
+        };
+        auto fetch_tail = [&](GramOps &o, int r) {          // the split's last rows: beyond r1 the weight is 0 and the row clamped
 #pragma unroll
             for (int u = 0; u < KU; u++) {
                 const int row = r + 4 * u + kk;
                 const int rc = min(row, l - 1);
-                nq[u] = (row < r1 && (!EDGE || aq)) ? wd[rc] : 0.0;
+                o.q[u] = (row < r1) ? wd[rc] : 0.0;
                 const float *__restrict__ xr = X + (int64_t)rc * ld;
-                na[u] = *reinterpret_cast<const float4 *>(xr + cm);
-                nb[u] = *reinterpret_cast<const float4 *>(xr + cn);
+                o.a[u] = *reinterpret_cast<const float4 *>(xr + cm);
+                o.b[u] = *reinterpret_cast<const float4 *>(xr + cn);
             }
         };
-        if (r0 < r1) fetch(r0);
-        for (int r = r0; r < r1; r += 4 * KU) {
-#pragma unroll
-            for (int u = 0; u < KU; u++) { ca[u] = na[u]; cb[u] = nb[u]; cq[u] = nq[u]; }
-            if (r + 4 * KU < r1) fetch(r + 4 * KU);
+        auto compute = [&](const GramOps &o) {
 #pragma unroll
             for (int u = 0; u < KU; u++) {
-                const double qq = cq[u];
-                const double xa[4] = {(double)ca[u].x, (double)ca[u].y, (double)ca[u].z, (double)ca[u].w};
-                const double xb[4] = {(double)cb[u].x, (double)cb[u].y, (double)cb[u].z, (double)cb[u].w};
+                const double qq = (!EDGE || aq) ? o.q[u] : 0.0;
+                const double xa[4] = {(double)o.a[u].x, (double)o.a[u].y, (double)o.a[u].z, (double)o.a[u].w};
+                const double xb[4] = {(double)o.b[u].x, (double)o.b[u].y, (double)o.b[u].z, (double)o.b[u].w};
                 double a[4], b[4];
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
@@ -2833,7 +2845,22 @@ k_gram_f64(const float *__restrict__ X, int64_t ld, int l, const double *__restr
                     for (int nt = 0; nt < 4; nt++)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
             }
+        };
+        constexpr int BR = 4 * KU;
+        const int nfull = (r1 - r0) / BR;
+        GramOps A, B;
+        if (nfull > 0) {
+            fetch_full(A, r0);
+            int i = 0;
+            for (; i + 2 <= nfull; i += 2) {                 // A holds batch i
+                fetch_full(B, r0 + (i + 1) * BR);
+                compute(A);
+                fetch_full(A, r0 + min(i + 2, nfull - 1) * BR);       // (unconditional -- the last trip's may be a repeat: a branch here
+                compute(B);                                          //  makes compute(B) wait for ALL loads, the fresh ones included)
+            }
+            if (i < nfull) compute(A);
         }
+        if (r0 + nfull * BR < r1) { fetch_tail(A, r0 + nfull * BR); compute(A); }
     };
     if ((bb.x + 1) * 128 > nf) run(std::true_type{});        // (bb.y <= bb.x: the column range is never further out than the row range)
     else run(std::false_type{});
