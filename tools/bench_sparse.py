@@ -23,7 +23,7 @@ SEED = 20260925
 FIELDS, LEVELS = 20, 5000
 
 
-def gen(rows, partitions, rng):
+def gen(rows, partitions, rng, valued=False):
     """-> list of PartitionBlock (binary, partition-local ids), n_global."""
     from mlease_amd.dataset import PartitionBlock
     p = np.arange(1, LEVELS + 1, dtype=np.float64) ** -1.1
@@ -41,7 +41,10 @@ def gen(rows, partitions, rng):
         y = np.where(rng.random(l) < 1 / (1 + np.exp(-logit)), 1, -1).astype(np.int8)
         uniq, inv = np.unique(gid.reshape(-1), return_inverse=True)                 # partition-local compaction
         ci = np.sort(inv.reshape(l, FIELDS).astype(np.int32), axis=1).reshape(-1)
-        blocks.append(PartitionBlock(k, l, len(uniq) + 1, np.arange(0, (l + 1) * FIELDS, FIELDS, dtype=np.int64), ci, None, y,
+        val = None
+        if valued:      # (--valued: the same pattern with real values, for the HASVAL kernels; labels stay those of the binary model)
+            val = rng.lognormal(0.0, 0.3, l * FIELDS).astype(np.float32)
+        blocks.append(PartitionBlock(k, l, len(uniq) + 1, np.arange(0, (l + 1) * FIELDS, FIELDS, dtype=np.int64), ci, val, y,
                                      np.ones(l, np.float32), np.zeros(l, np.float32),
                                      np.concatenate([uniq.astype(np.int32), [ng - 1]]).astype(np.int32)))
     return blocks, ng
@@ -56,6 +59,7 @@ def main():
     ap.add_argument("--lambdas", type=str, default="1.0")
     ap.add_argument("--cpu-sample", type=int, default=0)
     ap.add_argument("--no-profile", action="store_true", help="no per-launch-class HIP events (needed for MLX_STREAMS=2)")
+    ap.add_argument("--valued", action="store_true", help="real-valued entries (the HASVAL kernels) instead of binary.feature")
     ap.add_argument("--check", type=int, default=0, help="verify the first N partitions' models of iteration 1 against the oracle")
     args = ap.parse_args()
 
@@ -65,7 +69,7 @@ def main():
 
     rng = np.random.default_rng(SEED)
     t0 = time.time()
-    blocks, ng = gen(args.rows, args.partitions, rng)
+    blocks, ng = gen(args.rows, args.partitions, rng, args.valued)
     tgen = time.time() - t0
     lam = sorted(float(x) for x in args.lambdas.split(","))
     rho = [1.0 if l <= 100 else 10.0 for l in lam]

@@ -52,6 +52,32 @@ def betas(o, P):
     return np.stack([o.partition_model(k, 0)[0] for k in range(P)])
 
 
+VB_FIELDS, VB_LEVELS = 12, 3000
+
+
+def valued_b_partition(pid, rows, seed=777):
+    """The second data set (--dataset valued_b): flatter level frequencies, fewer and valued entries per row, weights, offsets."""
+    rng = np.random.default_rng([seed, 3, pid])
+    p = np.arange(1, VB_LEVELS + 1, dtype=np.float64) ** -0.8
+    cdf = np.cumsum(p / p.sum())
+    beta = np.random.default_rng([seed, 2]).normal(0, 0.4, VB_FIELDS * VB_LEVELS)
+    ng = VB_FIELDS * VB_LEVELS + 1
+    lev = np.minimum(np.searchsorted(cdf, rng.random((rows, VB_FIELDS))), VB_LEVELS - 1).astype(np.int32)
+    gid = lev + (np.arange(VB_FIELDS, dtype=np.int32) * VB_LEVELS)[None, :]
+    val = rng.lognormal(0.0, 0.35, (rows, VB_FIELDS)).astype(np.float32)
+    logit = (beta[gid] * val).sum(axis=1) - 1.0
+    y = np.where(rng.random(rows) < 1 / (1 + np.exp(-logit)), 1, -1).astype(np.int8)
+    uniq, inv = np.unique(gid.reshape(-1), return_inverse=True)
+    loc = inv.reshape(rows, VB_FIELDS).astype(np.int32)
+    order = np.argsort(loc, axis=1, kind="stable")
+    ci = np.take_along_axis(loc, order, axis=1).reshape(-1)
+    vv = np.take_along_axis(val, order, axis=1).reshape(-1)
+    l2g = np.concatenate([uniq.astype(np.int32), [ng - 1]]).astype(np.int32)
+    wt = rng.uniform(0.5, 2.0, rows).astype(np.float32)
+    off = rng.normal(0, 0.2, rows).astype(np.float32)
+    return PartitionBlock(pid, rows, len(l2g), np.arange(0, (rows + 1) * VB_FIELDS, VB_FIELDS, dtype=np.int64), ci, vv, y, wt, off, l2g)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--partitions", type=int, default=8)
@@ -62,12 +88,20 @@ def main():
     ap.add_argument("--json", default="")
     ap.add_argument("--minimal", action="store_true", help="only the base oracle, the permuted oracles and (--gpu) the HIP path")
     ap.add_argument("--gpu", action="store_true", help="add the HIP product path (needs an MI355X) as one more variant")
+    ap.add_argument("--dataset", choices=["onehot", "valued_b"], default="onehot",
+                    help="onehot = tools/synth_data.onehot_partition (configs[2]); valued_b = a SECOND data set for the head-column choice of the "
+                         "grid-rounded dots: 12 fields x 3000 levels, Zipf exponent 0.8, 27 %% positives, real values, row weights and offsets")
+    ap.add_argument("--heads-only", action="store_true", help="only the permuted oracles and the grid-rounded-dot variants (head 64 / 256 / running prefix, trees)")
     a = ap.parse_args()
     P = a.partitions
     blocks, ng = [], None
     for k in range(P):
-        rp, ci, y, l2g, ng = sd.onehot_partition(k, a.rows)
-        blocks.append(PartitionBlock(k, a.rows, len(l2g), rp, ci, None, y, np.ones(a.rows, np.float32), np.zeros(a.rows, np.float32), l2g))
+        if a.dataset == "onehot":
+            rp, ci, y, l2g, ng = sd.onehot_partition(k, a.rows)
+            blocks.append(PartitionBlock(k, a.rows, len(l2g), rp, ci, None, y, np.ones(a.rows, np.float32), np.zeros(a.rows, np.float32), l2g))
+        else:
+            blocks.append(valued_b_partition(k, a.rows))
+            ng = VB_FIELDS * VB_LEVELS + 1
     L = ol.lib()
     L.orc_set_sum_mode.argtypes = [__import__("ctypes").c_int]
     base = ol.OracleAdmm(blocks, ng, [1.0], [1.0])
@@ -89,7 +123,7 @@ def main():
             rowid = np.repeat(np.arange(b.l, dtype=np.int64), np.diff(b.row_ptr))
             srt = np.lexsort((cols, rowid))
             l2g = np.concatenate([b.local_to_global[:nf][order], b.local_to_global[nf:]]).astype(np.int32)
-            return PartitionBlock(b.partition_id, b.l, b.n_local, b.row_ptr, cols[srt].astype(np.int32), None, b.y, b.weight, b.offset, l2g)
+            return PartitionBlock(b.partition_id, b.l, b.n_local, b.row_ptr, cols[srt].astype(np.int32), None if b.val is None else b.val[srt], b.y, b.weight, b.offset, l2g)
         fb = [freq_order(b) for b in blocks]
         for name, mode in (("freq_order", 0), ("freq_order+grid2048", 128), ("freq_order+grid2048+passes", 130), ("freq_order+tree+passes", 66)):
             variants[name] = (mode, ol.OracleAdmm(fb, ng, [1.0], [1.0]))
@@ -116,6 +150,10 @@ def main():
                   "fo:all sites grid,+passes": ({}, 130)}
     for name in ([] if a.minimal else site_mixes):
         variants[name] = (("mix", name), ol.OracleAdmm(fb, ng, [1.0], [1.0]))
+    if a.heads_only:
+        keep = ("perm", "freq_order", "fo:sites012=grid,345=tree,+passes", "fo:sites012=grid_first256,345=tree,+passes",
+                "fo:sites012=grid_first64,345=tree,+passes", "freq_order+tree+passes")
+        variants = {k: v for k, v in variants.items() if k.startswith("perm") and not k.startswith("perm+") or k in keep}
     e, mind = np.float32(0.01), 99999999.0
     out = []
     t0 = time.time()
@@ -166,9 +204,10 @@ def main():
             print("   gpu: equal %d (perms %d..%d)  median %.2e (perms %.2e..%.2e)  max %.2e (perms %.2e..%.2e)" % (
                 rec["gpu"]["equal"], min(p["equal"] for p in pe_), max(p["equal"] for p in pe_), rec["gpu"]["median"],
                 min(p["median"] for p in pe_), max(p["median"] for p in pe_), rec["gpu"]["max"], min(p["max"] for p in pe_), max(p["max"] for p in pe_)), flush=True)
-        if a.minimal:
+        if a.minimal or a.heads_only:
             mind = base.finish()[1]
             out.append(rec)
+            print("it %d eps %.3g cg/solve %.1f | %s  (%.0f s)" % (it, eps, rec["cg_per_solve"], {k: rec[k]["equal"] for k in variants}, time.time() - t0), flush=True)
             continue
         # `all` against `all+perm`: order independence of the compensated arithmetic itself
         ea = rel_err(betas(variants["all+perm"][1], P), betas(variants["all"][1], P))
@@ -188,7 +227,7 @@ def main():
         print("  %-22s %s  sum %d" % (name, [r[name]["equal"] for r in out], sum(r[name]["equal"] for r in out)))
     if a.json:
         with open(a.json, "w") as fh:
-            json.dump({"partitions": P, "rows": a.rows, "perms": a.perms, "per_iteration": out}, fh, indent=1)
+            json.dump({"partitions": P, "rows": a.rows, "perms": a.perms, "dataset": a.dataset, "per_iteration": out}, fh, indent=1)
 
 
 if __name__ == "__main__":
