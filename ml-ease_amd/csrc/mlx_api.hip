@@ -1411,7 +1411,12 @@ int mlx_finalize(mlx_handle h)
         int64_t total_groups = 0;
         for (auto &p : h->parts) if (!p.dense) total_groups += (int64_t)nl * p.n_rgroups;
         int ngc = 16;                                    // 16 * {1, 2, 4, 8}: the row pass is compiled for these group counts per wave
-        while (ngc < 128 && total_groups / ngc > 768) ngc *= 2;
+        // (valued partitions stop at 64: with 8 groups per wave the valued row kernel spills -- 70 scratch instructions in its loops;
+        //  a configs[2]-size valued job: 2 915 solves/s at 128 groups, 3 113 at 64, attic/tools/gpu_r5s.sh)
+        bool any_val = false;
+        for (auto &p : h->parts) if (!p.dense) any_val = any_val || p.hasval;
+        const int ngc_max = any_val ? 64 : 128;
+        while (ngc < ngc_max && total_groups / ngc > 768) ngc *= 2;
         if (const char *e = getenv("MLX_ROW_NG")) { ngc = 16; while (ngc < 128 && ngc < atoi(e)) ngc *= 2; }
         h->row_ngc = ngc;
         for (auto &p : h->parts) if (!p.dense) {

@@ -47,11 +47,13 @@ def main():
 
     def run(numerics, record_states=False, profile=False):
         t0 = time.perf_counter()
-        eng = HipAdmmEngine(ng, lam, rho, P, numerics=numerics)
+        opts = {"tick_streams": int(os.environ["RO_STREAMS"])} if (numerics == "reference_order" and os.environ.get("RO_STREAMS")) else None      # (A/B: tick streams of the reference-order handle)
+        eng = HipAdmmEngine(ng, lam, rho, P, numerics=numerics, options=opts)
         eng.add_partitions(blocks)
         eng.finalize()
         prep = time.perf_counter() - t0
         kern = eng.get_option("numerics_kernels")
+        sys.stderr.write("[ro_probe] %s: tick streams %s (probe rejects %s)\n" % (numerics, eng.get_option("tick_streams"), eng.get_option("stream_probe_rejects")))
         eps = 0.01
         per, states = [], []
         for it in range(iters):
