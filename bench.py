@@ -1106,7 +1106,7 @@ def sparse_timed_run(args, C, eng, blocks, lam, warmup, steps, snapshot):
     # every pass launch of this leg (finalize's c0 pass: one row + one column pass per partition, + warm-up + timed): what a
     # rocprofv3 run of this command sees, used to turn its FETCH_SIZE / WRITE_SIZE sums into bytes per algorithmic byte
     allrun = dict(alg=sum(2.0 * (4.0 * b.nnz + 8.0 * b.l + 8.0 * b.n_local) for b in blocks), ticks=1)
-    fin, snap, eps_all, step_s = None, None, [], []
+    fin, snap, eps_all, step_s, tick_logs = None, None, [], [], []
     eng.set_profiling(False)
     tstart = time.perf_counter()
     for it in range(1, warmup + steps + 1):
@@ -1128,6 +1128,7 @@ def sparse_timed_run(args, C, eng, blocks, lam, warmup, steps, snapshot):
         allrun["ticks"] += st.ticks
         if it > warmup:
             step_s.append(time.perf_counter() - ts)
+            tick_logs.append(eng.tick_log())
             acc["solves"] += st.solves; acc["cg"] += st.cg_iters; acc["newton"] += st.newton_iters
             acc["pref"] += st.x_passes_ref; acc["pdev"] += st.x_passes_dev; acc["ticks"] += st.ticks
             acc["alg"] += st.alg_bytes_dev
@@ -1169,9 +1170,34 @@ def sparse_timed_run(args, C, eng, blocks, lam, warmup, steps, snapshot):
     alone["wall"] = C["reduce_max"](time.perf_counter() - t0)
     eng.set_profiling(False)
     prof["alone"] = alone
+    prof["active_histogram"] = active_histogram(tick_logs, P * nl, sum(2.0 * (4.0 * b.nnz + 8.0 * b.l + 8.0 * b.n_local) for b in blocks) * nl)
     allrun["alg"] += alone["alg"]
     allrun["ticks"] += alone["ticks"]
     return acc, allrun, dt, fin, (snap if snapshot else None), eps_all, step_s, prof
+
+
+def active_histogram(tick_logs, nprob, alg_bytes_full_tick):
+    """How the active set shrinks over the solves of the timed iterations, and what the ticks achieve while it does (the library's
+    "tick_log": batches of four lock-step ticks with the number of finished problems -- read one batch late -- and the time the GPU
+    finished the batch). Per decile of the active share at the START of a batch: batches, ticks, their GPU time, and the algorithmic
+    bytes per second of those ticks -- a tick's bytes taken as (active problems / all) x the bytes of a tick with every problem
+    active (problems of a one-hot job are the same size to within a few percent)."""
+    bins = [{"active_share": "%d-%d %%" % (10 * i, 10 * i + 10), "batches": 0, "ticks": 0, "ms": 0.0, "alg_GB": 0.0} for i in range(10)]
+    for log in tick_logs:
+        for (t0, d0, u0), (t1, d1, u1) in zip(log[:-1], log[1:]):
+            act = max(0.0, 1.0 - d0 / max(1, nprob))
+            b = bins[min(9, int(act * 10))]
+            b["batches"] += 1
+            b["ticks"] += int(t1 - t0)
+            b["ms"] += (u1 - u0) * 1e-3
+            b["alg_GB"] += act * alg_bytes_full_tick * (t1 - t0) * 1e-9
+    out = []
+    for b in bins:
+        if b["batches"]:
+            out.append({"active_share": b["active_share"], "batches": b["batches"], "ticks": b["ticks"], "ms": round(b["ms"], 2),
+                        "us_per_tick": round(1e3 * b["ms"] / max(1, b["ticks"]), 1), "alg_GB_per_s": round(b["alg_GB"] / max(1e-9, b["ms"] * 1e-3), 1)})
+    return {"definition": "batches of 4 ticks by the share of unfinished problems at their start (done counts lag one batch); the first batch of a solve is not in the log",
+            "bins_high_to_low": out[::-1]}
 
 
 def sparse_rooflines(prof, n_mean, row_kernel, col_kernel):
@@ -1209,7 +1235,7 @@ def sparse_rooflines(prof, n_mean, row_kernel, col_kernel):
                  "us_per_tick": {"rowpass": round(1e3 * al["rms"] / max(1, al["ticks"]), 1), "colpass": round(1e3 * al["cms"] / max(1, al["ticks"]), 1),
                                  "step": round(1e3 * al["sms"] / max(1, al["ticks"]), 1)},
                  "wall_ms": round(al["wall"] * 1e3, 1), "ticks": al["ticks"]}
-    return {"measured_in": how, "alone": alone,
+    return {"measured_in": how, "alone": alone, "active_histogram": prof.get("active_histogram"),
             "kernels": [roof(row_kernel, prof["rbusy"], prof["rms"], half, "B_pass = nnz*4 + 8l + 8n per active problem; the cold column slices run as their own launch in front of the row kernel"),
                         roof(col_kernel, prof["cbusy"], prof["cms"], half, "B_pass = nnz*4 + 8l + 8n per active problem"),
                         roof("k_step_a+b+c+commit", prof["sbusy"], prof["sms"], 0.0,

@@ -135,7 +135,10 @@ int mlx_set_numerics(mlx_handle h, int32_t mode);
  *   "comm_always"         0 | 1  run the RCCL exchange at nranks == 1 too (tests)
  *   "trace"               0 | 1  tick progress and stream-probe results on stderr
  * mlx_get_option additionally answers "numerics_kernels" (after mlx_finalize: fast | reference_order_ticks |
- * reference_order_one_launch: what the handle actually runs) and "stream_probe_rejects". Unknown key: MLX_ERR_INVALID. */
+ * reference_order_one_launch: what the handle actually runs), "stream_probe_rejects" and "tick_log": the last solve's batches of
+ * four lock-step ticks as "ticks:done:us;..." -- ticks queued, problems finished (read one batch late) and microseconds since the
+ * solve's first launch when the GPU had finished that batch (monitoring: how the active set shrinks over a solve; give a buffer
+ * of a few KB). Unknown key: MLX_ERR_INVALID. */
 int mlx_set_option(mlx_handle h, const char *key, const char *value);
 int mlx_get_option(mlx_handle h, const char *key, char *out, size_t out_len);
 

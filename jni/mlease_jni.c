@@ -186,12 +186,16 @@ JFN(jstring, getOption)(JNIEnv *env, jobject self, jstring key)
 {
     mlx_handle h = handle_of(env, self);
     if (!key) { bad_arg(env, "getOption: key is null"); return NULL; }
-    char buf[64];
+    enum { CAP = 1 << 17 };                    /* ("tick_log" of a long solve is a few KB) */
+    char *buf = (char *)malloc(CAP);
+    if (!buf) { bad_arg(env, "getOption: out of memory"); return NULL; }
     const char *k = (*env)->GetStringUTFChars(env, key, NULL);
-    const int rc = k ? mlx_get_option(h, k, buf, sizeof buf) : MLX_ERR_INVALID;
+    const int rc = k ? mlx_get_option(h, k, buf, CAP) : MLX_ERR_INVALID;
     if (k) (*env)->ReleaseStringUTFChars(env, key, k);
-    if (rc) { throw_for(env, h, rc); return NULL; }
-    return (*env)->NewStringUTF(env, buf);
+    if (rc) { free(buf); throw_for(env, h, rc); return NULL; }
+    jstring out = (*env)->NewStringUTF(env, buf);
+    free(buf);
+    return out;
 }
 
 JFN(jstring, version)(JNIEnv *env, jclass cls)

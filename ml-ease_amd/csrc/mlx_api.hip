@@ -20,6 +20,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <chrono>
 
 #include "../../include/mlease_admm.h"
 #include "mlx_kernels.h"
@@ -119,6 +120,8 @@ struct mlx_context {
     int *h_donex = nullptr;                 // [MAX_TS][2] pinned
     int nstreams = 1;
     int stream_probe_rejects = 0;           // tick-stream candidates that shared a hardware queue with another tick stream (pick_tick_streams)
+    std::vector<double> tick_log;           // the last solve's batches: (ticks queued before the batch's done count was read, problems done, us since the solve's first launch) x n
+    std::chrono::steady_clock::time_point tick_t0;
     int small_ticks = SMALL_TICKS_PER_LAUNCH;   // ticks one k_solve_small launch may run (MLX_SMALL_TICKS: the tests shrink it to walk the relaunch path)
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
     std::vector<hipEvent_t> ev_pool;        // profiling: a chain of marks; the interval from mark i to mark i+1 belongs to ev_kind[i]
@@ -350,6 +353,8 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
         return run_ticks_small_more(h, first, count, qsmall, nqs, ticks_out);
     }
     if (nqs > 0) { launch_small(); HIPCHECK(h, hipGetLastError()); }
+    h->tick_log.clear();
+    h->tick_t0 = std::chrono::steady_clock::now();
     const int batch = 4;
     int64_t ticks = 0;
     int slot = 0;
@@ -421,6 +426,12 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
             for (int t = 1; t < NS; t++) {
                 HIPCHECK(h, hipEventSynchronize(h->ev_batchx[t][slot ^ 1]));
                 done = std::max(done, h->h_donex[t * 2 + (slot ^ 1)]);        // snapshots of ONE monotone counter: the largest is the latest
+            }
+            // (the host runs one batch ahead, so this moment is when the GPU finished the batch: the log's time differences are the
+            //  batches' durations -- mlx_get_option("tick_log"))
+            if (h->tick_log.size() < 3 * 4096) {
+                h->tick_log.push_back((double)(ticks - batch)); h->tick_log.push_back((double)done);
+                h->tick_log.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h->tick_t0).count());
             }
             if (h->trace) fprintf(stderr, "[mlx] ticks=%lld done=%d/%d\n", (long long)(ticks - batch), done, count);
             if (done >= count) break;      // the batch just queued runs as no-ops
@@ -712,6 +723,13 @@ int mlx_get_option(mlx_handle h, const char *key, char *out, size_t out_len)
     else if (k == "comm_always") v = h->comm_always ? "1" : "0";
     else if (k == "small_ticks") v = std::to_string(h->small_ticks);
     else if (k == "one_launch_small") v = h->use_small ? "1" : "0";
+    else if (k == "tick_log") {
+        char b[64];
+        for (size_t i = 0; i + 2 < h->tick_log.size(); i += 3) {
+            snprintf(b, sizeof b, "%.0f:%.0f:%.0f;", h->tick_log[i], h->tick_log[i + 1], h->tick_log[i + 2]);
+            v += b;
+        }
+    }
     else return fail(h, MLX_ERR_INVALID, "mlx_get_option: unknown key '%s'", key);
     if (v.size() + 1 > out_len) return fail(h, MLX_ERR_INVALID, "mlx_get_option: buffer too small");
     memcpy(out, v.c_str(), v.size() + 1);

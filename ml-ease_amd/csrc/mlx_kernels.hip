@@ -1027,7 +1027,10 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
         // slice of a configs[2] block); here 16 batches are in flight and the chain runs at the speed of the adds.
         __shared__ double relay_run[64];
         __shared__ volatile int relay_turn;
-        constexpr int PB = HASVAL ? 2 : 8, LONG_T = 64;
+#ifndef RO_LONG_T
+#define RO_LONG_T 64          // slices of more packs than this run as a relay (A/B: tools/ablate_build.sh -DRO_LONG_T=n)
+#endif
+        constexpr int PB = HASVAL ? 2 : 8, LONG_T = RO_LONG_T;
         for (; s0n < s1; s0n++) {
             const int b0 = __builtin_amdgcn_readfirstlane(gld(cs_ptr + s0n));
             const int L = (__builtin_amdgcn_readfirstlane(gld(cs_ptr + s0n + 1)) - b0) >> 8;
@@ -1071,6 +1074,7 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
             }
             __syncthreads();
         }
+        PT_MARK(12);
     }
     // (slice s0 + wave + 16 t: slices are sorted by length, so this deals the long ones evenly; batches of consecutive slices
     // per wave -- one offset load instead of 16 -- put a hot unit's 16 long slices on 2 waves: 196 -> 278 us)

@@ -213,10 +213,16 @@ class HipAdmmEngine:
             value = int(value)
         self._ck(self.L.mlx_set_option(self.h, str(key).encode(), str(value).encode()))
 
-    def get_option(self, key: str) -> str:
-        buf = C.create_string_buffer(64)
-        self._ck(self.L.mlx_get_option(self.h, str(key).encode(), buf, 64))
+    def get_option(self, key: str, size: int = 64) -> str:
+        buf = C.create_string_buffer(size)
+        self._ck(self.L.mlx_get_option(self.h, str(key).encode(), buf, size))
         return buf.value.decode()
+
+    def tick_log(self):
+        """The last solve_local's batches of 4 ticks: [(ticks queued, problems done, us since the solve's first launch), ...] -- the
+        done counts are read one batch late, the time differences are the batches' durations on the GPU."""
+        s = self.get_option("tick_log", 1 << 17)
+        return [tuple(float(x) for x in rec.split(":")) for rec in s.split(";") if rec]
 
     def set_profiling(self, enable, one_stream: bool = False):
         """Per-launch-class HIP events on / off (every tick stream carries its own chain of marks). one_stream=True also keeps all ticks

@@ -1404,3 +1404,28 @@ def test_reference_order_numerics_cover_the_remaining_solver_modes(c1, variant):
                 for a, b in zip(eng.partition_model(k, li), oc.partition_model(k, li)):
                     assert np.array_equal(a, b), "%s iteration %d partition %d lambda %d" % (variant, it + 1, k, li)
     eng.close()
+
+
+def test_tick_log_shows_the_active_set_shrinking():
+    """mlx_get_option("tick_log") (round 5, the verdict's "active problems per tick"): the batches of four lock-step ticks of the last
+    solve with the number of finished problems and the time the GPU finished each batch. 16 one-hot partitions of 12 000 rows on the
+    tick kernels: the log is monotone in all three columns, ends with every problem done, and covers the ticks the solve reports."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth_data as sd
+    from mlease_amd.dataset import PartitionBlock
+    blocks, ng = [], None
+    for k in range(16):
+        rp, ci, y, l2g, ng = sd.onehot_partition(k, 12000)
+        blocks.append(PartitionBlock(k, 12000, len(l2g), rp, ci, None, y, np.ones(12000, np.float32), np.zeros(12000, np.float32), l2g))
+    eng = HipAdmmEngine(ng, [1.0, 30.0], [1.0, 1.0], 16)
+    eng.add_partitions(blocks)
+    eng.finalize()
+    assert eng.get_option("numerics_kernels") == "fast"
+    st = eng.iterate(0.01)
+    log = eng.tick_log()
+    assert len(log) >= 2
+    a = np.array(log)
+    assert np.all(np.diff(a[:, 0]) == 4) and np.all(np.diff(a[:, 1]) >= 0) and np.all(np.diff(a[:, 2]) > 0)
+    assert a[-1, 1] == 32 and a[0, 1] < 32                     # every (partition, lambda) problem done at the end, not at the start
+    assert a[-1, 0] + 4 <= st.ticks <= a[-1, 0] + 8            # (the host queues one batch ahead of the count it reads)
+    eng.close()

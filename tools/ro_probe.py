@@ -27,6 +27,9 @@ import synth_data as sd  # noqa: E402
 import oracle_lib as ol  # noqa: E402
 
 
+LIBS = []
+
+
 def cnts(o):
     return np.array([(s.newton_iters, s.accepted, s.cg_iters, s.x_passes) for s in o.stats()], np.int32)
 
@@ -53,6 +56,7 @@ def main():
         eng.finalize()
         prep = time.perf_counter() - t0
         kern = eng.get_option("numerics_kernels")
+        LIBS.append(eng.L)
         sys.stderr.write("[ro_probe] %s: tick streams %s (probe rejects %s)\n" % (numerics, eng.get_option("tick_streams"), eng.get_option("stream_probe_rejects")))
         eps = 0.01
         per, states = [], []
@@ -81,8 +85,19 @@ def main():
         eng.close()
         return {"kernels": kern, "prep_s": round(prep, 1), "per_iteration": per, "one_stream_profile_of_next_iteration": prof}, states
 
-    out["fast"], _ = run("fast", profile=True)
-    out["reference_order"], states = run("reference_order", record_states=True, profile=True)
+    if os.environ.get("RO_ONLY") == "1":      # (timing-experiment builds: only the reference-order handle's workgroups in the phase sums)
+        out["reference_order"], states = run("reference_order", record_states=True, profile=False)
+        out["fast"] = out["reference_order"]
+    else:
+        out["fast"], _ = run("fast", profile=True)
+        out["reference_order"], states = run("reference_order", record_states=True, profile=True)
+    try:                                         # timing-experiment builds only (tools/ablate_build.sh -DMLX_PHASE_TIMING)
+        import ctypes
+        pt = (ctypes.c_double * 16)()
+        if LIBS[-1].mlx_debug_phase_times(pt) == 0:
+            out["phase_us_sum_over_workgroups"] = [round(v, 1) for v in pt]
+    except Exception:
+        pass
     f = np.mean([x["solves_per_s"] for x in out["fast"]["per_iteration"][1:]] or [0])
     r = np.mean([x["solves_per_s"] for x in out["reference_order"]["per_iteration"][1:]] or [0])
     out["solves_per_s_after_first_iteration"] = {"fast": round(float(f), 1), "reference_order": round(float(r), 1), "ratio": round(float(f / max(r, 1e-9)), 2)}
