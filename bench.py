@@ -133,7 +133,7 @@ def main():
     ap.add_argument("--sweep-partitions", type=int, default=128, help="partitions per GPU of the lambda-sweep leg")
     ap.add_argument("--sweep-steps", type=int, default=3)
     ap.add_argument("--sweep-warmup", type=int, default=1)
-    ap.add_argument("--sweep-cpu-sample", type=int, default=8, help="partitions (x 8 lambdas) of the lambda-sweep CPU / parity sample (0 = skip)")
+    ap.add_argument("--sweep-cpu-sample", type=int, default=32, help="partitions (x 8 lambdas) of the lambda-sweep CPU / parity sample (0 = skip)")
     ap.add_argument("--full-json", default="", help="where the full record goes (default: bench_full.json beside bench.py, + gpurun_out/)")
     ap.add_argument("--envelope-partitions", type=int, default=32, help="partitions of the sparse leg's permutation envelope")
     ap.add_argument("--envelope-perms", type=int, default=8, help="permuted oracles of that envelope")

@@ -63,13 +63,14 @@ def main():
         for it in range(iters):
             if record_states:
                 Z = eng.z()[0].copy()
-                u = np.stack([np.stack([eng.partition_model(k, li)[2] for li in range(nl)]) for k in range(nv)]) if it else np.zeros((nv, nl, ng), np.float32)
+                u = np.stack([np.stack([eng.partition_model(k, li)[2] for li in range(nl)]) for k in range(nv)]) if (it and nv) else np.zeros((nv, nl, ng), np.float32)
             t0 = time.perf_counter()
             st = eng.solve_local(eps, 1.0)
             dt = time.perf_counter() - t0
             if record_states:
                 pm = [eng.partition_model(k, li) for k in range(nv) for li in range(nl)]
-                states.append((Z, u, eps, np.stack([m[0] for m in pm]), np.stack([m[1] for m in pm]), eng.solve_counters()[:nv * nl].copy()))
+                if nv:
+                    states.append((Z, u, eps, np.stack([m[0] for m in pm]), np.stack([m[1] for m in pm]), eng.solve_counters()[:nv * nl].copy()))
             fin = eng.consensus_finish()
             per.append({"it": it + 1, "s": round(dt, 4), "solves_per_s": round(st.solves / dt, 1), "ticks": int(st.ticks), "cg": int(st.cg_iters),
                         "newton": int(st.newton_iters), "maxdiff": fin.maxdiff})
