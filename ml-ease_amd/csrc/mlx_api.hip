@@ -778,7 +778,7 @@ int mlx_set_regularizer(mlx_handle h, int32_t regularizer)
 struct CsrPrep {
     PartHost ph;
     std::vector<int32_t> rp, pcol, cri, item_ptr, item_dst, col_ptr, ishort, ilong, l2g_perm, rs_ptr, cs_ptr, cw_blk, cw_slice;
-    std::vector<int32_t> item_init, item_last;   // reference-order numerics on the tick kernels (PartDev::item_init / item_last)
+    std::vector<int32_t> item_init, item_last, item_chain;   // reference-order numerics on the tick kernels (PartDev::item_init / item_last / item_chain)
     std::vector<uint16_t> rs_idx, cs_idx;
     std::vector<float> pvalv, cval, rs_val, cs_val;
     std::vector<int32_t> rowperm;            // library row i = the caller's row rowperm[i] (empty: identity)
@@ -1020,17 +1020,22 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
             if (item_col[(size_t)it] >= 0) item_dst[(size_t)it] = nxt[(size_t)item_col[(size_t)it]]++;
         ph.n_slots = col_ptr[(size_t)nf];
     }
-    std::vector<int32_t> item_init, item_last;
+    std::vector<int32_t> item_init, item_last, item_chain;
     if (ro == 1) {
-        // a column's slots are in block order (one item per block at most): the item of a later block continues the earlier sum
-        item_init.assign((size_t)ph.n_items, -1); item_last.assign((size_t)ph.n_items, -1);
+        // One item per column and block at most: the item of a later block continues the sum of the column's item in the block before.
+        // The hand-over goes through a slot array indexed by the RECEIVING item (item_chain[t] = the column's next item, -1: none; the
+        // receiver reads slot t itself: item_init[t] = t, -1: starts from 0.0), so the reads of a slice's 64 lanes are one contiguous
+        // 512-byte load and the scatter is on the writing side, where nothing waits for it (indexed by the column's slot, the reads
+        // were 8-byte gathers: the launch of the second block took 435 us against 333 for the first, longer block).
+        item_init.assign((size_t)ph.n_items, -1); item_last.assign((size_t)ph.n_items, -1); item_chain.assign((size_t)ph.n_items, -1);
+        std::vector<int32_t> prev((size_t)nf, -1);
         for (int it = 0; it < ph.n_items; it++) {
             const int32_t c = item_col[(size_t)it];
             if (c < 0) continue;
-            const int32_t slot = item_dst[(size_t)it];
-            if (slot > col_ptr[(size_t)c]) item_init[(size_t)it] = slot - 1;
-            if (slot == col_ptr[(size_t)c + 1] - 1) item_last[(size_t)it] = c;
+            if (prev[(size_t)c] >= 0) { item_chain[(size_t)prev[(size_t)c]] = it; item_init[(size_t)it] = it; }
+            prev[(size_t)c] = it;
         }
+        for (int j = 0; j < nf; j++) if (prev[(size_t)j] >= 0) item_last[(size_t)prev[(size_t)j]] = j;
     }
     cri.swap(cri_b);
     cval.swap(cval_b);
@@ -1172,7 +1177,7 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
     P.hasval = (val != nullptr);
     P.rp = std::move(rp); P.pcol = std::move(pcol); P.pvalv = std::move(pvalv); P.cri = std::move(cri); P.cval = std::move(cval);
     P.item_ptr = std::move(item_ptr); P.item_dst = std::move(item_dst); P.col_ptr = std::move(col_ptr); P.ishort = std::move(ishort); P.ilong = std::move(ilong);
-    P.item_init = std::move(item_init); P.item_last = std::move(item_last);
+    P.item_init = std::move(item_init); P.item_last = std::move(item_last); P.item_chain = std::move(item_chain);
     P.l2g_perm = std::move(l2g_perm);
     P.rowperm = std::move(rowperm);
     P.rs_ptr = std::move(rs_ptr); P.rs_idx = std::move(rs_idx); P.rs_val = std::move(rs_val);
@@ -1222,12 +1227,13 @@ static int commit_csr(mlx_handle h, CsrPrep &P, int32_t l, int32_t n_local, int6
         ph.dev.rs_ptr = d_a; ph.dev.rs_idx = d_b; ph.dev.cs_ptr = d_c; ph.dev.cs_idx = d_d; ph.dev.cw_blk = d_e; ph.dev.cw_slice = d_h; ph.dev.n_cunits = ph.n_cunits;
         ph.dev.rs_val = d_f; ph.dev.cs_val = d_g;
     }
-    ph.dev.item_init = nullptr; ph.dev.item_last = nullptr;
+    ph.dev.item_init = nullptr; ph.dev.item_last = nullptr; ph.dev.item_chain = nullptr;
     if (!P.item_init.empty()) {
-        int32_t *d_ii, *d_il;
+        int32_t *d_ii, *d_il, *d_ic;
         if ((rc = dev_upload(h, &d_ii, P.item_init.data(), P.item_init.size()))) return rc;
         if ((rc = dev_upload(h, &d_il, P.item_last.data(), P.item_last.size()))) return rc;
-        ph.dev.item_init = d_ii; ph.dev.item_last = d_il;
+        if ((rc = dev_upload(h, &d_ic, P.item_chain.data(), P.item_chain.size()))) return rc;
+        ph.dev.item_init = d_ii; ph.dev.item_last = d_il; ph.dev.item_chain = d_ic;
     }
     ph.dev.items_short = d_ishort; ph.dev.items_long = d_ilong; ph.dev.n_short = ph.n_short; ph.dev.n_long = ph.n_long;
     ph.dev.item_ptr = d_item; ph.dev.item_dst = d_itemdst; ph.dev.col_ptr = d_colptr; ph.dev.n_slots = ph.n_slots; ph.dev.l2g = d_l2g; ph.dev.X = nullptr;

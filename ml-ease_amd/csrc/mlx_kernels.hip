@@ -1008,7 +1008,7 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     const uint16_t *__restrict__ cs_idx = pa.cs_idx;
     const float *__restrict__ cs_val = pa.cs_val;
     const int32_t *__restrict__ cs_ptr = pa.cs_ptr;
-    const int32_t *__restrict__ item_dst = pa.item_dst;
+    const int32_t *__restrict__ item_dst = RO ? pa.item_chain : pa.item_dst;      // (RO: where the running sum is handed on, PartDev::item_chain)
     double *__restrict__ out = pr.parts;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // COL_B item slices per wave and round: their offsets, then their destinations and first packs, are fetched together

@@ -73,6 +73,7 @@ struct PartDev {
     // its sum densely at xtc[item_last[t]] (item_last[t] = column id, -1 otherwise). The column pass runs once per row block.
     const int32_t *item_init;  // [n_items] or nullptr
     const int32_t *item_last;  // [n_items] or nullptr
+    const int32_t *item_chain; // [n_items] or nullptr: where an item hands its sum on (the slot of the column's item in the next block it has rows in, -1: none)
     int32_t rowgroup;      // lanes per row in the CSR row pass (8..64)
     const int8_t *y;       // +1/-1
     const float *wt;       // instance weight
