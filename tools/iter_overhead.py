@@ -25,5 +25,5 @@ for it in range(12):
     if it > 4: eps = max(eps / 10, 1e-12)
     t0 = time.perf_counter(); st = eng.solve_local(eps, 1.0); t1 = time.perf_counter()
     fin = eng.consensus_finish(); t2 = time.perf_counter()
-    print("it %2d eps %.0e ticks %3d solve_local %.3f ms (device total %.3f, xpass %.3f, step %.3f) finish %.3f ms" % (
-        it + 1, eps, st.ticks, (t1 - t0) * 1e3, st.total_ms, st.xpass_ms, st.step_ms, (t2 - t1) * 1e3))
+    print("it %2d eps %.0e ticks %3d solve_local %.3f ms (device total %.3f, xpass busy %.3f, step busy %.3f) finish %.3f ms" % (
+        it + 1, eps, st.ticks, (t1 - t0) * 1e3, st.total_ms, st.xpass_busy_ms, st.step_busy_ms, (t2 - t1) * 1e3))
