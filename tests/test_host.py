@@ -492,6 +492,22 @@ def test_bench_roofline_keys_are_frozen():
     assert 'roof = {"bound": "hbm", "kernel": "k_xpass_dense<4,4>", "achieved": alone["achieved"]' in src      # frac comes from the one-stream replay
 
 
+def test_bench_active_histogram_bins_the_tick_log():
+    """bench.py turns the library's tick_log (batches of four ticks: ticks queued, problems done -- read one batch late --, GPU time)
+    into ticks, time and algorithmic bytes per second by the share of unfinished problems at the start of a batch."""
+    import bench
+    # 100 problems; a full tick moves 1e9 algorithmic bytes; three batches at 100 % active (400 us each), one at 50 %, one at 5 %
+    log = [(4, 0, 400.0), (8, 0, 800.0), (12, 0, 1200.0), (16, 50, 1600.0), (20, 95, 1800.0), (24, 100, 1820.0)]
+    h = bench.active_histogram([log, log], 100, 1e9)
+    bins = {b["active_share"]: b for b in h["bins_high_to_low"]}
+    assert list(bins) == ["90-100 %", "50-60 %", "0-10 %"]            # high to low; empty bins left out
+    top = bins["90-100 %"]
+    assert top["batches"] == 6 and top["ticks"] == 24 and abs(top["ms"] - 2.4) < 1e-9 and top["us_per_tick"] == 100.0
+    assert abs(top["alg_GB_per_s"] - 10000.0) < 1e-6                  # 24 ticks x 1e9 bytes / 2.4 ms
+    assert bins["50-60 %"]["ticks"] == 8 and abs(bins["50-60 %"]["alg_GB_per_s"] - 0.5 * 8e9 / 0.4e-3 / 1e9) < 1e-6
+    assert bins["0-10 %"]["ticks"] == 8 and bins["0-10 %"]["us_per_tick"] == 5.0
+
+
 def test_bench_and_tools_call_only_names_that_exist():
     """bench.py cannot run here (no GPU), so a function lost in an edit shows up only on the GPU box (round 4: run_sparse).
     Static check: every plain-name call in bench.py and the tools resolves to a definition, an import, an assignment or a builtin."""
