@@ -8,18 +8,20 @@
 //     other, one thread per row, one running sum over the row's entries in ascending column id, the bias entry last;
 //   * column sums (XTv, :131-150): k_colpass_lds<.., RO>, one launch per row block in block order; an item = ALL entries of a column
 //     inside the block, one thread per item, rows ascending, started from the sum the column reached in the earlier blocks
-//     (PartDev::item_init) -- one chain per column over all its rows; the intercept's column is one lane's chain over the staged
-//     coefficients (csump[block]);
+//     (handed on through PartDev::item_chain / item_init: the writer scatters, the reader loads its own slot) -- one chain per column
+//     over all its rows; the longest slices run as a relay over the workgroup's 16 waves; the intercept's column (the sum of the row
+//     coefficients in row order) is one more folding lane of the step's first pass;
 //   * every n- or l-long dot / norm / loss sum of Tron.tron / trcg / fun (bw/Tron.java:30-252, llf/LogisticRegressionL2.java:156-193):
-//     k_ro_step below -- one 256-thread workgroup per problem walks the vectors in chunks of 1024 elements; all threads do the
-//     elementwise work of the chunk (the daxpy / scale statements, Hs[i] = s[i]*priorVar_inv[i] + Hs[i], the products a[i]*b[i] of
-//     Tron.dot) and leave the chunk's TERMS in LDS; up to six lanes of the first wave then fold one term array each IN INDEX ORDER
-//     (p += term: the loop of Tron.dot :204-213), so the six reductions a CG step needs at once cost one chain, not six.
+//     k_ro_step below -- one 320-thread workgroup per problem walks the vectors in chunks of 1024 elements; waves 1-4 do the
+//     elementwise work of a chunk (the daxpy / scale statements, Hs[i] = s[i]*priorVar_inv[i] + Hs[i], the products a[i]*b[i] of
+//     Tron.dot) and leave the chunk's TERMS in one of two LDS buffers; up to six lanes of wave 0 meanwhile fold one term array each IN
+//     INDEX ORDER out of the other buffer (p += term: the loop of Tron.dot :204-213), so the six reductions a CG step needs at once
+//     cost one chain, not six, and the staging costs the chain nothing.
 //     euclideanNorm (:220-252) keeps a running scale: its update is `sum = 1 + sum*(scale/a)^2` when |v_i| exceeds the scale and
 //     `sum += (a/scale)^2` otherwise. The scale before element i is the running maximum of |v| -- an exclusive prefix maximum, exact
 //     in any association -- so the chunk's threads compute it by a scan, form every element's (m, c) with sum' = c + sum*m in
-//     parallel (the divisions are off the chain), and the folding lane runs the chain; chunks without a new maximum (all but the
-//     first few) take the plain `sum += c` loop.
+//     parallel (the divisions are off the chain), and the folding lane runs the chain; 32-term sub-blocks without a new maximum
+//     (all but ~ln n of them) take the plain `sum += c` loop.
 //   * exp / log1p: the portable forms of portable_math.h, as the oracle's verification twin evaluates them (device and host libm
 //     differ in the last bit).
 // Same statements in the same order as tron_step_body<SEQ> (which is bit-identical to the oracle): the tests run both.
