@@ -27,14 +27,18 @@
 // Same statements in the same order as tron_step_body<SEQ> (which is bit-identical to the oracle): the tests run both.
 #pragma once
 
-constexpr int RO_T = 320, RO_CH = 1024, RO_CHP = RO_CH + 2, RO_NF = 6, RO_NN = 2;      // one folding wave + four staging waves
+#ifndef RO_CHUNK
+#define RO_CHUNK 1024        // elements per chunk (a multiple of 256: one staging wave per 256; A/B: tools/ablate_build.sh -DRO_CHUNK=512)
+#endif
+constexpr int RO_CH = RO_CHUNK, RO_NSW = RO_CH / 256, RO_T = 64 * (1 + RO_NSW), RO_CHP = RO_CH + 2, RO_NF = 6, RO_NN = 2;      // one folding wave + RO_NSW staging waves
+static_assert(RO_CH % 256 == 0 && RO_NSW >= 1 && RO_NSW <= 4, "chunk = 256 elements per staging wave, at most 32 sub-blocks of 32 terms");
 struct RoLds {
     double C[2][RO_NF][RO_CHP];    // terms of a chunk, one array per folding lane (norm arrays first); two buffers: folded / being staged
     double M[2][RO_NN][RO_CHP];    // multipliers of the norm arrays (1.0 except where the running scale changes)
-    double wtot[RO_NN][4];         // scan: the staging waves' maxima of the chunk being staged
+    double wtot[RO_NN][RO_NSW];    // scan: the staging waves' maxima of the chunk being staged
     double res[RO_NF], mcfin[RO_NN];
-    volatile int seq[4];           // chunk number (+ 1) each staging wave has published its maximum for
-    unsigned mask8[2][4];          // per buffer and staging wave, bit k: terms 32 k .. 32 k + 31 of its quarter hold a change of a running scale
+    volatile int seq[RO_NSW];      // chunk number (+ 1) each staging wave has published its maximum for
+    unsigned mask8[2][RO_NSW];     // per buffer and staging wave, bit k: terms 32 k .. 32 k + 31 of its 256 hold a change of a running scale
     double pad[64];                // ro_fold32 reads up to 48 doubles ahead of the last term it adds
 };
 struct RoV4 { double v[4]; };
@@ -180,7 +184,7 @@ __device__ __forceinline__ void ro_pass(RoLds &sh, int len, const int *lens, con
     // running maximum of a norm's operand among themselves: each publishes its quarter's maximum in LDS and its chunk number behind it
     // (sh.seq), and reads the others' when all four numbers are there.
     const bool folder = wave == 0;
-    const int sw = wave - 1, stid = tid - 64;                 // staging wave 0..3, staging thread 0..255
+    const int sw = wave - 1, stid = tid - 64;                 // staging wave 0..RO_NSW-1, staging thread 0..RO_CH/4-1
     const int nch = (len + RO_CH - 1) / RO_CH;
     const int mylen = (folder && lens != nullptr) ? lens[lane < NF ? lane : 0] : len;      // (wave 0: the array this lane folds)
     double acc = 0.0;
@@ -213,14 +217,14 @@ __device__ __forceinline__ void ro_pass(RoLds &sh, int len, const int *lens, con
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) sh.seq[sw] = c + 1;
-            for (int w = 0; w < 4; w++) while (sh.seq[w] < c + 1) __builtin_amdgcn_s_sleep(1);
+            for (int w = 0; w < RO_NSW; w++) while (sh.seq[w] < c + 1) __builtin_amdgcn_s_sleep(1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
             for (int q = 0; q < NN; q++) {
                 double ex = __shfl_up(x[q], 1);
                 if (lane == 0) ex = 0.0;
                 double P = fmax(mc[q], ex);
-                for (int w = 0; w < 4; w++) {
+                for (int w = 0; w < RO_NSW; w++) {
                     const double t = sh.wtot[q][w];
                     if (w < sw) P = fmax(P, t);
                     mc[q] = fmax(mc[q], t);
@@ -253,7 +257,7 @@ __device__ __forceinline__ void ro_pass(RoLds &sh, int len, const int *lens, con
             cp[0] = (d2v_t){ct[k][0], ct[k][1]}; cp[1] = (d2v_t){ct[k][2], ct[k][3]};
         }
     };
-    if (NN > 0 && tid < 4) sh.seq[tid] = 0;
+    if (NN > 0 && tid < RO_NSW) sh.seq[tid] = 0;
     __syncthreads();
     if (!folder) stage(0);
     __syncthreads();
@@ -266,7 +270,11 @@ __device__ __forceinline__ void ro_pass(RoLds &sh, int len, const int *lens, con
             const double *cp = &sh.C[b][lane][0];
             const double *mp = &sh.M[b][lane < NN ? lane : 0][0];
             const bool isn = lane < NN;
-            const unsigned mask = NN > 0 ? (sh.mask8[b][0] | (sh.mask8[b][1] << 8) | (sh.mask8[b][2] << 16) | (sh.mask8[b][3] << 24)) : 0u;
+            unsigned mask = 0u;
+            if (NN > 0) {
+#pragma unroll
+                for (int w = 0; w < RO_NSW; w++) mask |= sh.mask8[b][w] << (8 * w);
+            }
             double s = acc;
             // p += term: ONE dependent add per element. Sub-blocks of 32 terms common to the folding lanes run in ro_fold32 (the LDS
             // reads of the next 16 terms in flight while 16 are added) -- except the few sub-blocks in which a norm's running scale
