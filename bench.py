@@ -1000,6 +1000,8 @@ def dense_ro_leg(C, sample, states, nf, N):
                 out["solves_bit_identical_beta_and_uplusx"] += int(np.array_equal(gb, ob) and np.array_equal(gu, ou))
         out["value"] = round(out["solves"] / max(1e-9, out["gpu_seconds"]), 1)
         out["unit"] = "solves/s"
+        out["value_is"] = ("a parity check with %d problems on the chip (every launch of a tick is latency-bound at that count), not the mode's throughput: "
+                           "that is sparse.reference_order, 256 problems side by side" % nb)
         out["gpu_seconds"] = round(out["gpu_seconds"], 3); out["cpu_seconds"] = round(out["cpu_seconds"], 2)
         eng.close()
         return out
