@@ -768,6 +768,9 @@ __device__ __forceinline__ void sell_gather_round(double *a, const uint16_t *__r
 #ifndef ROW_KP
 #define ROW_KP 1       // packs per group and round of the hot slice
 #endif
+#ifndef RO_LONG_T
+#define RO_LONG_T 64   // reference-order column pass: slices of more packs than this run as a relay over the workgroup's waves (16 / 32 / 64: no difference, profiles/r5_notes.md)
+#endif
 // RO (reference-order numerics, mlx_ro_kernels.h): every slice is hot, so a row's entries join ONE running sum in ascending column
 // id -- Xv's order (llf/LogisticRegressionL2.java:115-129); the row map evaluates the portable exp / log1p the oracle's twin uses and
 // leaves the row's loss in rowtmp[] for the step's sequential fold; no per-group partial sums.
@@ -1027,9 +1030,6 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
         // slice of a configs[2] block); here 16 batches are in flight and the chain runs at the speed of the adds.
         __shared__ double relay_run[64];
         __shared__ volatile int relay_turn;
-#ifndef RO_LONG_T
-#define RO_LONG_T 64          // slices of more packs than this run as a relay (A/B: tools/ablate_build.sh -DRO_LONG_T=n)
-#endif
         constexpr int PB = HASVAL ? 2 : 8, LONG_T = RO_LONG_T;
         for (; s0n < s1; s0n++) {
             const int b0 = __builtin_amdgcn_readfirstlane(gld(cs_ptr + s0n));
