@@ -508,6 +508,20 @@ def test_bench_active_histogram_bins_the_tick_log():
     assert bins["0-10 %"]["ticks"] == 8 and bins["0-10 %"]["us_per_tick"] == 5.0
 
 
+def test_every_option_key_the_library_accepts_is_documented_in_the_header():
+    """what a host can choose per handle lives in the C-ABI. Static check: every key mlx_set_option / mlx_get_option
+    compare against in mlx_api.hip is named in include/mlease_admm.h (and so reaches the JNI and job-file users)."""
+    import re
+    src = open(os.path.join(ROOT, "ml-ease_amd", "csrc", "mlx_api.hip")).read()
+    a = src.index("int mlx_set_option(")
+    b = src.index("int mlx_set_profiling(")
+    keys = set(re.findall(r'k == "([a-z_]+)"', src[a:b]))
+    assert {"numerics", "tick_streams", "grid_rounded_dots", "numerics_kernels", "tick_log"} <= keys
+    hdr = open(os.path.join(ROOT, "include", "mlease_admm.h")).read()
+    missing = [k for k in sorted(keys) if '"%s"' % k not in hdr]
+    assert not missing, missing
+
+
 def test_bench_and_tools_call_only_names_that_exist():
     """bench.py cannot run here (no GPU), so a function lost in an edit shows up only on the GPU box (round 4: run_sparse).
     Static check: every plain-name call in bench.py and the tools resolves to a definition, an import, an assignment or a builtin."""
