@@ -117,7 +117,9 @@ int mlx_set_profiling(mlx_handle h, int enable);
  * norms in index order -- on the same tick kernels (csrc/mlx_ro_kernels.h), with exp / log1p evaluated by portable +,-,*,/
  * sequences (csrc/portable_math.h; device and host libm differ in the last bit). Every output is then bit-identical to the
  * reference algorithm evaluated with the same elementary functions (oracle/liboracle_pm.so). Slower (the sequential chains).
- * Dense tiles are stored and summed like CSR partitions in this mode.
+ * Dense tiles stay tiles (round 6, csrc/mlx_ro_dense.h): one lane per row for Xv, one lane per column walking all rows for XTv --
+ * two reads of the tile per tick where the fast contract reads it once; the zeros a tile holds add +-0.0 to a running sum, which
+ * keeps every bit, so the sums equal the entry-by-entry sums over the non-zeros.
  * MLX_NUMERICS_REFERENCE_ORDER_ONE_LAUNCH: the same arithmetic on the one-workgroup-per-problem verification kernel (one thread per
  * reduction; orders of magnitude slower) -- the independent cross-check of the mode above; one row block per partition.
  * Call before the first mlx_add_partition_* (the HBM layout depends on it). The Java driver's job key: mlease.numerics. */
@@ -135,7 +137,8 @@ int mlx_set_numerics(mlx_handle h, int32_t mode);
  *   "comm_always"         0 | 1  run the RCCL exchange at nranks == 1 too (tests)
  *   "trace"               0 | 1  tick progress and stream-probe results on stderr
  * mlx_get_option additionally answers "numerics_kernels" (after mlx_finalize: fast | reference_order_ticks |
- * reference_order_one_launch: what the handle actually runs), "stream_probe_rejects" and "tick_log": the last solve's batches of
+ * reference_order_one_launch: what the handle actually runs), "dense_tiles" (how many of the handle's partitions are stored as dense
+ * tiles), "stream_probe_rejects" and "tick_log": the last solve's batches of
  * four lock-step ticks as "ticks:done:us;..." -- ticks queued, problems finished (read one batch late) and microseconds since the
  * solve's first launch when the GPU had finished that batch (monitoring: how the active set shrinks over a solve; give a buffer
  * of a few KB). Unknown key: MLX_ERR_INVALID. */

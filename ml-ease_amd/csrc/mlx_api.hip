@@ -67,6 +67,9 @@ struct mlx_context {
                                            // verification kernel only (k_solve_small<.., SEQ>; MLX_FAITHFUL=2: the independent cross-check)
     bool ro_ticks = false;                 // decided at mlx_finalize: this handle runs the reference-order TICK kernels
     int ro_blocks = 0;                     // ... whose column pass runs once per row block: the largest n_rblk
+    bool ro_dense_as_csr = false;          // MLX_RO_DENSE_AS_CSR=1 (A/B, tests): a dense tile of this mode through the CSR kernels, entry by entry (round 5's
+                                           // form; the one-launch verification mode always takes it) instead of mlx_ro_dense.h
+    int max_l_dense = 0;                   // rows of the longest dense tile (grid of the reference-order dense passes)
     // host-selectable behaviour (mlx_set_option; the MLX_* environment variables only seed these defaults at mlx_create)
     bool trace = false;                    // "trace": tick progress / stream probe on stderr
     bool stream_probe = true;              // "stream_probe": test that the tick streams sit on different hardware queues
@@ -272,7 +275,11 @@ int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
     };
     if (nqd > 0) h->n_xpass_launched++;
     if (nqc > 0) h->n_xpass_launched++;
-    if (nqd > 0 && bracket(0, [&] { return mlxk_xpass_dense(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->maxblk_dense, h->max_nfeat_dense, h->n_lambda == 1); }))
+    if (nqd > 0 && h->ro_ticks) {
+        // reference-order numerics on dense tiles: Xv (one lane per row), then XTv (one lane per column over all rows) -- two reads
+        for (int which = 1; which <= 2; which++)
+            bracket(which, [&] { mlxk_ro_dense_passes(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->max_l_dense, h->max_nfeat_dense, h->n_lambda == 1, which); return 0; });
+    } else if (nqd > 0 && bracket(0, [&] { return mlxk_xpass_dense(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->maxblk_dense, h->max_nfeat_dense, h->n_lambda == 1); }))
         return fail(h, MLX_ERR_INVALID, "dense tile wider than 2048 features is not supported; use the CSR form");
     if (nqc > 0)
         for (int which = 1; which <= 2; which++)
@@ -287,7 +294,11 @@ int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
 void launch_step(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int nqc)
 {
     mark(h, 3);
-    if (h->ro_ticks) { mlxk_ro_step(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->d_done); return; }      // (no dense tiles in this mode)
+    if (h->ro_ticks) {
+        mlxk_ro_step(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->d_done);
+        mlxk_ro_step(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->d_done);
+        return;
+    }
     mlxk_tron_step(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->step_threads, h->d_done);
     // (launching A, B, C per group of problems so that Hd / r' / s stay in the memory-side cache between phases was measured: every
     // group size is slower than one launch per phase, profiles/r3_notes.md)
@@ -325,13 +336,14 @@ static int run_ticks_small_more(mlx_handle h, int first, int count, const int *q
 // whole iteration -- finds out whether every problem finished (it returns MLX_MORE_TICKS if not; then run_ticks_small_more()).
 constexpr int MLX_MORE_TICKS = 1;      // internal, never crosses the C-ABI
 // qsmall / nqs: the problems of SMALL CSR partitions, solved by the one-launch kernel -- a property of the partition, not of the
-// handle: a small partition takes that path (and its arithmetic: tree dots) whatever else the handle holds; beside larger
+// handle: a small partition takes that path (same arithmetic as the tick kernels: grid-rounded d.Hd / r.r) whatever else the handle holds; beside larger
 // partitions the launch is enqueued in front of the ticks and once more per batch (a no-op once its problems are done).
 int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, const int *qcsr, int nqc, const int *qsmall, int nqs,
               int64_t *ticks_out, bool *deferred = nullptr)
 {
     HIPCHECK(h, hipMemsetAsync(h->d_done, 0, sizeof(int), h->stream));
     h->h_done[0] = h->h_done[1] = 0;
+    h->tick_log.clear();                             // "tick_log" = the LAST solve's batches: a solve without tick batches leaves it empty
     if (nqs > 0 && h->profiling && !h->faithful) {
         // per-launch-class events: every CSR problem on the tick kernels (whole-handle calls only)
         if (count != h->nprob) return fail(h, MLX_ERR_INVALID, "internal: profiling reroutes whole-handle solves only");
@@ -353,7 +365,6 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
         return run_ticks_small_more(h, first, count, qsmall, nqs, ticks_out);
     }
     if (nqs > 0) { launch_small(); HIPCHECK(h, hipGetLastError()); }
-    h->tick_log.clear();
     h->tick_t0 = std::chrono::steady_clock::now();
     const int batch = 4;
     int64_t ticks = 0;
@@ -451,12 +462,12 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
     return MLX_OK;
 }
 
-double alg_bytes_per_tick(const PartHost &p)
+double alg_bytes_per_tick(const PartHost &p, bool ro_ticks)
 {
     // DESIGN.md "Algorithmic bytes": dense fused pass 4*l*n_feat + 8*l + 8*n ; CSR tick = row pass + column pass,
-    // each nnz*(4+s_val) + 8*l + 8*n.
+    // each nnz*(4+s_val) + 8*l + 8*n. Reference-order numerics read a dense tile twice per tick (Xv, then XTv).
     const double l = p.l, n = p.n_local;
-    if (p.dense) return 4.0 * l * p.n_feat + 8.0 * l + 8.0 * n;
+    if (p.dense) return (ro_ticks ? 2.0 : 1.0) * (4.0 * l * p.n_feat + 8.0 * l + 8.0 * n);
     const double sval = p.hasval ? 4.0 : 0.0;
     return 2.0 * ((double)p.nnz * (4.0 + sval) + 8.0 * l + 8.0 * n);
 }
@@ -518,6 +529,16 @@ static bool streams_serialize(mlx_handle h, hipStream_t a, hipStream_t b)
     const bool clash = best < 1e29f && best * 1e3 > 1.6 * spin_us;
     if (h->trace) fprintf(stderr, "[mlx] stream probe: two %.0f us waves took %.1f us -> %s\n", spin_us, best * 1e3, clash ? "ONE hardware queue" : "overlap");
     return clash;
+}
+
+// true when the handle's stream may be synchronised now: its own, or a caller's that neither captures a graph nor holds queued work
+static bool stream_can_sync(mlx_handle h)
+{
+    if (h->own_stream) return true;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return false; }
+    if (hipStreamQuery(h->stream) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return true;
 }
 
 static void pick_tick_streams(mlx_handle h)
@@ -605,6 +626,7 @@ int mlx_create(int device_id, mlx_handle *out)
     if (h->faithful && !h->streams_explicit) want_streams = 4;
     if (const char *pe = getenv("MLX_PROFILE_ONE_STREAM")) h->prof_one_stream = atoi(pe) != 0;
     if (const char *pe = getenv("MLX_SEQ_DOTS")) h->seq_dots = atoi(pe) != 0;
+    if (const char *pe = getenv("MLX_RO_DENSE_AS_CSR")) h->ro_dense_as_csr = atoi(pe) != 0;
     if (const char *pe = getenv("MLX_TRACE")) h->trace = atoi(pe) != 0 || pe[0] == '\0';
     if (const char *pe = getenv("MLX_NO_STREAM_PROBE")) h->stream_probe = atoi(pe) == 0;
     if (getenv("MLX_NO_SMALL")) h->use_small = false;
@@ -670,7 +692,9 @@ int mlx_set_numerics(mlx_handle h, int32_t mode)
         // the tick kernels of the reference-order numerics are latency-bound chains: four lists of problems side by side fill the
         // chip better than two (the product path: two, measured -- profiles/r3_notes.md, r4_notes.md)
         const int want = h->faithful ? 4 : 2;
-        if (want != h->nstreams) { hipSetDevice(h->device); hipStreamSynchronize(h->stream); setup_tick_streams(h, want); }
+        // (a caller-owned stream that captures or holds work is left alone: the side streams are the handle's own, pick_tick_streams
+        //  skips its probe on such a stream)
+        if (want != h->nstreams) { hipSetDevice(h->device); if (stream_can_sync(h)) hipStreamSynchronize(h->stream); setup_tick_streams(h, want); }
     }
     return MLX_OK;
 }
@@ -689,7 +713,7 @@ int mlx_set_option(mlx_handle h, const char *key, const char *value)
     }
     if (k == "tick_streams") {
         if (iv < 1 || iv > (int)mlx_context::MAX_TS) return fail(h, MLX_ERR_INVALID, "tick_streams must be 1..%d", (int)mlx_context::MAX_TS);
-        hipStreamSynchronize(h->stream);
+        if (stream_can_sync(h)) hipStreamSynchronize(h->stream);
         setup_tick_streams(h, iv);
         h->streams_explicit = true;
         return MLX_OK;
@@ -714,6 +738,7 @@ int mlx_get_option(mlx_handle h, const char *key, char *out, size_t out_len)
     std::string v;
     if (k == "numerics") v = !h->faithful ? "fast" : (h->ro_mode == 2 ? "reference_order_one_launch" : "reference_order");
     else if (k == "numerics_kernels") v = !h->finalized ? "undecided" : (!h->faithful ? "fast" : (h->ro_ticks ? "reference_order_ticks" : "reference_order_one_launch"));
+    else if (k == "dense_tiles") { int nd = 0; for (auto &p : h->parts) nd += p.dense ? 1 : 0; v = std::to_string(nd); }
     else if (k == "tick_streams") v = std::to_string(h->nstreams);
     else if (k == "stream_probe_rejects") v = std::to_string(h->stream_probe_rejects);
     else if (k == "stream_probe") v = h->stream_probe ? "1" : "0";
@@ -741,7 +766,7 @@ int mlx_set_profiling(mlx_handle h, int enable)
     if (!h) return MLX_ERR_INVALID;
     h->profiling = enable != 0;
     if (enable == 2) h->prof_one_stream = true;        // events AND all ticks on one stream: a launch's duration is the kernel's alone
-    else if (enable == 1) h->prof_one_stream = getenv("MLX_PROFILE_ONE_STREAM") != nullptr && atoi(getenv("MLX_PROFILE_ONE_STREAM")) != 0;
+    // (enable == 1 leaves "profile_one_stream" as the host set it: the environment variable only seeded the default at mlx_create)
     return MLX_OK;
 }
 
@@ -1273,6 +1298,10 @@ static bool csr_is_dense_enough(int32_t l, int32_t n_local, int64_t nnz, const i
     return true;
 }
 
+// mostly-filled CSR input becomes a tile under the fast contract and under the reference-order TICK kernels (not under the one-launch
+// verification kernel, which sums entry by entry, nor with MLX_RO_DENSE_AS_CSR=1)
+static bool tile_wanted(mlx_handle h) { return !h->faithful || (h->ro_mode == 1 && !h->ro_dense_as_csr); }
+
 static int add_csr_as_dense_tile(mlx_handle h, int32_t partition_id, int32_t l, int32_t n_local, const int64_t *row_ptr,
                                  const int32_t *col_idx, const float *val, const int8_t *y, const float *weight,
                                  const float *offset, const int32_t *local_to_global)
@@ -1292,7 +1321,9 @@ int mlx_add_partition_csr(mlx_handle h, int32_t partition_id, int32_t l, int32_t
     hipSetDevice(h->device);
     int rc = check_common_rows(h, partition_id, l, local_to_global, n_local);
     if (rc) return rc;
-    if (!h->faithful && csr_is_dense_enough(l, n_local, nnz, row_ptr, col_idx)) return add_csr_as_dense_tile(h, partition_id, l, n_local, row_ptr, col_idx, val, y, weight, offset, local_to_global);
+    // (reference-order numerics: a tile too, when the handle runs the tick kernels -- the zeros a tile holds where the CSR rows have no
+    //  entry add +-0.0 to the running sums: same bits, mlx_ro_dense.h)
+    if (tile_wanted(h) && csr_is_dense_enough(l, n_local, nnz, row_ptr, col_idx)) return add_csr_as_dense_tile(h, partition_id, l, n_local, row_ptr, col_idx, val, y, weight, offset, local_to_global);
     CsrPrep P;
     if ((rc = prep_csr(P, h->n_global, partition_id, l, n_local, nnz, row_ptr, col_idx, val, y, local_to_global, h->faithful ? h->ro_mode : 0, h->n_lambda)))
         return fail(h, rc, "%s", P.error.c_str());
@@ -1327,7 +1358,7 @@ int mlx_add_partitions_csr(mlx_handle h, int32_t count, const int32_t *partition
         for (int j = 0; j < nb; j++)
             th.emplace_back([&, j] {
                 const int k = b0 + j;
-                if (!h->faithful && csr_is_dense_enough(l[k], n_local[k], nnz[k], row_ptr[k], col_idx[k])) { as_tile[(size_t)j] = 1; return; }
+                if (tile_wanted(h) && csr_is_dense_enough(l[k], n_local[k], nnz[k], row_ptr[k], col_idx[k])) { as_tile[(size_t)j] = 1; return; }
                 prep_csr(preps[(size_t)j], h->n_global, partition_id[k], l[k], n_local[k], nnz[k], row_ptr[k], col_idx[k],
                          val ? val[k] : nullptr, y[k], local_to_global[k], h->faithful ? h->ro_mode : 0, h->n_lambda);
             });
@@ -1357,8 +1388,10 @@ int mlx_add_partition_dense(mlx_handle h, int32_t partition_id, int32_t l, int32
     int rc = check_common_rows(h, partition_id, l, local_to_global, n_local);
     if (rc) return rc;
     if (!X || !y || n_feat < 1 || ld < n_feat) return fail(h, MLX_ERR_INVALID, "bad dense tile arguments");
-    if (n_feat > 2048 || h->faithful) {
-        // (reference-order numerics: a tile's rows and columns are summed entry by entry like any other partition's)
+    const bool ro_tile = h->faithful && h->ro_mode == 1 && !h->ro_dense_as_csr;      // reference-order numerics on the tile itself (mlx_ro_dense.h)
+    if ((n_feat > 2048 || h->faithful) && !ro_tile) {
+        // (reference-order numerics, one-launch verification kernel / MLX_RO_DENSE_AS_CSR=1: a tile's rows and columns are summed entry
+        // by entry like any other partition's)
         // The fused dense pass keeps a row's slice in registers (<= 2048 columns); wider tiles run the sparse passes on their
         // non-zero entries (same sums: the zeros they skip add +0.0), every column still present (n_local = n_feat + 1).
         std::vector<float> Xh((size_t)l * n_feat), wv, ov;
@@ -1404,6 +1437,7 @@ int mlx_add_partition_dense(mlx_handle h, int32_t partition_id, int32_t l, int32
     ph.n_units = (l + rpb - 1) / rpb;
     ph.upw = 1;
     ph.nblk = ph.n_units;                    // stored partials = workgroups; mlx_finalize may pair the units (upw = 2)
+    if (ro_tile) { ph.rows_per_blk = 256; ph.n_units = (l + 255) / 256; ph.nblk = 1; }      // (no partial sums in that mode: one chain per row / column)
     if ((rc = upload_row_meta(h, ph, l, y, weight, offset, x_on_device != 0))) return rc;
     return finish_part(h, ph);
 }
@@ -1464,11 +1498,11 @@ int mlx_finalize(mlx_handle h)
     // with 512-row chunks, round 2). The partial sums are per unit either way: the choice changes no result. MLX_DENSE_UPW forces it.
     {
         int64_t dense_rows = 0;
-        for (auto &p : h->parts) if (p.dense && p.l >= 4096) dense_rows += (int64_t)nl * p.l;
+        for (auto &p : h->parts) if (p.dense && p.l >= 4096 && !h->faithful) dense_rows += (int64_t)nl * p.l;
         const int64_t want = getenv("MLX_DENSE_WGS") ? std::max(64, atoi(getenv("MLX_DENSE_WGS"))) : 512;
         int upw = dense_rows / 512 < want ? 1 : 2;
         if (const char *e = getenv("MLX_DENSE_UPW")) upw = std::max(1, std::min(2, atoi(e)));
-        for (auto &p : h->parts) if (p.dense && p.l >= 4096) {
+        for (auto &p : h->parts) if (p.dense && p.l >= 4096 && !h->faithful) {
             p.upw = upw; p.dev.units_per_wg = upw;
             p.nblk = (p.n_units + upw - 1) / upw;
             p.dev.nblk = p.nblk;
@@ -1484,7 +1518,7 @@ int mlx_finalize(mlx_handle h)
         if (!p.all_present) h->any_absent = true;
         const int64_t plen = p.dense ? (int64_t)p.nblk * p.n_local : (int64_t)p.n_items;
         h->max_parts_len = std::max(h->max_parts_len, plen);
-        if (p.dense) { h->maxblk_dense = std::max(h->maxblk_dense, p.nblk); h->max_nfeat_dense = std::max(h->max_nfeat_dense, p.n_feat); }
+        if (p.dense) { h->maxblk_dense = std::max(h->maxblk_dense, p.nblk); h->max_nfeat_dense = std::max(h->max_nfeat_dense, p.n_feat); h->max_l_dense = std::max(h->max_l_dense, p.l); }
         else {
             h->maxblk_csr = std::max(h->maxblk_csr, p.nblk); h->max_items = std::max(h->max_items, p.n_items);
             h->max_short = std::max(h->max_short, p.n_short); h->max_long = std::max(h->max_long, p.n_long);
@@ -1603,7 +1637,7 @@ int mlx_finalize(mlx_handle h)
     size_t slab_bytes = vec_bytes(h->max_nlocal, h->max_l, h->max_parts_len, scratch_blk, false) + carve_size((size_t)h->max_nlocal);
     for (int k = 0; k < np; k++) {
         const PartHost &p = h->parts[k];
-        slab_bytes += (size_t)nl * vec_bytes(p.n_local, p.l, p.dense ? (int64_t)p.nblk * p.n_local : (int64_t)p.n_items, std::max(p.nblk, p.dev.n_rowparts), p.dense);
+        slab_bytes += (size_t)nl * vec_bytes(p.n_local, p.l, p.dense ? (int64_t)p.nblk * p.n_local : (int64_t)p.n_items, std::max(p.nblk, p.dev.n_rowparts), p.dense && !h->faithful);
     }
     uint8_t *slab = nullptr;
     if ((rc = dev_alloc(h, &slab, slab_bytes))) return rc;
@@ -1630,7 +1664,8 @@ int mlx_finalize(mlx_handle h)
         for (int li = 0; li < nl; li++) {
             ProbDev &pr = h->h_probs[k * nl + li];
             pr.part = k; pr.lambda_idx = li; pr.phase = PH_DONE;
-            alloc_vecs(pr, p.n_local, p.l, p.dense ? (int64_t)p.nblk * p.n_local : (int64_t)p.n_items, std::max(p.nblk, p.dev.n_rowparts), p.dense);
+            // (a dense tile under the reference-order numerics carries a CSR problem's vectors: coef[], the second residual buffer)
+            alloc_vecs(pr, p.n_local, p.l, p.dense ? (int64_t)p.nblk * p.n_local : (int64_t)p.n_items, std::max(p.nblk, p.dev.n_rowparts), p.dense && !h->faithful);
         }
     }
     {
@@ -1805,8 +1840,8 @@ static int collect_solve_stats(mlx_handle h, int64_t ticks, mlx_stats *stats, bo
         s.newton_iters += pr.newton; s.accepted += pr.accepted; s.cg_iters += pr.cg_total;
         s.x_passes_ref += 3 + 2 * (int64_t)pr.cg_total + pr.newton + pr.accepted;
         const PartHost &p = h->parts[pr.part];
-        s.x_passes_dev += (int64_t)pr.ticks * (p.dense ? 1 : 2);
-        s.alg_bytes_dev += (double)pr.ticks * alg_bytes_per_tick(p);
+        s.x_passes_dev += (int64_t)pr.ticks * ((p.dense && !h->ro_ticks) ? 1 : 2);      // (reference-order numerics read a dense tile twice per tick)
+        s.alg_bytes_dev += (double)pr.ticks * alg_bytes_per_tick(p, h->ro_ticks);
     }
     float ms = 0;
     hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1);
@@ -2161,6 +2196,10 @@ int mlx_solve_one(mlx_handle h, int32_t local_index, double *w, const double *pr
     pr.f = pr.delta = pr.gnorm = pr.gnorm1 = pr.rTr = pr.cgtol = pr.prered = pr.gs = 0;
     pr.rsel = 0; pr.gsq = pr.snorm = 0;
     HIPCHECK(h, hipMemcpy(h->d_probs + h->nprob, &pr, sizeof(ProbDev), hipMemcpyHostToDevice));
+    // Reference-order tick kernels: the chained column pass stores xtc[j] through the column's LAST item only, so a column without
+    // entries is never written. The handle's own problems rely on the slab's memset; the scratch problem is shared by every
+    // partition, and a column empty in this one may hold what an earlier solve on another partition left there.
+    if (h->ro_ticks && pr.c0f) HIPCHECK(h, hipMemsetAsync(pr.c0f, 0, sizeof(double) * (size_t)h->max_nlocal, h->stream));
     const bool prof = h->profiling;
     h->profiling = false;
     int rc = run_ticks(h, h->nprob, 1, h->d_qscratch, p.dense ? 1 : 0, h->d_qscratch, (!p.dense && !p.small) ? 1 : 0, h->d_qscratch, p.small ? 1 : 0, nullptr);
@@ -2445,13 +2484,13 @@ int mlx_posterior_variance(mlx_handle h, int32_t local_index, const double *w, c
         ld = (nf + 3) / 4 * 4;
         if (ld == 0) ld = 4;
         if ((rc = talloc((void **)&Xtmp, sizeof(float) * (size_t)l * ld))) return rc;
-        hipMemsetAsync(Xtmp, 0, sizeof(float) * (size_t)l * ld, h->stream);
+        if (hipMemsetAsync(Xtmp, 0, sizeof(float) * (size_t)l * ld, h->stream) != hipSuccess) { cleanup(); return fail(h, MLX_ERR_HIP, "posterior variance: clearing the temporary tile failed"); }
         mlxk_densify(h->stream, l, p.dev.rp, p.dev.ci, p.dev.val, Xtmp, ld);
         X = Xtmp;
     }
     double *d_pinv;
     if ((rc = talloc((void **)&d_pinv, sizeof(double) * n))) return rc;
-    hipMemcpyAsync(d_pinv, pinv.data(), sizeof(double) * n, hipMemcpyHostToDevice, h->stream);
+    if (hipMemcpyAsync(d_pinv, pinv.data(), sizeof(double) * n, hipMemcpyHostToDevice, h->stream) != hipSuccess) { cleanup(); return fail(h, MLX_ERR_HIP, "posterior variance: upload of the prior precisions failed"); }
     std::vector<double> out((size_t)n);
     if (!full) {
         // (dense tiles; CSR partitions took the item path above)
@@ -2462,8 +2501,8 @@ int mlx_posterior_variance(mlx_handle h, int32_t local_index, const double *w, c
         mlxk_hess_colsums(h->stream, X, ld, l, d_wd, d_part, nchunk, rows_per_chunk, d_cs);
         // hessianDiagonal + 1/H (llf/LogisticRegressionL2.java:304-327, llf/LibLinear.java:331-334)
         std::vector<double> cs((size_t)(2 * ld + 1));
-        hipMemcpyAsync(cs.data(), d_cs, sizeof(double) * cs.size(), hipMemcpyDeviceToHost, h->stream);
-        if (hipStreamSynchronize(h->stream) != hipSuccess || hipGetLastError() != hipSuccess) { cleanup(); return fail(h, MLX_ERR_HIP, "posterior variance kernels failed"); }
+        const hipError_t ce = hipMemcpyAsync(cs.data(), d_cs, sizeof(double) * cs.size(), hipMemcpyDeviceToHost, h->stream);
+        if (ce != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess || hipGetLastError() != hipSuccess) { cleanup(); return fail(h, MLX_ERR_HIP, "posterior variance kernels failed"); }
         for (int j = 0; j < nf; j++) out[(size_t)j] = 1.0 / (pinv[(size_t)j] + cs[(size_t)(ld + j)]);
         out[(size_t)nf] = 1.0 / (pinv[(size_t)nf] + cs[(size_t)(2 * ld)]);
     } else {
@@ -2494,14 +2533,14 @@ int mlx_posterior_variance(mlx_handle h, int32_t local_index, const double *w, c
         if ((rc = talloc((void **)&d_blocks, sizeof(int) * blocks.size()))) return rc;
         if ((rc = talloc((void **)&d_P, sizeof(double) * (size_t)(ksplit / 2) * npad * npad))) return rc;   // one partial block per workgroup (= two row splits)
         if ((rc = talloc((void **)&d_H, sizeof(double) * (size_t)n * n))) return rc;
-        hipMemcpyAsync(d_blocks, blocks.data(), sizeof(int) * blocks.size(), hipMemcpyHostToDevice, h->stream);
+        if (hipMemcpyAsync(d_blocks, blocks.data(), sizeof(int) * blocks.size(), hipMemcpyHostToDevice, h->stream) != hipSuccess) { cleanup(); return fail(h, MLX_ERR_HIP, "posterior variance: upload of the block list failed"); }
         hipEventRecord(h->ev_t0, h->stream);
         mlxk_gram_f64(h->stream, X, ld, l, d_wd, d_blocks, nblocks, ksplit, rows_per_split, d_P, npad, nf);
         hipEventRecord(h->ev_t1, h->stream);
         mlxk_gram_finish(h->stream, d_P, ksplit / 2, npad, nf, d_pinv, d_H);
         std::vector<double> H((size_t)n * n), V;
-        hipMemcpyAsync(H.data(), d_H, sizeof(double) * H.size(), hipMemcpyDeviceToHost, h->stream);
-        if (hipStreamSynchronize(h->stream) != hipSuccess || hipGetLastError() != hipSuccess) { cleanup(); return fail(h, MLX_ERR_HIP, "posterior variance kernels failed"); }
+        const hipError_t he = hipMemcpyAsync(H.data(), d_H, sizeof(double) * H.size(), hipMemcpyDeviceToHost, h->stream);
+        if (he != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess || hipGetLastError() != hipSuccess) { cleanup(); return fail(h, MLX_ERR_HIP, "posterior variance kernels failed"); }
         if (gram_ms) { float ms = 0; hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1); *gram_ms = ms; }
         const int cr = cholesky_inverse(n, H, V);
         if (cr == -3) { cleanup(); return fail(h, MLX_ERR_INVALID, "posterior covariance: out of host memory for the %d x %d factorisation", n, n); }

@@ -3062,6 +3062,7 @@ static void set_max_lds(const void *func, int bytes)
     const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) fprintf(stderr, "[mlease_hip] hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed: %s\n", bytes, hipGetErrorString(e));
 }
+#include "mlx_ro_dense.h"
 
 int mlxk_xpass_dense(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
                      int max_nfeat, bool stream_once)

@@ -345,6 +345,7 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
     if (phase == PH_DONE) return;
     const PartDev &pa = parts[pr.part];
     const int n = pa.n_local, nf = pa.n_feat, l = pa.l, tid = threadIdx.x;
+    const bool dn = pa.dense != 0;                                // dense tile (mlx_ro_dense.h): the two l-long chains are done already
     const double *__restrict__ xtc = pr.c0f;                      // X'c of this tick, columns 0 .. nf-1 (k_colpass_lds<.., RO>)
     const double *__restrict__ coef = pr.coef;                    // the row coefficients: their sum in row order is the intercept's column
     const double *__restrict__ pvec = pr.pinv_vec;
@@ -360,9 +361,10 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
         // Hd for the feature columns and the first nf terms of Tron.dot(d, Hd) on one lane; beside it, on a second lane, the intercept's
         // column of XTv: the sum of the row coefficients in row order (the bias entry closes every row). The dot's last term needs
         // that sum and is added after the pass: the same chain.
+        // (dense tiles: k_ro_dense_cols ran that chain on a spare lane and left it in csump[0])
         struct RA { RoV4 d, x, p, c; };
-        const int lensA[2] = {nf, l};
-        ro_pass<2, 0, RA>(sh, max(nf, l), lensA, zero6, res,
+        const int lensA[2] = {nf, dn ? 0 : l};
+        ro_pass<2, 0, RA>(sh, dn ? nf : max(nf, l), lensA, zero6, res,
             [&](int j0, RA &R) { R.d = ro_ld4c(d, j0, n); R.x = ro_ld4c(xtc, j0, n); if (pvec) R.p = ro_ld4s(pvec, j0, n); R.c = ro_ld4c(coef, j0, l); },
             [&](int j0, RA &R, double (&ct)[2][4], double (&nv)[1][4]) {
                 double hd[4];
@@ -374,6 +376,7 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
                 }
                 ro_st4(Hd, j0, nf, hd);
             });
+        if (dn) res[1] = pr.csump[0];
         const double rTr0 = pr.rTr, delta0 = pr.delta, cgtol0 = pr.cgtol;
         const double d_icpt = d[nf];
         const double hd_icpt = d_icpt * (pvec ? pvec[nf] : pscal) + res[1];
@@ -476,7 +479,8 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
     // ---- PH_EVAL0 / PH_EVAL: fun(w_new) and the gradient candidate (llf/LogisticRegressionL2.java:156-225)
     const double *__restrict__ rowtmp = pr.rowtmp;
     struct RR { RoV4 x, c; };
-    ro_pass<2, 0, RR>(sh, l, nullptr, zero6, res,
+    if (dn) { res[0] = pr.lossp[0]; res[1] = pr.csump[0]; }
+    else ro_pass<2, 0, RR>(sh, l, nullptr, zero6, res,
         [&](int j0, RR &R) { R.x = ro_ld4c(rowtmp, j0, l); R.c = ro_ld4c(coef, j0, l); },
         [&](int j0, RR &R, double (&ct)[2][4], double (&nv)[1][4]) {
 #pragma unroll

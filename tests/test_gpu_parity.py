@@ -949,8 +949,12 @@ def test_two_cold_slices_on_wide_partitions(monkeypatch):
         eng.close()
 
 
-def test_tight_epsilon_differences_are_summation_order_only(monkeypatch):
-    """Under the driver's epsilon schedule the liblinear epsilon reaches 1e-7 by ADMM iteration 9 and keeps falling; from there
+@pytest.mark.parametrize("ro_route", ["tile", "csr"])
+def test_tight_epsilon_differences_are_summation_order_only(ro_route, monkeypatch):
+    """(ro_route: the reference-order engine keeps the partitions as dense tiles -- round 6, csrc/mlx_ro_dense.h: one lane per row,
+    one lane per column over all rows -- or, MLX_RO_DENSE_AS_CSR=1, runs them entry by entry through the CSR kernels of the mode in
+    three row blocks: round 5's form. Both must be bit-identical to the oracle twin over the whole schedule.)
+    Under the driver's epsilon schedule the liblinear epsilon reaches 1e-7 by ADMM iteration 9 and keeps falling; from there
     a solve ends on bw/Tron.java:115-122 (|actred|, |prered| <= 1e-12 |f|), where actred = f - fnew is the rounding noise of two
     l-term sums, so whether the LAST step is accepted (:102, actred > eta0 * prered) depends on the summation order. On dense
     data (configs[1] in the small) through epsilon 1e-11:
@@ -963,9 +967,13 @@ def test_tight_epsilon_differences_are_summation_order_only(monkeypatch):
     lam, rho = [1.0], [1.0]
     oc = ol.OracleAdmm(pd.blocks, pd.n_global, lam, rho, pm=True)
     monkeypatch.setenv("MLX_RBMAX", "1536")            # (4 000-row partitions in three row blocks: the chained column sums)
+    if ro_route == "csr":
+        monkeypatch.setenv("MLX_RO_DENSE_AS_CSR", "1")
     engf = make_engine(pd, lam, rho, numerics="reference_order")
     assert engf.get_option("numerics_kernels") == "reference_order_ticks"
+    assert engf.get_option("dense_tiles") == ("4" if ro_route == "tile" else "0")
     monkeypatch.delenv("MLX_RBMAX")
+    monkeypatch.delenv("MLX_RO_DENSE_AS_CSR", raising=False)
     eng = make_engine(pd, lam, rho)                    # dense-enough CSR -> dense tiles: the headline kernels
     oc2 = ol.OracleAdmm(pd.blocks, pd.n_global, lam, rho)
     accept_diffs = 0
@@ -1313,8 +1321,8 @@ def test_results_do_not_depend_on_the_chunking_the_handle_picks(kind, monkeypatc
 
 
 def test_a_small_partition_takes_the_same_kernel_whatever_else_its_handle_holds():
-    """Round-4 advisor finding: whether a CSR partition ran the one-launch solver (tree dots) or the tick kernels (grid-rounded d.Hd /
-    r.r) was decided from the LARGEST partition of its handle, so a small partition's bits depended on what else the handle -- i.e.
+    """Round-4 advisor finding: whether a CSR partition ran the one-launch solver (tree dots in round 4; the same grid-rounded d.Hd /
+    r.r as the tick kernels since round 5) or the tick kernels was decided from the LARGEST partition of its handle, so a small partition's bits depended on what else the handle -- i.e.
     its rank -- held. The choice is per partition now (<= 64 K non-zeros, <= 16 K rows / columns: one launch): three small partitions
     give bit-identical solves (the LibLinear.train seam, mlx_solve_one) alone and beside a 40 000-row one-hot partition, which itself
     runs the tick kernels; an ADMM iteration of the mixed handle finishes with every problem done."""
@@ -1428,4 +1436,116 @@ def test_tick_log_shows_the_active_set_shrinking():
     assert np.all(np.diff(a[:, 0]) == 4) and np.all(np.diff(a[:, 1]) >= 0) and np.all(np.diff(a[:, 2]) > 0)
     assert a[-1, 1] == 32 and a[0, 1] < 32                     # every (partition, lambda) problem done at the end, not at the start
     assert a[-1, 0] + 4 <= st.ticks <= a[-1, 0] + 8            # (the host queues one batch ahead of the count it reads)
+    eng.close()
+
+
+def _dense_job(seed, l, nf, parts, zero_frac=0.02, zero_col=True, weights=True, offsets=True):
+    """Dense partitions with exact zeros sprinkled in (and one all-zero column): (X, y, wt, off) per partition for
+    mlx_add_partition_dense, and the same rows as CSR blocks WITHOUT the zero entries for the oracle (what the reference's sparse
+    rows would hold)."""
+    from mlease_amd.dataset import PartitionBlock, PartitionedData
+    rng = np.random.default_rng(seed)
+    beta = rng.normal(0, 0.3, nf)
+    tiles, blocks = [], []
+    for k in range(parts):
+        X = rng.normal(0, 1, (l, nf)).astype(np.float32)
+        X[rng.random((l, nf)) < zero_frac] = 0.0
+        if zero_col:
+            X[:, nf // 3] = 0.0
+        y = np.where(rng.random(l) < 1 / (1 + np.exp(-(X.astype(np.float64) @ beta - 0.5))), 1, -1).astype(np.int8)
+        wt = rng.uniform(0.5, 2.0, l).astype(np.float32) if weights else np.ones(l, np.float32)
+        off = rng.normal(0, 0.2, l).astype(np.float32) if offsets else np.zeros(l, np.float32)
+        nzr, nzc = np.nonzero(X)
+        rp = np.concatenate([[0], np.cumsum(np.bincount(nzr, minlength=l))]).astype(np.int64)
+        tiles.append((X, y, wt, off))
+        blocks.append(PartitionBlock(k, l, nf + 1, rp, nzc.astype(np.int32), X[nzr, nzc], y, wt, off, np.arange(nf + 1, dtype=np.int32)))
+    return tiles, PartitionedData(blocks, [str(i + 1) for i in range(nf)], parts)
+
+
+@pytest.mark.parametrize("shape", [(1000, 37), (4097, 1000), (300, 2100), (8200, 129)])
+def test_reference_order_dense_tiles_are_bit_identical_to_the_oracle(shape, monkeypatch):
+    """Round 6: dense tiles under the reference-order contract stay tiles (csrc/mlx_ro_dense.h). Xv = one lane per row walking the
+    columns in ascending id, the bias entry last; XTv = one lane per column walking ALL rows in order, with the intercept's column and
+    the loss sum as two more chains on spare lanes. Ragged shapes (rows not a multiple of 64, columns not a multiple of 64 / 4 / wider
+    than the fast path's 2048), exact zeros and an all-zero column in the tile, weights, offsets, two lambdas: every TRON/CG counter
+    equal and every output (beta, u + beta, u per partition; the driver's double z) bit-identical to the oracle twin fed the same
+    rows WITHOUT their zero entries -- and to the same engine with the tile run entry by entry through the CSR kernels of the mode
+    (MLX_RO_DENSE_AS_CSR=1), and to the one-launch verification kernel where the partition is small enough for it."""
+    l, nf = shape
+    tiles, pd = _dense_job(3 + nf, l, nf, 3)
+    lam, rho = [0.5, 8.0], [1.0, 2.0]
+
+    def dense_engine(numerics="reference_order"):
+        eng = HipAdmmEngine(pd.n_global, lam, rho, pd.num_blocks, numerics=numerics)
+        for k, (X, y, wt, off) in enumerate(tiles):
+            eng.add_partition_dense(k, X, y, wt, off)
+        eng.finalize()
+        return eng
+
+    eng = dense_engine()
+    assert eng.get_option("numerics_kernels") == "reference_order_ticks" and eng.get_option("dense_tiles") == "3"
+    monkeypatch.setenv("MLX_RO_DENSE_AS_CSR", "1")
+    engc = dense_engine()
+    assert engc.get_option("dense_tiles") == "0"
+    monkeypatch.delenv("MLX_RO_DENSE_AS_CSR")
+    eng1 = dense_engine("reference_order_one_launch") if l * nf <= 400000 else None
+    oc = ol.OracleAdmm(pd.blocks, pd.n_global, lam, rho, pm=True)
+    for it, eps in enumerate((0.01, 0.01, 1e-4, 1e-9)):
+        st = eng.iterate(eps)
+        mo = oc.iterate(eps, 1.0, nthreads=6)
+        assert np.array_equal(eng.solve_counters(), _counters(oc)), "iteration %d: TRON/CG counters differ" % (it + 1)
+        assert np.array_equal(eng.z()[0], oc.z()[0]) and st.maxdiff == mo[0], "iteration %d: driver z not bit-identical" % (it + 1)
+        others = [engc] + ([eng1] if eng1 is not None else [])
+        for e2 in others:
+            e2.iterate(eps)
+            assert np.array_equal(e2.solve_counters(), eng.solve_counters()) and np.array_equal(e2.z()[0], eng.z()[0])
+        for k in range(3):
+            for li in range(2):
+                for a, b, name in zip(eng.partition_model(k, li), oc.partition_model(k, li), ("beta", "uplusx", "u_next")):
+                    assert np.array_equal(a, b), "iteration %d partition %d lambda %d: %s not bit-identical" % (it + 1, k, li, name)
+    # the LibLinear.train seam on a tile (scratch problem), per-coordinate prior variances and a warm start
+    rng = np.random.default_rng(5)
+    n = nf + 1
+    init, pm, pv = rng.normal(0, 0.2, n), rng.normal(0, 0.1, n), rng.uniform(0.25, 4.0, n)
+    ds = ol.OracleDataset.from_block(pd.blocks[1], pm=True)
+    wo, sto = ds.train(init, pm, pv, 1e-5)
+    wg, cnt, (f, gn, gn1) = eng.solve_one(1, init, pm, pv, 1e-5)
+    assert (cnt[0], cnt[1], cnt[2]) == (sto.newton_iters, sto.accepted, sto.cg_iters)
+    assert np.array_equal(wg, wo) and f == sto.f and gn == sto.gnorm and gn1 == sto.gnorm1
+    for e2 in [eng, engc] + ([eng1] if eng1 is not None else []):
+        e2.close()
+
+
+def test_reference_order_scratch_problem_forgets_the_previous_partition():
+    """Round-5 advisor finding: the chained column pass of the reference-order tick kernels stores xtc[j] through a column's LAST
+    item only, so a column WITHOUT entries is never written; mlx_solve_one shares one scratch problem between partitions, and a
+    solve on a partition with an empty column read what an earlier solve on another partition had left there. Two CSR partitions,
+    the second with a column no row touches: solve_one on the first, then on the second, against the oracle twin."""
+    from mlease_amd.dataset import PartitionBlock, PartitionedData
+    rng = np.random.default_rng(17)
+    l, nf = 5000, 40
+    blocks = []
+    for k in range(2):
+        rows = []
+        for i in range(l):
+            cols = np.sort(rng.choice(nf, 6, replace=False))
+            if k == 1:
+                cols = cols[cols != 7]                        # column 7 of the second partition stays empty
+            rows.append(cols)
+        rp = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+        ci = np.concatenate(rows).astype(np.int32)
+        val = rng.normal(0, 1, len(ci)).astype(np.float32)
+        y = np.where(rng.random(l) < 0.4, 1, -1).astype(np.int8)
+        blocks.append(PartitionBlock(k, l, nf + 1, rp, ci, val, y, np.ones(l, np.float32), np.zeros(l, np.float32), np.arange(nf + 1, dtype=np.int32)))
+    pd = PartitionedData(blocks, [str(i + 1) for i in range(nf)], 2)
+    eng = make_engine(pd, [1.0], [1.0], numerics="reference_order")
+    assert eng.get_option("numerics_kernels") == "reference_order_ticks" and eng.get_option("dense_tiles") == "0"
+    n = nf + 1
+    init, pm, pv = rng.normal(0, 0.5, n), rng.normal(0, 0.3, n), rng.uniform(0.5, 2.0, n)
+    for k in (0, 1, 0, 1):
+        ds = ol.OracleDataset.from_block(blocks[k], pm=True)
+        wo, sto = ds.train(init, pm, pv, 1e-6)
+        wg, cnt, (f, gn, gn1) = eng.solve_one(k, init, pm, pv, 1e-6)
+        assert (cnt[0], cnt[1], cnt[2]) == (sto.newton_iters, sto.accepted, sto.cg_iters), k
+        assert np.array_equal(wg, wo) and f == sto.f, "partition %d: the scratch problem's X'c was not cleared" % k
     eng.close()
