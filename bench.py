@@ -141,7 +141,7 @@ def main():
     ap.add_argument("--sparse-test-rows", type=int, default=1000000)
     ap.add_argument("--no-ingest", action="store_true", help="skip the avro -> CSR / prep + upload measurement of the sparse leg")
     ap.add_argument("--ingest-rows", type=int, default=500000, help="rows of the avro -> CSR measurement")
-    ap.add_argument("--dense-ro-partitions", type=int, default=8, help="partitions of the reference-order-numerics check on configs[1] (0 = skip)")
+    ap.add_argument("--no-dense-ro", action="store_true", help="skip the reference-order-numerics leg on configs[1] (all partitions, the headline's iterations)")
     ap.add_argument("--sparse-cpu-sample", type=int, default=256, help="partitions of the sparse CPU-baseline / parity sample (0 = skip)")
     args = ap.parse_args()
 
@@ -299,8 +299,8 @@ def compact_record(full):
                      "dtype", "data"])
     cfg = full.get("config") or {}
     c["config"] = _pick(cfg, ["workload", "rows", "features", "partitions", "partitions_per_gpu", "admm_iterations_timed"])
-    if len(c["config"].get("workload", "")) > 200:
-        c["config"]["workload"] = c["config"]["workload"][:200]
+    if len(c["config"].get("workload", "")) > 150:
+        c["config"]["workload"] = c["config"]["workload"][:150]
     roof = full.get("roofline")
     if roof:
         c["roofline"] = _pick(roof, ["kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "alg_bytes_per_launch", "avg_launch_ms",
@@ -309,37 +309,46 @@ def compact_record(full):
             if isinstance(c["roofline"].get(k), float):
                 c["roofline"][k] = round(c["roofline"][k])
         c["roofline"]["avg_launch_ms"] = _r(c["roofline"].get("avg_launch_ms"), 5)
-        c["roofline"]["measured_in"] = roof.get("measured_in_short", "timed region")
-        c["roofline"]["traffic_source"] = None if not roof.get("traffic_source") else "profiles/traffic.json ratio (committed rocprofv3 --pmc passes) x this run's bytes per launch"
+        c["roofline"]["measured_in"] = "frac: launch alone (one-stream replay); busy_union / by_durations: timed region" if roof.get("measured_in_short", "").startswith("frac: launch alone") else roof.get("measured_in_short", "timed region")[:80]
+        c["roofline"]["traffic_source"] = None if not roof.get("traffic_source") else "profiles/traffic.json PMC ratio x bytes per launch"
         if roof.get("kernel_alone") and "frac_busy_union" not in roof:      # (records of rounds 3-4: frac was the busy-union figure)
             c["roofline"]["frac_kernel_alone_one_stream"] = roof["kernel_alone"]["frac"]
     c["whole_step_frac"] = (full.get("whole_step") or {}).get("frac_of_hbm_peak")
+    # the two numerics contracts side by side: `value` is the fast contract's, value_reference_order the bit-exact one's
+    c["numerics"] = "fast"
+    dro = full.get("reference_order") or {}
+    if dro.get("value") is not None:
+        c["value_reference_order"] = dro.get("value")
+        ks = ((dro.get("roofline") or {}).get("kernels")) or [{}, {}, {}]
+        c["reference_order"] = {"partitions": dro.get("partitions"), "iterations": dro.get("admm_iterations_timed"), "value": dro.get("value"),
+                                "ms_per_step": dro.get("ms_per_step"),
+                                "bit_identical": None if dro.get("solves") is None else "%s/%s" % (dro.get("solves_bit_identical_beta_and_uplusx"), dro.get("solves")),
+                                "equal_counters": None if dro.get("solves") is None else "%s/%s" % (dro.get("solves_with_equal_counters"), dro.get("solves")),
+                                "frac": {"rows": ks[0].get("frac"), "cols": ks[1].get("frac")}, "whole_step_frac": dro.get("whole_step_frac"),
+                                "kernels": dro.get("kernels"), "eps_min": dro.get("smallest_epsilon")}
+    elif dro.get("error"):
+        c["reference_order"] = {"error": dro["error"][:120]}
     cb = full.get("cpu_baseline")
     if cb:
         c["cpu_baseline"] = _pick(cb, ["value", "unit", "cores", "kind"])
-        c["cpu_baseline"]["sample"] = cb.get("sample_short", cb.get("sample", ""))[:110]
+        c["cpu_baseline"]["sample"] = cb.get("sample_short", cb.get("sample", ""))[:96]
         c["gpu_over_cpu"] = (full.get("gpu_over_cpu") or {}).get("solves_per_s")
     par = {}
     c1 = full.get("config1_latency") or {}
     if c1:
-        par["config1"] = {"z32_bit_identical_to_golden_20_iterations": c1.get("z32_bit_identical_to_golden_run"),
+        par["config1"] = {"z32_bit_identical_20_its": c1.get("z32_bit_identical_to_golden_run"),
                           "gpu_ms": c1.get("ms_20_iterations"), "cpu_ms": c1.get("cpu_oracle_ms_20_iterations")}
     pc = full.get("parity_check") or {}
     vo = ((full.get("time_to_ref_loglik") or {}).get("vs_oracle_run")) or {}
     if pc or vo:
         par["config2"] = {"tolerance": 1e-5, "iterations_checked": (full.get("gpu_over_cpu") or {}).get("same_iterations"),
                           "max_rel_err_z": _r(pc.get("max_rel_err_z"), 9), "tron_counters_equal": pc.get("tron_counters_equal"),
-                          "counters_equal_through_iteration": pc.get("counters_equal_through_iteration"),
+                          "counters_eq_through_it": pc.get("counters_equal_through_iteration"),
                           "bit_identical_f32": pc.get("bit_identical_float32_fraction"),
-                          "run20_max_rel_err_through_eps_1e-6": _r(vo.get("max_rel_err_z32_through_epsilon_1e-6"), 9),
-                          "run20_max_rel_err": _r(vo.get("max_rel_err_z32_over_iterations"), 9),
-                          "run20_oracle_rowperm_max_rel_err": _r(vo.get("oracle_rowperm_max_rel_err_z32_over_iterations"), 9),
-                          "run20_iterations_all_counters_equal": vo.get("iterations_with_all_counters_equal")}
-        dro = full.get("reference_order") or {}
-        if dro.get("solves"):
-            par["config2"]["reference_order"] = {"bit_identical": "%s/%s" % (dro.get("solves_bit_identical_beta_and_uplusx"), dro.get("solves")),
-                                                 "equal_counters": "%s/%s" % (dro.get("solves_with_equal_counters"), dro.get("solves")),
-                                                 "partitions": dro.get("partitions"), "iterations": dro.get("iterations"), "value": dro.get("value")}
+                          "run20_err_to_eps_1e-6": _r(vo.get("max_rel_err_z32_through_epsilon_1e-6"), 9),
+                          "run20_err": _r(vo.get("max_rel_err_z32_over_iterations"), 9),
+                          "run20_oracle_rowperm_err": _r(vo.get("oracle_rowperm_max_rel_err_z32_over_iterations"), 9),
+                          "run20_its_all_counters_eq": vo.get("iterations_with_all_counters_equal")}
     sp = full.get("sparse") or {}
     spc = sp.get("parity_check") or {}
     if spc:
@@ -349,7 +358,7 @@ def compact_record(full):
                               "counters_perm_min_max": sm.get("equal_counters_perm_min_max"), "gpu_within_envelope": sm.get("gpu_within_envelope"),
                               "ok": {"counters": sm.get("envelope_counters_ok"), "easy_loo": sm.get("envelope_easy_solves_ok"), "median_err": sm.get("envelope_median_err_ok")},
                               "loo_keep": {"perm_min_max": sm.get("leave_one_out_keep_rate_perm_min_max"), "gpu": sm.get("leave_one_out_keep_rate_gpu")},
-                              "reference_order": sm.get("reference_order")}
+                              }
         else:
             par["config3"] = sm
     if par:
@@ -365,8 +374,8 @@ def compact_record(full):
             o[name + "_us_per_tick"] = k.get("us_per_tick")
         if d.get("reference_order"):
             ro = d["reference_order"]
-            o["reference_order"] = {"value": ro.get("value"), "bit_identical": "%s/%s" % (ro.get("solves_bit_identical_beta_and_uplusx"), ro.get("solves")),
-                                    "kernels": ro.get("kernels")}
+            o["value_reference_order"] = ro.get("value")
+            o["reference_order"] = {"bit_identical": "%s/%s" % (ro.get("solves_bit_identical_beta_and_uplusx"), ro.get("solves")), "step_us_per_tick": ro.get("step_us_per_tick")}
         ll = d.get("time_to_ref_loglik") or {}
         if ll.get("ref_loglik") is not None:
             o["time_to_ref_loglik_s"] = ll.get("seconds_to_ref_loglik")
@@ -395,6 +404,8 @@ def compact_record(full):
         c["time_to_ref_loglik"] = _pick(ll, ["seconds_to_ref_loglik", "reached_at_iteration", "seconds_all_iterations", "iterations"])
     if full.get("gram"):
         c["gram"] = _pick(full["gram"], ["achieved", "peak", "unit", "frac"])
+        c["gram"]["peak_source"] = "MI355X datasheet fp64 matrix"
+        c["gram"]["kernel"] = "k_gram_f64 (v_mfma_f64_16x16x4_f64), X'DX of one partition"
     if full.get("dense_8_per_gpu"):
         c["dense_8_per_gpu"] = _pick(full["dense_8_per_gpu"], ["value", "ms_per_step", "whole_step_frac"])
     hh = full.get("host_handover") or {}
@@ -407,10 +418,10 @@ def compact_record(full):
         c["all_xpass_launches"] = _pick(al, ["timed_by_events", "avg_us", "alg_bytes_timed_by_events"])
     if full.get("test_mode"):
         c["test_mode"] = "MLX_BENCH_SHARE_GPU=1 (control-flow check, not a measurement)"
-    c["full_record"] = "bench_full.json (also on stderr)"
+    c["full_record"] = "bench_full.json"
     c = _finite(c)
     # never exceed the limit: drop the optional blocks, least important first
-    for k in ("all_xpass_launches", "gram", "pcie_inclusive", "dense_8_per_gpu", "time_to_ref_loglik", "lambda_sweep", "sparse", "parity", "gpu_over_cpu"):
+    for k in ("all_xpass_launches", "pcie_inclusive", "dense_8_per_gpu", "time_to_ref_loglik", "gram", "lambda_sweep", "sparse", "parity", "gpu_over_cpu"):
         if len(json.dumps(c, allow_nan=False)) <= COMPACT_LIMIT:
             break
         c.pop(k, None)
@@ -645,9 +656,13 @@ def run_dense(args, C):
     # the per-iteration test loglik (jobs/RegressionAdmmTrain.java:766-845) on the 100 000 held-out rows; the target is
     # the ORACLE's value after its 20th iteration on the same data (tests/golden/c2_ref_loglik.json). Outside the timed region.
     loglik = None
-    ro_states, ro_parts = [], (min(args.dense_ro_partitions, P) if (want_cpu and world == 1) else 0)
     if args.loglik_iters > 0:
-        loglik = loglik_run(args, C, eng, P, nf, N, rows_total, ro_states, ro_parts)
+        loglik = loglik_run(args, C, eng, P, nf, N, rows_total)
+
+    # ---- the reference-order contract on the same job, the same iterations (every rank takes part: it shards like the headline)
+    ro_full = None
+    if not args.no_dense_ro:
+        ro_full = dense_ro_leg(args, C, sample if want_cpu else [], rows, nf, N, mine)
 
     out = None
     if rank == 0:
@@ -721,6 +736,9 @@ def run_dense(args, C):
                "whole_step": {"alg_bytes_per_s_GB": round(tot_alg / dt / 1e9, 1), "frac_of_hbm_peak": round(tot_alg / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
                               "definition": "sum over solves of device passes x B_pass (SURVEY 8d: 4 l n + 8 l + 8 n per pass) / wall time of the timed iterations"},
                "time_to_ref_loglik": loglik}
+        if ro_full is not None:
+            out["reference_order"] = ro_full
+            out["value_reference_order"] = ro_full.get("value")
         if not args.no_gram:
             out["gram"] = gram_leg(eng, rows, nf)
             allrun["untimed_launches"] += 3                    # mlx_posterior_variance evaluates D at w with one pass over its partition
@@ -729,8 +747,6 @@ def run_dense(args, C):
             out["dense_8_per_gpu"] = d8
         if world == 1 and not args.no_handover:
             out["host_handover"] = handover_leg(args, C, rows, nf, N, dt / args.steps)
-        if want_cpu and ro_parts > 0 and ro_states:
-            out["reference_order"] = dense_ro_leg(C, sample[:ro_parts], ro_states, nf, N)
         if want_cpu:
             cpu_leg(args, C, eng, out, sample, snap, eps_used, step_times, nf, N)
         # every k_xpass_dense launch of the process: the numbers a `rocprofv3 --kernel-trace --stats` of this command must show
@@ -953,60 +969,130 @@ def loglik_run(args, C, eng, P, nf, N, rows_total, ro_states=None, ro_parts=0):
     return res
 
 
-def dense_ro_leg(C, sample, states, nf, N):
-    """Reference-order numerics on configs[1]: the first partitions of the job (their rows stored and summed entry by entry like any CSR
-    partition: mlx_set_numerics) against the oracle twin (portable exp / log1p on both sides) over EVERY iteration of the 20-iteration
-    run -- the liblinear epsilon falls from 1e-2 to 1e-18, so this covers the regime where the product path's last accept / reject
-    depends on the summation order. Every solve starts from the product run's state at that iteration; counters must be
-    equal and beta / u+beta bit-identical."""
+def dense_ro_leg(args, C, sample, rows, nf, N, mine):
+    """The REFERENCE-ORDER contract on the headline job itself (round 6): all partitions of configs[1] as dense tiles under
+    mlx_set_numerics(REFERENCE_ORDER) (csrc/mlx_ro_dense.h: Xv one lane per row, XTv one lane per column over all rows -- two reads of
+    the tile per tick), the SAME warm-up and timed ADMM iterations as the headline (the driver's epsilon schedule), timed the same way
+    (barrier + synchronize, max over ranks). Then, off the clock: a one-stream replay with events (per-pass rooflines), and -- at one
+    GPU, with the CPU leg on -- EVERY timed solve of EVERY partition re-run by the oracle twin (oracle/liboracle_pm.so, portable exp /
+    log1p on both sides) from the engine's own state at that iteration: TRON counters equal, beta and u + beta bit-identical."""
+    torch, dev, world, rank, sd, admm = C["torch"], C["dev"], C["world"], C["rank"], C["sd"], C["admm"]
     try:
-        import oracle_lib as ol
-        from mlease_amd.dataset import PartitionBlock
-        blocks = []
-        for k, (Xh, yh) in enumerate(sample):
-            l = Xh.shape[0]
-            blocks.append(PartitionBlock(k, l, nf + 1, np.arange(0, (l + 1) * nf, nf, dtype=np.int64), np.tile(np.arange(nf, dtype=np.int32), l),
-                                         Xh.reshape(-1), yh, np.ones(l, np.float32), np.zeros(l, np.float32), np.arange(nf + 1, dtype=np.int32)))
-        nb = len(blocks)
+        P = len(mine)
         t0 = time.perf_counter()
         eng = C["HipAdmmEngine"](nf + 1, [1.0], [1.0], N, device=C["local_rank"], stream=C["stream"], numerics="reference_order")
-        eng.add_partitions(blocks)
+        for k in mine:
+            X, y = sd.dense_rows_torch(torch, dev, k, rows, nf, stride=N)
+            torch.cuda.synchronize()
+            eng.add_partition_dense_device(k, X.data_ptr(), rows, nf, nf, y.data_ptr())
+            del X, y
         eng.finalize()
+        torch.cuda.synchronize()
         prep = time.perf_counter() - t0
-        oc = ol.OracleAdmm(blocks, nf + 1, [1.0], [1.0], num_blocks=N, pm=True)
-        out = {"workload": "the first %d partitions of the configs[1] job (%d x %d each), all %d iterations of the 20-iteration run" % (nb, blocks[0].l, nf, len(states)),
-               "numerics": eng.get_option("numerics"), "kernels": eng.get_option("numerics_kernels"), "partitions": nb, "iterations": len(states),
-               "solves": 0, "solves_with_equal_counters": 0, "solves_bit_identical_beta_and_uplusx": 0, "prep_and_upload_s": round(prep, 2),
-               "smallest_epsilon": min(e for _, _, e in states), "gpu_seconds": 0.0, "cpu_seconds": 0.0}
-        eng.set_state(states[0][0], states[0][1])
-        eng.solve_local(states[0][2], 1.0)                       # (untimed: first launches)
-        threads = min(usable_cores(), nb)
-        for Z, u, e in states:
-            eng.set_state(Z, u)
-            t0 = time.perf_counter()
-            eng.solve_local(e, 1.0)
-            out["gpu_seconds"] += time.perf_counter() - t0
-            oc.set_state(Z, u)
-            t0 = time.perf_counter()
-            oc.solve_local(e, 1.0, nthreads=threads)
-            out["cpu_seconds"] += time.perf_counter() - t0
-            gc = eng.solve_counters()
-            cc = np.array([(s.newton_iters, s.accepted, s.cg_iters, s.x_passes) for s in oc.stats()], np.int32)
-            for k in range(nb):
-                gb, gu, _ = eng.partition_model(k, 0)
-                ob, ou, _ = oc.partition_model(k, 0)
-                out["solves"] += 1
-                out["solves_with_equal_counters"] += int(np.array_equal(gc[k], cc[k]))
-                out["solves_bit_identical_beta_and_uplusx"] += int(np.array_equal(gb, ob) and np.array_equal(gu, ou))
-        out["value"] = round(out["solves"] / max(1e-9, out["gpu_seconds"]), 1)
-        out["unit"] = "solves/s"
-        out["value_is"] = ("a parity check with %d problems on the chip (every launch of a tick is latency-bound at that count), not the mode's throughput: "
-                           "that is sparse.reference_order, 256 problems side by side" % nb)
-        out["gpu_seconds"] = round(out["gpu_seconds"], 3); out["cpu_seconds"] = round(out["cpu_seconds"], 2)
+        sched = EpsSchedule(admm)
+        eps_used = []
+
+        def step():
+            eps = sched.next()
+            eps_used.append(eps)
+            st = eng.solve_local(eps, 1.0)
+            C["all_reduce"](eng.consensus_tensor())
+            fin = eng.consensus_finish()
+            sched.mindiff = fin.mindiff
+            return st, fin
+
+        for _ in range(args.warmup):
+            step()
+        snap = (eng.z()[0].copy(), np.stack([eng.partition_model(i, 0)[2] for i in range(P)])[:, None, :].copy())
+        acc = dict(solves=0, ticks=0, alg=0.0, cg=0, newton=0)
+        C["barrier"]()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            st, fin = step()
+            acc["solves"] += st.solves; acc["ticks"] += st.ticks; acc["alg"] += st.alg_bytes_dev; acc["cg"] += st.cg_iters; acc["newton"] += st.newton_iters
+        C["barrier"]()
+        dt = C["reduce_max"](time.perf_counter() - t0)
+        tot_solves, tot_alg = C["reduce_sum"]([acc["solves"], acc["alg"]])
+        z_end = eng.z()[0].copy()
+        out = {"workload": "BASELINE configs[1], ALL %d partitions (%d x %d each) as dense tiles, ADMM iterations %d..%d (the headline's)" % (N, rows, nf, args.warmup + 1, args.warmup + args.steps),
+               "numerics": eng.get_option("numerics"), "kernels": eng.get_option("numerics_kernels"), "dense_tiles": int(eng.get_option("dense_tiles")),
+               "partitions": N, "partitions_per_gpu": P, "admm_iterations_timed": [args.warmup + 1, args.warmup + args.steps],
+               "value": round(tot_solves / dt, 2), "unit": "solves/s", "ms_per_step": round(dt * 1e3 / args.steps, 3), "ticks": acc["ticks"],
+               "smallest_epsilon": min(eps_used[args.warmup:]), "prep_and_upload_s": round(prep, 2),
+               "whole_step_frac": round(tot_alg / dt / 1e9 / (HBM_PEAK_GBS * world), 4),
+               "x_reads_per_tick": 2, "last_maxdiff": fin.maxdiff}
+        timed_eps = eps_used[args.warmup:args.warmup + args.steps]
+        # ---- the passes alone on the chip: replay of the first timed iterations, events on, one stream
+        if not args.no_profile:
+            it5 = min(args.steps, 5)
+            eng.set_state(snap[0], snap[1])
+            eng.set_profiling(True, one_stream=True)
+            pr = dict(row=0.0, col=0.0, step=0.0, alg=0.0, ticks=0, launches=0)
+            for eps in timed_eps[:it5]:
+                s2 = eng.solve_local(eps, 1.0)
+                C["all_reduce"](eng.consensus_tensor())
+                eng.consensus_finish()
+                pr["row"] += s2.rowpass_ms; pr["col"] += s2.colpass_ms; pr["step"] += s2.step_ms; pr["alg"] += s2.alg_bytes_dev; pr["ticks"] += s2.ticks
+                pr["launches"] += s2.xpass_launches
+            eng.set_profiling(False)
+            if pr["row"] > 0 and pr["col"] > 0:
+                half = pr["alg"] / 2.0                 # (each pass reads the tile once: 4 l n + 8 l + 8 n per unfinished problem)
+                out["roofline"] = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "kernels": [{"kernel": "k_ro_dense_rows", "frac": round(half / (pr["row"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                "achieved": round(half / (pr["row"] * 1e-3) / 1e9, 1), "us_per_tick": round(1e3 * pr["row"] / pr["ticks"], 1)},
+                                               {"kernel": "k_ro_dense_cols", "frac": round(half / (pr["col"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                "achieved": round(half / (pr["col"] * 1e-3) / 1e9, 1), "us_per_tick": round(1e3 * pr["col"] / pr["ticks"], 1)},
+                                               {"kernel": "k_ro_step", "us_per_tick": round(1e3 * pr["step"] / pr["ticks"], 1)}],
+                                   "alg_bytes_per_launch": half / max(1, pr["ticks"]),
+                                   "measured_in": "a replay of the first %d timed iterations (same state, same epsilons) with events on, all ticks on one stream; "
+                                                  "algorithmic bytes of the problems still unfinished in a launch / the launch class's time" % it5}
+        # ---- every timed solve against the oracle twin
+        if sample and world == 1:
+            import oracle_lib as ol
+            from mlease_amd.dataset import PartitionBlock
+            eng.set_state(snap[0], snap[1])
+            states = []
+            for eps in timed_eps:
+                Z = eng.z()[0].copy()
+                u = np.stack([eng.partition_model(i, 0)[2] for i in range(P)])[:, None, :].copy()
+                eng.solve_local(eps, 1.0)
+                models = [eng.partition_model(i, 0)[:2] for i in range(P)]
+                states.append((Z, u, eps, models, eng.solve_counters().copy()))
+                eng.consensus_finish()
+            out["replay_reproduced_timed_run"] = bool(np.array_equal(eng.z()[0], z_end))
+            blocks = []
+            col = None
+            for k, (Xh, yh) in enumerate(sample):
+                l = Xh.shape[0]
+                if col is None or len(col) != l * nf:
+                    col = np.tile(np.arange(nf, dtype=np.int32), l)
+                blocks.append(PartitionBlock(k, l, nf + 1, np.arange(0, (l + 1) * nf, nf, dtype=np.int64), col, Xh.reshape(-1), yh,
+                                             np.ones(l, np.float32), np.zeros(l, np.float32), np.arange(nf + 1, dtype=np.int32)))
+            oc = ol.OracleAdmm(blocks, nf + 1, [1.0], [1.0], num_blocks=N, pm=True)
+            del blocks
+            threads = min(usable_cores(), P)
+            chk = dict(solves=0, eqc=0, bit=0, first_mismatch=None)
+            tc = time.perf_counter()
+            for i, (Z, u, e, models, gc) in enumerate(states):
+                oc.set_state(Z, u)
+                oc.solve_local(e, 1.0, nthreads=threads)
+                cc = np.array([(s.newton_iters, s.accepted, s.cg_iters, s.x_passes) for s in oc.stats()], np.int32)
+                for k in range(P):
+                    ob, ou, _ = oc.partition_model(k, 0)
+                    eqc = bool(np.array_equal(gc[k], cc[k]))
+                    eqb = bool(np.array_equal(models[k][0], ob) and np.array_equal(models[k][1], ou))
+                    chk["solves"] += 1; chk["eqc"] += int(eqc); chk["bit"] += int(eqb)
+                    if not (eqc and eqb) and chk["first_mismatch"] is None:
+                        chk["first_mismatch"] = {"iteration": args.warmup + 1 + i, "partition": k, "gpu_counters": gc[k].tolist(), "oracle_counters": cc[k].tolist()}
+            out.update({"solves": chk["solves"], "solves_with_equal_counters": chk["eqc"], "solves_bit_identical_beta_and_uplusx": chk["bit"],
+                        "first_mismatch": chk["first_mismatch"], "oracle_twin_seconds": round(time.perf_counter() - tc, 1), "oracle_twin_threads": threads,
+                        "iterations": len(states)})
+            del oc
         eng.close()
         return out
     except Exception as ex:                                       # a checker leg must not take the headline down
-        return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+        import traceback
+        return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300]), "trace": traceback.format_exc()[-600:]}
 
 
 def cpu_leg(args, C, eng, out, sample, snap, eps_used, step_times, nf, N):

@@ -70,6 +70,7 @@ struct mlx_context {
     bool ro_dense_as_csr = false;          // MLX_RO_DENSE_AS_CSR=1 (A/B, tests): a dense tile of this mode through the CSR kernels, entry by entry (round 5's
                                            // form; the one-launch verification mode always takes it) instead of mlx_ro_dense.h
     int max_l_dense = 0;                   // rows of the longest dense tile (grid of the reference-order dense passes)
+    int *d_claim = nullptr;                // [MAX_TS][2] work counters of the reference-order dense column kernel, one pair per tick stream (zero between launches)
     // host-selectable behaviour (mlx_set_option; the MLX_* environment variables only seed these defaults at mlx_create)
     bool trace = false;                    // "trace": tick progress / stream probe on stderr
     bool stream_probe = true;              // "stream_probe": test that the tick streams sit on different hardware queues
@@ -278,7 +279,8 @@ int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
     if (nqd > 0 && h->ro_ticks) {
         // reference-order numerics on dense tiles: Xv (one lane per row), then XTv (one lane per column over all rows) -- two reads
         for (int which = 1; which <= 2; which++)
-            bracket(which, [&] { mlxk_ro_dense_passes(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->max_l_dense, h->max_nfeat_dense, h->n_lambda == 1, which); return 0; });
+            bracket(which, [&] { mlxk_ro_dense_passes(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->max_l_dense, h->max_nfeat_dense, h->n_lambda == 1, which,
+                                                      h->d_claim + 2 * h->mark_sidx); return 0; });
     } else if (nqd > 0 && bracket(0, [&] { return mlxk_xpass_dense(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->maxblk_dense, h->max_nfeat_dense, h->n_lambda == 1); }))
         return fail(h, MLX_ERR_INVALID, "dense tile wider than 2048 features is not supported; use the CSR form");
     if (nqc > 0)
@@ -382,7 +384,9 @@ int run_ticks(mlx_handle h, int first, int count, const int *qdense, int nqd, co
     int NS = 1;
     if (h->nstreams > 1 && !(h->profiling && h->prof_one_stream)) {
         if (nqd == 0 && nqc >= 32) NS = std::min(h->nstreams, nqc / 16);
-        else if (nqc == 0 && nqd >= 4) NS = std::min(h->nstreams, nqd / 2);
+        // (reference-order numerics on dense tiles: both passes fill the chip by themselves and the column kernel's workgroups are
+        //  placed one launch at a time -- several lists side by side were measured slower, profiles/r6_notes.md)
+        else if (nqc == 0 && nqd >= 4 && !h->ro_ticks) NS = std::min(h->nstreams, nqd / 2);
     }
     int c0[mlx_context::MAX_TS + 1], d0[mlx_context::MAX_TS + 1];      // part t = list positions [c0[t], c0[t+1]) / [d0[t], d0[t+1])
     for (int t = 0; t <= NS; t++) {
@@ -1418,6 +1422,10 @@ int mlx_add_partition_dense(mlx_handle h, int32_t partition_id, int32_t l, int32
     ph.pid = partition_id; ph.l = l; ph.n_local = n_local; ph.n_feat = n_feat; ph.dense = true; ph.hasval = true;
     ph.nnz = (int64_t)l * n_feat; ph.all_present = (n_local == h->n_global);
     ph.ld = (n_feat + 3) / 4 * 4;
+    // Reference-order tiles: rows on 128-byte boundaries (zero padded). Both kernels of the mode read a row in 256-byte pieces; on
+    // 4 000-byte rows three pieces of four straddle three cache lines and the streaming loads fetch the shared lines twice: row pass
+    // 744 -> 534 us per tick at configs[1] (profiles/r6_notes.md). MLX_RO_LD_ALIGN = floats (A/B knob).
+    if (ro_tile) { const int a = getenv("MLX_RO_LD_ALIGN") ? std::max(4, atoi(getenv("MLX_RO_LD_ALIGN")) / 4 * 4) : 32; ph.ld = (n_feat + a - 1) / a * a; }
     float *dX;
     if ((rc = dev_alloc(h, &dX, (size_t)l * ph.ld))) return rc;
     if (ph.ld != n_feat) HIPCHECK(h, hipMemset(dX, 0, sizeof(float) * (size_t)l * ph.ld));
@@ -1680,6 +1688,8 @@ int mlx_finalize(mlx_handle h)
 
     if ((rc = dev_alloc(h, &h->d_done, 1))) return rc;
     HIPCHECK(h, hipMemset(h->d_done, 0, sizeof(int)));
+    if ((rc = dev_alloc(h, &h->d_claim, 2 * (size_t)mlx_context::MAX_TS))) return rc;
+    HIPCHECK(h, hipMemset(h->d_claim, 0, sizeof(int) * 2 * mlx_context::MAX_TS));
 
     // c0 = X' t0: one EVAL pass at w = 0 on the first problem of every partition
     std::vector<int> qfirst_d, qfirst_c, qfirst_all;

@@ -16,8 +16,9 @@ int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const i
                    int ro_blocks /* > 0: reference-order numerics (mlx_ro_kernels.h); the column pass runs once per row block, that many times */);
 // reference-order numerics on DENSE tiles (mlx_ro_dense.h): which & 1 = Xv, one lane per row; which & 2 = XTv, one lane per column
 // over all rows (+ the intercept's column and the loss sum as two more chains)
+// claim: two zeroed ints of device memory per concurrently running launch (the column kernel's work counter; it clears them itself)
 void mlxk_ro_dense_passes(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int max_l, int max_nfeat,
-                          bool stream_once, int which);
+                          bool stream_once, int which, int *claim);
 // TRON/CG step of the reference-order numerics: one workgroup per problem, every reduction folded in index order
 void mlxk_ro_step(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int *done_counter);
 // TRON/CG control flow for the problems in qlist: one workgroup per problem (dense tiles)

@@ -3047,7 +3047,7 @@ template <typename F>
 static void per_device_once(int slot, F &&fn)
 {
     static std::mutex mu;
-    static bool done[8][64] = {};
+    static bool done[10][64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { fn(); return; }
     std::lock_guard<std::mutex> lk(mu);
@@ -3368,7 +3368,7 @@ void mlxk_hess_diag_items(hipStream_t st, int n_items, const int32_t *item_ptr, 
 void mlxk_gram_f64(hipStream_t st, const float *X, int64_t ld, int l, const double *wd, const int *blocks_xy, int nblocks,
                    int ksplit, int rows_per_split, double *P, int npad, int nf)
 {
-    per_device_once(4, [&] { set_max_lds(reinterpret_cast<const void *>(&k_gram_f64<4>), 4 * 4096 * (int)sizeof(double)); });
+    per_device_once(8, [&] { set_max_lds(reinterpret_cast<const void *>(&k_gram_f64<4>), 4 * 4096 * (int)sizeof(double)); });
     hipLaunchKernelGGL((k_gram_f64<4>), dim3(nblocks, ksplit / 2), dim3(512), 4 * 4096 * sizeof(double), st, X, ld, l, wd,
                        reinterpret_cast<const int2 *>(blocks_xy), rows_per_split, P, npad, nf);
 }
