@@ -27,6 +27,7 @@
 #include "mlx_types.h"
 #include "portable_math.h"
 #include "mlx_wave.h"
+#include "mlx_seqfold.h"
 
 // Global-memory accesses said to be global. The kernels take their pointers out of PartDev / ProbDev records in memory, so to the
 // compiler they are generic and every access became a FLAT instruction: 64-bit per-lane addresses, and -- what costs -- a FLAT load
@@ -1008,6 +1009,40 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     }
     __syncthreads();
     PT_MARK(8);
+    if (RO) {
+        // The intercept's column of X'c -- XTv[n-1] += v[i] * 1.0 over ALL rows in row order (llf/LogisticRegressionL2.java:143-145; the
+        // bias entry closes every row) -- is one more chain, carried from row block to row block like every column's: the last wave of
+        // the block's first work unit folds the block's coefficients (they sit in LDS anyway) onto the sum the earlier blocks left in
+        // csump[0]. Round 5 folded it in the step kernel. It is the one chain of a tick whose running sum stays as small as its terms
+        // (93 % of the rows push it up a little, 7 % pull it down a lot: the binade changes every few terms), so the exact parallel
+        // fold of mlx_seqfold.h has nothing to hold on to and the LITERAL chain runs -- here, where the launch hides it: 20 160 terms
+        // are ~0.15 ms of one wave inside a pass of ~0.23 ms.
+        const bool first_unit = bx_ == 0 || gld(pa.cw_blk + bx_ - 1) != blk;
+        if (first_unit && (threadIdx.x >> 6) == 15) {
+            // (every lane runs the same chain on the same addresses: LDS broadcasts, nothing diverges. Sixteen terms per trip; the
+            //  16-byte reads of the next eight are pinned in front of the eight adds they hide behind -- left to itself the scheduler
+            //  sinks every read next to its use and the chain pays one LDS latency per pair)
+            typedef double d2v_t __attribute__((ext_vector_type(2)));
+            double s = blk == 0 ? 0.0 : gld(pr.csump);
+            const d2v_t *c2 = reinterpret_cast<const d2v_t *>(cf);      // (nr <= 20 160 doubles + the zero slot behind them; r0 is a multiple of 64)
+            const int n16 = nr & ~15;
+            d2v_t A0, A1, A2, A3, B0, B1, B2, B3;
+            if (n16 > 0) { A0 = c2[0]; A1 = c2[1]; A2 = c2[2]; A3 = c2[3]; }
+            for (int j = 0; j < n16; j += 16) {
+                const int jb = (j + 8) >> 1, ja = min(j + 16, n16 - 8) >> 1;
+                B0 = c2[jb]; B1 = c2[jb + 1]; B2 = c2[jb + 2]; B3 = c2[jb + 3];
+                __builtin_amdgcn_sched_barrier(0);
+                s = s + A0.x; s = s + A0.y; s = s + A1.x; s = s + A1.y; s = s + A2.x; s = s + A2.y; s = s + A3.x; s = s + A3.y;
+                __builtin_amdgcn_sched_barrier(0);
+                A0 = c2[ja]; A1 = c2[ja + 1]; A2 = c2[ja + 2]; A3 = c2[ja + 3];
+                __builtin_amdgcn_sched_barrier(0);
+                s = s + B0.x; s = s + B0.y; s = s + B1.x; s = s + B1.y; s = s + B2.x; s = s + B2.y; s = s + B3.x; s = s + B3.y;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            for (int j = n16; j < nr; j++) s = s + cf[j];
+            if ((threadIdx.x & 63) == 0) gst(pr.csump, s);
+        }
+    }
     const uint16_t *__restrict__ cs_idx = pa.cs_idx;
     const float *__restrict__ cs_val = pa.cs_val;
     const int32_t *__restrict__ cs_ptr = pa.cs_ptr;

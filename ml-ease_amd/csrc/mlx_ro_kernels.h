@@ -12,314 +12,297 @@
 //     over all its rows; the longest slices run as a relay over the workgroup's 16 waves; the intercept's column (the sum of the row
 //     coefficients in row order) is one more folding lane of the step's first pass;
 //   * every n- or l-long dot / norm / loss sum of Tron.tron / trcg / fun (bw/Tron.java:30-252, llf/LogisticRegressionL2.java:156-193):
-//     k_ro_step below -- one 320-thread workgroup per problem walks the vectors in chunks of 1024 elements; waves 1-4 do the
+//     k_ro_step below -- one 640-thread workgroup per problem walks the vectors in chunks of 1024 elements; four staging waves do the
 //     elementwise work of a chunk (the daxpy / scale statements, Hs[i] = s[i]*priorVar_inv[i] + Hs[i], the products a[i]*b[i] of
-//     Tron.dot) and leave the chunk's TERMS in one of two LDS buffers; up to six lanes of wave 0 meanwhile fold one term array each IN
-//     INDEX ORDER out of the other buffer (p += term: the loop of Tron.dot :204-213), so the six reductions a CG step needs at once
-//     cost one chain, not six, and the staging costs the chain nothing.
+//     Tron.dot) and leave the chunk's TERMS in one of two LDS buffers; up to six folding WAVES meanwhile fold one term array each out
+//     of the other buffer -- the loop of Tron.dot :204-213, `p += term` in index order, evaluated exactly WITHOUT its dependency chain
+//     (mlx_seqfold.h, round 6: inside a binade of the running sum the chain equals the exact sum of grid-rounded terms, a scan; every
+//     sub-block's prefix range is checked and a failed check re-runs that sub-block as the literal chain; round 5 folded literally,
+//     one lane per array, 12.4 cycles per term). The six reductions a CG step needs at once run side by side.
 //     euclideanNorm (:220-252) keeps a running scale: its update is `sum = 1 + sum*(scale/a)^2` when |v_i| exceeds the scale and
 //     `sum += (a/scale)^2` otherwise. The scale before element i is the running maximum of |v| -- an exclusive prefix maximum, exact
-//     in any association -- so the chunk's threads compute it by a scan, form every element's (m, c) with sum' = c + sum*m in
-//     parallel (the divisions are off the chain), and the folding lane runs the chain; 32-term sub-blocks without a new maximum
-//     (all but ~ln n of them) take the plain `sum += c` loop.
+//     in any association -- so the chunk's threads compute it by a scan and form every element's (m, c) with sum' = c + sum*m in
+//     parallel (the divisions are off the fold); the ~ln n sub-blocks of a vector that hold a new maximum take that two-operation
+//     form as a literal chain, all others are plain sums of c.
 //   * exp / log1p: the portable forms of portable_math.h, as the oracle's verification twin evaluates them (device and host libm
 //     differ in the last bit).
 // Same statements in the same order as tron_step_body<SEQ> (which is bit-identical to the oracle): the tests run both.
 #pragma once
 
-#ifndef RO_CHUNK
-#define RO_CHUNK 1024        // elements per chunk (a multiple of 256: one staging wave per 256; A/B: tools/ablate_build.sh -DRO_CHUNK=512)
+#include "mlx_seqfold.h"
+
+constexpr int RO_CH = 64 * SGF_K;                   // elements per chunk: one sub-block of SGF_K terms per lane of a folding wave
+#ifndef RO_EPT
+#define RO_EPT 2                                     // consecutive elements per staging thread and chunk (A/B: tools/ablate_build.sh -DRO_EPT=4)
 #endif
-constexpr int RO_CH = RO_CHUNK, RO_NSW = RO_CH / 256, RO_T = 64 * (1 + RO_NSW), RO_CHP = RO_CH + 2, RO_NF = 6, RO_NN = 2;      // one folding wave + RO_NSW staging waves
-static_assert(RO_CH % 256 == 0 && RO_NSW >= 1 && RO_NSW <= 4, "chunk = 256 elements per staging wave, at most 32 sub-blocks of 32 terms");
+constexpr int RO_E = RO_EPT;
+// RO_NF folding waves + RO_NSW staging waves (64 RO_E elements each). The staging waves are the critical path since the folds stopped
+// being literal chains (a chunk: wait for the operands, the elementwise statements, a max-scan and a hand-shake between the staging
+// waves for the norms' running scale, two divisions per element, the LDS writes): eight waves with two elements per thread halve it.
+constexpr int RO_NSW = RO_CH / (64 * RO_E), RO_NF = 4, RO_NN = 2, RO_T = 64 * (RO_NF + RO_NSW);
+static_assert((RO_E == 2 || RO_E == 4) && SGF_K % RO_E == 0 && RO_NSW >= 1 && RO_NSW <= 12, "a staging thread's elements lie inside one sub-block");
+constexpr int RO_PITCH = 65, RO_CA = SGF_K * RO_PITCH;
 struct RoLds {
-    double C[2][RO_NF][RO_CHP];    // terms of a chunk, one array per folding lane (norm arrays first); two buffers: folded / being staged
-    double M[2][RO_NN][RO_CHP];    // multipliers of the norm arrays (1.0 except where the running scale changes)
+    // terms of a chunk, one array per folding wave (norm arrays first), TRANSPOSED: element e = L * SGF_K + i of the chunk -- term i of
+    // lane L's sub-block -- sits at [i * 65 + L]: a folding wave's load of term i is 64 consecutive doubles at a constant offset from
+    // one base address, and the pitch of 65 keeps the four staging threads of a sub-block (rows i0 .. i0 + 3 of one column) and
+    // their neighbours on different LDS banks when they write. Two buffers: folded / being staged.
+    double C[2][RO_NF][RO_CA];
+    double M[2][RO_NN][RO_CA];     // multipliers of the norm arrays (1.0 except where the running scale changes), same layout
+    unsigned char hm[2][RO_NN][64];// sub-block L of a norm array holds a change of the running scale
     double wtot[RO_NN][RO_NSW];    // scan: the staging waves' maxima of the chunk being staged
     double res[RO_NF], mcfin[RO_NN];
     volatile int seq[RO_NSW];      // chunk number (+ 1) each staging wave has published its maximum for
-    unsigned mask8[2][RO_NSW];     // per buffer and staging wave, bit k: terms 32 k .. 32 k + 31 of its 256 hold a change of a running scale
-    double pad[64];                // ro_fold32 reads up to 48 doubles ahead of the last term it adds
 };
-struct RoV4 { double v[4]; };
+struct RoV4 { double v[RO_E]; };                    // RO_E consecutive elements of a vector
 
-// four consecutive elements j0 .. j0+3 of a 32-byte aligned vector (the work vectors: 256-byte aligned pieces of the slab, padded so
+// RO_E consecutive elements j0 .. of a 32-byte aligned vector (the work vectors: 256-byte aligned pieces of the slab, padded so
 // that the last quad stays inside the piece -- mlx_finalize's carve_size)
 __device__ __forceinline__ RoV4 ro_ld4(const double *__restrict__ p, int j0)
 {
     typedef double d2v_t __attribute__((ext_vector_type(2)));
-    const d2v_t a = gld(reinterpret_cast<const d2v_t *>(p + j0)), b = gld(reinterpret_cast<const d2v_t *>(p + j0 + 2));
-    RoV4 r; r.v[0] = a.x; r.v[1] = a.y; r.v[2] = b.x; r.v[3] = b.y;
+    RoV4 r;
+#pragma unroll
+    for (int e = 0; e < RO_E; e += 2) {
+        const d2v_t a = gld(reinterpret_cast<const d2v_t *>(p + j0 + e));
+        r.v[e] = a.x; r.v[e + 1] = a.y;
+    }
     return r;
 }
-__device__ __forceinline__ RoV4 ro_ld4c(const double *__restrict__ p, int j0, int n)       // ... of a vector of n elements, clamped to its last quad
+__device__ __forceinline__ RoV4 ro_ld4c(const double *__restrict__ p, int j0, int n)       // ... of a vector of n elements, clamped to its last group
 {
-    return ro_ld4(p, min(j0, ((n - 1) >> 2) << 2));
+    return ro_ld4(p, min(j0, ((n - 1) / RO_E) * RO_E));
 }
 __device__ __forceinline__ RoV4 ro_ld4s(const double *__restrict__ p, int j0, int n)      // any alignment, clamped
 {
     RoV4 r;
 #pragma unroll
-    for (int e = 0; e < 4; e++) r.v[e] = gld(p + min(j0 + e, n - 1));
+    for (int e = 0; e < RO_E; e++) r.v[e] = gld(p + min(j0 + e, n - 1));
     return r;
 }
-__device__ __forceinline__ void ro_st4(double *__restrict__ p, int j0, int n, const double (&x)[4])
+__device__ __forceinline__ void ro_st4(double *__restrict__ p, int j0, int n, const double (&x)[RO_E])
 {
 #pragma unroll
-    for (int e = 0; e < 4; e++) if (j0 + e < n) gst(p + j0 + e, x[e]);
+    for (int e = 0; e < RO_E; e++) if (j0 + e < n) gst(p + j0 + e, x[e]);
 }
 
-// s += t[0]; s += t[1]; ... over 32 * nit consecutive doubles at the LDS address t, one dependent v_add_f64 per term: 16 terms are
-// added while the ds_reads of the next 16 are in flight (written as one asm block: the compiler sinks a read-ahead written in C back
-// into the iteration that uses it, which costs one LDS latency per batch -- 16 cycles per term instead of 8). nit is wave-uniform,
-// >= 1; the last trip reads 16 doubles ahead of its terms (inside the LDS allocation: RoLds is padded), unused.
-__device__ __forceinline__ double ro_fold32(double s, const double *t, int nit)
+// inclusive / exclusive prefix MAXIMUM of non-negative values over the 64 lanes, on the VALU (the DPP row shifts and row broadcasts of
+// mlx_seqfold.h's scan; lanes without a source read 0.0, the identity here) -- the __shfl_up form was 24 ds_bpermute per chunk
+__device__ __forceinline__ double ro_wave_inclusive_max(double v)
 {
-    unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) const double *)t;
-    // registers v[192:223] / v[224:255] hold 16 terms each; the eight 16-byte reads of one half are issued between the first adds of
-    // the other half (an add waits for its predecessor anyway: the reads ride in those stalls)
-    asm volatile(
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "ds_read_b128 v[192:195], %[a] offset:0\n\t"
-        "ds_read_b128 v[196:199], %[a] offset:16\n\t"
-        "ds_read_b128 v[200:203], %[a] offset:32\n\t"
-        "ds_read_b128 v[204:207], %[a] offset:48\n\t"
-        "ds_read_b128 v[208:211], %[a] offset:64\n\t"
-        "ds_read_b128 v[212:215], %[a] offset:80\n\t"
-        "ds_read_b128 v[216:219], %[a] offset:96\n\t"
-        "ds_read_b128 v[220:223], %[a] offset:112\n\t"
-        "1:\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_add_f64 %[s], %[s], v[192:193]\n\t"
-        "ds_read_b128 v[224:227], %[a] offset:128\n\t"
-        "v_add_f64 %[s], %[s], v[194:195]\n\t"
-        "ds_read_b128 v[228:231], %[a] offset:144\n\t"
-        "v_add_f64 %[s], %[s], v[196:197]\n\t"
-        "ds_read_b128 v[232:235], %[a] offset:160\n\t"
-        "v_add_f64 %[s], %[s], v[198:199]\n\t"
-        "ds_read_b128 v[236:239], %[a] offset:176\n\t"
-        "v_add_f64 %[s], %[s], v[200:201]\n\t"
-        "ds_read_b128 v[240:243], %[a] offset:192\n\t"
-        "v_add_f64 %[s], %[s], v[202:203]\n\t"
-        "ds_read_b128 v[244:247], %[a] offset:208\n\t"
-        "v_add_f64 %[s], %[s], v[204:205]\n\t"
-        "ds_read_b128 v[248:251], %[a] offset:224\n\t"
-        "v_add_f64 %[s], %[s], v[206:207]\n\t"
-        "ds_read_b128 v[252:255], %[a] offset:240\n\t"
-        "v_add_f64 %[s], %[s], v[208:209]\n\t"
-        "v_add_f64 %[s], %[s], v[210:211]\n\t"
-        "v_add_f64 %[s], %[s], v[212:213]\n\t"
-        "v_add_f64 %[s], %[s], v[214:215]\n\t"
-        "v_add_f64 %[s], %[s], v[216:217]\n\t"
-        "v_add_f64 %[s], %[s], v[218:219]\n\t"
-        "v_add_f64 %[s], %[s], v[220:221]\n\t"
-        "v_add_f64 %[s], %[s], v[222:223]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_add_u32 %[a], 0x100, %[a]\n\t"
-        "s_sub_u32 %[n], %[n], 1\n\t"
-        "v_add_f64 %[s], %[s], v[224:225]\n\t"
-        "ds_read_b128 v[192:195], %[a] offset:0\n\t"
-        "v_add_f64 %[s], %[s], v[226:227]\n\t"
-        "ds_read_b128 v[196:199], %[a] offset:16\n\t"
-        "v_add_f64 %[s], %[s], v[228:229]\n\t"
-        "ds_read_b128 v[200:203], %[a] offset:32\n\t"
-        "v_add_f64 %[s], %[s], v[230:231]\n\t"
-        "ds_read_b128 v[204:207], %[a] offset:48\n\t"
-        "v_add_f64 %[s], %[s], v[232:233]\n\t"
-        "ds_read_b128 v[208:211], %[a] offset:64\n\t"
-        "v_add_f64 %[s], %[s], v[234:235]\n\t"
-        "ds_read_b128 v[212:215], %[a] offset:80\n\t"
-        "v_add_f64 %[s], %[s], v[236:237]\n\t"
-        "ds_read_b128 v[216:219], %[a] offset:96\n\t"
-        "v_add_f64 %[s], %[s], v[238:239]\n\t"
-        "ds_read_b128 v[220:223], %[a] offset:112\n\t"
-        "v_add_f64 %[s], %[s], v[240:241]\n\t"
-        "v_add_f64 %[s], %[s], v[242:243]\n\t"
-        "v_add_f64 %[s], %[s], v[244:245]\n\t"
-        "v_add_f64 %[s], %[s], v[246:247]\n\t"
-        "v_add_f64 %[s], %[s], v[248:249]\n\t"
-        "v_add_f64 %[s], %[s], v[250:251]\n\t"
-        "v_add_f64 %[s], %[s], v[252:253]\n\t"
-        "v_add_f64 %[s], %[s], v[254:255]\n\t"
-        "s_cmp_lg_u32 %[n], 0\n\t"
-        "s_cbranch_scc1 1b\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : [s] "+v"(s), [a] "+v"(a), [n] "+s"(nit)
-        :
-        : "memory", "scc",
-          "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
-    return s;
+    v = fmax(v, sgf_dpp_or_zero<0x111, 0xF>(v));
+    v = fmax(v, sgf_dpp_or_zero<0x112, 0xF>(v));
+    v = fmax(v, sgf_dpp_or_zero<0x114, 0xF>(v));
+    v = fmax(v, sgf_dpp_or_zero<0x118, 0xF>(v));
+    v = fmax(v, sgf_dpp_or_zero<0x142, 0xA>(v));      // row_bcast:15 into rows 1 and 3
+    v = fmax(v, sgf_dpp_or_zero<0x143, 0xC>(v));      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ double ro_wave_shift_up_or_zero(double v) { return sgf_dpp_or_zero<0x138, 0xF>(v); }     // wave_shr:1 (lane 0: 0.0)
+
+// Workgroup barrier that orders LDS accesses ONLY. __syncthreads() is a workgroup-scope fence over every address space: it waits for
+// the wave's outstanding GLOBAL loads and stores too (s_waitcnt vmcnt(0)), so the operands a staging wave prefetches for the chunk after
+// next would have to land before every chunk's barrier -- one memory latency per chunk, which round 5's literal folds (5 us per chunk)
+// hid and the wave folds no longer do (step 1 635 -> see profiles/r6_notes.md).
+__device__ __forceinline__ void ro_lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// One folding wave, one chunk: the wave's array out of LDS (term i of lane L's sub-block at cp[i * RO_PITCH + L]; nvalid = how many of
+// this lane's SGF_K terms lie inside the vector, the others count as -0.0) into the running sum. NOT inlined: k_ro_step folds in seven
+// passes, up to four arrays each -- as inlined copies they made the kernel 135 KB and left the register allocator spilling loop
+// invariants of every copy into scratch, inside the chunk loop (profiles/r6_notes.md); two functions now, each with registers of its own.
+typedef const __attribute__((address_space(3))) double *ro_lds_cptr;
+template <bool MUL>
+__device__ __attribute__((noinline)) double ro_fold_chunk(double acc, ro_lds_cptr cp, ro_lds_cptr mp, int nvalid, int has, int &hostile)
+{
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & 63;
+    double t[SGF_K], m[SGF_K];
+#pragma unroll
+    for (int i = 0; i < SGF_K; i++) {
+        const double x = cp[RO_PITCH * i + lane];
+        t[i] = i < nvalid ? x : -0.0;                          // behind the end: x + (-0.0) == x
+        m[i] = 1.0;
+    }
+    if (MUL && __ballot(has != 0) != 0ull) {                   // (~ln n sub-blocks per vector hold a scale change)
+#pragma unroll
+        for (int i = 0; i < SGF_K; i++) { const double y = mp[RO_PITCH * i + lane]; m[i] = (has != 0 && i < nvalid) ? y : 1.0; }
+    }
+    return sgf_wave_fold<SGF_K, MUL>(acc, t, m, has != 0, hostile);
 }
 
 // One pass over elements 0 .. len-1. load(j0, R) fetches the operands of elements j0 .. j0+3 (it clamps to the last quad of each
 // vector itself), emit(j0, R, ct, nv) does their elementwise work (stores included, elements beyond a vector's end masked) and
-// returns the terms of the dot arrays ct[k][e] (k >= NN) and the raw values of the norm arrays nv[q][e] (q < NN). Lane k of the
-// first wave folds array k over its first lens[k] elements (lens == nullptr: len for all): norms from sum = 1, dots from init[k].
+// returns the terms of the dot arrays ct[k][e] (k >= NN) and the raw values of the norm arrays nv[q][e] (q < NN). Folding wave k
+// folds array k over its first lens[k] elements (lens == nullptr: len for all): norms from sum = 1, dots from init[k].
 // result[k] (every thread): the norm scale*sqrt(sum) / the dot.
+// Round 5 folded with one LANE per array -- a literal chain of dependent adds, 12.4 cycles per term; since round 6 a WAVE folds an array
+// with sgf_wave_fold (mlx_seqfold.h): the same bits -- the sequential loop's -- from grid-rounded terms and a scan wherever the
+// running sum stays inside a binade, the literal chain for the sub-blocks where it does not.
 template <int NF, int NN, typename R, typename LD, typename EM>
 __device__ __forceinline__ void ro_pass(RoLds &sh, int len, const int *lens, const double *init, double *result, LD load, EM emit)
 {
 #pragma clang fp contract(off)
     static_assert(NF <= RO_NF && NN <= RO_NN && NN <= NF, "fold arrays");
     constexpr int NFX = NF > 0 ? NF : 1, NNX = NN > 0 ? NN : 1;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     if (NF == 0) {
-        // elementwise only: no terms, no barriers; four quads per thread in flight (a single one leaves every trip waiting for HBM)
-        for (int base = 0; base < len; base += 16 * RO_T) {
+        // elementwise only: no terms, no barriers; four groups per thread in flight (a single one leaves every trip waiting for HBM)
+        for (int base = 0; base < len; base += 4 * RO_E * RO_T) {
             R r4[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) load(base + u * 4 * RO_T + 4 * tid, r4[u]);
+            for (int u = 0; u < 4; u++) load(base + u * RO_E * RO_T + RO_E * tid, r4[u]);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                double ct[NFX][4], nv[NNX][4];
-                emit(base + u * 4 * RO_T + 4 * tid, r4[u], ct, nv);
+                double ct[NFX][RO_E], nv[NNX][RO_E];
+                emit(base + u * RO_E * RO_T + RO_E * tid, r4[u], ct, nv);
             }
         }
         __syncthreads();
         return;
     }
-    // Wave 0 FOLDS; waves 1-4 (256 threads) STAGE: while the folding wave runs the chains of chunk c out of one LDS buffer, the staging
-    // waves load, compute and store chunk c + 1 into the other (their work -- memory latency, the scan, the divisions of the norms'
-    // terms -- is off the chains' critical path: one barrier per chunk, the folding wave never stages). The staging waves agree on the
-    // running maximum of a norm's operand among themselves: each publishes its quarter's maximum in LDS and its chunk number behind it
-    // (sh.seq), and reads the others' when all four numbers are there.
-    const bool folder = wave == 0;
-    const int sw = wave - 1, stid = tid - 64;                 // staging wave 0..RO_NSW-1, staging thread 0..RO_CH/4-1
+    // Waves 0 .. RO_NF-1 FOLD (wave k array k; waves k >= NF only keep the barriers); waves RO_NF .. STAGE: while the folding waves work
+    // on chunk c out of one LDS buffer, the staging waves compute chunk c + 1 into the other from operands they loaded one chunk earlier
+    // (two register sets: the loads of chunk c + 2 are in flight meanwhile) -- memory latency, the scan, the divisions of the norms' terms
+    // are off the folds' path: one barrier per chunk. The staging waves agree on the running maximum of a norm's operand among
+    // themselves: each publishes its part's maximum in LDS and its chunk number behind it (sh.seq), and reads the others' when all are there.
+    const bool folder = wave < RO_NF;
+    const int sw = wave - RO_NF, stid = tid - 64 * RO_NF;     // staging wave 0..RO_NSW-1, staging thread 0..RO_CH/RO_E-1
     const int nch = (len + RO_CH - 1) / RO_CH;
-    const int mylen = (folder && lens != nullptr) ? lens[lane < NF ? lane : 0] : len;      // (wave 0: the array this lane folds)
+    const int mylen = (folder && lens != nullptr) ? lens[wave < NF ? wave : 0] : len;      // (folding wave: the array it folds)
     double acc = 0.0;
-    if (folder) acc = (lane < NN) ? 1.0 : init[lane < NF ? lane : 0];
+    int hostile = 0;                                          // (a folding wave's array: did the last chunk run out of budget? mlx_seqfold.h)
+    if (folder) acc = (wave < NN) ? 1.0 : init[wave < NF ? wave : 0];
     double mc[NNX];
 #pragma unroll
     for (int q = 0; q < NNX; q++) mc[q] = 0.0;
-    auto stage = [&](int c) {
+#ifdef MLX_PHASE_TIMING
+    // (timing-experiment builds: shader-clock cycles per phase, kept in registers by lane 0 of every folding wave and of the first
+    //  staging wave, added to g_phase[] once at the end of the pass -- no atomics inside the loop)
+    unsigned long long pt_t = clock64(), pt_a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool pt_on = lane == 0 && (wave < NF || wave == RO_NF);
+#define RO_PT(slot) do { if (pt_on) { const unsigned long long t_ = clock64(); pt_a[slot] += t_ - pt_t; pt_t = t_; } } while (0)
+#else
+#define RO_PT(slot) do { } while (0)
+#endif
+    // element e of the chunk (e = RO_E stid ..) -> term i = e % SGF_K of sub-block L = e / SGF_K, at [i * 65 + L]
+    const int ti0 = (RO_E * stid) % SGF_K, tL = (RO_E * stid) / SGF_K;
+    auto tpos = [&](int e) { return (ti0 + e) * RO_PITCH + tL; };
+    auto stage = [&](int c, R &regs) {
         const int b = c & 1;
-        const int j0 = c * RO_CH + 4 * stid;
-        R regs;
-        load(j0, regs);
-        double ct[NFX][4], nv[NNX][4];
+        const int j0 = c * RO_CH + RO_E * stid;
+        double ct[NFX][RO_E], nv[NNX][RO_E];
+        RO_PT(2);
         emit(j0, regs, ct, nv);
-        int flag = 0;
+        RO_PT(3);
         if (NN > 0) {
             // euclideanNorm's running scale in front of every element = exclusive prefix maximum of |v| (zeros never raise it)
-            double a[NNX][4], x[NNX];
+            double a[NNX][RO_E], x[NNX];
+            int flag[NNX];
 #pragma unroll
             for (int q = 0; q < NN; q++) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) a[q][e] = (j0 + e < (lens != nullptr ? lens[q] : len)) ? fabs(nv[q][e]) : 0.0;
-                x[q] = fmax(fmax(a[q][0], a[q][1]), fmax(a[q][2], a[q][3]));
+                for (int e = 0; e < RO_E; e++) a[q][e] = (j0 + e < (lens != nullptr ? lens[q] : len)) ? fabs(nv[q][e]) : 0.0;
+                x[q] = a[q][0];
 #pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const double y = __shfl_up(x[q], d);
-                    if (lane >= d) x[q] = fmax(x[q], y);
-                }
+                for (int e = 1; e < RO_E; e++) x[q] = fmax(x[q], a[q][e]);
+                x[q] = ro_wave_inclusive_max(x[q]);
                 if (lane == 63) sh.wtot[q][sw] = x[q];
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");      // (LDS only: the prefetched operands stay in flight)
             if (lane == 0) sh.seq[sw] = c + 1;
             for (int w = 0; w < RO_NSW; w++) while (sh.seq[w] < c + 1) __builtin_amdgcn_s_sleep(1);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            RO_PT(4);
 #pragma unroll
             for (int q = 0; q < NN; q++) {
-                double ex = __shfl_up(x[q], 1);
-                if (lane == 0) ex = 0.0;
+                const double ex = ro_wave_shift_up_or_zero(x[q]);
                 double P = fmax(mc[q], ex);
                 for (int w = 0; w < RO_NSW; w++) {
                     const double t = sh.wtot[q][w];
                     if (w < sw) P = fmax(P, t);
                     mc[q] = fmax(mc[q], t);
                 }
-                double mm[4], cc[4];
+                flag[q] = 0;
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
+                for (int e = 0; e < RO_E; e++) {
                     const double ae = a[q][e];
-                    if (!(ae != 0.0)) { mm[e] = 1.0; cc[e] = 0.0; }               // v[i] == 0: skipped
-                    else if (P < ae) { const double t = P / ae; mm[e] = t * t; cc[e] = 1.0; flag = 1; }      // sum = 1 + sum * (t * t); scale = a
-                    else { const double t = ae / P; mm[e] = 1.0; cc[e] = t * t; }                                // sum += t * t
+                    double mm, cc;
+                    if (!(ae != 0.0)) { mm = 1.0; cc = 0.0; }                       // v[i] == 0: skipped
+                    else if (P < ae) { const double t = P / ae; mm = t * t; cc = 1.0; flag[q] = 1; }      // sum = 1 + sum * (t * t); scale = a
+                    else { const double t = ae / P; mm = 1.0; cc = t * t; }           // sum += t * t
                     P = fmax(P, ae);
+                    sh.C[b][q][tpos(e)] = cc;
+                    sh.M[b][q][tpos(e)] = mm;
                 }
-                typedef double d2v_t __attribute__((ext_vector_type(2)));
-                d2v_t *cp = reinterpret_cast<d2v_t *>(&sh.C[b][q][4 * stid]), *mp = reinterpret_cast<d2v_t *>(&sh.M[b][q][4 * stid]);
-                cp[0] = (d2v_t){cc[0], cc[1]}; cp[1] = (d2v_t){cc[2], cc[3]};
-                mp[0] = (d2v_t){mm[0], mm[1]}; mp[1] = (d2v_t){mm[2], mm[3]};
+                // the threads of a sub-block (SGF_K = 16 elements): does it hold a change of the running scale?
+                const unsigned long long bal = __ballot(flag[q] != 0);
+                constexpr int TPS = SGF_K / RO_E;              // threads per sub-block
+                if ((lane % TPS) == 0) sh.hm[b][q][(RO_E * stid) / SGF_K] = ((bal >> (lane - lane % TPS)) & ((1ull << TPS) - 1ull)) ? 1 : 0;
             }
-            // which of this wave's eight 32-term sub-blocks hold a change of a running scale (lanes 8 k .. 8 k + 7 own sub-block k)
-            const unsigned long long bal = __ballot(flag != 0);
-            unsigned m8 = 0u;
-#pragma unroll
-            for (int k = 0; k < 8; k++) if ((bal >> (8 * k)) & 0xFFull) m8 |= 1u << k;
-            if (lane == 0) sh.mask8[b][sw] = m8;
         }
+        RO_PT(5);
 #pragma unroll
         for (int k = NN; k < NF; k++) {
-            typedef double d2v_t __attribute__((ext_vector_type(2)));
-            d2v_t *cp = reinterpret_cast<d2v_t *>(&sh.C[b][k][4 * stid]);
-            cp[0] = (d2v_t){ct[k][0], ct[k][1]}; cp[1] = (d2v_t){ct[k][2], ct[k][3]};
+#pragma unroll
+            for (int e = 0; e < RO_E; e++) sh.C[b][k][tpos(e)] = ct[k][e];
         }
+    };
+    auto fold = [&](int c) {
+        if (wave >= NF) return;
+        const int b = c & 1;
+        const int cnt = max(0, min(RO_CH, mylen - c * RO_CH));
+        if (cnt == 0) return;                                   // (this array ends before the chunk: wave-uniform)
+        const bool isn = wave < NN;
+        const int has = (isn && sh.hm[b][isn ? wave : 0][lane] != 0) ? 1 : 0;
+        const int nvalid = max(0, min(SGF_K, cnt - lane * SGF_K));
+        ro_lds_cptr cp = (ro_lds_cptr)&sh.C[b][wave][0];
+        ro_lds_cptr mp = (ro_lds_cptr)&sh.M[b][isn ? wave : 0][0];
+        RO_PT(7);
+        if (isn) acc = ro_fold_chunk<true>(acc, cp, mp, nvalid, has, hostile);
+        else acc = ro_fold_chunk<false>(acc, cp, mp, nvalid, 0, hostile);
     };
     if (NN > 0 && tid < RO_NSW) sh.seq[tid] = 0;
     __syncthreads();
-    if (!folder) stage(0);
-    __syncthreads();
-    for (int c = 0; c < nch; c++) {
-        if (!folder) {
-            if (c + 1 < nch) stage(c + 1);
-        } else if (lane < NF) {
-            const int b = c & 1, base = c * RO_CH;
-            const int cnt = max(0, min(RO_CH, mylen - base));
-            const double *cp = &sh.C[b][lane][0];
-            const double *mp = &sh.M[b][lane < NN ? lane : 0][0];
-            const bool isn = lane < NN;
-            unsigned mask = 0u;
-            if (NN > 0) {
-#pragma unroll
-                for (int w = 0; w < RO_NSW; w++) mask |= sh.mask8[b][w] << (8 * w);
-            }
-            double s = acc;
-            // p += term: ONE dependent add per element. Sub-blocks of 32 terms common to the folding lanes run in ro_fold32 (the LDS
-            // reads of the next 16 terms in flight while 16 are added) -- except the few sub-blocks in which a norm's running scale
-            // changes (euclideanNorm's `sum = 1 + sum * (scale/a)^2`: about ln n of them per vector): those, and what is left of a
-            // lane's chunk behind the common part, take the per-term form sum = c + sum * m (m = 1.0 wherever nothing changes:
-            // c + sum * 1.0 is sum + c bit for bit).
-            int T = RO_CH / 32;
-#pragma unroll
-            for (int k = 0; k < NF; k++) {
-                const int ck = __shfl(cnt, k);
-                if (ck >= 32) T = min(T, ck >> 5);
-            }
-            T = __builtin_amdgcn_readfirstlane(T);
-            int i = 0;
-            if (cnt >= 32) {
-                int bq = 0;
-                while (bq < T) {
-                    const unsigned rest = mask >> bq;
-                    if (rest & 1u) {
-                        for (int e = 32 * bq; e < 32 * bq + 32; e += 8) {
-                            double c8[8], m8[8];
-#pragma unroll
-                            for (int u = 0; u < 8; u++) { c8[u] = cp[e + u]; m8[u] = isn ? mp[e + u] : 1.0; }
-#pragma unroll
-                            for (int u = 0; u < 8; u++) s = c8[u] + s * m8[u];
-                        }
-                        bq += 1;
-                    } else {
-                        int run = rest == 0u ? T - bq : min(T - bq, (int)__builtin_ctz(rest));
-                        run = __builtin_amdgcn_readfirstlane(run);
-                        s = ro_fold32(s, cp + 32 * bq, run);
-                        bq += run;
-                    }
-                }
-                i = T << 5;
-            }
-            for (; i < cnt; i++) {
-                const double m = isn ? mp[i] : 1.0;
-                s = cp[i] + s * m;
-            }
-            acc = s;
-        }
-        __syncthreads();
+    R ra, rb;
+    if (!folder) {
+        load(RO_E * stid, ra);
+        load(RO_CH + RO_E * stid, rb);                            // (clamped inside load: a pass of one chunk reads its last quads again)
+        stage(0, ra);
     }
-    if (folder && lane < NF) sh.res[lane] = acc;
+    __syncthreads();
+    for (int c = 0; c < nch; c += 2) {
+        // chunk c is folded while chunk c + 1 is staged from rb and the operands of chunk c + 2 arrive in ra; then the roles swap
+        if (!folder) { if (c + 1 < nch) { load((c + 2) * RO_CH + RO_E * stid, ra); stage(c + 1, rb); } }
+        else fold(c);
+        RO_PT(folder ? 0 : 2);
+        ro_lds_barrier();
+        RO_PT(folder ? 1 : 6);
+#ifdef MLX_PHASE_TIMING
+        pt_a[7] += 100;
+#endif
+        if (c + 1 >= nch) break;
+        if (!folder) { if (c + 2 < nch) { load((c + 3) * RO_CH + RO_E * stid, rb); stage(c + 2, ra); } }
+        else fold(c + 1);
+        RO_PT(folder ? 0 : 2);
+        ro_lds_barrier();
+        RO_PT(folder ? 1 : 6);
+    }
+#if defined(MLX_PHASE_TIMING) && !defined(MLX_SGF_STATS)
+    if (pt_on) {
+        if (folder) {
+            atomicAdd(&g_phase[wave], pt_a[0]); atomicAdd(&g_phase[4 + wave], pt_a[1]);
+            if (wave == 1) atomicAdd(&g_phase[14], pt_a[7]);
+        }
+        else { for (int i = 2; i <= 7; i++) atomicAdd(&g_phase[6 + i], pt_a[i]); }
+    }
+#endif
+#undef RO_PT
+    if (folder && wave < NF && lane == 0) sh.res[wave] = acc;
     if (NN > 0 && stid == 0) {
 #pragma unroll
         for (int q = 0; q < NN; q++) sh.mcfin[q] = mc[q];
@@ -345,7 +328,11 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
     if (phase == PH_DONE) return;
     const PartDev &pa = parts[pr.part];
     const int n = pa.n_local, nf = pa.n_feat, l = pa.l, tid = threadIdx.x;
-    const bool dn = pa.dense != 0;                                // dense tile (mlx_ro_dense.h): the two l-long chains are done already
+    // The intercept's column of X'c (the sum of the row coefficients in row order) is folded by the column pass: k_ro_dense_cols on a
+    // spare lane (which also leaves the loss sum: dn), k_colpass_lds<.., RO> block by block (csum_done); a partition without a column
+    // work unit (no feature column at all) folds it here.
+    const bool dn = pa.dense != 0;
+    const bool csum_done = dn || pa.n_cunits > 0;
     const double *__restrict__ xtc = pr.c0f;                      // X'c of this tick, columns 0 .. nf-1 (k_colpass_lds<.., RO>)
     const double *__restrict__ coef = pr.coef;                    // the row coefficients: their sum in row order is the intercept's column
     const double *__restrict__ pvec = pr.pinv_vec;
@@ -353,7 +340,7 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
     double *__restrict__ w = pr.w, *__restrict__ w_new = pr.w_new, *__restrict__ g = pr.g, *__restrict__ s = pr.s,
            *__restrict__ d = pr.d, *__restrict__ Hd = pr.Hd;
     const double *__restrict__ m = pr.m;
-    const double zero6[RO_NF] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const double zero6[RO_NF] = {0.0, 0.0, 0.0, 0.0};
     double res[RO_NF];
 
     if (phase == PH_CG) {
@@ -363,20 +350,20 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
         // that sum and is added after the pass: the same chain.
         // (dense tiles: k_ro_dense_cols ran that chain on a spare lane and left it in csump[0])
         struct RA { RoV4 d, x, p, c; };
-        const int lensA[2] = {nf, dn ? 0 : l};
-        ro_pass<2, 0, RA>(sh, dn ? nf : max(nf, l), lensA, zero6, res,
+        const int lensA[2] = {nf, csum_done ? 0 : l};
+        ro_pass<2, 0, RA>(sh, csum_done ? nf : max(nf, l), lensA, zero6, res,
             [&](int j0, RA &R) { R.d = ro_ld4c(d, j0, n); R.x = ro_ld4c(xtc, j0, n); if (pvec) R.p = ro_ld4s(pvec, j0, n); R.c = ro_ld4c(coef, j0, l); },
-            [&](int j0, RA &R, double (&ct)[2][4], double (&nv)[1][4]) {
-                double hd[4];
+            [&](int j0, RA &R, double (&ct)[2][RO_E], double (&nv)[1][RO_E]) {
+                double hd[RO_E];
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
+                for (int e = 0; e < RO_E; e++) {
                     hd[e] = R.d.v[e] * (pvec ? R.p.v[e] : pscal) + R.x.v[e];      // Hs[i] = (s[i]*priorVar_inv[i] + Hs[i]) * 1
                     ct[0][e] = R.d.v[e] * hd[e];                                   // Tron.dot(d, Hd)
                     ct[1][e] = R.c.v[e];                                           // XTv[n-1] += v[i]
                 }
                 ro_st4(Hd, j0, nf, hd);
             });
-        if (dn) res[1] = pr.csump[0];
+        if (csum_done) res[1] = pr.csump[0];
         const double rTr0 = pr.rTr, delta0 = pr.delta, cgtol0 = pr.cgtol;
         const double d_icpt = d[nf];
         const double hd_icpt = d_icpt * (pvec ? pvec[nf] : pscal) + res[1];
@@ -386,21 +373,18 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
         const double nalpha = -alpha;
         const double *__restrict__ rc = pr.rb[pr.rsel];
         double *__restrict__ rn = pr.rb[pr.rsel ^ 1];
-        // daxpy(alpha, d, s); the norm of s; and, from the same operands, both continuations: r' = r - alpha Hd with r'.r' and |r'|
-        // (:169-171, :144 of the next trip) and the three dots of the boundary case on the stepped-back s (:152-155)
+        // daxpy(alpha, d, s); the norm of s; and the continuation r' = r - alpha Hd with r'.r' and |r'| (:169-171, :144 of the next trip)
         struct RB { RoV4 d, s, r, h; };
-        ro_pass<6, 2, RB>(sh, n, nullptr, zero6, res,
+        ro_pass<3, 2, RB>(sh, n, nullptr, zero6, res,
             [&](int j0, RB &R) { R.d = ro_ld4c(d, j0, n); R.s = ro_ld4c(s, j0, n); R.r = ro_ld4c(rc, j0, n); R.h = ro_ld4c(Hd, j0, n); },
-            [&](int j0, RB &R, double (&ct)[6][4], double (&nv)[2][4]) {
-                double s1[4], r1[4];
+            [&](int j0, RB &R, double (&ct)[3][RO_E], double (&nv)[2][RO_E]) {
+                double s1[RO_E], r1[RO_E];
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
+                for (int e = 0; e < RO_E; e++) {
                     s1[e] = R.s.v[e] + alpha * R.d.v[e];                     // daxpy(alpha, d, s)
                     r1[e] = R.r.v[e] + nalpha * R.h.v[e];                    // daxpy(-alpha, Hd, r)
-                    const double sb = s1[e] + nalpha * R.d.v[e];             // the boundary case steps back first (:153)
                     nv[0][e] = s1[e]; nv[1][e] = r1[e];
                     ct[2][e] = r1[e] * r1[e];
-                    ct[3][e] = sb * R.d.v[e]; ct[4][e] = sb * sb; ct[5][e] = R.d.v[e] * R.d.v[e];
                 }
                 ro_st4(s, j0, n, s1);
                 ro_st4(rn, j0, n, r1);
@@ -408,10 +392,23 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
         const double snorm = res[0];
         bool boundary = false, end_cg = false, nan = !(snorm == snorm);
         double alpha2 = 0.0, beta = 0.0;
-        const double rnew = res[2];
+        const double rnew = res[2], rnorm_new = res[1];
         if (snorm > delta0) {
-            // cg reaches trust region boundary (:150-168)
-            const double std_ = res[3], sts = res[4], dtd = res[5];
+            // cg reaches trust region boundary (:150-168): the three dots on the stepped-back s (:152-155). (Round 5 computed them
+            // speculatively in the pass above -- six folds side by side; with the folds no longer the bottleneck the common CG step
+            // carries three, and the boundary step -- at most one per trcg call -- pays a pass of its own.)
+            struct RB2 { RoV4 d, s; };
+            double res2[RO_NF];
+            ro_pass<3, 0, RB2>(sh, n, nullptr, zero6, res2,
+                [&](int j0, RB2 &R) { R.d = ro_ld4c(d, j0, n); R.s = ro_ld4c(s, j0, n); },
+                [&](int j0, RB2 &R, double (&ct)[3][RO_E], double (&nv)[1][RO_E]) {
+#pragma unroll
+                    for (int e = 0; e < RO_E; e++) {
+                        const double sb = R.s.v[e] + nalpha * R.d.v[e];      // daxpy(-alpha, d, s) (:153)
+                        ct[0][e] = sb * R.d.v[e]; ct[1][e] = sb * sb; ct[2][e] = R.d.v[e] * R.d.v[e];
+                    }
+                });
+            const double std_ = res2[0], sts = res2[1], dtd = res2[2];
             const double dsq = delta0 * delta0;
             const double rad = sqrt(std_ * std_ + dtd * (dsq - sts));
             if (std_ >= 0) alpha2 = (dsq - sts) / (std_ + rad);
@@ -419,7 +416,7 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
             boundary = true; end_cg = true;
         } else {
             beta = rnew / rTr0;
-            if (res[1] <= cgtol0) end_cg = true;                 // loop-top test of the next trip (:144)
+            if (rnorm_new <= cgtol0) end_cg = true;              // loop-top test of the next trip (:144)
         }
         if (nan) end_cg = true;
         const double nalpha2 = -alpha2;
@@ -430,10 +427,10 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
             else { R.r1 = ro_ld4c(rn, j0, n); if (end_cg) R.s = ro_ld4c(s, j0, n); }
             if (end_cg) { R.w = ro_ld4c(w, j0, n); R.g = ro_ld4c(g, j0, n); }
         };
-        auto emc = [&](int j0, RC &R, double (&ct)[3][4], double (&nv)[1][4]) {
-            double sf[4], rf[4], dn[4], wn[4];
+        auto emc = [&](int j0, RC &R, double (&ct)[3][RO_E], double (&nv)[1][RO_E]) {
+            double sf[RO_E], rf[RO_E], dn[RO_E], wn[RO_E];
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
+            for (int e = 0; e < RO_E; e++) {
                 sf[e] = R.s.v[e]; rf[e] = R.r1.v[e];
                 if (boundary) {
                     const double sb = R.s.v[e] + nalpha * R.d.v[e];          // daxpy(-alpha, d, s)
@@ -457,7 +454,7 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
         };
         if (end_cg) ro_pass<3, 1, RC>(sh, n, nullptr, zero6, res, ldc, emc);
         else ro_pass<0, 0, RC>(sh, n, nullptr, zero6, res, ldc,
-                               [&](int j0, RC &R, double (&ct)[1][4], double (&nv)[1][4]) { double c3[3][4], n1[1][4]; emc(j0, R, c3, n1); });
+                               [&](int j0, RC &R, double (&ct)[1][RO_E], double (&nv)[1][RO_E]) { double c3[3][RO_E], n1[1][RO_E]; emc(j0, R, c3, n1); });
         if (tid == 0) {
             if (!boundary) pr.rTr = rnew;
             pr.rsel ^= 1;
@@ -479,19 +476,21 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
     // ---- PH_EVAL0 / PH_EVAL: fun(w_new) and the gradient candidate (llf/LogisticRegressionL2.java:156-225)
     const double *__restrict__ rowtmp = pr.rowtmp;
     struct RR { RoV4 x, c; };
+    const int lensR[2] = {l, csum_done ? 0 : l};
     if (dn) { res[0] = pr.lossp[0]; res[1] = pr.csump[0]; }
-    else ro_pass<2, 0, RR>(sh, l, nullptr, zero6, res,
+    else ro_pass<2, 0, RR>(sh, l, lensR, zero6, res,
         [&](int j0, RR &R) { R.x = ro_ld4c(rowtmp, j0, l); R.c = ro_ld4c(coef, j0, l); },
-        [&](int j0, RR &R, double (&ct)[2][4], double (&nv)[1][4]) {
+        [&](int j0, RR &R, double (&ct)[2][RO_E], double (&nv)[1][RO_E]) {
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
+            for (int e = 0; e < RO_E; e++) {
                 ct[0][e] = R.x.v[e];                                         // f += weight * log(1 + exp(..)) in row order (:172-183)
                 ct[1][e] = R.c.v[e];                                         // the intercept's column of XTv: the coefficients in row order
             }
         });
+    if (csum_done) res[1] = pr.csump[0];
     double fnew = 2.0 * res[0];
     const double csum = res[1];
-    const double init4[RO_NF] = {0.0, 0.0, fnew, 0.0, 0.0, 0.0};
+    const double init4[RO_NF] = {0.0, 0.0, fnew, 0.0};
     const double *__restrict__ c0 = pa.c0;
     const bool e0 = (phase == PH_EVAL0);
     struct RE { RoV4 w, m, x, p, c; };
@@ -501,10 +500,10 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
             if (pvec) R.p = ro_ld4s(pvec, j0, n);
             if (e0) R.c = ro_ld4s(c0, j0, n);
         },
-        [&](int j0, RE &R, double (&ct)[4][4], double (&nv)[2][4]) {
-            double hd[4];
+        [&](int j0, RE &R, double (&ct)[4][RO_E], double (&nv)[2][RO_E]) {
+            double hd[RO_E];
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
+            for (int e = 0; e < RO_E; e++) {
                 const int j = j0 + e;
                 const double xa = (j == nf) ? csum : R.x.v[e];
                 const double pj = pvec ? R.p.v[e] : pscal;
@@ -583,10 +582,10 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
                 if (copy_w || nullstep) R.wn = ro_ld4c(w_new, j0, n);
                 if (nullstep && !copy_w) R.w = ro_ld4c(w, j0, n);
             },
-            [&](int j0, RT &R, double (&ct)[1][4], double (&nv)[1][4]) {
-                double z4[4], rj[4], wz[4];
+            [&](int j0, RT &R, double (&ct)[1][RO_E], double (&nv)[1][RO_E]) {
+                double z4[RO_E], rj[RO_E], wz[RO_E];
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
+                for (int e = 0; e < RO_E; e++) {
                     const double gj = copy_g ? R.h.v[e] : R.g.v[e];
                     z4[e] = 0.0; rj[e] = -gj;
                     wz[e] = (copy_w ? R.wn.v[e] : R.w.v[e]) + 1.0 * 0.0;

@@ -256,6 +256,20 @@ def test_valu_wave_butterflies_equal_the_shuffle_forms_bit_for_bit():
     assert r.stdout.count("bit-identical") == 9, r.stdout
 
 
+def test_sequential_sums_evaluated_in_parallel_equal_the_plain_loops_bit_for_bit():
+    """csrc/mlx_seqfold.h on the GPU (round 6): the wave code that evaluates `for (i) s += t[i]` -- and euclideanNorm's
+    `sum = c + sum * m` -- exactly, in parallel (grid-rounded terms inside a binade, a DPP scan, every sub-block's prefix range
+    checked, failed checks re-run as the literal chain) against the host's sequential loops: 600 vectors of 15 kinds (positive,
+    random walks, ties, cancellations, powers of two, signed zeros, NaN / Inf, tiny, huge), both forms, identical bits."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "seqfold_selftest")
+    if not os.path.exists(exe):          # (normally built by __graft_entry__.build(); hipcc is on the GPU box too)
+        subprocess.run(["make", "-C", os.path.join(ROOT, "ml-ease_amd", "csrc"), "-s", "../../tools/seqfold_selftest"], check=False, timeout=300)
+    assert os.path.exists(exe), "run `make -C ml-ease_amd/csrc` (or __graft_entry__.build())"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "600 vectors x 2 forms, 0 mismatches" in r.stdout, r.stdout + r.stderr
+
+
 def test_rho_adapt_rate_penalize_intercept_and_resume(c1):
     lam, rho = [1.0], [1.0]
     oc = ol.OracleAdmm(c1.blocks, c1.n_global, lam, rho, penalize_intercept=True)

@@ -1,0 +1,12 @@
+mkdir -p gpurun_out/r6m
+RO_ONLY=1 RO_STREAMS=1 MLX_LIB_PATH=$PWD/tools/abl/libmlease_hip_pt.so timeout 900 python tools/ro_probe.py 256 3 0 > gpurun_out/r6m/ro_probe_pt.json 2> gpurun_out/r6m/ro_probe_pt.err; python - <<'PY'
+import json
+d=json.load(open("gpurun_out/r6m/ro_probe_pt.json"))
+print([x["ticks"] for x in d["reference_order"]["per_iteration"]], [x["s"] for x in d["reference_order"]["per_iteration"]])
+pt=[v*100 for v in d.get("phase_us_sum_over_workgroups")]
+n=pt[13]/100*2   # chunk-steps counted once per two chunks? (one increment per loop half) 
+print("chunk-steps (half-loops):", pt[13]/100)
+n=pt[13]/100
+print("per chunk-step cycles: stager load-issue+dot-writes %.0f emit %.0f scan+sync %.0f norm %.0f barrier-wait %.0f" % tuple(pt[i]/n for i in (8,9,10,11,12)))
+print("per chunk-step cycles: fold wave0..3 %s, their barrier waits %s" % ([round(pt[i]/n) for i in range(4)], [round(pt[4+i]/n) for i in range(4)]))
+PY

@@ -1,0 +1,8 @@
+mkdir -p gpurun_out/r6h
+tools/seqfold_selftest > gpurun_out/r6h/selftest.txt 2>&1; tail -3 gpurun_out/r6h/selftest.txt
+timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "reference_order or order_faithful or tight_epsilon or scratch_problem or sequential_sums" > gpurun_out/r6h/pytest_ro.log 2>&1; tail -5 gpurun_out/r6h/pytest_ro.log
+timeout 900 python tools/ro_probe.py 256 4 8 > gpurun_out/r6h/ro_probe.json 2> gpurun_out/r6h/ro_probe.err; python - <<'PY'
+import json
+d=json.load(open("gpurun_out/r6h/ro_probe.json"))
+print(d["solves_per_s_after_first_iteration"]); print(d["reference_order"]["one_stream_profile_of_next_iteration"]); print(d["fast"]["one_stream_profile_of_next_iteration"]); print(d.get("vs_oracle_twin"))
+PY
