@@ -405,9 +405,9 @@ k_xpass_dense(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
 // used for speed only, never for correctness). All chunks of one problem are given to ONE XCD (problem index % 8), so
 // the randomly gathered fp64 vectors of the 1-3 problems an XCD works on at a time (d / w_new: 8*n_local bytes, coef:
 // 8*l bytes) stay in that XCD's 4 MiB L2 instead of being re-fetched through the fabric by all eight L2s.
-__device__ __forceinline__ bool xcd_map(int nq, int gx, int &pi, int &bx)
+__device__ __forceinline__ bool xcd_map(int nq, int gx, int &pi, int &bx, int lead = 0 /* workgroups in front of the mapped ones (a multiple of 8) */)
 {
-    const int L = blockIdx.x, xcd = L & 7, s = L >> 3;
+    const int L = (int)blockIdx.x - lead, xcd = L & 7, s = L >> 3;
     pi = (s / gx) * 8 + xcd;
     bx = s % gx;
     return pi < nq;
@@ -981,15 +981,82 @@ k_rowcold(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
 // a block and start from the sum their column reached in the earlier blocks (item_init), so a column's sum is ONE chain over its rows
 // in ascending order -- XTv's order (llf/LogisticRegressionL2.java:140-145); a column's last item also stores the sum at xtc[column]
 // (ProbDev::c0f). (The intercept's column -- the sum of all coefficients in row order -- is folded by the step kernel, k_ro_step.)
+// Reference-order numerics: the intercept's column of X'c -- XTv[n-1] += v[i] * 1.0 over ALL rows in row order
+// (llf/LogisticRegressionL2.java:143-145; the bias entry closes every row) -- is a LITERAL chain over the l row coefficients: its running
+// sum stays as small as its terms, so mlx_seqfold.h's exact parallel fold has nothing to hold on to. It needs the row pass only, so it
+// runs BESIDE the column pass: the first `lead` workgroups of the column pass's first launch are chain workgroups -- the dispatcher
+// starts workgroups in index order, so they are resident before the pass fills the chip -- one problem per wave; 1/8 of
+// the CUs for the ~0.2 ms the chain takes, and the step kernel finds csump[0] ready instead of running the chain on its critical path
+// (tried before: the chain on one wave of a pass workgroup -- the pass keeps the CU's LDS pipe and registers full, +160 ... +660 us
+// per tick; a kernel of its own on a side stream -- it is placed only when the pass drains, +365 us; profiles/r6_notes.md).
+// Eight waves per chain workgroup (two per SIMD: four chains per SIMD would share its one add per four cycles and crawl at 48 cycles
+// per term), one problem each. A wave copies 1 024 coefficients at a time into an LDS region of its own (coalesced loads, the next 1 024
+// in flight behind the chain) and walks them with 16-byte broadcast reads -- every lane adds the same terms, one v_add_f64 per term;
+// the reads of the next eight terms are pinned in front of the eight adds they hide behind (left to itself the scheduler sinks every
+// read next to its use and the chain pays one LDS latency per pair).
+constexpr int RO_CSUM_WAVES = 8, RO_CSUM_CH = 1024;
+__device__ __forceinline__ void ro_csum_chain(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, double *lds)
+{
+#pragma clang fp contract(off)
+    typedef double d2v_t __attribute__((ext_vector_type(2)));
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wave >= RO_CSUM_WAVES) return;
+    const int qi = blockIdx.x * RO_CSUM_WAVES + wave;
+    if (qi >= nq) return;
+    ProbDev &pr = probs[qlist[qi]];
+    if (pr.phase == PH_DONE) return;
+    const PartDev &pa = parts[pr.part];
+    if (pa.dense || !pa.sell || pa.n_cunits <= 0) return;
+    const int l = pa.l;
+    const double *__restrict__ coef = pr.coef;
+    double *reg = lds + wave * (2 * RO_CSUM_CH);              // two regions of 1 024 doubles: being chained / being filled
+    double q[16];
+    auto fetch = [&](int c) {                                 // chunk c -> registers (terms behind the end: -0.0, x + (-0.0) == x)
+#pragma unroll
+        for (int u = 0; u < 16; u++) { const int j = c * RO_CSUM_CH + u * 64 + lane; const double x = gld(coef + min(j, l - 1)); q[u] = j < l ? x : -0.0; }
+    };
+    auto put = [&](int c) {
+        double *r = reg + (c & 1) * RO_CSUM_CH;
+#pragma unroll
+        for (int u = 0; u < 16; u++) r[u * 64 + lane] = q[u];
+    };
+    const int nch = (l + RO_CSUM_CH - 1) / RO_CSUM_CH;
+    fetch(0);
+    put(0);
+    double s = 0.0;
+    for (int c = 0; c < nch; c++) {
+        fetch(c + 1);                                         // (behind the end: clamped re-reads, all terms -0.0)
+        const d2v_t *c2 = reinterpret_cast<const d2v_t *>(reg + (c & 1) * RO_CSUM_CH);
+        d2v_t A0 = c2[0], A1 = c2[1], A2 = c2[2], A3 = c2[3], B0, B1, B2, B3;
+        for (int j = 0; j < RO_CSUM_CH / 2; j += 8) {
+            const int jb = j + 4, ja = min(j + 8, RO_CSUM_CH / 2 - 4);
+            B0 = c2[jb]; B1 = c2[jb + 1]; B2 = c2[jb + 2]; B3 = c2[jb + 3];
+            __builtin_amdgcn_sched_barrier(0);
+            s = s + A0.x; s = s + A0.y; s = s + A1.x; s = s + A1.y; s = s + A2.x; s = s + A2.y; s = s + A3.x; s = s + A3.y;
+            __builtin_amdgcn_sched_barrier(0);
+            A0 = c2[ja]; A1 = c2[ja + 1]; A2 = c2[ja + 2]; A3 = c2[ja + 3];
+            __builtin_amdgcn_sched_barrier(0);
+            s = s + B0.x; s = s + B0.y; s = s + B1.x; s = s + B1.y; s = s + B2.x; s = s + B2.y; s = s + B3.x; s = s + B3.y;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        put(c + 1);                                           // (the other region: nobody reads it before the next trip)
+    }
+    if (lane == 0) gst(pr.csump, s);
+}
+
 template <bool HASVAL, bool NT, bool RO = false>
 __global__ void __launch_bounds__(1024)
-k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx, int only_blk)
+k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx, int only_blk, int lead)
 {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) double cf[];      // [rblk_rows + 1]: the block's coefficients, then the zero slot
     PT_INIT;
+    if (RO && (int)blockIdx.x < lead) {
+        if ((int)blockIdx.x * RO_CSUM_WAVES < nq) ro_csum_chain(parts, probs, qlist, nq, cf);      // (needs 128 KiB of the launch's dynamic LDS: mlxk_xpass_csr)
+        return;
+    }
     int pi_, bx_;
-    if (!xcd_map(nq, gx, pi_, bx_)) return;
+    if (!xcd_map(nq, gx, pi_, bx_, RO ? lead : 0)) return;
     const int q = qlist[pi_];
     ProbDev &pr = probs[q];
     if (pr.phase == PH_DONE) return;
@@ -1009,40 +1076,6 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     }
     __syncthreads();
     PT_MARK(8);
-    if (RO) {
-        // The intercept's column of X'c -- XTv[n-1] += v[i] * 1.0 over ALL rows in row order (llf/LogisticRegressionL2.java:143-145; the
-        // bias entry closes every row) -- is one more chain, carried from row block to row block like every column's: the last wave of
-        // the block's first work unit folds the block's coefficients (they sit in LDS anyway) onto the sum the earlier blocks left in
-        // csump[0]. Round 5 folded it in the step kernel. It is the one chain of a tick whose running sum stays as small as its terms
-        // (93 % of the rows push it up a little, 7 % pull it down a lot: the binade changes every few terms), so the exact parallel
-        // fold of mlx_seqfold.h has nothing to hold on to and the LITERAL chain runs -- here, where the launch hides it: 20 160 terms
-        // are ~0.15 ms of one wave inside a pass of ~0.23 ms.
-        const bool first_unit = bx_ == 0 || gld(pa.cw_blk + bx_ - 1) != blk;
-        if (first_unit && (threadIdx.x >> 6) == 15) {
-            // (every lane runs the same chain on the same addresses: LDS broadcasts, nothing diverges. Sixteen terms per trip; the
-            //  16-byte reads of the next eight are pinned in front of the eight adds they hide behind -- left to itself the scheduler
-            //  sinks every read next to its use and the chain pays one LDS latency per pair)
-            typedef double d2v_t __attribute__((ext_vector_type(2)));
-            double s = blk == 0 ? 0.0 : gld(pr.csump);
-            const d2v_t *c2 = reinterpret_cast<const d2v_t *>(cf);      // (nr <= 20 160 doubles + the zero slot behind them; r0 is a multiple of 64)
-            const int n16 = nr & ~15;
-            d2v_t A0, A1, A2, A3, B0, B1, B2, B3;
-            if (n16 > 0) { A0 = c2[0]; A1 = c2[1]; A2 = c2[2]; A3 = c2[3]; }
-            for (int j = 0; j < n16; j += 16) {
-                const int jb = (j + 8) >> 1, ja = min(j + 16, n16 - 8) >> 1;
-                B0 = c2[jb]; B1 = c2[jb + 1]; B2 = c2[jb + 2]; B3 = c2[jb + 3];
-                __builtin_amdgcn_sched_barrier(0);
-                s = s + A0.x; s = s + A0.y; s = s + A1.x; s = s + A1.y; s = s + A2.x; s = s + A2.y; s = s + A3.x; s = s + A3.y;
-                __builtin_amdgcn_sched_barrier(0);
-                A0 = c2[ja]; A1 = c2[ja + 1]; A2 = c2[ja + 2]; A3 = c2[ja + 3];
-                __builtin_amdgcn_sched_barrier(0);
-                s = s + B0.x; s = s + B0.y; s = s + B1.x; s = s + B1.y; s = s + B2.x; s = s + B2.y; s = s + B3.x; s = s + B3.y;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            for (int j = n16; j < nr; j++) s = s + cf[j];
-            if ((threadIdx.x & 63) == 0) gst(pr.csump, s);
-        }
-    }
     const uint16_t *__restrict__ cs_idx = pa.cs_idx;
     const float *__restrict__ cs_val = pa.cs_val;
     const int32_t *__restrict__ cs_ptr = pa.cs_ptr;
@@ -3135,7 +3168,8 @@ int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const i
     if (nq <= 0) return 0;
     if (sell && ro_blocks > 0) {
         // reference-order numerics (mlx_ro_kernels.h): every slice of the row pass hot, the column pass once per row block
-        const size_t lds_col = ((size_t)max_rblk_rows + 1) * sizeof(double), lds_row = ((size_t)row_slw + 1) * sizeof(double);
+        const size_t lds_col = std::max(((size_t)max_rblk_rows + 1) * sizeof(double), (size_t)RO_CSUM_WAVES * 2 * RO_CSUM_CH * sizeof(double));
+        const size_t lds_row = ((size_t)row_slw + 1) * sizeof(double);
         per_device_once(6, [&] {
 #define SETLDS_RO(HV)                                                                                                                          \
             set_max_lds(reinterpret_cast<const void *>(&k_colpass_lds<HV, false, true>), 160 * 1024 - 1024);   /* (+ 528 bytes of static LDS: the relay) */ \
@@ -3156,8 +3190,11 @@ int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const i
                 default: LAUNCH_ROW_RO(HV, 8); break;                                                                                          \
             }                                                                                                                                  \
             if (do_col && max_cunits > 0)                                                                                                      \
-                for (int b = 0; b < ro_blocks; b++)                                                                                            \
-                    hipLaunchKernelGGL((k_colpass_lds<HV, false, true>), dim3(XGRID(nq, max_cunits)), dim3(1024), lds_col, st, parts, probs, qlist, nq, max_cunits, b); \
+                for (int b = 0; b < ro_blocks; b++) {                                                                                          \
+                    /* (the chain workgroups of the intercept's column lead the first launch: a multiple of 8, so the XCD mapping holds) */   \
+                    const int lead = b == 0 ? ((nq + RO_CSUM_WAVES - 1) / RO_CSUM_WAVES + 7) / 8 * 8 : 0;                                      \
+                    hipLaunchKernelGGL((k_colpass_lds<HV, false, true>), dim3(XGRID(nq, max_cunits) + lead), dim3(1024), lds_col, st, parts, probs, qlist, nq, max_cunits, b, lead); \
+                }                                                                                                                              \
         } while (0)
         if (hasval) LAUNCH_RO(true); else LAUNCH_RO(false);
 #undef LAUNCH_RO
@@ -3188,7 +3225,7 @@ int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const i
                 default: LAUNCH_ROW(HV, NTF, 8); break;                                                                                        \
             }                                                                                                                                  \
             if (do_col && max_cunits > 0)                                                                                                      \
-                hipLaunchKernelGGL((k_colpass_lds<HV, NTF>), dim3(XGRID(nq, max_cunits)), dim3(1024), lds_col, st, parts, probs, qlist, nq, max_cunits, -1); \
+                hipLaunchKernelGGL((k_colpass_lds<HV, NTF>), dim3(XGRID(nq, max_cunits)), dim3(1024), lds_col, st, parts, probs, qlist, nq, max_cunits, -1, 0); \
         } while (0)
         if (hasval) { if (stream_once) LAUNCH_SELL(true, true); else LAUNCH_SELL(true, false); }
         else { if (stream_once) LAUNCH_SELL(false, true); else LAUNCH_SELL(false, false); }

@@ -135,6 +135,26 @@ __device__ __attribute__((noinline)) double ro_fold_chunk(double acc, ro_lds_cpt
     return sgf_wave_fold<SGF_K, MUL>(acc, t, m, has != 0, hostile);
 }
 
+// The LITERAL chain over one chunk of an array staged LINEARLY (element e of the chunk at cp[e]): for sums the grid cannot help. One LDS
+// read per lane fetches 64 consecutive terms (the next read is in flight behind the chain), and the chain walks the register lane by
+// lane as scalars -- v_readlane with constant lane numbers (a run-time lane select costs ~70 cycles per term); every lane adds the same
+// terms, nothing diverges: ~12 cycles per term.
+__device__ __attribute__((noinline)) double ro_chain_chunk(double acc, ro_lds_cptr cp, int cnt)
+{
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & 63;
+    const int ntrip = (cnt + 63) >> 6;
+    double nxt = lane < cnt ? cp[lane] : -0.0;                    // x + (-0.0) == x
+    for (int tr = 0; tr < ntrip; tr++) {
+        const double cur = nxt;
+        const int j = (tr + 1) * 64 + lane;
+        nxt = j < cnt ? cp[min(j, RO_CH - 1)] : -0.0;
+#pragma unroll
+        for (int L = 0; L < 64; L++) acc = acc + mlx_wave_bcast(cur, L);
+    }
+    return acc;
+}
+
 // One pass over elements 0 .. len-1. load(j0, R) fetches the operands of elements j0 .. j0+3 (it clamps to the last quad of each
 // vector itself), emit(j0, R, ct, nv) does their elementwise work (stores included, elements beyond a vector's end masked) and
 // returns the terms of the dot arrays ct[k][e] (k >= NN) and the raw values of the norm arrays nv[q][e] (q < NN). Folding wave k
@@ -143,7 +163,8 @@ __device__ __attribute__((noinline)) double ro_fold_chunk(double acc, ro_lds_cpt
 // Round 5 folded with one LANE per array -- a literal chain of dependent adds, 12.4 cycles per term; since round 6 a WAVE folds an array
 // with sgf_wave_fold (mlx_seqfold.h): the same bits -- the sequential loop's -- from grid-rounded terms and a scan wherever the
 // running sum stays inside a binade, the literal chain for the sub-blocks where it does not.
-template <int NF, int NN, typename R, typename LD, typename EM>
+// LIN: bit k set = array k (a dot array) is staged linearly and folded as a literal chain (ro_chain_chunk).
+template <int NF, int NN, int LIN, typename R, typename LD, typename EM>
 __device__ __forceinline__ void ro_pass(RoLds &sh, int len, const int *lens, const double *init, double *result, LD load, EM emit)
 {
 #pragma clang fp contract(off)
@@ -215,15 +236,18 @@ __device__ __forceinline__ void ro_pass(RoLds &sh, int len, const int *lens, con
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");      // (LDS only: the prefetched operands stay in flight)
             if (lane == 0) sh.seq[sw] = c + 1;
-            for (int w = 0; w < RO_NSW; w++) while (sh.seq[w] < c + 1) __builtin_amdgcn_s_sleep(1);
+            // (lane w watches staging wave w: one LDS read per poll instead of RO_NSW dependent ones)
+            while (__ballot(lane < RO_NSW && sh.seq[lane < RO_NSW ? lane : 0] < c + 1) != 0ull) __builtin_amdgcn_s_sleep(1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
             RO_PT(4);
 #pragma unroll
             for (int q = 0; q < NN; q++) {
                 const double ex = ro_wave_shift_up_or_zero(x[q]);
                 double P = fmax(mc[q], ex);
+                const double tw = sh.wtot[q][lane < RO_NSW ? lane : 0];          // (lane w: staging wave w's maximum -- one LDS read, then scalars)
+#pragma unroll
                 for (int w = 0; w < RO_NSW; w++) {
-                    const double t = sh.wtot[q][w];
+                    const double t = mlx_wave_bcast(tw, w);
                     if (w < sw) P = fmax(P, t);
                     mc[q] = fmax(mc[q], t);
                 }
@@ -249,7 +273,7 @@ __device__ __forceinline__ void ro_pass(RoLds &sh, int len, const int *lens, con
 #pragma unroll
         for (int k = NN; k < NF; k++) {
 #pragma unroll
-            for (int e = 0; e < RO_E; e++) sh.C[b][k][tpos(e)] = ct[k][e];
+            for (int e = 0; e < RO_E; e++) sh.C[b][k][((LIN >> k) & 1) ? RO_E * stid + e : tpos(e)] = ct[k][e];
         }
     };
     auto fold = [&](int c) {
@@ -263,7 +287,8 @@ __device__ __forceinline__ void ro_pass(RoLds &sh, int len, const int *lens, con
         ro_lds_cptr cp = (ro_lds_cptr)&sh.C[b][wave][0];
         ro_lds_cptr mp = (ro_lds_cptr)&sh.M[b][isn ? wave : 0][0];
         RO_PT(7);
-        if (isn) acc = ro_fold_chunk<true>(acc, cp, mp, nvalid, has, hostile);
+        if ((LIN >> wave) & 1) acc = ro_chain_chunk(acc, cp, cnt);
+        else if (isn) acc = ro_fold_chunk<true>(acc, cp, mp, nvalid, has, hostile);
         else acc = ro_fold_chunk<false>(acc, cp, mp, nvalid, 0, hostile);
     };
     if (NN > 0 && tid < RO_NSW) sh.seq[tid] = 0;
@@ -328,11 +353,14 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
     if (phase == PH_DONE) return;
     const PartDev &pa = parts[pr.part];
     const int n = pa.n_local, nf = pa.n_feat, l = pa.l, tid = threadIdx.x;
-    // The intercept's column of X'c (the sum of the row coefficients in row order) is folded by the column pass: k_ro_dense_cols on a
-    // spare lane (which also leaves the loss sum: dn), k_colpass_lds<.., RO> block by block (csum_done); a partition without a column
-    // work unit (no feature column at all) folds it here.
+    // The intercept's column of X'c (the sum of the row coefficients in row order) is folded before this kernel runs: dense tiles by
+    // k_ro_dense_cols (on a spare lane, with the loss sum), sliced CSR partitions by the chain workgroups of the column pass's first
+    // launch (k_colpass_lds<.., RO>: ro_csum_chain). It is the one chain of a tick the exact parallel fold cannot help: its running sum
+    // stays as small as its terms (93 % of the rows push it up a little, 7 % pull it down a lot), the binade changes every few terms --
+    // a LITERAL chain of l dependent adds, 0.25 ms at configs[2], which sat on this kernel's critical path (between the d.Hd pass and
+    // alpha) while it ran here. (Only a partition without any column work unit still folds it here: ro_chain_chunk.)
     const bool dn = pa.dense != 0;
-    const bool csum_done = dn || pa.n_cunits > 0;
+    const bool csum_done = dn || (pa.sell != 0 && pa.n_cunits > 0);
     const double *__restrict__ xtc = pr.c0f;                      // X'c of this tick, columns 0 .. nf-1 (k_colpass_lds<.., RO>)
     const double *__restrict__ coef = pr.coef;                    // the row coefficients: their sum in row order is the intercept's column
     const double *__restrict__ pvec = pr.pinv_vec;
@@ -351,7 +379,7 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
         // (dense tiles: k_ro_dense_cols ran that chain on a spare lane and left it in csump[0])
         struct RA { RoV4 d, x, p, c; };
         const int lensA[2] = {nf, csum_done ? 0 : l};
-        ro_pass<2, 0, RA>(sh, csum_done ? nf : max(nf, l), lensA, zero6, res,
+        ro_pass<2, 0, 2, RA>(sh, csum_done ? nf : max(nf, l), lensA, zero6, res,
             [&](int j0, RA &R) { R.d = ro_ld4c(d, j0, n); R.x = ro_ld4c(xtc, j0, n); if (pvec) R.p = ro_ld4s(pvec, j0, n); R.c = ro_ld4c(coef, j0, l); },
             [&](int j0, RA &R, double (&ct)[2][RO_E], double (&nv)[1][RO_E]) {
                 double hd[RO_E];
@@ -375,7 +403,7 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
         double *__restrict__ rn = pr.rb[pr.rsel ^ 1];
         // daxpy(alpha, d, s); the norm of s; and the continuation r' = r - alpha Hd with r'.r' and |r'| (:169-171, :144 of the next trip)
         struct RB { RoV4 d, s, r, h; };
-        ro_pass<3, 2, RB>(sh, n, nullptr, zero6, res,
+        ro_pass<3, 2, 0, RB>(sh, n, nullptr, zero6, res,
             [&](int j0, RB &R) { R.d = ro_ld4c(d, j0, n); R.s = ro_ld4c(s, j0, n); R.r = ro_ld4c(rc, j0, n); R.h = ro_ld4c(Hd, j0, n); },
             [&](int j0, RB &R, double (&ct)[3][RO_E], double (&nv)[2][RO_E]) {
                 double s1[RO_E], r1[RO_E];
@@ -399,7 +427,7 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
             // carries three, and the boundary step -- at most one per trcg call -- pays a pass of its own.)
             struct RB2 { RoV4 d, s; };
             double res2[RO_NF];
-            ro_pass<3, 0, RB2>(sh, n, nullptr, zero6, res2,
+            ro_pass<3, 0, 0, RB2>(sh, n, nullptr, zero6, res2,
                 [&](int j0, RB2 &R) { R.d = ro_ld4c(d, j0, n); R.s = ro_ld4c(s, j0, n); },
                 [&](int j0, RB2 &R, double (&ct)[3][RO_E], double (&nv)[1][RO_E]) {
 #pragma unroll
@@ -452,8 +480,8 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
             else ro_st4(d, j0, n, dn);
             if (end_cg) ro_st4(w_new, j0, n, wn);
         };
-        if (end_cg) ro_pass<3, 1, RC>(sh, n, nullptr, zero6, res, ldc, emc);
-        else ro_pass<0, 0, RC>(sh, n, nullptr, zero6, res, ldc,
+        if (end_cg) ro_pass<3, 1, 0, RC>(sh, n, nullptr, zero6, res, ldc, emc);
+        else ro_pass<0, 0, 0, RC>(sh, n, nullptr, zero6, res, ldc,
                                [&](int j0, RC &R, double (&ct)[1][RO_E], double (&nv)[1][RO_E]) { double c3[3][RO_E], n1[1][RO_E]; emc(j0, R, c3, n1); });
         if (tid == 0) {
             if (!boundary) pr.rTr = rnew;
@@ -478,7 +506,7 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
     struct RR { RoV4 x, c; };
     const int lensR[2] = {l, csum_done ? 0 : l};
     if (dn) { res[0] = pr.lossp[0]; res[1] = pr.csump[0]; }
-    else ro_pass<2, 0, RR>(sh, l, lensR, zero6, res,
+    else ro_pass<2, 0, 2, RR>(sh, l, lensR, zero6, res,
         [&](int j0, RR &R) { R.x = ro_ld4c(rowtmp, j0, l); R.c = ro_ld4c(coef, j0, l); },
         [&](int j0, RR &R, double (&ct)[2][RO_E], double (&nv)[1][RO_E]) {
 #pragma unroll
@@ -494,7 +522,7 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
     const double *__restrict__ c0 = pa.c0;
     const bool e0 = (phase == PH_EVAL0);
     struct RE { RoV4 w, m, x, p, c; };
-    ro_pass<4, 2, RE>(sh, n, nullptr, init4, res,
+    ro_pass<4, 2, 0, RE>(sh, n, nullptr, init4, res,
         [&](int j0, RE &R) {
             R.w = ro_ld4c(w_new, j0, n); R.m = ro_ld4c(m, j0, n); R.x = ro_ld4c(xtc, j0, n);
             if (pvec) R.p = ro_ld4s(pvec, j0, n);
@@ -575,7 +603,7 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
         // w = w_new, g = grad(w_new); trcg prologue (:133-141): s = 0, r = -g, d = r
         double *__restrict__ r0 = pr.rb[0];
         struct RT { RoV4 h, g, wn, w; };
-        ro_pass<0, 0, RT>(sh, n, nullptr, zero6, res,
+        ro_pass<0, 0, 0, RT>(sh, n, nullptr, zero6, res,
             [&](int j0, RT &R) {
                 R.h = ro_ld4c(Hd, j0, n);
                 if (!copy_g) R.g = ro_ld4c(g, j0, n);

@@ -227,7 +227,9 @@ __device__ __forceinline__ double sgf_wave_fold(double s, const double (&t)[K], 
     // four literal sub-blocks, and round 6's first form spent 24 of them per chunk on such chains (the intercept's column of X'c)
     int pos = 0, budget = hostile ? SGF_BUDGET_HOSTILE : SGF_BUDGET;
     hostile = 0;
-    auto literal = [&](int k) {                   // sub-block k's chain on its own lane, then to everybody
+    // sub-block k's chain on its own lane, then to everybody. (Every lane running it on lane k's terms read as scalars was measured:
+    // v_readlane with a run-time lane select costs ~70 cycles per term, profiles/r6_notes.md.)
+    auto literal = [&](int k) {
         double x = s;
         if (lane == k) {
 #pragma unroll

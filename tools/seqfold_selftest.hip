@@ -9,13 +9,14 @@
 #include "../ml-ease_amd/csrc/mlx_seqfold.h"
 
 template <bool MUL>
-__global__ void __launch_bounds__(64) k_fold(const double *__restrict__ t, const double *__restrict__ m, const long *__restrict__ off, const double *__restrict__ s0, double *__restrict__ out)
+__global__ void __launch_bounds__(64) k_fold(const double *__restrict__ t, const double *__restrict__ m, const long *__restrict__ off, const double *__restrict__ s0, double *__restrict__ out, long long *__restrict__ cyc)
 {
 #pragma clang fp contract(off)
     const int v = blockIdx.x, lane = threadIdx.x;
     const long b0 = off[v], n = off[v + 1] - b0;
     double s = s0[v];
     int hostile = 0;
+    long long ctot = 0, nch = 0;
     for (long base = 0; base < n; base += 64 * SGF_K) {
         double x[SGF_K], mm[SGF_K];
         bool hm = false;
@@ -26,9 +27,13 @@ __global__ void __launch_bounds__(64) k_fold(const double *__restrict__ t, const
             mm[i] = (MUL && j < n) ? m[b0 + j] : 1.0;
             hm = hm || (mm[i] != 1.0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const long long c0 = clock64();
         s = sgf_wave_fold<SGF_K, MUL>(s, x, mm, hm, hostile);
+        ctot += clock64() - c0;
+        nch++;
     }
-    if (lane == 0) out[v] = s;
+    if (lane == 0) { out[v] = s; cyc[2 * v] = ctot; cyc[2 * v + 1] = nch; }
 }
 
 int main()
@@ -77,16 +82,25 @@ int main()
     const int nv = (int)s0.size();
     double *dt, *dm, *ds, *dout;
     long *doff;
+    long long *dcyc;
+    hipMalloc(&dcyc, (size_t)s0.size() * 16);
     hipMalloc(&dt, t.size() * 8); hipMalloc(&dm, m.size() * 8); hipMalloc(&ds, nv * 8); hipMalloc(&dout, nv * 8); hipMalloc(&doff, off.size() * 8);
     hipMemcpy(dt, t.data(), t.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dm, m.data(), m.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(ds, s0.data(), nv * 8, hipMemcpyHostToDevice); hipMemcpy(doff, off.data(), off.size() * 8, hipMemcpyHostToDevice);
     std::vector<double> got(nv);
     long bad = 0;
     for (int mul = 0; mul < 2; mul++) {
-        if (mul) hipLaunchKernelGGL(k_fold<true>, dim3(nv), dim3(64), 0, 0, dt, dm, doff, ds, dout);
-        else hipLaunchKernelGGL(k_fold<false>, dim3(nv), dim3(64), 0, 0, dt, dm, doff, ds, dout);
+        if (mul) hipLaunchKernelGGL(k_fold<true>, dim3(nv), dim3(64), 0, 0, dt, dm, doff, ds, dout, dcyc);
+        else hipLaunchKernelGGL(k_fold<false>, dim3(nv), dim3(64), 0, 0, dt, dm, doff, ds, dout, dcyc);
         if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(hipGetLastError())); return 2; }
         hipMemcpy(got.data(), dout, nv * 8, hipMemcpyDeviceToHost);
+        std::vector<long long> cy(2 * (size_t)nv);
+        hipMemcpy(cy.data(), dcyc, (size_t)nv * 16, hipMemcpyDeviceToHost);
+        for (int kind = 0; kind < NK; kind++) {                 // shader-clock cycles per chunk of 1 024 terms, the long vectors of each kind
+            long long c = 0, n = 0;
+            for (int rep = PER / 2; rep < PER; rep++) { c += cy[2 * (size_t)(kind * PER + rep)]; n += cy[2 * (size_t)(kind * PER + rep) + 1]; }
+            printf("form %d kind %2d: %7.0f cycles per chunk\n", mul, kind, n ? (double)c / (double)n : 0.0);
+        }
         for (int v = 0; v < nv; v++) {
             double s = s0[v];
             for (long j = off[v]; j < off[v + 1]; j++) s = mul ? t[j] + s * m[j] : s + t[j];
