@@ -88,7 +88,11 @@ struct mlx_context {
     PartDev *d_parts = nullptr;
     ProbDev *d_probs = nullptr;            // nprob + 1 (scratch problem for mlx_solve_one)
     std::vector<ProbDev> h_probs;
-    bool h_probs_pinned = false;
+    ProbDev *h_probs_pin = nullptr;        // hipHostMalloc'ed landing buffer of the per-iteration descriptor read-back (nprob + 1). Rounds 3-5
+                                           // page-locked the vector above IN PLACE (hipHostRegister): its pages are shared with other heap
+                                           // objects, among them the sources of pageable hipMemcpy calls, which the runtime locks and unlocks
+                                           // in place -- the rare "Memory access fault by GPU" on a host-heap address (profiles/r5_notes.md;
+                                           // seen twice more in round 6 before this buffer replaced the registration)
     int *d_qdense = nullptr, *d_qcsr = nullptr, *d_qscratch = nullptr;
     int *d_qsmall = nullptr, *d_qcsr_all = nullptr;   // problems of the small CSR partitions (one-launch kernel); every CSR problem (ticks for all: profiling)
     int nq_dense = 0, nq_csr = 0, nq_small = 0, nq_csr_all = 0;
@@ -651,7 +655,7 @@ int mlx_destroy(mlx_handle h)
     hipDeviceSynchronize();
     if (h->comm) ncclCommDestroy(h->comm);
     for (void *p : h->allocs) hipFree(p);
-    if (h->h_probs_pinned) hipHostUnregister(h->h_probs.data());
+    if (h->h_probs_pin) hipHostFree(h->h_probs_pin);
     if (h->h_done) hipHostFree(h->h_done);
     if (h->h_diff) hipHostFree(h->h_diff);
     for (auto e : h->ev_pool) hipEventDestroy(e);
@@ -1626,11 +1630,9 @@ int mlx_finalize(mlx_handle h)
     }
 
     // problems (+1 scratch for mlx_solve_one)
-    if (h->h_probs_pinned) { hipHostUnregister(h->h_probs.data()); h->h_probs_pinned = false; }
     h->h_probs.assign(h->nprob + 1, ProbDev{});
-    // (page-locked: the per-iteration read-back of the descriptors is then a true asynchronous copy)
-    if (hipHostRegister(h->h_probs.data(), h->h_probs.size() * sizeof(ProbDev), hipHostRegisterDefault) == hipSuccess) h->h_probs_pinned = true;
-    else (void)hipGetLastError();
+    if (h->h_probs_pin) { hipHostFree(h->h_probs_pin); h->h_probs_pin = nullptr; }
+    HIPCHECK(h, hipHostMalloc((void **)&h->h_probs_pin, sizeof(ProbDev) * (size_t)(h->nprob + 1)));
     // All work vectors of all problems are carved out of ONE allocation (256-byte aligned pieces): thousands of problems
     // (configs #4/#5: 1024 partitions x 8 lambdas) must not become 10^5 hipMalloc calls of a few hundred KB each.
     auto carve_size = [](size_t count) { return (count * sizeof(double) + 255) / 256 * 256; };
@@ -1826,9 +1828,10 @@ int mlx_admm_solve_local(mlx_handle h, double liblinear_epsilon, float rho_adapt
 static int collect_solve_stats(mlx_handle h, int64_t ticks, mlx_stats *stats, bool deferred)
 {
     HIPCHECK(h, hipEventRecord(h->ev_t1, h->stream));
-    HIPCHECK(h, hipMemcpyAsync(h->h_probs.data(), h->d_probs, sizeof(ProbDev) * h->nprob, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(h->h_probs_pin, h->d_probs, sizeof(ProbDev) * h->nprob, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
     HIPCHECK(h, hipGetLastError());
+    memcpy(h->h_probs.data(), h->h_probs_pin, sizeof(ProbDev) * (size_t)h->nprob);
     if (deferred) {
         int mx = 0;
         for (int q = 0; q < h->nprob; q++) {

@@ -379,6 +379,24 @@ int run_job(const JobConfig &props)
         for (int li = 0; li < nl; li++) write_model_record(w, java_float_to_string(lam[(size_t)li]), zf.data() + (size_t)li * ng, ds);
         w.close();
     }
+    {
+        // Which numerics contract produced this model (nothing in the outputs said): the run log, and a side file next to
+        // lambda-rho whose leading underscore hides it from Hadoop's input listings (FileInputFormat skips "_*" and ".*"), so a consumer of
+        // final-model / best-model sees the reference's files only.
+        char nbuf[64] = "", kbuf[64] = "", tbuf[32] = "";
+        mlx_get_option(hs[0], "numerics", nbuf, sizeof nbuf);
+        mlx_get_option(hs[0], "numerics_kernels", kbuf, sizeof kbuf);
+        mlx_get_option(hs[0], "dense_tiles", tbuf, sizeof tbuf);
+        fprintf(stderr, "[mlease] numerics contract: %s (kernels: %s; dense tiles on device 0: %s) -- %s\n", nbuf, kbuf, tbuf,
+                std::string(nbuf) == "fast" ? "parallel reduction trees; job key mlease.numerics=reference_order runs the reference's sequential sums bit for bit"
+                                            : "every reduction in the reference's order");
+        FILE *mf = fopen((out + "/_mlease_run.json").c_str(), "w");
+        if (mf) {
+            fprintf(mf, "{\"library\": \"%s\", \"numerics\": \"%s\", \"numerics_kernels\": \"%s\", \"gpus\": %d, \"admm_iterations\": %d, \"num_blocks\": %d, \"lambdas\": %d}\n",
+                    mlx_version(), nbuf, kbuf, G, std::min(i, niter), nblocks, nl);
+            fclose(mf);
+        }
+    }
     for (auto h : hs) mlx_destroy(h);
     fprintf(stderr, "[mlease] done: index %.2f s, upload %.2f s, %d ADMM iterations in %.3f s, total %.2f s\n",
             std::chrono::duration<double>(t_indexed - t_start).count(), std::chrono::duration<double>(t_uploaded - t_indexed).count(),

@@ -239,6 +239,15 @@ def test_cli_job_key_selects_the_reference_order_numerics(tmp_path, c1):
     for it in range(5):
         oc.iterate(0.01, 1.0, nthreads=2)
     assert np.array_equal(models["1.0"].astype(np.float32), oc.z()[1][0]), "reference-order job: final-model differs from the oracle twin"
+    # round 6: the run says which contract produced the model -- in the log and in <out>/_mlease_run.json (hidden from Hadoop listings)
+    import json
+    meta = json.loads((tmp_path / "out" / "_mlease_run.json").read_text())
+    assert meta["numerics"] == "reference_order" and meta["numerics_kernels"].startswith("reference_order") and meta["admm_iterations"] == 5
+    assert "numerics contract: reference_order" in r.stderr
+    job.write_text((text % "fast").replace("mlease.numerics=fast\n", ""))          # the default
+    r = subprocess.run([os.path.join(HOST, "mlease_admm_train"), str(job)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and json.loads((tmp_path / "out" / "_mlease_run.json").read_text())["numerics"] == "fast"
+    assert "numerics contract: fast" in r.stderr and "mlease.numerics=reference_order" in r.stderr
     job.write_text(text % "fastest")
     r = subprocess.run([os.path.join(HOST, "mlease_admm_train"), str(job)], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "numerics must be" in (r.stderr + r.stdout)

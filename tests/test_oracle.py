@@ -634,3 +634,22 @@ def test_experiment_switches_live_in_their_own_translation_unit(c1):
     w2, st2 = ds.train(init, pm, pv, 1e-6)
     assert np.array_equal(w0, w2) and st0.cg_iters == st2.cg_iters
     assert not np.array_equal(w0, w1) and np.max(np.abs(w1 - w0)) <= 1e-9 * max(1.0, np.max(np.abs(w0)))
+
+
+def test_portable_exp_and_log1p_against_libm_in_ulps(tmp_path):
+    """the reference-order contract evaluates csrc/portable_math.h on BOTH sides (kernels and oracle twin), so
+    bit-identity to the twin pins the summation order but says nothing about these two functions. Direct sweep against glibc
+    (tests/native/pm_ulp_sweep.c): pm_exp over [-745, 709] with dense bands around 0 and the logistic range, pm_log1p over (-1, 1e308)
+    on both signs, around 0, near -1 and on u = exp(-z) -- what row_eval feeds it. Bounds: exp 1 ulp, log1p 3 ulp (Java specifies
+    Math.exp / Math.log1p to 1 ulp); the special values (0, +-inf, NaN, the overflow / underflow thresholds, log1p(-1), log1p(< -1))
+    agree."""
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "pm_ulp_sweep")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "ml-ease_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "native", "pm_ulp_sweep.c"), "-o", exe, "-lm"], check=True, timeout=120)
+    out = subprocess.run([exe, "400000"], capture_output=True, text=True, check=True, timeout=300).stdout
+    vals = {ln.split()[0]: float(ln.split()[1]) for ln in out.splitlines() if ln.split() and ln.split()[0] in ("exp_max_ulp", "log1p_max_ulp", "specials_bad")}
+    assert vals["exp_max_ulp"] <= 1.0, out
+    assert vals["log1p_max_ulp"] <= 3.0, out
+    assert vals["specials_bad"] == 0, out
