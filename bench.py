@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--no-sparse", action="store_true", help="skip the configs[2]/[3] leg")
     ap.add_argument("--no-handover", action="store_true", help="skip the host -> HBM handover measurement (PCIe-inclusive job rate)")
     ap.add_argument("--no-dense8", action="store_true", help="skip the 8-partitions-per-GPU dense shape (the 8-GPU share of configs[1])")
+    ap.add_argument("--no-sparse128", action="store_true", help="skip the 128-partitions-per-GPU one-hot shape (the 8-GPU share of configs[3])")
     ap.add_argument("--no-gram", action="store_true", help="skip the fp64-MFMA Gram measurement (posterior covariance of one partition)")
     ap.add_argument("--sparse-only", action="store_true", help="run only the sparse leg (development / profiling)")
     ap.add_argument("--sparse-steps", type=int, default=5)
@@ -252,7 +253,16 @@ def main():
     if world == 1 and not (args.sparse_only or args.sweep_only or args.no_config1):
         leg("configs[0] latency")
         out["config1_latency"] = run_config1(ctx)
+    # how many ranks the collective backend really joined (the first real 8-GPU run must prove N ranks): every rank adds 1
+    ranks_seen = None
+    if dist is not None:
+        t1 = torch.ones(1, device=dev, dtype=torch.float64)
+        _collective(t1, dist.ReduceOp.SUM)
+        ranks_seen = int(round(float(t1.item())))
     if rank == 0:
+        if ranks_seen is not None:
+            out["rccl_ranks_seen"] = ranks_seen
+            out["collective_backend"] = "gloo (shared-GPU test mode)" if share else "nccl (RCCL)"
         if share:
             out["test_mode"] = "MLX_BENCH_SHARE_GPU=1: all ranks on ONE device, collectives over gloo -- control-flow check, not a measurement"
         emit(out, json_fd, args)
@@ -387,6 +397,9 @@ def compact_record(full):
         al = (d.get("roofline") or {}).get("alone") or {}
         if al:
             o["roofline_alone"] = {"row": al.get("rowpass_frac"), "col": al.get("colpass_frac")}
+        s128 = d.get("sparse_128_per_gpu") or {}
+        if s128.get("value") is not None:
+            o["per_gpu_128"] = {"value": s128.get("value"), "value_reference_order": s128.get("value_reference_order")}
         if d.get("cpu_baseline"):
             o["cpu_baseline"] = _pick(d["cpu_baseline"], ["value", "cores", "kind"])
             o["gpu_over_cpu"] = (d.get("gpu_over_cpu") or {}).get("solves_per_s")
@@ -416,6 +429,8 @@ def compact_record(full):
     al = full.get("all_launches") or {}
     if al:
         c["all_xpass_launches"] = _pick(al, ["timed_by_events", "avg_us", "alg_bytes_timed_by_events"])
+    if full.get("rccl_ranks_seen") is not None:
+        c["rccl_ranks_seen"] = full["rccl_ranks_seen"]
     if full.get("test_mode"):
         c["test_mode"] = "MLX_BENCH_SHARE_GPU=1 (control-flow check, not a measurement)"
     c["full_record"] = "bench_full.json"
@@ -1385,7 +1400,50 @@ def run_sparse(args, C):
         if want_checks:
             sparse_checks(args, C, eng, blocks, ng, Ptot, snap, eps_all, step_s, res)
     eng.close()
+    if rank == 0 and world == 1 and not args.no_sparse128 and Ptot == SP_PARTS_1GPU and args.sparse_rows == SP_ROWS:
+        res["sparse_128_per_gpu"] = sparse128_leg(args, C)
     return res
+
+
+def sparse128_leg(args, C):
+    """The share ONE of 8 GPUs holds of BASELINE configs[3] (1024 one-hot partitions sharded over 8 GPUs, single lambda): 128 partitions of
+    9 765 rows as a closed 128-block job on one GPU (no exchange), both numerics contracts -- the per-GPU rate at that shape, so that
+    8 x it is the ceiling of the 8-GPU run before any exchange cost (VERDICT r5 #6; dense_8_per_gpu is the same for configs[1])."""
+    torch, sd = C["torch"], C["sd"]
+    from mlease_amd.dataset import PartitionBlock
+    try:
+        P, rows = 128, SP_ROWS // SP_PARTS_MULTI
+        blocks, ng = [], None
+        for k in range(P):
+            rp, ci, y, l2g, ng = sd.onehot_partition(8 * k, rows)           # partitions 0, 8, 16, ... of the 1024-partition job
+            blocks.append(PartitionBlock(k, rows, len(l2g), rp, ci, None, y, np.ones(rows, np.float32), np.zeros(rows, np.float32), l2g))
+        out = {"workload": "128 partitions x %d rows (one-hot, ~%d local features) on one GPU (the per-GPU share of configs[3] at 8 GPUs), closed 128-block job, lambda=1" % (
+            rows, int(np.mean([b.n_local for b in blocks]))), "unit": "solves/s", "steps": args.sparse_steps, "warmup": args.sparse_warmup}
+        for numerics in ("fast", "reference_order"):
+            eng = C["HipAdmmEngine"](ng, [1.0], [1.0], P, device=C["local_rank"], stream=None, numerics=None if numerics == "fast" else numerics)
+            eng.add_partitions(blocks)
+            eng.finalize()
+            solves, alg = 0, 0.0
+            for it in range(args.sparse_warmup + args.sparse_steps):
+                if it == args.sparse_warmup:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                st = eng.solve_local(0.01, 1.0)
+                eng.consensus_finish()
+                if it >= args.sparse_warmup:
+                    solves += st.solves; alg += st.alg_bytes_dev
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            eng.close()
+            key = "value" if numerics == "fast" else "value_reference_order"
+            out[key] = round(solves / dt, 2)
+            out[("x8" if numerics == "fast" else "x8_reference_order")] = round(8 * solves / dt, 1)
+            if numerics == "fast":
+                out["ms_per_step"] = round(dt * 1e3 / args.sparse_steps, 3)
+                out["whole_step_frac"] = round(alg / dt / 1e9 / HBM_PEAK_GBS, 4)
+        return out
+    except Exception as ex:                                       # an extra: never takes the leg down
+        return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
 
 
 def sparse_loglik_run(args, C, eng, P, ng, rows, Ptot):
