@@ -665,6 +665,48 @@ __device__ __forceinline__ double sell_lds_sum_pipe(double a, const uint16_t *__
     return a;
 }
 
+// The deep part of NI work items AT ONCE (reference-order column pass: unsplit column items, 3 .. 64 packs long in the slices behind the
+// relayed ones). One item after the other, every batch of LSU packs pays a memory latency of its own -- 2-8 dependent latencies per
+// slice, 8 slices per round: 53 of the 130 us a work unit took (profiles/r6_notes.md). Here batch k of ALL live items is in flight
+// together (NI x U packs, one latency), the NI chains' adds interleave, and what is left of the one or two longest items once the others
+// are through goes to the read-ahead loop. L4s must not increase with the item index (slices are sorted by length); bases / L4s are
+// wave-uniform, so the per-item tests are scalar branches.
+template <bool HASVAL, bool NT, int NI>
+__device__ __forceinline__ void sell_lds_deep_multi(double (&a)[NI], const uint16_t *__restrict__ idx, const float *__restrict__ val,
+                                                    const int (&base)[NI], const int (&L4)[NI], int kb, int lane,
+                                                    const double *__restrict__ lds, int zslot)
+{
+#pragma clang fp contract(off)
+    const unsigned zz = (unsigned)zslot | ((unsigned)zslot << 16);
+    constexpr int U = HASVAL ? 1 : 2, TAIL = 2;              // items left to the read-ahead loop
+    static_assert(NI > TAIL, "items");
+    int k = kb;
+    for (; k < L4[TAIL]; k += U) {
+        u2v_t q[NI][U];
+        f4v_t xv[NI][U];
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+            if (k < L4[i]) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int kk = min(k + u, L4[i] - 1);
+                    q[i][u] = pack_load<NT>(idx, base[i], kk, lane);
+                    if (HASVAL) xv[i][u] = pack_load_val<NT>(val, base[i], kk, lane);
+                    if (k + u >= L4[i]) { q[i][u].x = zz; q[i][u].y = zz; }
+                }
+            }
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+            if (k < L4[i]) {
+#pragma unroll
+                for (int u = 0; u < U; u++) a[i] = pack_sum<HASVAL>(a[i], q[i][u], xv[i][u], lds);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < TAIL; i++)
+        if (k < L4[i]) a[i] = sell_lds_sum_pipe<HASVAL, NT>(a[i], idx, val, base[i], k, L4[i], lane, lds, zslot);
+}
+
 // The first KP packs of NI work items at once (NI*KP loads in flight, ONE memory latency for all of them): what makes
 // the short items -- the 0-3 entries a row has in a cold column slice, the rare features' column items -- cheap, where a
 // loop over items pays a full dependent-load latency per item. bases / L4s are wave-uniform.
@@ -1076,6 +1118,9 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     }
     __syncthreads();
     PT_MARK(8);
+#if defined(MLX_PHASE_TIMING) && defined(MLX_PT_PASSES_ONLY)
+    if (threadIdx.x == 0) atomicAdd(&g_phase[13], 100ull);       // work units run (x 0.01 in mlx_debug_phase_times)
+#endif
     const uint16_t *__restrict__ cs_idx = pa.cs_idx;
     const float *__restrict__ cs_val = pa.cs_val;
     const int32_t *__restrict__ cs_ptr = pa.cs_ptr;
@@ -1156,26 +1201,51 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
             base[u] = __builtin_amdgcn_readfirstlane(gld(cs_ptr + sc));
             const int nx = __builtin_amdgcn_readfirstlane(gld(cs_ptr + sc + 1));
             L4[u] = (sl < s1) ? (nx - base[u]) >> 8 : 0;
+#if defined(MLX_ABLATE) && (MLX_ABLATE & 8)      /* timing experiments only: no item meta data */
+            dst[u] = (sl < s1) ? sc * 64 + lane : -1; a[u] = 0.0; dlast[u] = -1;
+            if (false) {
+#else
             const int dl = gld_nt(item_dst + sc * 64 + lane);   // unconditional, clamped; read once per tick
             dst[u] = (sl < s1) ? dl : -1;
             a[u] = 0.0;
             dlast[u] = -1;
             if (RO) {
+#endif
+                // Every load of the round unconditional and independent of the others: the first form fetched the start value under
+                // `if (di >= 0)` and the last-item flag under `if (sl < s1)` -- two branches per slice, and the compiler waited for ALL
+                // outstanding loads in front of each: eight full memory latencies per round, one after the other (28 of the 130 us of
+                // a work unit). The hand-over slot of an item IS its own index (item_init[t] = t or -1), so the start value is read
+                // from slot t whether or not there is one (a slot nobody wrote is never used: selected away below).
                 const int di = gld(item_init + sc * 64 + lane);
-                dlast[u] = (sl < s1) ? gld(item_last + sc * 64 + lane) : -1;
-                if (sl < s1 && di >= 0) a[u] = gld(out + di);  // (written by the previous block's launch)
+                const int dla = gld(item_last + sc * 64 + lane);
+                const double ov = gld(out + sc * 64 + lane);   // (written by the previous block's launch)
+                dlast[u] = (sl < s1) ? dla : -1;
+                a[u] = (sl < s1 && di >= 0) ? ov : 0.0;
             }
         }
         PT_MARK(9);
+#if defined(MLX_ABLATE) && (MLX_ABLATE & 16)     /* timing experiments only: no packs at all */
+        if (false)
+#endif
         sell_lds_first<HASVAL, NT, COL_B, KP>(a, cs_idx, cs_val, base, L4, 0, lane, cf, zs);
         PT_MARK(10);
+#if defined(MLX_ABLATE) && (MLX_ABLATE & 16)
+        if (false) {
+#else
+        if (RO) {
+#endif
+            // (unsplit items: the deep parts of the round's slices together, sell_lds_deep_multi)
+            if (L4[0] > KP) sell_lds_deep_multi<HASVAL, NT, COL_B>(a, cs_idx, cs_val, base, L4, KP, lane, cf, zs);
+        }
 #pragma unroll
         for (int u = 0; u < COL_B; u++) {
-            // (the read-ahead loop only for long items: on a medium one its two batches in flight are mostly clamped re-reads)
-            if (L4[u] > KP) a[u] = (RO && L4[u] > 48) ? sell_lds_sum_pipe<HASVAL, NT>(a[u], cs_idx, cs_val, base[u], KP, L4[u], lane, cf, zs)
-                                                      : sell_lds_sum<HASVAL, NT>(a[u], cs_idx, cs_val, base[u], KP, L4[u], lane, cf, zs);
+            if (!RO && L4[u] > KP) a[u] = sell_lds_sum<HASVAL, NT>(a[u], cs_idx, cs_val, base[u], KP, L4[u], lane, cf, zs);
+#if defined(MLX_ABLATE) && (MLX_ABLATE & 4)      /* timing experiments only: one store per lane and round instead of up to 16 */
+            if (u == 0 && dst[u] >= 0) gst(out + sb * 64 + lane, a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7]);
+#else
             if (dst[u] >= 0) gst(out + dst[u], a[u]);          // (plain store: phase A reads the slots from L2 right after; a streaming store cost the pass 13 %)
             if (RO && dlast[u] >= 0) gst(xtc + dlast[u], a[u]);
+#endif
         }
         PT_MARK(11);
     }

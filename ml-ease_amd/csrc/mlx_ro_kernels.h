@@ -52,6 +52,7 @@ struct RoLds {
     unsigned char hm[2][RO_NN][64];// sub-block L of a norm array holds a change of the running scale
     double wtot[RO_NN][RO_NSW];    // scan: the staging waves' maxima of the chunk being staged
     double res[RO_NF], mcfin[RO_NN];
+    double red[RO_NF + RO_NSW];    // one partial per wave: side sums of the staging threads (ro_block_sum)
     volatile int seq[RO_NSW];      // chunk number (+ 1) each staging wave has published its maximum for
 };
 struct RoV4 { double v[RO_E]; };                    // RO_E consecutive elements of a vector
@@ -155,6 +156,46 @@ __device__ __attribute__((noinline)) double ro_chain_chunk(double acc, ro_lds_cp
     return acc;
 }
 
+// Elementwise statements over elements 0 .. len-1 by all threads of the workgroup, no reductions: G groups of RO_E elements per thread
+// and half-trip, two register sets used in turn -- the loads of the next half-trip are issued before the statements of the current one,
+// so the vectors stream without a stop between trips (round 6's first form loaded four groups, waited, computed, stored, and only
+// then issued the next loads: one memory latency per trip, 100 us per CG tick for the 3 vectors of d = beta d + r at configs[2]).
+// load() clamps to the last group of each vector, emit() masks its stores: trips behind the end cost clamped re-reads only.
+template <int G, typename R, typename LD, typename EM>
+__device__ __forceinline__ void ro_stream(int len, LD load, EM emit)
+{
+    const int tid = threadIdx.x;
+    constexpr int GS = RO_E * RO_T, HS = G * GS;               // elements per group sweep / per half-trip
+    R a[G], b[G];
+#pragma unroll
+    for (int u = 0; u < G; u++) load(u * GS + RO_E * tid, a[u]);
+    for (int base = 0; base < len; base += 2 * HS) {
+#pragma unroll
+        for (int u = 0; u < G; u++) load(base + HS + u * GS + RO_E * tid, b[u]);
+#pragma unroll
+        for (int u = 0; u < G; u++) emit(base + u * GS + RO_E * tid, a[u]);
+#pragma unroll
+        for (int u = 0; u < G; u++) load(base + 2 * HS + u * GS + RO_E * tid, a[u]);
+#pragma unroll
+        for (int u = 0; u < G; u++) emit(base + HS + u * GS + RO_E * tid, b[u]);
+    }
+}
+
+// Sum of one value per thread over the workgroup (a fixed tree: wave butterflies, then the waves' sums in wave order). NOT one of the
+// reference's sums: only for quantities that are compared against a threshold with a margin (the CG step's |s| and |r| tests below).
+__device__ __forceinline__ double ro_block_sum(RoLds &sh, double v)
+{
+    v = mlx_wave_allreduce_sum(v);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh.red[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < RO_NF + RO_NSW; w++) t += sh.red[w];
+    __syncthreads();
+    return t;
+}
+
 // One pass over elements 0 .. len-1. load(j0, R) fetches the operands of elements j0 .. j0+3 (it clamps to the last quad of each
 // vector itself), emit(j0, R, ct, nv) does their elementwise work (stores included, elements beyond a vector's end masked) and
 // returns the terms of the dot arrays ct[k][e] (k >= NN) and the raw values of the norm arrays nv[q][e] (q < NN). Folding wave k
@@ -172,17 +213,8 @@ __device__ __forceinline__ void ro_pass(RoLds &sh, int len, const int *lens, con
     constexpr int NFX = NF > 0 ? NF : 1, NNX = NN > 0 ? NN : 1;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     if (NF == 0) {
-        // elementwise only: no terms, no barriers; four groups per thread in flight (a single one leaves every trip waiting for HBM)
-        for (int base = 0; base < len; base += 4 * RO_E * RO_T) {
-            R r4[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) load(base + u * RO_E * RO_T + RO_E * tid, r4[u]);
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                double ct[NFX][RO_E], nv[NNX][RO_E];
-                emit(base + u * RO_E * RO_T + RO_E * tid, r4[u], ct, nv);
-            }
-        }
+        // elementwise only: no terms, no barriers
+        ro_stream<2, R>(len, load, [&](int j0, R &r) { double ct[NFX][RO_E], nv[NNX][RO_E]; emit(j0, r, ct, nv); });
         __syncthreads();
         return;
     }
@@ -201,7 +233,7 @@ __device__ __forceinline__ void ro_pass(RoLds &sh, int len, const int *lens, con
     double mc[NNX];
 #pragma unroll
     for (int q = 0; q < NNX; q++) mc[q] = 0.0;
-#ifdef MLX_PHASE_TIMING
+#if defined(MLX_PHASE_TIMING) && !defined(MLX_PT_PASSES_ONLY)
     // (timing-experiment builds: shader-clock cycles per phase, kept in registers by lane 0 of every folding wave and of the first
     //  staging wave, added to g_phase[] once at the end of the pass -- no atomics inside the loop)
     unsigned long long pt_t = clock64(), pt_a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -307,7 +339,7 @@ __device__ __forceinline__ void ro_pass(RoLds &sh, int len, const int *lens, con
         RO_PT(folder ? 0 : 2);
         ro_lds_barrier();
         RO_PT(folder ? 1 : 6);
-#ifdef MLX_PHASE_TIMING
+#if defined(MLX_PHASE_TIMING) && !defined(MLX_PT_PASSES_ONLY)
         pt_a[7] += 100;
 #endif
         if (c + 1 >= nch) break;
@@ -317,7 +349,7 @@ __device__ __forceinline__ void ro_pass(RoLds &sh, int len, const int *lens, con
         ro_lds_barrier();
         RO_PT(folder ? 1 : 6);
     }
-#if defined(MLX_PHASE_TIMING) && !defined(MLX_SGF_STATS)
+#if defined(MLX_PHASE_TIMING) && !defined(MLX_SGF_STATS) && !defined(MLX_PT_PASSES_ONLY)
     if (pt_on) {
         if (folder) {
             atomicAdd(&g_phase[wave], pt_a[0]); atomicAdd(&g_phase[4 + wave], pt_a[1]);
@@ -337,6 +369,58 @@ __device__ __forceinline__ void ro_pass(RoLds &sh, int len, const int *lens, con
     for (int k = 0; k < NF; k++) result[k] = (k < NN) ? sh.mcfin[k] * sqrt(sh.res[k]) : sh.res[k];
     __syncthreads();
 }
+
+// euclideanNorm(v) (bw/Tron.java:220-252) as a pass of its own: the CG step below decides `|s| > delta` and `|r| <= cgtol` from sums it
+// has anyway and comes here only when such a sum is too close to its threshold to decide. Not inlined: rarely run, registers of its own.
+__device__ __attribute__((noinline)) double ro_exact_norm(const double *__restrict__ v, int n)
+{
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) unsigned char ro_smem[];
+    RoLds &sh = *reinterpret_cast<RoLds *>(ro_smem);
+    const double z[RO_NF] = {0.0, 0.0, 0.0, 0.0};
+    double r[RO_NF];
+    struct RN { RoV4 x; };
+    ro_pass<1, 1, 0, RN>(sh, n, nullptr, z, r,
+        [&](int j0, RN &R) { R.x = ro_ld4c(v, j0, n); },
+        [&](int j0, RN &R, double (&ct)[1][RO_E], double (&nv)[1][RO_E]) {
+#pragma unroll
+            for (int e = 0; e < RO_E; e++) nv[0][e] = R.x.v[e];
+        });
+    return r[0];
+}
+
+// Can `norm > thr` (equivalently `norm <= thr`) be decided from ssq, a sum of the vector's squares in ANY order or the sequential dot
+// v.v? euclideanNorm's n-step recurrence and either sum of squares lie within (n/2 + 25) 2^-53 of the true norm (relative; every
+// term is non-negative), so they agree on the comparison whenever sqrt(ssq) is further than 8 (n + 64) 2^-53 from the threshold -- a
+// margin of 8x over the two errors together. Sums outside the range where squares are exact to relative precision, infinite or NaN sums,
+// and thresholds that are not finite are never decided here.
+__device__ __forceinline__ bool ro_norm_decided(double ssq, double thr, int n)
+{
+    const double tol = (double)(n + 64) * 8.881784197001252e-16;       // 2^-50
+    const double a = sqrt(ssq);
+    return (ssq > 1e-280) && (ssq < 1e300) && (thr == thr) && (fabs(thr) < 1e300) && (fabs(a - thr) > tol * fabs(thr));
+}
+
+// (timing-experiment builds, tools/ablate_build.sh -DMLX_RO_PASS_TIMING: 100 MHz wall-clock ticks thread 0 of every workgroup spends in each
+//  pass of k_ro_step -- [0] CG pass A, [1] CG pass B, [2] the boundary pass, [3] CG pass C, [4] EVAL row folds, [5] EVAL pass over n,
+//  [6] EVAL copy pass, [8] CG ticks, [9] EVAL ticks; read back with mlx_debug_ropass_times())
+#ifdef MLX_RO_PASS_TIMING
+__device__ unsigned long long g_ropass[16];
+extern "C" int mlx_debug_ropass_times(double *out16)
+{
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ropass), sizeof h) != hipSuccess) return -1;
+    for (int i = 0; i < 16; i++) out16[i] = (double)h[i];
+    return 0;
+}
+#define ROP_INIT unsigned long long rop_last = wall_clock64()
+#define ROP_MARK(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_ropass[k], t_ - rop_last); rop_last = t_; } } while (0)
+#define ROP_COUNT(k) do { if (threadIdx.x == 0) atomicAdd(&g_ropass[k], 1ull); } while (0)
+#else
+#define ROP_INIT
+#define ROP_MARK(k)
+#define ROP_COUNT(k)
+#endif
 
 // The TRON/CG step of one tick, reference-order numerics: one workgroup per problem (bw/Tron.java:30-179; statement order of
 // tron_step_body<SEQ>).
@@ -370,8 +454,10 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
     const double *__restrict__ m = pr.m;
     const double zero6[RO_NF] = {0.0, 0.0, 0.0, 0.0};
     double res[RO_NF];
+    ROP_INIT;
 
     if (phase == PH_CG) {
+        ROP_COUNT(8);
         // ---- one trip of trcg's loop (bw/Tron.java:145-175)
         // Hd for the feature columns and the first nf terms of Tron.dot(d, Hd) on one lane; beside it, on a second lane, the intercept's
         // column of XTv: the sum of the row coefficients in row order (the bias entry closes every row). The dot's last term needs
@@ -380,17 +466,18 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
         struct RA { RoV4 d, x, p, c; };
         const int lensA[2] = {nf, csum_done ? 0 : l};
         ro_pass<2, 0, 2, RA>(sh, csum_done ? nf : max(nf, l), lensA, zero6, res,
-            [&](int j0, RA &R) { R.d = ro_ld4c(d, j0, n); R.x = ro_ld4c(xtc, j0, n); if (pvec) R.p = ro_ld4s(pvec, j0, n); R.c = ro_ld4c(coef, j0, l); },
+            [&](int j0, RA &R) { R.d = ro_ld4c(d, j0, n); R.x = ro_ld4c(xtc, j0, n); if (pvec) R.p = ro_ld4s(pvec, j0, n); if (!csum_done) R.c = ro_ld4c(coef, j0, l); },
             [&](int j0, RA &R, double (&ct)[2][RO_E], double (&nv)[1][RO_E]) {
                 double hd[RO_E];
 #pragma unroll
                 for (int e = 0; e < RO_E; e++) {
                     hd[e] = R.d.v[e] * (pvec ? R.p.v[e] : pscal) + R.x.v[e];      // Hs[i] = (s[i]*priorVar_inv[i] + Hs[i]) * 1
                     ct[0][e] = R.d.v[e] * hd[e];                                   // Tron.dot(d, Hd)
-                    ct[1][e] = R.c.v[e];                                           // XTv[n-1] += v[i]
+                    ct[1][e] = csum_done ? 0.0 : R.c.v[e];                         // XTv[n-1] += v[i]
                 }
                 ro_st4(Hd, j0, nf, hd);
             });
+        ROP_MARK(0);
         if (csum_done) res[1] = pr.csump[0];
         const double rTr0 = pr.rTr, delta0 = pr.delta, cgtol0 = pr.cgtol;
         const double d_icpt = d[nf];
@@ -401,27 +488,39 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
         const double nalpha = -alpha;
         const double *__restrict__ rc = pr.rb[pr.rsel];
         double *__restrict__ rn = pr.rb[pr.rsel ^ 1];
-        // daxpy(alpha, d, s); the norm of s; and the continuation r' = r - alpha Hd with r'.r' and |r'| (:169-171, :144 of the next trip)
+        // daxpy(alpha, d, s) and the continuation r' = r - alpha Hd with r'.r' (:169-171). The two norms of this step are only COMPARED:
+        // `euclideanNorm(s) > delta` (:150) and `euclideanNorm(r) <= cgtol` (:144 of the next trip). Round 6's first form evaluated
+        // both recurrences in every CG step (two of the three folds, and the staging waves' scan, hand-shake and two divisions per
+        // element were the pass's critical path: 245 us of a 490 us step). Now the staging threads add s'^2 on the side (any order),
+        // r'.r' is there anyway, and the recurrence runs only when such a sum is too close to its threshold (ro_norm_decided).
         struct RB { RoV4 d, s, r, h; };
-        ro_pass<3, 2, 0, RB>(sh, n, nullptr, zero6, res,
+        double ssq_part = 0.0;
+        ro_pass<1, 0, 0, RB>(sh, n, nullptr, zero6, res,
             [&](int j0, RB &R) { R.d = ro_ld4c(d, j0, n); R.s = ro_ld4c(s, j0, n); R.r = ro_ld4c(rc, j0, n); R.h = ro_ld4c(Hd, j0, n); },
-            [&](int j0, RB &R, double (&ct)[3][RO_E], double (&nv)[2][RO_E]) {
+            [&](int j0, RB &R, double (&ct)[1][RO_E], double (&nv)[1][RO_E]) {
                 double s1[RO_E], r1[RO_E];
 #pragma unroll
                 for (int e = 0; e < RO_E; e++) {
                     s1[e] = R.s.v[e] + alpha * R.d.v[e];                     // daxpy(alpha, d, s)
                     r1[e] = R.r.v[e] + nalpha * R.h.v[e];                    // daxpy(-alpha, Hd, r)
-                    nv[0][e] = s1[e]; nv[1][e] = r1[e];
-                    ct[2][e] = r1[e] * r1[e];
+                    ct[0][e] = r1[e] * r1[e];
+                    if (j0 + e < n) ssq_part = ssq_part + s1[e] * s1[e];
                 }
                 ro_st4(s, j0, n, s1);
                 ro_st4(rn, j0, n, r1);
             });
-        const double snorm = res[0];
-        bool boundary = false, end_cg = false, nan = !(snorm == snorm);
+        ROP_MARK(1);
+        const double rnew = res[0];
+        const double ssq = ro_block_sum(sh, ssq_part);
+        bool boundary = false, end_cg = false, nan = false;
+        if (ro_norm_decided(ssq, delta0, n)) boundary = sqrt(ssq) > delta0;
+        else {
+            const double snorm = ro_exact_norm(s, n);
+            nan = !(snorm == snorm);
+            boundary = snorm > delta0;
+        }
         double alpha2 = 0.0, beta = 0.0;
-        const double rnew = res[2], rnorm_new = res[1];
-        if (snorm > delta0) {
+        if (boundary) {
             // cg reaches trust region boundary (:150-168): the three dots on the stepped-back s (:152-155). (Round 5 computed them
             // speculatively in the pass above -- six folds side by side; with the folds no longer the bottleneck the common CG step
             // carries three, and the boundary step -- at most one per trcg call -- pays a pass of its own.)
@@ -436,15 +535,18 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
                         ct[0][e] = sb * R.d.v[e]; ct[1][e] = sb * sb; ct[2][e] = R.d.v[e] * R.d.v[e];
                     }
                 });
+            ROP_MARK(2);
             const double std_ = res2[0], sts = res2[1], dtd = res2[2];
             const double dsq = delta0 * delta0;
             const double rad = sqrt(std_ * std_ + dtd * (dsq - sts));
             if (std_ >= 0) alpha2 = (dsq - sts) / (std_ + rad);
             else alpha2 = (rad - std_) / dtd;
-            boundary = true; end_cg = true;
+            end_cg = true;
         } else {
             beta = rnew / rTr0;
-            if (rnorm_new <= cgtol0) end_cg = true;              // loop-top test of the next trip (:144)
+            // loop-top test of the next trip (:144): euclideanNorm(r') <= cgtol
+            if (ro_norm_decided(rnew, cgtol0, n)) end_cg = sqrt(rnew) <= cgtol0;
+            else end_cg = ro_exact_norm(rn, n) <= cgtol0;
         }
         if (nan) end_cg = true;
         const double nalpha2 = -alpha2;
@@ -481,8 +583,24 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
             if (end_cg) ro_st4(w_new, j0, n, wn);
         };
         if (end_cg) ro_pass<3, 1, 0, RC>(sh, n, nullptr, zero6, res, ldc, emc);
-        else ro_pass<0, 0, 0, RC>(sh, n, nullptr, zero6, res, ldc,
-                               [&](int j0, RC &R, double (&ct)[1][RO_E], double (&nv)[1][RO_E]) { double c3[3][RO_E], n1[1][RO_E]; emc(j0, R, c3, n1); });
+        else {
+            // the common step (no boundary, trcg goes on): scale(beta, d); daxpy(one, r, d) (:172-174) -- two vectors in, one out, streamed
+            struct RD { RoV4 d, r1; };
+            ro_stream<4, RD>(n,
+                [&](int j0, RD &R) { R.d = ro_ld4c(d, j0, n); R.r1 = ro_ld4c(rn, j0, n); },
+                [&](int j0, RD &R) {
+                    double dn[RO_E];
+#pragma unroll
+                    for (int e = 0; e < RO_E; e++) {
+                        double dj = R.d.v[e];
+                        if (beta != 1.0) dj = dj * beta;                      // scale(beta, d)
+                        dn[e] = dj + 1.0 * R.r1.v[e];                         // daxpy(one, r, d)
+                    }
+                    ro_st4(d, j0, n, dn);
+                });
+            __syncthreads();
+        }
+        ROP_MARK(3);
         if (tid == 0) {
             if (!boundary) pr.rTr = rnew;
             pr.rsel ^= 1;
@@ -515,42 +633,69 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
                 ct[1][e] = R.c.v[e];                                         // the intercept's column of XTv: the coefficients in row order
             }
         });
+    ROP_COUNT(9);
+    ROP_MARK(4);
     if (csum_done) res[1] = pr.csump[0];
     double fnew = 2.0 * res[0];
     const double csum = res[1];
-    const double init4[RO_NF] = {0.0, 0.0, fnew, 0.0};
     const double *__restrict__ c0 = pa.c0;
     const bool e0 = (phase == PH_EVAL0);
     struct RE { RoV4 w, m, x, p, c; };
-    ro_pass<4, 2, 0, RE>(sh, n, nullptr, init4, res,
-        [&](int j0, RE &R) {
-            R.w = ro_ld4c(w_new, j0, n); R.m = ro_ld4c(m, j0, n); R.x = ro_ld4c(xtc, j0, n);
-            if (pvec) R.p = ro_ld4s(pvec, j0, n);
-            if (e0) R.c = ro_ld4s(c0, j0, n);
-        },
-        [&](int j0, RE &R, double (&ct)[4][RO_E], double (&nv)[2][RO_E]) {
-            double hd[RO_E];
+    auto lde = [&](int j0, RE &R) {
+        R.w = ro_ld4c(w_new, j0, n); R.m = ro_ld4c(m, j0, n); R.x = ro_ld4c(xtc, j0, n);
+        if (pvec) R.p = ro_ld4s(pvec, j0, n);
+        if (e0) R.c = ro_ld4s(c0, j0, n);
+    };
+    // one element: t t p (fun :187-188, added to the running f), the gradient candidate hd (grad :224, multiplier 1), grad(0) (bw/Tron.java:50-53)
+    auto el = [&](int j, const RE &R, int e, double &ttp, double &hd, double &g0) {
+        const double xa = (j == nf) ? csum : R.x.v[e];
+        const double pj = pvec ? R.p.v[e] : pscal;
+        const double t = R.w.v[e] - R.m.v[e];
+        ttp = t * t * pj;
+        hd = t * pj + xa;
+        g0 = e0 ? (0.0 - R.m.v[e]) * pj + R.c.v[e] : 0.0;
+    };
+    double gnorm1_c = 0.0;
+    if (e0) {
+        // the first evaluation of a solve: euclideanNorm(g), euclideanNorm(grad(0)), f, and r.r of the trcg call that starts from this g (r = -g)
+        const double init4[RO_NF] = {0.0, 0.0, fnew, 0.0};
+        ro_pass<4, 2, 0, RE>(sh, n, nullptr, init4, res, lde,
+            [&](int j0, RE &R, double (&ct)[4][RO_E], double (&nv)[2][RO_E]) {
+                double hd[RO_E];
 #pragma unroll
-            for (int e = 0; e < RO_E; e++) {
-                const int j = j0 + e;
-                const double xa = (j == nf) ? csum : R.x.v[e];
-                const double pj = pvec ? R.p.v[e] : pscal;
-                const double t = R.w.v[e] - R.m.v[e];
-                ct[2][e] = t * t * pj;                                       // fun :187-188, added to the running f
-                hd[e] = t * pj + xa;                                         // grad :224 (multiplier 1)
-                nv[0][e] = hd[e];                                            // euclideanNorm(g)
-                ct[3][e] = hd[e] * hd[e];                                    // r.r of the trcg call that starts from this g (r = -g)
-                nv[1][e] = e0 ? (0.0 - R.m.v[e]) * pj + R.c.v[e] : 0.0;      // grad(0) (bw/Tron.java:50-53)
-            }
-            ro_st4(Hd, j0, n, hd);
-        });
+                for (int e = 0; e < RO_E; e++) {
+                    el(j0 + e, R, e, ct[2][e], hd[e], nv[1][e]);
+                    nv[0][e] = hd[e];
+                    ct[3][e] = hd[e] * hd[e];
+                }
+                ro_st4(Hd, j0, n, hd);
+            });
+        gnorm1_c = res[1];
+    } else {
+        // every later one: no grad(0) -- one norm recurrence instead of two in the staging waves, three folds instead of four
+        const double init3[RO_NF] = {0.0, fnew, 0.0, 0.0};
+        double r3[RO_NF];
+        ro_pass<3, 1, 0, RE>(sh, n, nullptr, init3, r3, lde,
+            [&](int j0, RE &R, double (&ct)[3][RO_E], double (&nv)[1][RO_E]) {
+                double hd[RO_E], g0;
+#pragma unroll
+                for (int e = 0; e < RO_E; e++) {
+                    el(j0 + e, R, e, ct[1][e], hd[e], g0);
+                    nv[0][e] = hd[e];
+                    ct[2][e] = hd[e] * hd[e];
+                }
+                ro_st4(Hd, j0, n, hd);
+            });
+        res[0] = r3[0]; res[2] = r3[1]; res[3] = r3[2];
+    }
+    ROP_MARK(5);
     fnew = res[2] / 2.0;
     const double gnorm_c = res[0], gsq_c = res[3];
     bool start_trcg = false, finished = false, copy_w = false, copy_g = false;
     double gnorm_cur = pr.gnorm, gsq = pr.gsq;
     if (e0) {
         // Tron prologue (:47-62)
-        const double gnorm1 = res[1];
+        const double gnorm1 = gnorm1_c;
         if (tid == 0) { pr.f = fnew; pr.gnorm1 = gnorm1; pr.gnorm = gnorm_c; pr.delta = gnorm_c; pr.dsel ^= 1; pr.ticks += 1; }
         gnorm_cur = gnorm_c; gsq = gsq_c;
         copy_g = true;
@@ -626,6 +771,7 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
                 }
             });
     }
+    ROP_MARK(6);
     if (tid == 0) {
         pr.gsq = gsq;
         if (start_trcg) {

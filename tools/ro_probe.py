@@ -99,6 +99,17 @@ def main():
             out["phase_us_sum_over_workgroups"] = [round(v, 1) for v in pt]
     except Exception:
         pass
+    try:                                         # timing-experiment builds only (tools/ablate_build.sh -DMLX_RO_PASS_TIMING)
+        import ctypes
+        pt = (ctypes.c_double * 16)()
+        if LIBS[-1].mlx_debug_ropass_times(pt) == 0:
+            v = list(pt)
+            cg, ev = max(v[8], 1.0), max(v[9], 1.0)
+            out["ro_step_pass_us_per_tick"] = {"cg_ticks": v[8], "eval_ticks": v[9], "cg_pass_A": round(v[0] * 0.01 / cg, 1), "cg_pass_B": round(v[1] * 0.01 / cg, 1),
+                                               "cg_boundary_pass": round(v[2] * 0.01 / cg, 1), "cg_pass_C": round(v[3] * 0.01 / cg, 1),
+                                               "eval_row_folds": round(v[4] * 0.01 / ev, 1), "eval_pass_n": round(v[5] * 0.01 / ev, 1), "eval_copy": round(v[6] * 0.01 / ev, 1)}
+    except Exception:
+        pass
     f = np.mean([x["solves_per_s"] for x in out["fast"]["per_iteration"][1:]] or [0])
     r = np.mean([x["solves_per_s"] for x in out["reference_order"]["per_iteration"][1:]] or [0])
     out["solves_per_s_after_first_iteration"] = {"fast": round(float(f), 1), "reference_order": round(float(r), 1), "ratio": round(float(f / max(r, 1e-9)), 2)}
