@@ -385,7 +385,9 @@ def compact_record(full):
         if d.get("reference_order"):
             ro = d["reference_order"]
             o["value_reference_order"] = ro.get("value")
-            o["reference_order"] = {"bit_identical": "%s/%s" % (ro.get("solves_bit_identical_beta_and_uplusx"), ro.get("solves")), "step_us_per_tick": ro.get("step_us_per_tick")}
+            o["reference_order"] = {"bit_identical": "%s/%s" % (ro.get("solves_bit_identical_beta_and_uplusx"), ro.get("solves"))}
+            if ro.get("step_us_per_tick") is not None:
+                o["reference_order"]["step_us_per_tick"] = ro.get("step_us_per_tick")
         ll = d.get("time_to_ref_loglik") or {}
         if ll.get("ref_loglik") is not None:
             o["time_to_ref_loglik_s"] = ll.get("seconds_to_ref_loglik")

@@ -131,6 +131,9 @@ int mlx_set_numerics(mlx_handle h, int32_t mode);
  *   "tick_streams"        1..4   HIP streams the halves of the problem list tick on (default 2; re-tests the hardware queues)
  *   "stream_probe"        0 | 1  test that the tick streams sit on different hardware queues (default 1)
  *   "grid_rounded_dots"   0 | 1  d.Hd / r.r of every CSR solve (tick kernels and the one-launch solver of small partitions) as grid-rounded sums (default 1; 0 = plain trees, A/B and tests)
+ *   "ro_exact_norms"      0 | 1  reference-order numerics: a CG step runs euclideanNorm's recurrence for both of its norm TESTS always (default 0: only
+ *                                when the sum of squares it has anyway lies too close to the threshold to decide the test -- the outcome is the same by
+ *                                construction, the tests compare the two settings bit for bit)
  *   "profile_one_stream"  0 | 1  with profiling on, all ticks on one stream (= mlx_set_profiling(h, 2))
  *   "one_launch_small"    0 | 1  small CSR problems solve in one launch (default 1); before mlx_finalize
  *   "small_ticks"         ticks one such launch may run before the host looks (default 16384)

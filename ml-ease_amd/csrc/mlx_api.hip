@@ -75,6 +75,7 @@ struct mlx_context {
     bool trace = false;                    // "trace": tick progress / stream probe on stderr
     bool stream_probe = true;              // "stream_probe": test that the tick streams sit on different hardware queues
     bool use_small = true;                 // "one_launch_small": small CSR problems solve in one launch (k_solve_small)
+    bool ro_exact_norms = false;           // "ro_exact_norms": the reference-order CG step evaluates both norm recurrences always (tests: the guarded shortcut against them)
     bool streams_explicit = false;         // the tick-stream count was chosen by the host (MLX_STREAMS / "tick_streams"): numerics do not change it
     std::string err;
 
@@ -301,8 +302,8 @@ void launch_step(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
 {
     mark(h, 3);
     if (h->ro_ticks) {
-        mlxk_ro_step(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->d_done);
-        mlxk_ro_step(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->d_done);
+        mlxk_ro_step(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->d_done, h->ro_exact_norms);
+        mlxk_ro_step(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->d_done, h->ro_exact_norms);
         return;
     }
     mlxk_tron_step(h->stream, h->d_parts, h->d_probs, qdense, nqd, h->step_threads, h->d_done);
@@ -728,6 +729,7 @@ int mlx_set_option(mlx_handle h, const char *key, const char *value)
     }
     if (k == "stream_probe") { h->stream_probe = iv != 0; return MLX_OK; }
     if (k == "grid_rounded_dots") { h->seq_dots = iv != 0; return MLX_OK; }
+    if (k == "ro_exact_norms") { h->ro_exact_norms = iv != 0; return MLX_OK; }
     if (k == "profile_one_stream") { h->prof_one_stream = iv != 0; return MLX_OK; }
     if (k == "trace") { h->trace = iv != 0; return MLX_OK; }
     if (k == "comm_always") { h->comm_always = iv != 0; return MLX_OK; }
@@ -751,6 +753,7 @@ int mlx_get_option(mlx_handle h, const char *key, char *out, size_t out_len)
     else if (k == "stream_probe_rejects") v = std::to_string(h->stream_probe_rejects);
     else if (k == "stream_probe") v = h->stream_probe ? "1" : "0";
     else if (k == "grid_rounded_dots") v = h->seq_dots ? "1" : "0";
+    else if (k == "ro_exact_norms") v = h->ro_exact_norms ? "1" : "0";
     else if (k == "profile_one_stream") v = h->prof_one_stream ? "1" : "0";
     else if (k == "trace") v = h->trace ? "1" : "0";
     else if (k == "comm_always") v = h->comm_always ? "1" : "0";

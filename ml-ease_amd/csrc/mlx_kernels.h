@@ -20,7 +20,7 @@ int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const i
 void mlxk_ro_dense_passes(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int max_l, int max_nfeat,
                           bool stream_once, int which, int *claim);
 // TRON/CG step of the reference-order numerics: one workgroup per problem, every reduction folded in index order
-void mlxk_ro_step(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int *done_counter);
+void mlxk_ro_step(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int *done_counter, bool exact_norms);
 // TRON/CG control flow for the problems in qlist: one workgroup per problem (dense tiles)
 void mlxk_tron_step(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int threads,
                     int *done_counter);

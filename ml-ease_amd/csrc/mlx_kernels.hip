@@ -3391,11 +3391,11 @@ void mlxk_collect_c0(hipStream_t st, const PartDev *parts, const ProbDev *probs,
     else hipLaunchKernelGGL(k_collect_c0, dim3(nq), dim3(256), 0, st, parts, probs, qlist, c0_ptrs);
 }
 
-void mlxk_ro_step(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int *done_counter)
+void mlxk_ro_step(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int *done_counter, bool exact_norms)
 {
     if (nq <= 0) return;
     per_device_once(7, [&] { set_max_lds(reinterpret_cast<const void *>(&k_ro_step), (int)sizeof(RoLds)); });
-    hipLaunchKernelGGL(k_ro_step, dim3((unsigned)nq), dim3(RO_T), sizeof(RoLds), st, parts, probs, qlist, nq, done_counter);
+    hipLaunchKernelGGL(k_ro_step, dim3((unsigned)nq), dim3(RO_T), sizeof(RoLds), st, parts, probs, qlist, nq, done_counter, exact_norms ? 1 : 0);
 }
 
 void mlxk_setup(hipStream_t st, const PartDev *parts, ProbDev *probs, int nprob, int n_lambda, int n_global,

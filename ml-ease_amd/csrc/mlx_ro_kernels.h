@@ -426,7 +426,7 @@ extern "C" int mlx_debug_ropass_times(double *out16)
 // tron_step_body<SEQ>).
 __global__ void __launch_bounds__(RO_T)
 k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq,
-          int *__restrict__ done_counter)
+          int *__restrict__ done_counter, int exact_norms /* 1: every norm test of a CG step runs euclideanNorm's recurrence (option "ro_exact_norms") */)
 {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) unsigned char ro_smem[];
@@ -513,7 +513,7 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
         const double rnew = res[0];
         const double ssq = ro_block_sum(sh, ssq_part);
         bool boundary = false, end_cg = false, nan = false;
-        if (ro_norm_decided(ssq, delta0, n)) boundary = sqrt(ssq) > delta0;
+        if (!exact_norms && ro_norm_decided(ssq, delta0, n)) boundary = sqrt(ssq) > delta0;
         else {
             const double snorm = ro_exact_norm(s, n);
             nan = !(snorm == snorm);
@@ -545,7 +545,7 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
         } else {
             beta = rnew / rTr0;
             // loop-top test of the next trip (:144): euclideanNorm(r') <= cgtol
-            if (ro_norm_decided(rnew, cgtol0, n)) end_cg = sqrt(rnew) <= cgtol0;
+            if (!exact_norms && ro_norm_decided(rnew, cgtol0, n)) end_cg = sqrt(rnew) <= cgtol0;
             else end_cg = ro_exact_norm(rn, n) <= cgtol0;
         }
         if (nan) end_cg = true;

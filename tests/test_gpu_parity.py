@@ -1563,3 +1563,46 @@ def test_reference_order_scratch_problem_forgets_the_previous_partition():
         assert (cnt[0], cnt[1], cnt[2]) == (sto.newton_iters, sto.accepted, sto.cg_iters), k
         assert np.array_equal(wg, wo) and f == sto.f, "partition %d: the scratch problem's X'c was not cleared" % k
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["onehot", "valued", "dense"])
+def test_reference_order_norm_tests_decided_from_sums_equal_the_recurrence(kind, monkeypatch):
+    """Round 6: a reference-order CG step decides `euclideanNorm(s) > delta` (bw/Tron.java:150) and `euclideanNorm(r) <= cgtol` (:144)
+    from sums of squares it has anyway and runs the recurrence (:220-252) only when such a sum lies within 8 (n + 64) 2^-53 of its
+    threshold (k_ro_step: ro_norm_decided / ro_exact_norm). The option "ro_exact_norms" makes every step run the recurrence -- the
+    fallback path, which a normal solve almost never takes: both settings must give the same TRON counters and the same bits on every
+    output over an epsilon schedule that reaches the noise regime, and both must equal the oracle twin."""
+    from fixtures import dense_blocks, onehot_blocks
+    monkeypatch.setenv("MLX_NO_SMALL", "1")
+    if kind == "onehot":
+        pd, lam, rho = onehot_blocks(4 * 20000, 4), [1.0], [1.0]
+    elif kind == "valued":
+        pd, lam, rho = synth_sparse(23, 24000, 400, 10, 3, weights=True, offsets=True), [0.3, 30.0], [1.0, 1.0]
+    else:
+        pd, lam, rho = dense_blocks(4 * 3000, 200, 4), [1.0], [1.0]
+    eps = [1e-2, 1e-2, 1e-4, 1e-6, 1e-9]
+    runs = []
+    for exact in ("0", "1"):
+        eng = make_engine(pd, lam, rho, numerics="reference_order")
+        assert eng.get_option("numerics_kernels") == "reference_order_ticks"
+        eng.set_option("ro_exact_norms", exact)
+        assert eng.get_option("ro_exact_norms") == exact
+        rec = []
+        for e in eps:
+            eng.iterate(e)
+            rec.append((eng.solve_counters().copy(), eng.z()[0].copy(),
+                        [eng.partition_model(k, li)[0].copy() for k in range(len(pd.blocks)) for li in range(len(lam))]))
+        runs.append(rec)
+        eng.close()
+    for it, (a, b) in enumerate(zip(*runs)):
+        assert np.array_equal(a[0], b[0]), "iteration %d: TRON counters differ between the decided and the evaluated norm tests" % (it + 1)
+        assert np.array_equal(a[1], b[1]), "iteration %d: z differs" % (it + 1)
+        for x, y in zip(a[2], b[2]):
+            assert np.array_equal(x, y), "iteration %d: a partition model differs" % (it + 1)
+    assert runs[0][-1][0][:, 2].sum() > 0
+    oc = ol.OracleAdmm(pd.blocks, pd.n_global, lam, rho, pm=True)
+    for it, e in enumerate(eps):
+        oc.iterate(e, 1.0, nthreads=8)
+        assert np.array_equal(runs[0][it][0], _counters(oc)), "iteration %d: not the oracle twin's counters" % (it + 1)
+        assert np.array_equal(runs[0][it][1], oc.z()[0]), "iteration %d: not the oracle twin's consensus" % (it + 1)
