@@ -49,8 +49,13 @@ template <typename T> __device__ __forceinline__ void gst_nt(T *p, T v) { __buil
 // the 100 MHz wall-clock ticks it spent in each phase to g_phase[]; read back with mlx_debug_phase_times().
 #ifdef MLX_PHASE_TIMING
 __device__ unsigned long long g_phase[16];
+#ifdef MLX_SGF_STATS      /* (the fold's counters own all of g_phase[]: [3 pass + k], mlx_seqfold.h) */
+#define PT_INIT
+#define PT_MARK(k)
+#else
 #define PT_INIT unsigned long long pt_last = wall_clock64()
 #define PT_MARK(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_phase[k], t_ - pt_last); pt_last = t_; } } while (0)
+#endif
 extern "C" int mlx_debug_phase_times(double *out16)
 {
     unsigned long long h[16];

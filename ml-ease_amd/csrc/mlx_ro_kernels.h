@@ -36,6 +36,9 @@ constexpr int RO_CH = 64 * SGF_K;                   // elements per chunk: one s
 #define RO_EPT 2                                     // consecutive elements per staging thread and chunk (A/B: tools/ablate_build.sh -DRO_EPT=4)
 #endif
 constexpr int RO_E = RO_EPT;
+#ifndef RO_STREAM_G
+#define RO_STREAM_G 4                              // groups per thread and half-trip of the streamed d = beta d + r (A/B: tools/ablate_build.sh -DRO_STREAM_G=2)
+#endif
 // RO_NF folding waves + RO_NSW staging waves (64 RO_E elements each). The staging waves are the critical path since the folds stopped
 // being literal chains (a chunk: wait for the operands, the elementwise statements, a max-scan and a hand-shake between the staging
 // waves for the norms' running scale, two divisions per element, the LDS writes): eight waves with two elements per thread halve it.
@@ -458,6 +461,7 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
 
     if (phase == PH_CG) {
         ROP_COUNT(8);
+        SGF_PASS(0);
         // ---- one trip of trcg's loop (bw/Tron.java:145-175)
         // Hd for the feature columns and the first nf terms of Tron.dot(d, Hd) on one lane; beside it, on a second lane, the intercept's
         // column of XTv: the sum of the row coefficients in row order (the bias entry closes every row). The dot's last term needs
@@ -495,6 +499,7 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
         // r'.r' is there anyway, and the recurrence runs only when such a sum is too close to its threshold (ro_norm_decided).
         struct RB { RoV4 d, s, r, h; };
         double ssq_part = 0.0;
+        SGF_PASS(1);
         ro_pass<1, 0, 0, RB>(sh, n, nullptr, zero6, res,
             [&](int j0, RB &R) { R.d = ro_ld4c(d, j0, n); R.s = ro_ld4c(s, j0, n); R.r = ro_ld4c(rc, j0, n); R.h = ro_ld4c(Hd, j0, n); },
             [&](int j0, RB &R, double (&ct)[1][RO_E], double (&nv)[1][RO_E]) {
@@ -510,6 +515,7 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
                 ro_st4(rn, j0, n, r1);
             });
         ROP_MARK(1);
+        SGF_PASS(2);
         const double rnew = res[0];
         const double ssq = ro_block_sum(sh, ssq_part);
         bool boundary = false, end_cg = false, nan = false;
@@ -586,7 +592,7 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
         else {
             // the common step (no boundary, trcg goes on): scale(beta, d); daxpy(one, r, d) (:172-174) -- two vectors in, one out, streamed
             struct RD { RoV4 d, r1; };
-            ro_stream<4, RD>(n,
+            ro_stream<RO_STREAM_G, RD>(n,
                 [&](int j0, RD &R) { R.d = ro_ld4c(d, j0, n); R.r1 = ro_ld4c(rn, j0, n); },
                 [&](int j0, RD &R) {
                     double dn[RO_E];
@@ -623,6 +629,7 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
     const double *__restrict__ rowtmp = pr.rowtmp;
     struct RR { RoV4 x, c; };
     const int lensR[2] = {l, csum_done ? 0 : l};
+    SGF_PASS(3);
     if (dn) { res[0] = pr.lossp[0]; res[1] = pr.csump[0]; }
     else ro_pass<2, 0, 2, RR>(sh, l, lensR, zero6, res,
         [&](int j0, RR &R) { R.x = ro_ld4c(rowtmp, j0, l); R.c = ro_ld4c(coef, j0, l); },
@@ -635,6 +642,7 @@ k_ro_step(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const 
         });
     ROP_COUNT(9);
     ROP_MARK(4);
+    SGF_PASS(4);
     if (csum_done) res[1] = pr.csump[0];
     double fnew = 2.0 * res[0];
     const double csum = res[1];

@@ -213,9 +213,15 @@ __device__ __forceinline__ double sgf_bcast(double x, int src)       // lane `sr
 // sub-block with has_mul set holds updates `sum = c + sum * m` (m != 1 where the running scale changes): never on the grid.
 // (timing-experiment builds, tools/ablate_build.sh -DMLX_PHASE_TIMING -DMLX_SGF_STATS: how often the checks fail -- g_phase[13..15] in mlx_kernels.hip)
 #ifdef MLX_SGF_STATS
-#define SGF_COUNT(slot) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_phase[slot], 1ull); } while (0)
+// (per pass of k_ro_step: g_sgf_pass = 0 CG pass A (d.Hd), 1 CG pass B (r'.r'), 2 the other CG passes, 3 EVAL row folds, 4 EVAL pass over n;
+//  g_phase[3 pass + (slot - 13)]: literal sub-blocks (no grid / budget), failed checks, grid iterations)
+extern __device__ unsigned long long g_phase[16];
+__shared__ int g_sgf_pass;
+#define SGF_COUNT(slot) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_phase[3 * g_sgf_pass + ((slot) - 13)], 1ull); } while (0)
+#define SGF_PASS(p) do { __syncthreads(); if (threadIdx.x == 0) g_sgf_pass = (p); __syncthreads(); } while (0)
 #else
 #define SGF_COUNT(slot) do { } while (0)
+#define SGF_PASS(p) do { } while (0)
 #endif
 template <int K, bool MUL>
 __device__ __forceinline__ double sgf_wave_fold(double s, const double (&t)[K], const double (&m)[K], bool has_mul, int &hostile)
