@@ -1023,7 +1023,13 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
                     cntb[(size_t)j] = q - pos[(size_t)j];
                 }
                 for (int j = 0; j < nf; j++) jorder[(size_t)j] = j;
-                std::stable_sort(jorder.begin(), jorder.end(), [&](int32_t a, int32_t b) { return cntb[(size_t)a] > cntb[(size_t)b]; });
+                // (by PACKS, not by entries: a slice is padded to whole packs of 4 anyway, and inside a class the stable sort keeps the
+                //  items in column order -- the X'c stores and the hand-over stores of a slice's 64 lanes then go to neighbouring addresses.
+                //  Sorted by entries, the singletons, pairs, triples ... of a block were classes of their own and a slice of pairs spanned
+                //  ~430 columns: 5.5 M scattered 8-byte store requests per launch, more than all its reads; profiles/r6_notes.md)
+                static const bool by_entries = getenv("MLX_RO_SORT_ENTRIES") != nullptr;      // A/B
+                std::stable_sort(jorder.begin(), jorder.end(), [&](int32_t a, int32_t b) {
+                    return by_entries ? cntb[(size_t)a] > cntb[(size_t)b] : (cntb[(size_t)a] + 3) / 4 > (cntb[(size_t)b] + 3) / 4; });
             }
             for (int jj = 0; jj < nf; jj++) {
                 const int j = jorder[(size_t)jj];

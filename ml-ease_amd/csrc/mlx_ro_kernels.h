@@ -249,6 +249,9 @@ __device__ __forceinline__ void ro_pass(RoLds &sh, int len, const int *lens, con
     const int ti0 = (RO_E * stid) % SGF_K, tL = (RO_E * stid) / SGF_K;
     auto tpos = [&](int e) { return (ti0 + e) * RO_PITCH + tL; };
     auto stage = [&](int c, R &regs) {
+#if defined(MLX_ABLATE) && (MLX_ABLATE & 64)
+        if (NF == 2 && LIN == 2) { sh.C[c & 1][0][tpos(0)] = 1.0; sh.C[c & 1][0][tpos(1)] = 1.0; return; }
+#endif
         const int b = c & 1;
         const int j0 = c * RO_CH + RO_E * stid;
         double ct[NFX][RO_E], nv[NNX][RO_E];
@@ -312,6 +315,11 @@ __device__ __forceinline__ void ro_pass(RoLds &sh, int len, const int *lens, con
         }
     };
     auto fold = [&](int c) {
+#if defined(MLX_ABLATE) && (MLX_ABLATE & 32)     /* timing experiments only (results are wrong): the CG step's first pass without its fold */
+        if (NF == 2 && LIN == 2) return;
+#endif
+#if defined(MLX_ABLATE) && (MLX_ABLATE & 64)     /* timing experiments only: ... without its staging (terms = 1.0, no loads, no stores) */
+#endif
         if (wave >= NF) return;
         const int b = c & 1;
         const int cnt = max(0, min(RO_CH, mylen - c * RO_CH));
