@@ -1156,7 +1156,7 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
                   ro != 2;
         if (ro == 1 && !ph.sell && nb > 1)
             return P.fail(MLX_ERR_INVALID, "reference-order numerics: partition %d (%d rows, %lld non-zeros) is too ragged to slice and too long for "
-                                           "one row block", partition_id, l, (long long)nnz);
+                                           "one row block; the fast contract (mlx_set_numerics / job key mlease.numerics=fast) takes any partition", partition_id, l, (long long)nnz);
         if (ph.sell) {
             // (+256 entries of padding behind the last block: a wave whose trailing groups do not exist issues its unconditional,
             // clamped pack load at the END offset -- one 512-byte pack that must still be inside the allocation)
@@ -1484,7 +1484,7 @@ int mlx_finalize(mlx_handle h)
     if (h->faithful && !h->ro_ticks)
         for (auto &p : h->parts)
             if (p.n_rblk > 1) return fail(h, MLX_ERR_INVALID, "reference-order numerics: partition %d has %d row blocks but the handle runs the one-launch "
-                                                               "kernel (a partition could not be sliced)", p.pid, p.n_rblk);
+                                                               "kernel (a partition could not be sliced); the fast contract (mlx_set_numerics / job key mlease.numerics=fast) takes any partition", p.pid, p.n_rblk);
     for (auto &p : h->parts) if (!p.dense) h->ro_blocks = std::max(h->ro_blocks, p.n_rblk);
     if (h->csr_sell) {
         int64_t total_groups = 0;

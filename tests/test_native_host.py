@@ -244,7 +244,13 @@ def test_cli_job_key_selects_the_reference_order_numerics(tmp_path, c1):
     meta = json.loads((tmp_path / "out" / "_mlease_run.json").read_text())
     assert meta["numerics"] == "reference_order" and meta["numerics_kernels"].startswith("reference_order") and meta["admm_iterations"] == 5
     assert "numerics contract: reference_order" in r.stderr
-    job.write_text((text % "fast").replace("mlease.numerics=fast\n", ""))          # the default
+    job.write_text((text % "fast").replace("mlease.numerics=fast\n", ""))          # no key: the drop-in's default is the reference-order contract (round 6)
+    r = subprocess.run([os.path.join(HOST, "mlease_admm_train"), str(job)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and json.loads((tmp_path / "out" / "_mlease_run.json").read_text())["numerics"] == "reference_order"
+    assert "numerics contract: reference_order" in r.stderr and "mlease.numerics=fast" in r.stderr
+    models = admm.read_linear_models(str(tmp_path / "out" / "final-model" / "part-r-00000.avro"), c1.feature_names)
+    assert np.array_equal(models["1.0"].astype(np.float32), oc.z()[1][0]), "default job: final-model differs from the oracle twin"
+    job.write_text(text % "fast")                                                   # the faster contract, on request
     r = subprocess.run([os.path.join(HOST, "mlease_admm_train"), str(job)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and json.loads((tmp_path / "out" / "_mlease_run.json").read_text())["numerics"] == "fast"
     assert "numerics contract: fast" in r.stderr and "mlease.numerics=reference_order" in r.stderr
