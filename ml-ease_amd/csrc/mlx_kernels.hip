@@ -600,7 +600,11 @@ __device__ __forceinline__ u2v_t pack_load(const uint16_t *__restrict__ idx, int
 #if defined(MLX_ABLATE) && (MLX_ABLATE & 2)      /* timing experiments only: no index loads */
     u2v_t q; q.x = (unsigned)((lane * 37 + kk * 101 + base) & 0x3FFF) * 0x10001u; q.y = q.x + 0x00010001u; return q;
 #else
+#if defined(MLX_ABLATE) && (MLX_ABLATE & 128)     /* timing experiments only: every pack from the first 64 KB of the index array (cache-resident) */
+    const u2v_t *__restrict__ ip = reinterpret_cast<const u2v_t *>(idx + (base & 0x3FFF)) + (kk & 7) * 64 + lane;
+#else
     const u2v_t *__restrict__ ip = reinterpret_cast<const u2v_t *>(idx + base) + kk * 64 + lane;
+#endif
     return NT ? gld_nt(ip) : gld(ip);
 #endif
 }
@@ -1210,7 +1214,12 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
             dst[u] = (sl < s1) ? sc * 64 + lane : -1; a[u] = 0.0; dlast[u] = -1;
             if (false) {
 #else
-            const int dl = gld_nt(item_dst + sc * 64 + lane);   // unconditional, clamped; read once per tick
+#if defined(MLX_ABLATE) && (MLX_ABLATE & 256)     /* timing experiments only: every slice's meta data from slice (sc & 63): cache-resident */
+#define SCM ((sc & 63) + s0)
+#else
+#define SCM sc
+#endif
+            const int dl = gld_nt(item_dst + SCM * 64 + lane);   // unconditional, clamped; read once per tick
             dst[u] = (sl < s1) ? dl : -1;
             a[u] = 0.0;
             dlast[u] = -1;
@@ -1221,9 +1230,9 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
                 // outstanding loads in front of each: eight full memory latencies per round, one after the other (28 of the 130 us of
                 // a work unit). The hand-over slot of an item IS its own index (item_init[t] = t or -1), so the start value is read
                 // from slot t whether or not there is one (a slot nobody wrote is never used: selected away below).
-                const int di = gld(item_init + sc * 64 + lane);
-                const int dla = gld(item_last + sc * 64 + lane);
-                const double ov = gld(out + sc * 64 + lane);   // (written by the previous block's launch)
+                const int di = gld(item_init + SCM * 64 + lane);
+                const int dla = gld(item_last + SCM * 64 + lane);
+                const double ov = gld(out + SCM * 64 + lane);   // (written by the previous block's launch)
                 dlast[u] = (sl < s1) ? dla : -1;
                 a[u] = (sl < s1 && di >= 0) ? ov : 0.0;
             }
