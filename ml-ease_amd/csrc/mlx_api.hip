@@ -48,7 +48,7 @@ struct PartHost {
     bool small = false;                    // CSR partition solved by the one-launch kernel (k_solve_small): decided per PARTITION at mlx_finalize
     std::vector<int32_t> new2old;          // CSR partitions: library local id -> caller's local id (features only)
     std::vector<int32_t> col_ptr_h;        // CSR partitions: host copy of col_ptr (slots of each column)
-    int n_cs = 1, n_hs = 1, slw = 64, n_rgroups = 0, n_cslices = 0, n_rblk = 1, rblk_rows = 0, n_cunits = 0;
+    int n_cs = 1, n_hs = 1, slw = 64, n_rgroups = 0, n_cslices = 0, n_rblk = 1, rblk_rows = 0, n_cunits = 0, max_units_blk = 0;   // (max_units_blk: most column work units any ONE row block has)
     int upw = 1, n_units = 0;              // dense: row units per pass workgroup (1 or 2), number of units
     int nblk = 0, rows_per_blk = 0, n_items = 0, n_slots = 0, rowgroup = 64, pos = 0, neg = 0;
     PartDev dev{};
@@ -102,7 +102,7 @@ struct mlx_context {
     bool csr_hasval = false, any_absent = false, csr_sell = false, csr_small = false;
     int small_lds_doubles = 0;             // > 0: k_solve_small keeps every problem's work vectors in LDS (doubles needed by the largest)
     int small_xl = 0, small_xl_bytes = 0;  // X in LDS too (1: uint8 ids, 2: uint16 ids), total dynamic LDS bytes
-    int max_cunits = 0, max_rblk_rows = 0;
+    int max_cunits = 0, max_rblk_rows = 0, max_units_blk = 0;
     int max_row_lds = 0;                    // sliced row pass: columns of the widest hot slice (LDS doubles, + zero slot)
     int row_ngc = 16;                       // row groups per row-pass workgroup (16, 32, 64 or 128)
     int step_threads = 256;
@@ -292,7 +292,7 @@ int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
         for (int which = 1; which <= 2; which++)
             bracket(which, [&] {
                 return mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_short, h->max_long, h->rowgroup, h->csr_hasval, h->csr_sell, h->max_cunits, h->max_rblk_rows, h->max_row_lds, h->row_ngc, h->n_lambda == 1, which, h->cold_groups,
-                                      h->ro_ticks ? h->ro_blocks : 0);
+                                      h->ro_ticks ? h->ro_blocks : 0, h->max_units_blk);
             });
     return MLX_OK;
 }
@@ -1260,7 +1260,18 @@ static int commit_csr(mlx_handle h, CsrPrep &P, int32_t l, int32_t n_local, int6
         if ((rc = dev_upload(h, &d_b, P.rs_idx.data(), P.rs_idx.size()))) return rc;
         if ((rc = dev_upload(h, &d_c, P.cs_ptr.data(), P.cs_ptr.size()))) return rc;
         if ((rc = dev_upload(h, &d_d, P.cs_idx.data(), P.cs_idx.size()))) return rc;
-        if ((rc = dev_upload(h, &d_e, P.cw_blk.data(), P.cw_blk.size()))) return rc;
+        {
+            // cw_blk, then the first unit of every row block (n_rblk + 1 entries: k_colpass_lds<.., RO> launches one block's units only)
+            std::vector<int32_t> ext(P.cw_blk);
+            ph.max_units_blk = 0;
+            size_t u = 0;
+            for (int b = 0; b <= ph.n_rblk; b++) {
+                while (u < P.cw_blk.size() && P.cw_blk[u] < b) u++;
+                ext.push_back((int32_t)u);
+                if (b > 0) ph.max_units_blk = std::max(ph.max_units_blk, ext.back() - ext[ext.size() - 2]);
+            }
+            if ((rc = dev_upload(h, &d_e, ext.data(), ext.size()))) return rc;
+        }
         if ((rc = dev_upload(h, &d_h, P.cw_slice.data(), P.cw_slice.size()))) return rc;
         if (val) {
             if ((rc = dev_upload(h, &d_f, P.rs_val.data(), P.rs_val.size()))) return rc;
@@ -1548,7 +1559,7 @@ int mlx_finalize(mlx_handle h)
         if (p.dense) for (int li = 0; li < nl; li++) qd.push_back(k * nl + li);
     }
     // a single row-group width / value mode for all CSR partitions of the handle
-    for (auto &p : h->parts) if (!p.dense) { h->max_cunits = std::max(h->max_cunits, p.n_cunits); h->max_rblk_rows = std::max(h->max_rblk_rows, p.rblk_rows); }
+    for (auto &p : h->parts) if (!p.dense) { h->max_cunits = std::max(h->max_cunits, p.n_cunits); h->max_rblk_rows = std::max(h->max_rblk_rows, p.rblk_rows); h->max_units_blk = std::max(h->max_units_blk, p.max_units_blk); }
     // Which CSR partitions solve in one launch (k_solve_small) is a property of the PARTITION (round-4 advisor finding: it was
     // decided from the handle's largest partition, so a small partition's bits depended on what else its handle -- its rank --
     // held): <= 64 K non-zeros and <= 16 K rows / columns. Reference-order numerics: the one-launch verification kernel for every

@@ -13,7 +13,8 @@ int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const i
                    int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cunits, int max_rblk_rows, int row_slw, int row_ngc, bool stream_once,
                    int which /* 1 = row pass, 2 = column pass, 3 = both */,
                    int cold_groups /* > 0: the row pass's cold slices run as their own launch (k_rowcold) over that many row groups */,
-                   int ro_blocks /* > 0: reference-order numerics (mlx_ro_kernels.h); the column pass runs once per row block, that many times */);
+                   int ro_blocks /* > 0: reference-order numerics (mlx_ro_kernels.h); the column pass runs once per row block, that many times */,
+                   int ro_units_blk = 0 /* ... and the most column work units any one row block of a partition has: the grid of one block's launch */);
 // reference-order numerics on DENSE tiles (mlx_ro_dense.h): which & 1 = Xv, one lane per row; which & 2 = XTv, one lane per column
 // over all rows (+ the intercept's column and the loss sum as two more chains)
 // claim: two zeroed ints of device memory per concurrently running launch (the column kernel's work counter; it clears them itself)

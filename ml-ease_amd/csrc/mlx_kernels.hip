@@ -1112,6 +1112,13 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     ProbDev &pr = probs[q];
     if (pr.phase == PH_DONE) return;
     const PartDev &pa = parts[pr.part];
+    if (RO) {
+        // (reference order: the launch of row block only_blk; the first unit of every block sits behind cw_blk[], mlx_api.hip)
+        if (only_blk >= pa.n_rblk) return;
+        const int u0 = gld(pa.cw_blk + pa.n_cunits + only_blk), u1 = gld(pa.cw_blk + pa.n_cunits + only_blk + 1);
+        bx_ += u0;
+        if (bx_ >= u1) return;
+    }
     if (bx_ >= pa.n_cunits) return;
     const int blk = pa.cw_blk[bx_];
     if (RO && blk != only_blk) return;
@@ -3246,7 +3253,7 @@ static void launch_rowpass(hipStream_t st, const PartDev *parts, ProbDev *probs,
 
 int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
                    int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cunits, int max_rblk_rows, int row_slw, int row_ngc, bool stream_once, int which,
-                   int cold_groups, int ro_blocks)
+                   int cold_groups, int ro_blocks, int ro_units_blk)
 {
     const bool do_row = which & 1, do_col = which & 2;
     if (nq <= 0) return 0;
@@ -3264,6 +3271,9 @@ int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const i
             SETLDS_RO(true); SETLDS_RO(false);
 #undef SETLDS_RO
         });
+        // (one block's launch holds that block's units only: with all of a partition's units in the grid half of the 1 024-thread,
+        //  157 KB workgroups of a launch were placed just to find out that their block was not this launch's)
+        const int gxb = ro_units_blk > 0 ? ro_units_blk : max_cunits;
 #define LAUNCH_ROW_RO(HV, GP) hipLaunchKernelGGL((k_rowpass_lds<HV, false, GP, true>), dim3(XGRID(nq, maxblk)), dim3(1024), lds_row, st, parts, probs, qlist, nq, maxblk, 0)
 #define LAUNCH_RO(HV)                                                                                                                          \
         do {                                                                                                                                   \
@@ -3277,7 +3287,7 @@ int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const i
                 for (int b = 0; b < ro_blocks; b++) {                                                                                          \
                     /* (the chain workgroups of the intercept's column lead the first launch: a multiple of 8, so the XCD mapping holds) */   \
                     const int lead = b == 0 ? ((nq + RO_CSUM_WAVES - 1) / RO_CSUM_WAVES + 7) / 8 * 8 : 0;                                      \
-                    hipLaunchKernelGGL((k_colpass_lds<HV, false, true>), dim3(XGRID(nq, max_cunits) + lead), dim3(1024), lds_col, st, parts, probs, qlist, nq, max_cunits, b, lead); \
+                    hipLaunchKernelGGL((k_colpass_lds<HV, false, true>), dim3(XGRID(nq, gxb) + lead), dim3(1024), lds_col, st, parts, probs, qlist, nq, gxb, b, lead); \
                 }                                                                                                                              \
         } while (0)
         if (hasval) LAUNCH_RO(true); else LAUNCH_RO(false);
