@@ -70,6 +70,8 @@ struct mlx_context {
     bool ro_dense_as_csr = false;          // MLX_RO_DENSE_AS_CSR=1 (A/B, tests): a dense tile of this mode through the CSR kernels, entry by entry (round 5's
                                            // form; the one-launch verification mode always takes it) instead of mlx_ro_dense.h
     int max_l_dense = 0;                   // rows of the longest dense tile (grid of the reference-order dense passes)
+    int *d_coldone = nullptr;              // [nprob + 1] reference-order column pass in one launch: finished work units of a launch per problem (cleared by the row pass)
+    bool ro_col_merged = true;             // MLX_RO_COL_MERGED=0: one launch per row block (A/B)
     int *d_claim = nullptr;                // [MAX_TS][2] work counters of the reference-order dense column kernel, one pair per tick stream (zero between launches)
     // host-selectable behaviour (mlx_set_option; the MLX_* environment variables only seed these defaults at mlx_create)
     bool trace = false;                    // "trace": tick progress / stream probe on stderr
@@ -292,7 +294,8 @@ int launch_xpass(mlx_handle h, const int *qdense, int nqd, const int *qcsr, int 
         for (int which = 1; which <= 2; which++)
             bracket(which, [&] {
                 return mlxk_xpass_csr(h->stream, h->d_parts, h->d_probs, qcsr, nqc, h->maxblk_csr, h->max_short, h->max_long, h->rowgroup, h->csr_hasval, h->csr_sell, h->max_cunits, h->max_rblk_rows, h->max_row_lds, h->row_ngc, h->n_lambda == 1, which, h->cold_groups,
-                                      h->ro_ticks ? h->ro_blocks : 0, h->max_units_blk);
+                                      h->ro_ticks ? h->ro_blocks : 0, h->max_units_blk,
+                                      (h->ro_ticks && h->ro_col_merged) ? h->d_coldone : nullptr);
             });
     return MLX_OK;
 }
@@ -1710,6 +1713,9 @@ int mlx_finalize(mlx_handle h)
 
     if ((rc = dev_alloc(h, &h->d_done, 1))) return rc;
     HIPCHECK(h, hipMemset(h->d_done, 0, sizeof(int)));
+    if ((rc = dev_alloc(h, &h->d_coldone, (size_t)(h->nprob + 1)))) return rc;
+    HIPCHECK(h, hipMemset(h->d_coldone, 0, sizeof(int) * (size_t)(h->nprob + 1)));
+    if (const char *e = getenv("MLX_RO_COL_MERGED")) h->ro_col_merged = atoi(e) != 0;
     if ((rc = dev_alloc(h, &h->d_claim, 2 * (size_t)mlx_context::MAX_TS))) return rc;
     HIPCHECK(h, hipMemset(h->d_claim, 0, sizeof(int) * 2 * mlx_context::MAX_TS));
 

@@ -14,7 +14,8 @@ int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const i
                    int which /* 1 = row pass, 2 = column pass, 3 = both */,
                    int cold_groups /* > 0: the row pass's cold slices run as their own launch (k_rowcold) over that many row groups */,
                    int ro_blocks /* > 0: reference-order numerics (mlx_ro_kernels.h); the column pass runs once per row block, that many times */,
-                   int ro_units_blk = 0 /* ... and the most column work units any one row block of a partition has: the grid of one block's launch */);
+                   int ro_units_blk = 0 /* ... and the most column work units any one row block of a partition has: the grid of one block's launch */,
+                   int *coldone = nullptr /* reference order: [total problems] ints -> all row blocks of the column pass in ONE launch (the row pass clears a problem's counter, the column pass's units count themselves) */);
 // reference-order numerics on DENSE tiles (mlx_ro_dense.h): which & 1 = Xv, one lane per row; which & 2 = XTv, one lane per column
 // over all rows (+ the intercept's column and the loss sum as two more chains)
 // claim: two zeroed ints of device memory per concurrently running launch (the column kernel's work counter; it clears them itself)

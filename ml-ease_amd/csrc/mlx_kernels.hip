@@ -829,7 +829,7 @@ __device__ __forceinline__ void sell_gather_round(double *a, const uint16_t *__r
 template <bool HASVAL, bool NT, int GPW, bool RO = false>
 __global__ void __launch_bounds__(1024)
 k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx,
-              int cold_sep)
+              int cold_sep, int *__restrict__ coldone = nullptr /* RO: the column pass's per-problem unit counters, cleared here */)
 {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) double vs[];      // [slw + 1]: the staged hot slice, then the zero slot
@@ -843,6 +843,10 @@ k_rowpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     const PartDev &pa = parts[pr.part];
     const int c = bx_;
     if (c >= pa.nblk) return;
+    // (reference order, column pass in one launch: its counter of this problem's finished work units starts every tick at 0 -- cleared
+    //  HERE, by the row pass that precedes every column pass of the problem on the same stream, served at the memory side like the
+    //  column pass's own accesses to it)
+    if (RO && coldone != nullptr && c == 0 && threadIdx.x == 0) __hip_atomic_store(coldone + q, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool cg = (phase == PH_CG);
     const double *__restrict__ v = cg ? pr.d : pr.w_new;
     const double *__restrict__ wdcur = pr.wd[pr.dsel];
@@ -1095,9 +1099,17 @@ __device__ __forceinline__ void ro_csum_chain(const PartDev *__restrict__ parts,
     if (lane == 0) gst(pr.csump, s);
 }
 
+// Accesses served at the memory side (agent-scope relaxed atomics: global_load / global_store with sc1), for the few values one workgroup
+// hands to another INSIDE a launch: no cache maintenance (a device-scope fence writes back / invalidates a whole L2, profiles/r2_notes.md).
+__device__ __forceinline__ void st_coh(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_coh(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_coh(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ld_coh(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 template <bool HASVAL, bool NT, bool RO = false>
 __global__ void __launch_bounds__(1024)
-k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx, int only_blk, int lead)
+k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, const int *__restrict__ qlist, int nq, int gx, int only_blk, int lead,
+              int *__restrict__ coldone = nullptr /* RO, only_blk < 0: [total problems] finished work units of this launch per problem */)
 {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) double cf[];      // [rblk_rows + 1]: the block's coefficients, then the zero slot
@@ -1106,18 +1118,25 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
         if ((int)blockIdx.x * RO_CSUM_WAVES < nq) ro_csum_chain(parts, probs, qlist, nq, cf);      // (needs 128 KiB of the launch's dynamic LDS: mlxk_xpass_csr)
         return;
     }
+    // (reference order, only_blk < 0: ALL row blocks in one launch -- the grid is [chain workgroups][block 0's units of every problem]
+    //  [block 1's units] ...; a unit of a later block waits for its problem's earlier units below)
+    const bool merged = RO && only_blk < 0;
+    const int XG = ((nq + 7) / 8 * 8) * gx;
+    if (merged) only_blk = ((int)blockIdx.x - lead) / XG;
     int pi_, bx_;
-    if (!xcd_map(nq, gx, pi_, bx_, RO ? lead : 0)) return;
+    if (!xcd_map(nq, gx, pi_, bx_, RO ? lead + (merged ? only_blk * XG : 0) : 0)) return;
     const int q = qlist[pi_];
     ProbDev &pr = probs[q];
     if (pr.phase == PH_DONE) return;
     const PartDev &pa = parts[pr.part];
+    int ro_need = 0;
     if (RO) {
         // (reference order: the launch of row block only_blk; the first unit of every block sits behind cw_blk[], mlx_api.hip)
         if (only_blk >= pa.n_rblk) return;
         const int u0 = gld(pa.cw_blk + pa.n_cunits + only_blk), u1 = gld(pa.cw_blk + pa.n_cunits + only_blk + 1);
         bx_ += u0;
         if (bx_ >= u1) return;
+        ro_need = u0;                                          // units of the earlier blocks: all of them hand sums on to this block
     }
     if (bx_ >= pa.n_cunits) return;
     const int blk = pa.cw_blk[bx_];
@@ -1133,6 +1152,24 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
         if (threadIdx.x == 0) cf[pa.rblk_rows] = 0.0;
     }
     __syncthreads();
+    int *cnt_mine = nullptr;
+    if (merged) {
+        // The problem's counter of finished work units: cleared by the row pass in front of this launch (k_rowpass_lds<.., RO>). A unit
+        // of a later block has its coefficients
+        // staged by now and waits until every unit of the earlier blocks has counted itself (units are dispatched in grid order --
+        // earlier blocks first -- so whoever it waits for is running or done; a wait that outlasts ~0.5 s gives up and flags the problem).
+        cnt_mine = coldone + q;
+        if (threadIdx.x == 0) {
+            if (ro_need > 0) {
+                const unsigned long long t0 = wall_clock64();
+                while (ld_coh(cnt_mine) < ro_need) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (wall_clock64() - t0 > 50000000ull) { pr.status = ST_NAN; break; }
+                }
+            }
+        }
+        __syncthreads();
+    }
     PT_MARK(8);
 #if defined(MLX_PHASE_TIMING) && defined(MLX_PT_PASSES_ONLY)
     if (threadIdx.x == 0) atomicAdd(&g_phase[13], 100ull);       // work units run (x 0.01 in mlx_debug_phase_times)
@@ -1165,7 +1202,7 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
             const int L = (__builtin_amdgcn_readfirstlane(gld(cs_ptr + s0n + 1)) - b0) >> 8;
             if (L <= LONG_T) break;
             const int dl = gld_nt(item_dst + s0n * 64 + lane), di = gld(item_init + s0n * 64 + lane), dla = gld(item_last + s0n * 64 + lane);
-            if (wave == 0) relay_run[lane] = di >= 0 ? gld(out + di) : 0.0;      // (the column's sum over the earlier blocks)
+            if (wave == 0) relay_run[lane] = di >= 0 ? (merged ? ld_coh(out + di) : gld(out + di)) : 0.0;      // (the column's sum over the earlier blocks)
             if (threadIdx.x == 0) relay_turn = 0;
             __syncthreads();
             const unsigned zz = (unsigned)zs | ((unsigned)zs << 16);
@@ -1198,7 +1235,7 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
             __syncthreads();
             if (wave == 0) {
                 const double a = relay_run[lane];
-                if (dl >= 0 && di != -2) gst(out + dl, a);
+                if (dl >= 0 && di != -2) { if (merged) st_coh(out + dl, a); else gst(out + dl, a); }
                 if (dla >= 0) gst(xtc + dla, a);
             }
             __syncthreads();
@@ -1239,7 +1276,7 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
                 // from slot t whether or not there is one (a slot nobody wrote is never used: selected away below).
                 const int di = gld(item_init + SCM * 64 + lane);
                 const int dla = gld(item_last + SCM * 64 + lane);
-                const double ov = gld(out + SCM * 64 + lane);   // (written by the previous block's launch)
+                const double ov = merged ? ld_coh(out + SCM * 64 + lane) : gld(out + SCM * 64 + lane);   // (written by the previous block's launch / units)
                 dlast[u] = (sl < s1) ? dla : -1;
                 a[u] = (sl < s1 && di >= 0) ? ov : 0.0;
             }
@@ -1264,11 +1301,17 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
 #if defined(MLX_ABLATE) && (MLX_ABLATE & 4)      /* timing experiments only: one store per lane and round instead of up to 16 */
             if (u == 0 && dst[u] >= 0) gst(out + sb * 64 + lane, a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7]);
 #else
-            if (dst[u] >= 0) gst(out + dst[u], a[u]);          // (plain store: phase A reads the slots from L2 right after; a streaming store cost the pass 13 %)
+            if (dst[u] >= 0) { if (merged) st_coh(out + dst[u], a[u]); else gst(out + dst[u], a[u]); }      // (plain store: phase A reads the slots from L2 right after; a streaming store cost the pass 13 %)
             if (RO && dlast[u] >= 0) gst(xtc + dlast[u], a[u]);
 #endif
         }
         PT_MARK(11);
+    }
+    if (merged && only_blk + 1 < pa.n_rblk) {
+        // every hand-over store of this unit has been acknowledged at the memory side (the barrier waits for each wave's outstanding
+        // stores), then the unit counts itself
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt_mine, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -3253,7 +3296,7 @@ static void launch_rowpass(hipStream_t st, const PartDev *parts, ProbDev *probs,
 
 int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const int *qlist, int nq, int maxblk,
                    int max_short, int max_long, int rowgroup, bool hasval, bool sell, int max_cunits, int max_rblk_rows, int row_slw, int row_ngc, bool stream_once, int which,
-                   int cold_groups, int ro_blocks, int ro_units_blk)
+                   int cold_groups, int ro_blocks, int ro_units_blk, int *coldone)
 {
     const bool do_row = which & 1, do_col = which & 2;
     if (nq <= 0) return 0;
@@ -3274,7 +3317,7 @@ int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const i
         // (one block's launch holds that block's units only: with all of a partition's units in the grid half of the 1 024-thread,
         //  157 KB workgroups of a launch were placed just to find out that their block was not this launch's)
         const int gxb = ro_units_blk > 0 ? ro_units_blk : max_cunits;
-#define LAUNCH_ROW_RO(HV, GP) hipLaunchKernelGGL((k_rowpass_lds<HV, false, GP, true>), dim3(XGRID(nq, maxblk)), dim3(1024), lds_row, st, parts, probs, qlist, nq, maxblk, 0)
+#define LAUNCH_ROW_RO(HV, GP) hipLaunchKernelGGL((k_rowpass_lds<HV, false, GP, true>), dim3(XGRID(nq, maxblk)), dim3(1024), lds_row, st, parts, probs, qlist, nq, maxblk, 0, coldone)
 #define LAUNCH_RO(HV)                                                                                                                          \
         do {                                                                                                                                   \
             if (do_row) switch (row_ngc) {                                                                                                     \
@@ -3283,11 +3326,15 @@ int mlxk_xpass_csr(hipStream_t st, const PartDev *parts, ProbDev *probs, const i
                 case 64: LAUNCH_ROW_RO(HV, 4); break;                                                                                          \
                 default: LAUNCH_ROW_RO(HV, 8); break;                                                                                          \
             }                                                                                                                                  \
-            if (do_col && max_cunits > 0)                                                                                                      \
+            if (do_col && max_cunits > 0 && coldone != nullptr && ro_blocks > 1) {                                                              \
+                /* all row blocks in ONE launch (the units of a later block wait for their problem's earlier units inside it) */                \
+                const int lead = ((nq + RO_CSUM_WAVES - 1) / RO_CSUM_WAVES + 7) / 8 * 8;                                                        \
+                hipLaunchKernelGGL((k_colpass_lds<HV, false, true>), dim3(XGRID(nq, gxb) * ro_blocks + lead), dim3(1024), lds_col, st, parts, probs, qlist, nq, gxb, -1, lead, coldone); \
+            } else if (do_col && max_cunits > 0)                                                                                               \
                 for (int b = 0; b < ro_blocks; b++) {                                                                                          \
                     /* (the chain workgroups of the intercept's column lead the first launch: a multiple of 8, so the XCD mapping holds) */   \
                     const int lead = b == 0 ? ((nq + RO_CSUM_WAVES - 1) / RO_CSUM_WAVES + 7) / 8 * 8 : 0;                                      \
-                    hipLaunchKernelGGL((k_colpass_lds<HV, false, true>), dim3(XGRID(nq, gxb) + lead), dim3(1024), lds_col, st, parts, probs, qlist, nq, gxb, b, lead); \
+                    hipLaunchKernelGGL((k_colpass_lds<HV, false, true>), dim3(XGRID(nq, gxb) + lead), dim3(1024), lds_col, st, parts, probs, qlist, nq, gxb, b, lead, (int *)nullptr); \
                 }                                                                                                                              \
         } while (0)
         if (hasval) LAUNCH_RO(true); else LAUNCH_RO(false);

@@ -1606,3 +1606,43 @@ def test_reference_order_norm_tests_decided_from_sums_equal_the_recurrence(kind,
         oc.iterate(e, 1.0, nthreads=8)
         assert np.array_equal(runs[0][it][0], _counters(oc)), "iteration %d: not the oracle twin's counters" % (it + 1)
         assert np.array_equal(runs[0][it][1], oc.z()[0]), "iteration %d: not the oracle twin's consensus" % (it + 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["onehot", "valued"])
+def test_reference_order_column_pass_in_one_launch_equals_one_launch_per_row_block(kind, monkeypatch):
+    """Round 6: the reference-order column pass runs ALL row blocks in one launch -- a work unit of a later block waits, inside the
+    launch, until every unit of its problem's earlier blocks has counted itself (a per-problem counter the row pass clears; the
+    hand-over sums go through memory-side stores / loads), instead of one launch per block in block order
+    (llf/LogisticRegressionL2.java:131-150: one chain per column over all its rows). MLX_RO_COL_MERGED=0 restores the launches: both forms
+    must give the same bits on partitions cut into three row blocks with several work units each, and the oracle twin's."""
+    from fixtures import onehot_blocks
+    monkeypatch.setenv("MLX_NO_SMALL", "1")
+    if kind == "onehot":
+        pd, lam, rho = onehot_blocks(4 * 12000, 4), [1.0], [1.0]
+        monkeypatch.setenv("MLX_RBMAX", "4096"); monkeypatch.setenv("MLX_CUNIT", "16384")
+    else:
+        pd, lam, rho = synth_sparse(29, 9000, 300, 10, 3, weights=True, offsets=True), [0.3, 30.0], [1.0, 1.0]
+        monkeypatch.setenv("MLX_RBMAX", "1024"); monkeypatch.setenv("MLX_CUNIT", "4096")
+    eps = [1e-2, 1e-3, 1e-5]
+    runs = []
+    for merged in ("1", "0"):
+        monkeypatch.setenv("MLX_RO_COL_MERGED", merged)
+        eng = make_engine(pd, lam, rho, numerics="reference_order")
+        assert eng.get_option("numerics_kernels") == "reference_order_ticks" and eng.get_option("dense_tiles") == "0"
+        rec = []
+        for e in eps:
+            eng.iterate(e)
+            rec.append((eng.solve_counters().copy(), eng.z()[0].copy(),
+                        [eng.partition_model(k, li)[0].copy() for k in range(len(pd.blocks)) for li in range(len(lam))]))
+        runs.append(rec)
+        eng.close()
+    for it, (a, b) in enumerate(zip(*runs)):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), "iteration %d: the one-launch column pass differs from the per-block launches" % (it + 1)
+        for x, y in zip(a[2], b[2]):
+            assert np.array_equal(x, y), "iteration %d: a partition model differs" % (it + 1)
+    assert runs[0][-1][0][:, 2].sum() > 0
+    oc = ol.OracleAdmm(pd.blocks, pd.n_global, lam, rho, pm=True)
+    for it, e in enumerate(eps):
+        oc.iterate(e, 1.0, nthreads=8)
+        assert np.array_equal(runs[0][it][0], _counters(oc)) and np.array_equal(runs[0][it][1], oc.z()[0]), "iteration %d: not the oracle twin's bits" % (it + 1)
