@@ -1874,8 +1874,10 @@ static int collect_solve_stats(mlx_handle h, int64_t ticks, mlx_stats *stats, bo
     for (int q = 0; q < h->nprob; q++) {
         const ProbDev &pr = h->h_probs[q];
         if (pr.status != ST_OK || pr.phase != PH_DONE)
-            return fail(h, MLX_ERR_MODEL_FITTING, "Model fitting error! partition %d lambda %d: status %d (NaN in objective/gradient)",
-                        h->parts[pr.part].pid, pr.lambda_idx, pr.status);
+            return fail(h, MLX_ERR_MODEL_FITTING, "Model fitting error! partition %d lambda %d: status %d (%s)",
+                        h->parts[pr.part].pid, pr.lambda_idx, pr.status,
+                        pr.status == ST_SYNC ? "a column-pass work unit timed out waiting for its problem's earlier row blocks; MLX_RO_COL_MERGED=0 runs one launch per block"
+                                             : "NaN in objective/gradient");
         s.newton_iters += pr.newton; s.accepted += pr.accepted; s.cg_iters += pr.cg_total;
         s.x_passes_ref += 3 + 2 * (int64_t)pr.cg_total + pr.newton + pr.accepted;
         const PartHost &p = h->parts[pr.part];

@@ -1164,7 +1164,7 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
                 const unsigned long long t0 = wall_clock64();
                 while (ld_coh(cnt_mine) < ro_need) {
                     __builtin_amdgcn_s_sleep(8);
-                    if (wall_clock64() - t0 > 50000000ull) { pr.status = ST_NAN; break; }
+                    if (wall_clock64() - t0 > 50000000ull) { pr.status = ST_SYNC; break; }
                 }
             }
         }
@@ -1280,6 +1280,7 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
                 dlast[u] = (sl < s1) ? dla : -1;
                 a[u] = (sl < s1 && di >= 0) ? ov : 0.0;
             }
+#undef SCM
         }
         PT_MARK(9);
 #if defined(MLX_ABLATE) && (MLX_ABLATE & 16)     /* timing experiments only: no packs at all */

@@ -7,7 +7,7 @@
 #include <stdint.h>
 
 enum { PH_DONE = 0, PH_EVAL0 = 1, PH_CG = 2, PH_EVAL = 3 };
-enum { ST_OK = 0, ST_NAN = 1, ST_TICKCAP = 2 };
+enum { ST_OK = 0, ST_NAN = 1, ST_TICKCAP = 2, ST_SYNC = 3 /* a work unit of the one-launch reference-order column pass gave up waiting for its problem's earlier row blocks */ };
 enum { STEP_NP = 8 };       // doubles per workgroup and phase in ProbDev::pA/pB/pC
 
 struct PartDev {
