@@ -58,7 +58,8 @@ public final class MleaseHip implements AutoCloseable
   public native void setStream(long hipStreamOrZero) throws IOException;                    // mlx_set_stream
   public native void setProfiling(boolean enable) throws IOException;                       // mlx_set_profiling
   public static native String version();                                                    // mlx_version
-  /** Numerics contract: 0 = fast (default), 1 = reference order (every sum a sequential loop as in bw/Tron.java and
+  /** Numerics contract: 0 = fast (the library's default; the drop-in job -- INTEGRATION.md section 3, the native CLI -- asks for 1 unless
+   *  mlease.numerics=fast), 1 = reference order (every sum a sequential loop as in bw/Tron.java and
    *  liblinearfunc/LogisticRegressionL2.java; bit-identical to the Java algorithm up to Math.exp / Math.log1p), 2 = the same on the
    *  one-launch verification kernel. Before the first partition is added. Job key: mlease.numerics. */
   public static final int NUMERICS_FAST = 0, NUMERICS_REFERENCE_ORDER = 1, NUMERICS_REFERENCE_ORDER_ONE_LAUNCH = 2;
