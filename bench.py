@@ -319,7 +319,7 @@ def compact_record(full):
             if isinstance(c["roofline"].get(k), float):
                 c["roofline"][k] = round(c["roofline"][k])
         c["roofline"]["avg_launch_ms"] = _r(c["roofline"].get("avg_launch_ms"), 5)
-        c["roofline"]["measured_in"] = "frac: launch alone (one-stream replay); busy_union / by_durations: timed region" if roof.get("measured_in_short", "").startswith("frac: launch alone") else roof.get("measured_in_short", "timed region")[:80]
+        c["roofline"]["measured_in"] = "frac: launch alone (replay); busy_union / by_durations: timed region" if roof.get("measured_in_short", "").startswith("frac: launch alone") else roof.get("measured_in_short", "timed region")[:80]
         c["roofline"]["traffic_source"] = None if not roof.get("traffic_source") else "profiles/traffic.json PMC ratio x bytes per launch"
         if roof.get("kernel_alone") and "frac_busy_union" not in roof:      # (records of rounds 3-4: frac was the busy-union figure)
             c["roofline"]["frac_kernel_alone_one_stream"] = roof["kernel_alone"]["frac"]
@@ -341,7 +341,7 @@ def compact_record(full):
     cb = full.get("cpu_baseline")
     if cb:
         c["cpu_baseline"] = _pick(cb, ["value", "unit", "cores", "kind"])
-        c["cpu_baseline"]["sample"] = cb.get("sample_short", cb.get("sample", ""))[:96]
+        c["cpu_baseline"]["sample"] = cb.get("sample_short", cb.get("sample", ""))[:72]
         c["gpu_over_cpu"] = (full.get("gpu_over_cpu") or {}).get("solves_per_s")
     par = {}
     c1 = full.get("config1_latency") or {}
@@ -419,8 +419,8 @@ def compact_record(full):
         c["time_to_ref_loglik"] = _pick(ll, ["seconds_to_ref_loglik", "reached_at_iteration", "seconds_all_iterations", "iterations"])
     if full.get("gram"):
         c["gram"] = _pick(full["gram"], ["achieved", "peak", "unit", "frac"])
-        c["gram"]["peak_source"] = "MI355X datasheet fp64 matrix"
-        c["gram"]["kernel"] = "k_gram_f64 (v_mfma_f64_16x16x4_f64), X'DX of one partition"
+        c["gram"]["peak_source"] = "datasheet fp64 matrix"
+        c["gram"]["kernel"] = "k_gram_f64 (v_mfma_f64_16x16x4_f64)"
     if full.get("dense_8_per_gpu"):
         c["dense_8_per_gpu"] = _pick(full["dense_8_per_gpu"], ["value", "ms_per_step", "whole_step_frac"])
     hh = full.get("host_handover") or {}
