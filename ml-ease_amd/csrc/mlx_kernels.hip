@@ -1157,14 +1157,14 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
         // The problem's counter of finished work units: cleared by the row pass in front of this launch (k_rowpass_lds<.., RO>). A unit
         // of a later block has its coefficients
         // staged by now and waits until every unit of the earlier blocks has counted itself (units are dispatched in grid order --
-        // earlier blocks first -- so whoever it waits for is running or done; a wait that outlasts ~0.5 s gives up and flags the problem).
+        // earlier blocks first -- so whoever it waits for is running or done; a wait that outlasts 5 s gives up and flags the problem).
         cnt_mine = coldone + q;
         if (threadIdx.x == 0) {
             if (ro_need > 0) {
                 const unsigned long long t0 = wall_clock64();
                 while (ld_coh(cnt_mine) < ro_need) {
                     __builtin_amdgcn_s_sleep(8);
-                    if (wall_clock64() - t0 > 50000000ull) { pr.status = ST_SYNC; break; }
+                    if (wall_clock64() - t0 > 500000000ull) { pr.status = ST_SYNC; break; }      // (100 MHz: 5 s -- time-sliced GPUs included, nobody waits that long for a unit that is running)
                 }
             }
         }
