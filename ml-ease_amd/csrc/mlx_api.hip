@@ -1081,6 +1081,13 @@ static int prep_csr(CsrPrep &P, int32_t n_global, int32_t partition_id, int32_t 
             prev[(size_t)c] = it;
         }
         for (int j = 0; j < nf; j++) if (prev[(size_t)j] >= 0) item_last[(size_t)prev[(size_t)j]] = j;
+        // ONE word per item for the kernel (PartDev::item_chain): >= 0 the item that continues the column (the sum is handed to ITS slot);
+        // < 0: ~column for the column's last item (the sum is X'c of that column); INT32_MIN for a padding item. Whether an item continues
+        // an earlier one needs no flag: it starts from its own slot, and a slot nobody hands a sum to holds the 0.0 of the slab's memset
+        // for ever (the scratch problem's slots are cleared per solve, mlx_solve_one). Round 6's first form read three words per item.
+        for (int it = 0; it < ph.n_items; it++)
+            if (item_chain[(size_t)it] < 0)
+                item_chain[(size_t)it] = item_last[(size_t)it] >= 0 ? ~item_last[(size_t)it] : std::numeric_limits<int32_t>::min();
     }
     cri.swap(cri_b);
     cval.swap(cval_b);
@@ -1285,11 +1292,11 @@ static int commit_csr(mlx_handle h, CsrPrep &P, int32_t l, int32_t n_local, int6
     }
     ph.dev.item_init = nullptr; ph.dev.item_last = nullptr; ph.dev.item_chain = nullptr;
     if (!P.item_init.empty()) {
-        int32_t *d_ii, *d_il, *d_ic;
-        if ((rc = dev_upload(h, &d_ii, P.item_init.data(), P.item_init.size()))) return rc;
-        if ((rc = dev_upload(h, &d_il, P.item_last.data(), P.item_last.size()))) return rc;
+        // (the kernels read ONE word per item since round 6: item_chain, which encodes the hand-over target / the column of a last item /
+        //  padding; item_init and item_last stay on the host)
+        int32_t *d_ic;
         if ((rc = dev_upload(h, &d_ic, P.item_chain.data(), P.item_chain.size()))) return rc;
-        ph.dev.item_init = d_ii; ph.dev.item_last = d_il; ph.dev.item_chain = d_ic;
+        ph.dev.item_chain = d_ic;
     }
     ph.dev.items_short = d_ishort; ph.dev.items_long = d_ilong; ph.dev.n_short = ph.n_short; ph.dev.n_long = ph.n_long;
     ph.dev.item_ptr = d_item; ph.dev.item_dst = d_itemdst; ph.dev.col_ptr = d_colptr; ph.dev.n_slots = ph.n_slots; ph.dev.l2g = d_l2g; ph.dev.X = nullptr;
@@ -2241,6 +2248,9 @@ int mlx_solve_one(mlx_handle h, int32_t local_index, double *w, const double *pr
     // entries is never written. The handle's own problems rely on the slab's memset; the scratch problem is shared by every
     // partition, and a column empty in this one may hold what an earlier solve on another partition left there.
     if (h->ro_ticks && pr.c0f) HIPCHECK(h, hipMemsetAsync(pr.c0f, 0, sizeof(double) * (size_t)h->max_nlocal, h->stream));
+    // ... and an item that continues no earlier one starts from its own hand-over slot, which must hold 0.0: the slot may have been
+    // another partition's hand-over slot in an earlier solve on this scratch problem
+    if (h->ro_ticks && !p.dense && pr.parts) HIPCHECK(h, hipMemsetAsync(pr.parts, 0, sizeof(double) * (size_t)h->max_parts_len, h->stream));
     const bool prof = h->profiling;
     h->profiling = false;
     int rc = run_ticks(h, h->nprob, 1, h->d_qscratch, p.dense ? 1 : 0, h->d_qscratch, (!p.dense && !p.small) ? 1 : 0, h->d_qscratch, p.small ? 1 : 0, nullptr);

@@ -1184,7 +1184,6 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
     // (three dependent latencies per round instead of per slice); items longer than the first packs continue in the deep loop
     constexpr int COL_B = 8, KP = HASVAL ? 1 : 2;
     const int zs = pa.rblk_rows;
-    const int32_t *__restrict__ item_init = pa.item_init, *__restrict__ item_last = pa.item_last;
     double *__restrict__ xtc = pr.c0f;
     int s0n = s0;                                           // first slice of the loop below
     if (RO) {
@@ -1201,8 +1200,11 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
             const int b0 = __builtin_amdgcn_readfirstlane(gld(cs_ptr + s0n));
             const int L = (__builtin_amdgcn_readfirstlane(gld(cs_ptr + s0n + 1)) - b0) >> 8;
             if (L <= LONG_T) break;
-            const int dl = gld_nt(item_dst + s0n * 64 + lane), di = gld(item_init + s0n * 64 + lane), dla = gld(item_last + s0n * 64 + lane);
-            if (wave == 0) relay_run[lane] = di >= 0 ? (merged ? ld_coh(out + di) : gld(out + di)) : 0.0;      // (the column's sum over the earlier blocks)
+            // (one word per item: >= 0 the item the sum is handed to, ~column for the column's last item, INT32_MIN for padding; the start
+            //  value is the item's own slot -- 0.0 for ever where no earlier item hands a sum on: mlx_api.hip, prep_csr)
+            const int code = gld_nt(item_dst + s0n * 64 + lane);
+            const int dl = code >= 0 ? code : -1, dla = (code < 0 && code != (int)0x80000000) ? ~code : -1;
+            if (wave == 0) relay_run[lane] = merged ? ld_coh(out + s0n * 64 + lane) : gld(out + s0n * 64 + lane);      // (the column's sum over the earlier blocks)
             if (threadIdx.x == 0) relay_turn = 0;
             __syncthreads();
             const unsigned zz = (unsigned)zs | ((unsigned)zs << 16);
@@ -1235,7 +1237,7 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
             __syncthreads();
             if (wave == 0) {
                 const double a = relay_run[lane];
-                if (dl >= 0 && di != -2) { if (merged) st_coh(out + dl, a); else gst(out + dl, a); }
+                if (dl >= 0) { if (merged) st_coh(out + dl, a); else gst(out + dl, a); }
                 if (dla >= 0) gst(xtc + dla, a);
             }
             __syncthreads();
@@ -1272,13 +1274,12 @@ k_colpass_lds(const PartDev *__restrict__ parts, ProbDev *__restrict__ probs, co
                 // Every load of the round unconditional and independent of the others: the first form fetched the start value under
                 // `if (di >= 0)` and the last-item flag under `if (sl < s1)` -- two branches per slice, and the compiler waited for ALL
                 // outstanding loads in front of each: eight full memory latencies per round, one after the other (28 of the 130 us of
-                // a work unit). The hand-over slot of an item IS its own index (item_init[t] = t or -1), so the start value is read
-                // from slot t whether or not there is one (a slot nobody wrote is never used: selected away below).
-                const int di = gld(item_init + SCM * 64 + lane);
-                const int dla = gld(item_last + SCM * 64 + lane);
+                // a work unit). Now: ONE word per item (dl: >= 0 the item the sum is handed to, ~column for the column's last item,
+                // INT32_MIN for padding) and the item's own hand-over slot as the start value (0.0 for ever where nobody hands a sum on).
                 const double ov = merged ? ld_coh(out + SCM * 64 + lane) : gld(out + SCM * 64 + lane);   // (written by the previous block's launch / units)
-                dlast[u] = (sl < s1) ? dla : -1;
-                a[u] = (sl < s1 && di >= 0) ? ov : 0.0;
+                dst[u] = (sl < s1 && dl >= 0) ? dl : -1;
+                dlast[u] = (sl < s1 && dl < 0 && dl != (int)0x80000000) ? ~dl : -1;
+                a[u] = (sl < s1) ? ov : 0.0;
             }
 #undef SCM
         }

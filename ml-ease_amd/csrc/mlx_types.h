@@ -68,12 +68,13 @@ struct PartDev {
     const int32_t *cw_blk;     // [n_cunits]
     const int32_t *cw_slice;   // [n_cunits+1]
     // Reference-order numerics (MLX_NUMERICS_REFERENCE_ORDER, mlx_ro_kernels.h): a column's sum is ONE sequential chain over its
-    // rows (XTv, llf/LogisticRegressionL2.java:140-145). Items are unsplit inside a row block; the item of block b starts from the
-    // sum its column had reached in the earlier blocks (slot item_init[t], -1: from 0.0) and the column's LAST item also stores
-    // its sum densely at xtc[item_last[t]] (item_last[t] = column id, -1 otherwise). The column pass runs once per row block.
-    const int32_t *item_init;  // [n_items] or nullptr
-    const int32_t *item_last;  // [n_items] or nullptr
-    const int32_t *item_chain; // [n_items] or nullptr: where an item hands its sum on (the slot of the column's item in the next block it has rows in, -1: none)
+    // rows (XTv, llf/LogisticRegressionL2.java:140-145). Items are unsplit inside a row block; the item of block b starts from its own
+    // hand-over slot parts[t] -- the sum its column had reached in the earlier blocks, or the 0.0 of the slab's memset where no earlier
+    // item hands a sum on -- and ONE word per item says where its sum goes (round 6; three words before): >= 0 the column's item in the
+    // next block it has rows in (its slot), ~column for the column's last item (X'c of that column, stored densely), INT32_MIN for padding.
+    const int32_t *item_init;  // (unused since round 6: nullptr)
+    const int32_t *item_last;  // (unused since round 6: nullptr)
+    const int32_t *item_chain; // [n_items] or nullptr: the word described above
     int32_t rowgroup;      // lanes per row in the CSR row pass (8..64)
     const int8_t *y;       // +1/-1
     const float *wt;       // instance weight
